@@ -1,0 +1,86 @@
+// Shared helpers for the gfx950 kernels of libalive_vc.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/alive_vc.h"
+
+void alive_set_error(const char* fmt, ...);
+
+#define ALIVE_CHECK_ARG(cond, ...)                                   \
+    do {                                                              \
+        if (!(cond)) {                                                \
+            alive_set_error(__VA_ARGS__);                             \
+            return ALIVE_ERR_ARG;                                     \
+        }                                                             \
+    } while (0)
+
+#define ALIVE_CHECK_LAUNCH(what)                                      \
+    do {                                                              \
+        hipError_t e_ = hipGetLastError();                            \
+        if (e_ != hipSuccess) {                                       \
+            alive_set_error("%s: %s", what, hipGetErrorString(e_));   \
+            return ALIVE_ERR_LAUNCH;                                  \
+        }                                                             \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Bump allocator over the caller-provided workspace (no hipMalloc in any entry point).
+struct Arena {
+    char* base;
+    size_t off;
+    explicit Arena(void* p) : base((char*)p), off(0) {}
+    template <typename T>
+    T* take(size_t n) {
+        off = align_up(off, 256);
+        T* p = (T*)(base + off);
+        off += n * sizeof(T);
+        return p;
+    }
+    size_t used() const { return align_up(off, 256); }
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef __HIPCC__
+// exact-erf GELU in the association order of ATen's CPU kernel: (0.5*x) * (1 + erf(x/sqrt2))
+__device__ __forceinline__ float gelu_erf(float x) {
+    return (0.5f * x) * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// F.interpolate(mode='linear', align_corners=False) source coordinate:
+//   src = fmaf(scale, i + 0.5, -0.5) clamped at 0 (single rounding), see DESIGN.md "interp"
+struct Lerp {
+    int i0, i1;
+    float w0, w1;
+};
+__device__ __forceinline__ Lerp lerp_coord(int i, float ratio, int in_len) {
+    float src = fmaf(ratio, (float)i + 0.5f, -0.5f);
+    src = src < 0.0f ? 0.0f : src;
+    int i0 = (int)src;
+    if (i0 > in_len - 1) i0 = in_len - 1;
+    Lerp r;
+    r.i0 = i0;
+    r.i1 = i0 + (i0 < in_len - 1 ? 1 : 0);
+    r.w1 = src - (float)i0;
+    r.w0 = 1.0f - r.w1;
+    return r;
+}
+// value = fma(w0, a, round(w1*b))  -- bit-exact with ATen's CPU upsample_linear1d
+__device__ __forceinline__ float lerp_apply(const Lerp& l, float a, float b) {
+    return fmaf(l.w0, a, l.w1 * b);
+}
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rn(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+#endif

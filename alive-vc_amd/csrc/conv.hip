@@ -1,0 +1,220 @@
+// Conv1d / ConvTranspose1d(k == stride) as an implicit GEMM on the f32-input MFMA
+// (v_mfma_f32_16x16x4_f32: bit-for-bit a k-ordered fp32 fmaf chain), gfx950.
+//
+//   Y[n][co][t] = epilogue( bias[co] + sum_{ci,j} W[co][ci*KW + j] * X[n][ci][t*stride + j*dil - pad] )
+//
+// A operand = packed weights [Co_pad][K_pad] (K contiguous), B operand = the
+// im2col view of X, gathered on the fly while staging into LDS (never
+// materialised).  The accumulator starts at the bias, so a K == 1 conv is the
+// single fma(w, x, b) that ATen's CPU path produces (F0Encoder.c1 feeds sin()).
+//
+// Block: 256 threads = 4 waves, BK = 16 (four 16x16x4 k-steps).  Each lane
+// reads 4 consecutive k of its A row with one ds_read_b128; MFMA step s of
+// lane-group q consumes k = 4q + s for both operands, so the k permutation is
+// consistent and the sum is complete after the four steps.
+//
+// Reference call sites replaced: every nn.Conv1d / nn.ConvTranspose1d of
+// module/common.py:48-51,88-92, content_encoder.py:15-19, f0_estimator.py:15-20,
+// decoder.py:16-17,41,61,108-110,141,164-182.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 16;
+constexpr int A_LD = BK + 4;   // 20 floats = 80 B rows: keeps b128 reads 16-B aligned, spreads banks
+
+// Kept out of line: 64 inlined copies of erff/expf/sinf (one per accumulator element) blow the unrolled
+// epilogue past the point where the accumulators stay in registers.
+__device__ __attribute__((noinline)) float apply_act(float v, int act) {
+    if (act == 1) return gelu_erf(v);
+    if (act == 2) return expf(v);
+    return sinf(v);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(AliveConv p, unsigned kw_magic, float film_ratio) {
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MR = TM / 16, NR = TN / 16;
+    constexpr int B_LD = BN + 4;
+    constexpr int ROWS_PER_PASS = 256 / BN;        // B rows staged per pass of the block
+    constexpr int EPT = BK / ROWS_PER_PASS;        // B elements per thread per k-chunk
+    constexpr int A_VEC = (BM * 4 + 255) / 256;    // float4 per thread per k-chunk
+    static_assert(WM * WN == 4, "4 waves");
+    static_assert(256 % BN == 0 || BN == 256, "BN");
+
+    __shared__ __attribute__((aligned(16))) float As[2][BM][A_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][B_LD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int n = blockIdx.z;
+    const int m0 = blockIdx.y * BM;
+    const int t0 = blockIdx.x * BN;
+    const int K = p.Ci * p.KW;
+    const int co_pad = (p.Co + 15) & ~15;
+    const int nk = p.K_pad / BK;
+
+    // ---- per-thread B (im2col) coordinates: fixed column, k advances ----
+    const int tt = tid % BN;
+    const int kk0 = tid / BN;
+    const int t_col = t0 + tt;
+    const bool col_ok = t_col < p.Tout;
+    const int tin_base = t_col * p.stride - p.pad_left;
+    const float* Xn = p.X + (size_t)n * p.Ci * p.Tin;
+
+    f32x4 a_reg[A_VEC];
+    float b_reg[EPT];
+
+    auto load_global = [&](int kt) {
+        const int kbase = kt * BK;
+#pragma unroll
+        for (int v = 0; v < A_VEC; ++v) {
+            int i = tid + v * 256;
+            if (BM * 4 >= 256 || i < BM * 4) {
+                int row = i >> 2, c4 = i & 3;
+                int grow = m0 + row;
+                grow = grow < co_pad ? grow : co_pad - 1;
+                a_reg[v] = *(const f32x4*)(p.W + (size_t)grow * p.K_pad + kbase + c4 * 4);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+            int k = kbase + kk0 + r * ROWS_PER_PASS;
+            int ci, j;
+            if (p.KW == 1) { ci = k; j = 0; }
+            else if (kw_magic == 0) { ci = 0; j = k; }          // single input channel (DFT frames, source_in)
+            else { ci = (int)(((unsigned)k * kw_magic) >> 20); j = k - ci * p.KW; }
+            int tin = tin_base + j * p.dil;
+            if (tin < 0 && p.pad_mode != 0) tin = -tin;
+            if (tin >= p.Tin && p.pad_mode == 2) tin = 2 * (p.Tin - 1) - tin;
+            bool ok = col_ok && (k < K) && (tin >= 0) && (tin < p.Tin);
+            b_reg[r] = ok ? Xn[(size_t)ci * p.Tin + tin] : 0.0f;
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int v = 0; v < A_VEC; ++v) {
+            int i = tid + v * 256;
+            if (BM * 4 >= 256 || i < BM * 4) {
+                int row = i >> 2, c4 = i & 3;
+                *(f32x4*)&As[buf][row][c4 * 4] = a_reg[v];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) Bs[buf][kk0 + r * ROWS_PER_PASS][tt] = b_reg[r];
+    };
+
+    // ---- accumulators start at the bias ----
+    const int lr = lane & 15, lq = lane >> 4;
+    f32x4 acc[MR][NR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        f32x4 b4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int row = m0 + wm * TM + m * 16 + lq * 4 + r;
+            b4[r] = (p.bias != nullptr && row < p.Co) ? p.bias[row] : 0.0f;
+        }
+#pragma unroll
+        for (int nn = 0; nn < NR; ++nn) acc[m][nn] = b4;
+    }
+
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_global(kt + 1);
+        f32x4 a[MR];
+        float b[NR][4];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) a[m] = *(const f32x4*)&As[buf][wm * TM + m * 16 + lr][lq * 4];
+#pragma unroll
+        for (int nn = 0; nn < NR; ++nn)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) b[nn][s] = Bs[buf][lq * 4 + s][wn * TN + nn * 16 + lr];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int nn = 0; nn < NR; ++nn)
+                    acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[nn][s], acc[m][nn], 0, 0, 0);
+        if (kt + 1 < nk) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    const int Tfull = p.Tout * p.up;
+    const int co_out = p.Co / p.up;
+#pragma unroll
+    for (int nn = 0; nn < NR; ++nn) {
+        const int t = t0 + wn * TN + nn * 16 + lr;
+        if (t >= p.Tout) continue;
+        Lerp lp;
+        if (p.Z != nullptr) lp = lerp_coord(t, film_ratio, p.Lf);
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * TM + m * 16 + lq * 4 + r;
+                if (row >= p.Co) continue;
+                float v = acc[m][nn][r];
+                if (p.act != 0) v = apply_act(v, p.act);
+                if (p.post_add != nullptr) v = v + p.post_add[row];
+                if (p.ch_scale != nullptr) v = v * p.ch_scale[row];
+                if (p.up == 1) {
+                    const size_t o = ((size_t)n * p.Co + row) * p.Tout + t;
+                    if (p.residual != nullptr) v = v + p.residual[o];
+                    if (p.skip != nullptr) v = v + p.skip[o];
+                    if (p.Y != nullptr) p.Y[o] = v;
+                    if (p.Z != nullptr) {
+                        const float* fs = p.film + ((size_t)n * p.film_rows + p.film_scale_row + row) * p.Lf;
+                        const float* fh = p.film + ((size_t)n * p.film_rows + p.film_shift_row + row) * p.Lf;
+                        float sc = lerp_apply(lp, fs[lp.i0], fs[lp.i1]);
+                        float sh = lerp_apply(lp, fh[lp.i0], fh[lp.i1]);
+                        float g = apply_act(v, 1);
+                        p.Z[o] = g * sc + sh;
+                    }
+                } else {
+                    const int co = row / p.up, jj = row - co * p.up;
+                    p.Y[((size_t)n * co_out + co) * Tfull + (size_t)t * p.up + jj] = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int alive_conv1d(const AliveConv* d, void* stream) {
+    ALIVE_CHECK_ARG(d && d->W && d->X, "alive_conv1d: null W/X");
+    ALIVE_CHECK_ARG(d->N > 0 && d->Ci > 0 && d->Co > 0 && d->Tin > 0 && d->Tout > 0, "alive_conv1d: bad sizes");
+    ALIVE_CHECK_ARG(d->KW >= 1 && (d->KW <= 16 || d->Ci == 1) && d->stride >= 1 && d->dil >= 1 && d->up >= 1, "alive_conv1d: bad geometry");
+    ALIVE_CHECK_ARG(d->K_pad % 16 == 0 && d->K_pad >= d->Ci * d->KW, "alive_conv1d: K_pad %d for K %d", d->K_pad, d->Ci * d->KW);
+    ALIVE_CHECK_ARG(d->Ci * d->KW < 32768, "alive_conv1d: K too large");
+    ALIVE_CHECK_ARG(d->Y || d->Z, "alive_conv1d: no output");
+    if (d->up > 1) {
+        ALIVE_CHECK_ARG(d->Co % d->up == 0 && !d->residual && !d->skip && !d->Z && d->Y, "alive_conv1d: transposed conv has a plain epilogue");
+    }
+    ALIVE_CHECK_ARG(d->pad_mode >= 0 && d->pad_mode <= 2, "alive_conv1d: pad_mode");
+    if (d->pad_mode != 0) ALIVE_CHECK_ARG(d->pad_left < d->Tin, "alive_conv1d: reflect pad %d needs Tin > pad (Tin %d)", d->pad_left, d->Tin);
+    if (d->Z) ALIVE_CHECK_ARG(d->film && d->Lf > 0, "alive_conv1d: Z needs film");
+    const unsigned magic = d->Ci == 1 ? 0u : (unsigned)(((1u << 20) + d->KW - 1) / d->KW);
+    const float ratio = d->Z ? (float)d->Lf / (float)d->Tout : 0.0f;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->Co > 64) {
+        dim3 g(cdiv(d->Tout, 128), cdiv(d->Co, 128), d->N);
+        conv_gemm_kernel<128, 128, 2, 2><<<g, 256, 0, s>>>(*d, magic, ratio);
+    } else if (d->Co > 16) {
+        dim3 g(cdiv(d->Tout, 128), cdiv(d->Co, 64), d->N);
+        conv_gemm_kernel<64, 128, 1, 4><<<g, 256, 0, s>>>(*d, magic, ratio);
+    } else {
+        dim3 g(cdiv(d->Tout, 256), 1, d->N);
+        conv_gemm_kernel<16, 256, 1, 4><<<g, 256, 0, s>>>(*d, magic, ratio);
+    }
+    ALIVE_CHECK_LAUNCH("alive_conv1d");
+    return ALIVE_OK;
+}

@@ -1,0 +1,14 @@
+// thread-local error message + version of the C ABI (include/alive_vc.h)
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void alive_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* alive_last_error(void) { return g_err; }
+extern "C" int alive_version(void) { return 1; }

@@ -1,0 +1,540 @@
+// Cosine kNN regression against the voice library -- replaces match_features
+// (/root/reference/module/common.py:96-109) and VoiceLibrary.match (voice_library.py:15-33).
+//
+// The reference materialises cos[T][M] with an fp32 bmm and runs topk over it.
+// Here the [T][M] matrix never exists:
+//   1. knn_score_kernel   bf16 MFMA (v_mfma_f32_32x32x16_bf16) over L2-normalised
+//      library rows x normalised source frames, 128x128 output tiles; each
+//      wave folds its 64x64 accumulator tile straight into per-frame top-k'
+//      candidate lists kept in LDS (a register threshold rejects almost every
+//      score with one v_max3 chain; insertions are rare after the first tiles).
+//   2. knn_rescore_kernel every surviving candidate is re-scored in fp32 with the
+//      reference's arithmetic (normalise-then-dot) and the exact top-k is taken,
+//      so the bf16 pass only has to be a superset generator.
+//   3. knn_merge_gather_kernel merges per-shard exact lists (after an RCCL
+//      all-gather when the library is sharded), gathers the k rows, mean, blend.
+//
+// Layout: frames on the MFMA column/lane axis (B operand), library rows on the
+// row/register axis (A operand): a lane owns two frame columns and sees 32
+// library rows of each per tile, so list maintenance is lane-private.
+#include "common.h"
+
+namespace {
+
+constexpr int D = ALIVE_DIM;          // 768
+constexpr int KP = ALIVE_KPRIME;      // 16
+constexpr int TILE = 128;             // frames per block == library rows per tile
+constexpr int BK = 64;                // bf16 k per stage (128-B rows in LDS)
+constexpr int NKS = D / BK;           // 12
+constexpr int MAX_SPLIT = 32;         // max library splits (grid.y); candidates/frame = split*2*KP <= 1024
+
+// ----------------------------------------------------------------------------------------------
+// packing
+// ----------------------------------------------------------------------------------------------
+// tokens[D][M] -> norms[M], rows_f32[M][D], lib_bf16[M_pad][D] (normalised).  64 columns per block.
+__global__ __launch_bounds__(256) void lib_pack_kernel(const float* __restrict__ tok, int64_t M, int64_t M_pad,
+                                                       unsigned short* __restrict__ lib, float* __restrict__ rows,
+                                                       float* __restrict__ norms) {
+    __shared__ float red[4][64];
+    __shared__ float tile[64][65];
+    __shared__ float nrm[64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * 64;
+    const int64_t m = m0 + lane;
+    const bool ok = m < M;
+    float ss = 0.0f;
+    for (int d = wv; d < D; d += 4) {
+        float v = ok ? tok[(size_t)d * M + m] : 0.0f;
+        ss = fmaf(v, v, ss);
+    }
+    red[wv][lane] = ss;
+    __syncthreads();
+    if (wv == 0) {
+        float nn = sqrtf(red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+        nrm[lane] = nn;
+        if (ok) norms[m] = nn;
+    }
+    __syncthreads();
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        for (int r = wv; r < 64; r += 4) tile[r][lane] = ok ? tok[(size_t)(d0 + r) * M + m] : 0.0f;
+        __syncthreads();
+        for (int r = wv; r < 64; r += 4) {      // r = library row inside the block, lane = feature
+            const int64_t mm = m0 + r;
+            if (mm < M_pad) {
+                float v = tile[lane][r];
+                if (mm < M) rows[(size_t)mm * D + d0 + lane] = v;
+                float q = (mm < M) ? v / nrm[r] : 0.0f;
+                lib[(size_t)mm * D + d0 + lane] = f32_to_bf16_rn(q);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// src[N][D][T] -> s_f32[Tt][D] (normalised, fp32), s_bf16[Tt_pad][D]
+__global__ __launch_bounds__(256) void src_prep_kernel(const float* __restrict__ src, int T, int64_t Tt, int64_t Tt_pad,
+                                                       float* __restrict__ s_f32, unsigned short* __restrict__ s_bf16) {
+    __shared__ float red[4][64];
+    __shared__ float tile[64][65];
+    __shared__ float nrm[64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t f0 = (int64_t)blockIdx.x * 64;
+    const int64_t ft = f0 + lane;
+    const bool ok = ft < Tt;
+    const int64_t n = ok ? ft / T : 0;
+    const int t = ok ? (int)(ft - n * T) : 0;
+    const float* col = src + (size_t)n * D * T + t;
+    float ss = 0.0f;
+    for (int d = wv; d < D; d += 4) {
+        float v = ok ? col[(size_t)d * T] : 0.0f;
+        ss = fmaf(v, v, ss);
+    }
+    red[wv][lane] = ss;
+    __syncthreads();
+    if (wv == 0) nrm[lane] = sqrtf(red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+    __syncthreads();
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        for (int r = wv; r < 64; r += 4) tile[r][lane] = ok ? col[(size_t)(d0 + r) * T] : 0.0f;
+        __syncthreads();
+        for (int r = wv; r < 64; r += 4) {
+            const int64_t ff = f0 + r;
+            if (ff < Tt_pad) {
+                float q = (ff < Tt) ? tile[lane][r] / nrm[r] : 0.0f;
+                if (ff < Tt) s_f32[(size_t)ff * D + d0 + lane] = q;
+                s_bf16[(size_t)ff * D + d0 + lane] = f32_to_bf16_rn(q);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// scoring
+// ----------------------------------------------------------------------------------------------
+struct ListRef {
+    float* v;
+    int* i;
+};
+
+// insert (val, idx) into an unsorted KP-entry list if it beats the list minimum; returns the new minimum
+__device__ __forceinline__ float list_insert(ListRef L, float val, int idx) {
+    float mn = L.v[0];
+    int mp = 0;
+#pragma unroll 1
+    for (int e = 1; e < KP; ++e) {
+        float x = L.v[e];
+        if (x < mn) { mn = x; mp = e; }
+    }
+    if (val > mn) {
+        L.v[mp] = val;
+        L.i[mp] = idx;
+        mn = L.v[0];
+#pragma unroll 1
+        for (int e = 1; e < KP; ++e) mn = fminf(mn, L.v[e]);
+    }
+    return mn;
+}
+
+__global__ __launch_bounds__(256) void knn_score_kernel(const unsigned short* __restrict__ s_bf16,
+                                                        const unsigned short* __restrict__ lib, int64_t M, int tiles_total,
+                                                        int tiles_per_split, int P, float* __restrict__ cand_val,
+                                                        int* __restrict__ cand_idx) {
+    // one LDS array: [A tile 16 KB][B tile 16 KB][lists: 256 x KP x (val,idx) 32 KB]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE * BK * 2 + 2 * TILE * KP * 8];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + TILE * BK * 2;
+    float* Lv = (float*)(smem + 2 * TILE * BK * 2);
+    int* Li = (int*)(Lv + 2 * TILE * KP);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;              // wave tile: 64 library rows (wm) x 64 frames (wn)
+    const int lr = lane & 31, lh = lane >> 5;
+    const int64_t frame0 = (int64_t)blockIdx.x * TILE;
+    const int split = blockIdx.y;
+    const int tile_begin = split * tiles_per_split;
+    int tile_end = tile_begin + tiles_per_split;
+    if (tile_end > tiles_total) tile_end = tiles_total;
+
+    for (int e = tid; e < 2 * TILE * KP; e += 256) { Lv[e] = -INFINITY; Li[e] = -1; }
+
+    // staging map: 1024 16-B chunks per operand tile -> 4 per thread; chunk (row, c) lands at c ^ (row & 7)
+    const int st_row = tid >> 3, st_c = tid & 7;        // rows st_row + 32*i
+    const unsigned short* gB = s_bf16 + (size_t)(frame0 + st_row) * D + st_c * 8;
+
+    // this lane's two list slots (frame columns) inside the wm half
+    ListRef lists[2];
+    float thr[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        int col = wn * 64 + ni * 32 + lr;
+        lists[ni].v = Lv + (size_t)(wm * TILE + col) * KP;
+        lists[ni].i = Li + (size_t)(wm * TILE + col) * KP;
+        thr[ni] = -INFINITY;
+    }
+    __syncthreads();
+
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const int64_t row0 = (int64_t)tile * TILE;
+        const unsigned short* gA = lib + (size_t)(row0 + st_row) * D + st_c * 8;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+        u32x4 ra[4], rb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *(const u32x4*)(gA + (size_t)i * 32 * D);
+            rb[i] = *(const u32x4*)(gB + (size_t)i * 32 * D);
+        }
+        for (int ks = 0; ks < NKS; ++ks) {
+            __syncthreads();                            // previous stage fully consumed
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row = st_row + 32 * i;
+                int off = row * (BK * 2) + ((st_c ^ (row & 7)) << 4);
+                *(u32x4*)(As + off) = ra[i];
+                *(u32x4*)(Bs + off) = rb[i];
+            }
+            __syncthreads();
+            if (ks + 1 < NKS) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ra[i] = *(const u32x4*)(gA + (size_t)i * 32 * D + (ks + 1) * BK);
+                    rb[i] = *(const u32x4*)(gB + (size_t)i * 32 * D + (ks + 1) * BK);
+                }
+            }
+#pragma unroll
+            for (int k16 = 0; k16 < 4; ++k16) {
+                const int c = k16 * 2 + lh;             // 16-B chunk holding k = 16*k16 + 8*lh .. +7
+                bf16x8 fa[2], fb[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    int row = wm * 64 + a * 32 + lr;
+                    fa[a] = *(const bf16x8*)(As + row * (BK * 2) + ((c ^ (row & 7)) << 4));
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    int row = wn * 64 + b * 32 + lr;
+                    fb[b] = *(const bf16x8*)(Bs + row * (BK * 2) + ((c ^ (row & 7)) << 4));
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            }
+        }
+
+        // ---- fold the 64x64 wave tile into the per-frame candidate lists ----
+        // acc[a][b][r]: library row = row0 + wm*64 + a*32 + (r&3) + 8*(r>>2) + 4*lh, frame col = wn*64 + b*32 + lr
+        const bool ragged = row0 + TILE > M;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (ragged) {
+                        int64_t row = row0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (row >= M) acc[a][b][r] = -INFINITY;
+                    }
+                    mx = fmaxf(mx, acc[a][b][r]);
+                }
+            if (mx > thr[b]) {
+                // the two half-waves share a list: serialise them (LDS ops of one wave execute in order)
+#pragma unroll 1
+                for (int half = 0; half < 2; ++half) {
+                    if (lh == half) {
+                        float t = thr[b];
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                float v = acc[a][b][r];
+                                if (v > t) {
+                                    int row = (int)(row0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+                                    t = list_insert(lists[b], v, row);
+                                }
+                            }
+                        thr[b] = t;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- write this block's lists: cand[frame][P][KP], list id = split*2 + wm ----
+    __syncthreads();
+    for (int e = tid; e < 2 * TILE * KP; e += 256) {
+        int k = e % KP;
+        int col = (e / KP) % TILE;
+        int w = e / (KP * TILE);
+        size_t o = (((size_t)(frame0 + col)) * P + split * 2 + w) * KP + k;
+        cand_val[o] = Lv[e];
+        cand_idx[o] = Li[e];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// exact fp32 rescoring + top-k  (one wave per frame)
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// (value desc, index asc) ordering, wave-wide argmax; returns the winning lane
+__device__ __forceinline__ int wave_argbest(float v, int idx) {
+    float bv = v;
+    int bi = idx;
+    int bl = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(bv, o);
+        int oi = __shfl_xor(bi, o);
+        int ol = __shfl_xor(bl, o);
+        bool take = (ov > bv) || (ov == bv && (unsigned)oi < (unsigned)bi) || (ov == bv && oi == bi && ol < bl);
+        if (take) { bv = ov; bi = oi; bl = ol; }
+    }
+    return bl;
+}
+
+__global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
+                                                          int P, const float* __restrict__ s_f32,
+                                                          const float* __restrict__ rows, const float* __restrict__ norms,
+                                                          int64_t Tt, int64_t idx_base, int k, float* __restrict__ out_val,
+                                                          int* __restrict__ out_idx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ft = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ft >= Tt) return;
+    const int R = P * KP;
+    const float* cv = cand_val + (size_t)ft * R;
+    const int* ci = cand_idx + (size_t)ft * R;
+
+    // ---- candidate selection: this lane ends up with (at most) one candidate ----
+    int my_idx = -1;
+    if (R <= 64) {
+        if (lane < R) my_idx = ci[lane];
+    } else {
+        // keep the 64 best bf16 scores: R/64 candidates per lane in registers (R <= 1024)
+        float v[16];
+        int id[16];
+        const int per = (R + 63) / 64;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int e = j * 64 + lane;
+            bool in = (j < per) && (e < R);
+            v[j] = in ? cv[e] : -INFINITY;
+            id[j] = in ? ci[e] : -1;
+            if (id[j] < 0) v[j] = -INFINITY;
+        }
+        for (int sel = 0; sel < 64; ++sel) {
+            float bv = v[0];
+            int bj = 0;
+#pragma unroll
+            for (int j = 1; j < 16; ++j)
+                if (v[j] > bv) { bv = v[j]; bj = j; }
+            int bid = -1;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j == bj) bid = id[j];
+            int win = wave_argbest(bv, bid);
+            int widx = __shfl(bid, win);
+            float wval = __shfl(bv, win);
+            if (lane == sel) my_idx = (wval > -INFINITY) ? widx : -1;
+            if (lane == win) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (j == bj) v[j] = -INFINITY;
+            }
+        }
+    }
+
+    // ---- exact cosine: sum_d s_hat[d] * (row[d] / norm), lanes split d (3 x float4 each) ----
+    const f32x4* sp = (const f32x4*)(s_f32 + (size_t)ft * D);
+    f32x4 s0 = sp[lane], s1 = sp[lane + 64], s2 = sp[lane + 128];
+    float my_score = -INFINITY;
+    for (int c = 0; c < 64; ++c) {
+        int idx = __shfl(my_idx, c);
+        if (idx < 0) continue;                           // wave-uniform
+        const f32x4* rp = (const f32x4*)(rows + (size_t)idx * D);
+        float nn = norms[idx];
+        f32x4 r0 = rp[lane], r1 = rp[lane + 64], r2 = rp[lane + 128];
+        float p = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p = fmaf(s0[j], r0[j] / nn, p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p = fmaf(s1[j], r1[j] / nn, p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p = fmaf(s2[j], r2[j] / nn, p);
+        p = wave_sum(p);
+        if (lane == c) my_score = p;
+    }
+
+    // ---- exact top-k, descending, ties to the lower library index ----
+    for (int j = 0; j < k; ++j) {
+        int win = wave_argbest(my_score, my_idx < 0 ? 0x7fffffff : my_idx);
+        float wv = __shfl(my_score, win);
+        int wi = __shfl(my_idx, win);
+        if (lane == 0) {
+            out_val[(size_t)ft * k + j] = wv;
+            out_idx[(size_t)ft * k + j] = (wi < 0 || !(wv > -INFINITY)) ? -1 : (int)(idx_base + wi);
+        }
+        if (lane == win) my_score = -INFINITY;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// merge shards + gather + mean + blend.  Block = 32 consecutive frames of one window.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void knn_merge_gather_kernel(const float* __restrict__ cand_val,
+                                                               const int* __restrict__ cand_idx, int S, int k, float alpha,
+                                                               float one_minus, const float* __restrict__ rows, const float* __restrict__ src,
+                                                               int T, int64_t Tt, float* __restrict__ out,
+                                                               int* __restrict__ final_idx) {
+    __shared__ int sel[32][ALIVE_MAX_K];
+    __shared__ float tile[32][65];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = blockIdx.y;
+    const int t0 = blockIdx.x * 32;
+    const int nf = (T - t0) < 32 ? (T - t0) : 32;
+
+    // phase 1: each wave merges 8 frames; S*k <= 128 candidates -> two per lane
+    for (int f = wv * 8; f < wv * 8 + 8; ++f) {
+        if (f >= nf) break;
+        const int64_t ft = (int64_t)n * T + t0 + f;
+        float v[2];
+        int id[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int e = j * 64 + lane;
+            bool in = e < S * k;
+            int s = in ? e / k : 0, kk = in ? e % k : 0;
+            size_t o = ((size_t)s * Tt + ft) * k + kk;
+            id[j] = in ? cand_idx[o] : -1;
+            v[j] = (in && id[j] >= 0) ? cand_val[o] : -INFINITY;
+        }
+        for (int j = 0; j < k; ++j) {
+            bool second = (v[1] > v[0]) || (v[1] == v[0] && (unsigned)id[1] < (unsigned)id[0]);
+            float bv = second ? v[1] : v[0];
+            int bi = second ? id[1] : id[0];
+            int win = wave_argbest(bv, bi < 0 ? 0x7fffffff : bi);
+            int wi = __shfl(bi, win);
+            if (lane == 0) {
+                sel[f][j] = wi;
+                if (final_idx != nullptr) final_idx[(size_t)ft * k + j] = wi;
+            }
+            if (lane == win) {
+                if (second) v[1] = -INFINITY; else v[0] = -INFINITY;
+            }
+        }
+    }
+    __syncthreads();
+
+    // phase 2: 64-feature slabs; gather (lane = feature), transpose through LDS, store (lane = frame)
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        for (int f = wv; f < nf; f += 4) {
+            float acc = 0.0f;
+            for (int j = 0; j < k; ++j) {
+                int idx = sel[f][j];
+                float r = (idx >= 0) ? rows[(size_t)idx * D + d0 + lane] : __builtin_nanf("");
+                acc = (j == 0) ? r : acc + r;
+            }
+            tile[f][lane] = acc / (float)k;
+        }
+        __syncthreads();
+        for (int e = tid; e < 64 * 32; e += 256) {
+            int f = e & 31, d = e >> 5;
+            if (f < nf) {
+                size_t o = ((size_t)n * D + d0 + d) * T + t0 + f;
+                float m = tile[f][d];
+                out[o] = m * one_minus + src[o] * alpha;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static int choose_split(int64_t Tt_pad, int tiles_total) {
+    int64_t frame_tiles = Tt_pad / TILE;
+    int64_t want = (1024 + frame_tiles - 1) / frame_tiles;
+    if (want > MAX_SPLIT) want = MAX_SPLIT;
+    if (want > tiles_total) want = tiles_total;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+}  // namespace
+
+extern "C" int64_t alive_library_padded_rows(int64_t M) { return (M + TILE - 1) / TILE * TILE; }
+
+extern "C" int alive_library_pack(const float* tokens, int64_t M, int Dd, void* lib_bf16, float* rows_f32, float* norms,
+                                  void* stream) {
+    ALIVE_CHECK_ARG(tokens && lib_bf16 && rows_f32 && norms, "alive_library_pack: null pointer");
+    ALIVE_CHECK_ARG(Dd == D, "alive_library_pack: feature dim %d, expected %d", Dd, D);
+    ALIVE_CHECK_ARG(M >= 1 && M < (int64_t)1 << 31, "alive_library_pack: M out of range");
+    int64_t M_pad = alive_library_padded_rows(M);
+    lib_pack_kernel<<<(unsigned)(M_pad / 64), 256, 0, (hipStream_t)stream>>>(tokens, M, M_pad, (unsigned short*)lib_bf16,
+                                                                            rows_f32, norms);
+    ALIVE_CHECK_LAUNCH("alive_library_pack");
+    return ALIVE_OK;
+}
+
+extern "C" size_t alive_knn_workspace_bytes(int64_t Tt, int64_t M) {
+    int64_t Tt_pad = (Tt + TILE - 1) / TILE * TILE;
+    int tiles_total = (int)(alive_library_padded_rows(M) / TILE);
+    int split = choose_split(Tt_pad, tiles_total);
+    size_t b = 0;
+    b += align_up((size_t)Tt * D * 4, 256);                 // s_f32
+    b += align_up((size_t)Tt_pad * D * 2, 256);             // s_bf16
+    b += 2 * align_up((size_t)Tt_pad * split * 2 * KP * 4, 256);   // candidate lists
+    return b + 1024;
+}
+
+extern "C" int alive_knn_search(const float* src, int N, int T, const void* lib_bf16, const float* rows_f32,
+                                const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
+                                void* ws, void* stream) {
+    ALIVE_CHECK_ARG(src && lib_bf16 && rows_f32 && norms && out_val && out_idx && ws, "alive_knn_search: null pointer");
+    ALIVE_CHECK_ARG(N > 0 && T > 0, "alive_knn_search: empty source");
+    ALIVE_CHECK_ARG(k >= 1 && k <= ALIVE_MAX_K, "alive_knn_search: k=%d outside [1,%d]", k, ALIVE_MAX_K);
+    ALIVE_CHECK_ARG(M >= k, "alive_knn_search: library shard has %lld vectors, fewer than k=%d", (long long)M, k);
+    const int64_t Tt = (int64_t)N * T;
+    const int64_t Tt_pad = (Tt + TILE - 1) / TILE * TILE;
+    const int tiles_total = (int)(alive_library_padded_rows(M) / TILE);
+    const int split = choose_split(Tt_pad, tiles_total);
+    const int tiles_per_split = (tiles_total + split - 1) / split;
+    const int P = split * 2;
+    Arena a(ws);
+    float* s_f32 = a.take<float>((size_t)Tt * D);
+    unsigned short* s_bf16 = a.take<unsigned short>((size_t)Tt_pad * D);
+    float* cv = a.take<float>((size_t)Tt_pad * P * KP);
+    int* ci = a.take<int>((size_t)Tt_pad * P * KP);
+    hipStream_t s = (hipStream_t)stream;
+    src_prep_kernel<<<(unsigned)(Tt_pad / 64), 256, 0, s>>>(src, T, Tt, Tt_pad, s_f32, s_bf16);
+    knn_score_kernel<<<dim3((unsigned)(Tt_pad / TILE), split), 256, 0, s>>>(s_bf16, (const unsigned short*)lib_bf16, M,
+                                                                           tiles_total, tiles_per_split, P, cv, ci);
+    knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(cv, ci, P, s_f32, rows_f32, norms, Tt, idx_base, k, out_val,
+                                                               out_idx);
+    ALIVE_CHECK_LAUNCH("alive_knn_search");
+    return ALIVE_OK;
+}
+
+extern "C" int alive_knn_merge_gather(const float* cand_val, const int32_t* cand_idx, int n_shards, int k, double alpha,
+                                      const float* rows_f32_full, const float* src, int N, int T, float* out,
+                                      int32_t* final_idx, void* stream) {
+    ALIVE_CHECK_ARG(cand_val && cand_idx && rows_f32_full && src && out, "alive_knn_merge_gather: null pointer");
+    ALIVE_CHECK_ARG(k >= 1 && k <= ALIVE_MAX_K && n_shards >= 1 && n_shards * k <= 128,
+                    "alive_knn_merge_gather: n_shards*k = %d exceeds 128", n_shards * k);
+    ALIVE_CHECK_ARG(N > 0 && T > 0, "alive_knn_merge_gather: empty source");
+    knn_merge_gather_kernel<<<dim3(cdiv(T, 32), N), 256, 0, (hipStream_t)stream>>>(
+        cand_val, cand_idx, n_shards, k, (float)alpha, (float)(1.0 - alpha), rows_f32_full, src, T, (int64_t)N * T, out,
+        final_idx);
+    ALIVE_CHECK_LAUNCH("alive_knn_merge_gather");
+    return ALIVE_OK;
+}

@@ -1,0 +1,363 @@
+// Launch sequences of the three inference networks on top of the operator kernels.
+//   ContentEncoder.forward     /root/reference/module/content_encoder.py:21-25
+//   F0Estimator.estimate       /root/reference/module/f0_estimator.py:22-34
+//   Decoder.forward            /root/reference/module/decoder.py:43-48,66-102,184-195,205-210
+//   spectrogram                /root/reference/module/spectrogram.py:5-10
+// Pure stream-ordered launches into caller-provided scratch: no allocation, no
+// sync, so a whole forward is hipGraph-capturable.
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+int alive_magnitude(const float* ri, int N, int B, int T, float* out, hipStream_t s);
+
+namespace {
+
+constexpr int BINS = 641, NFFT = 1280, HOP = 320;
+constexpr int DFT_ROWS = 1296;                       // 2*641 = 1282 padded to x16
+constexpr int CE_C = 512, CE_H = 1536, CE_OUT = 768;
+constexpr int PE_C = 256, PE_H = 512, PE_OUT = 4096;
+constexpr int DEC_C = 512, DEC_H = 1536, NH = 64, SEG = 320;
+constexpr float SR = 16000.0f;
+constexpr float NORM_EPS = 1e-4f;
+constexpr int F_CH[4] = {256, 64, 16, 8};            // filter channels, coarse -> fine (decoder.py:157,171)
+constexpr int F_UP[4] = {10, 8, 2, 2};               // upsampling rates, coarse -> fine
+constexpr int FILM_ROWS = 6 * 2 * (256 + 64 + 16 + 8);   // 4128
+
+inline int pad16(int x) { return (x + 15) & ~15; }
+
+// ---- weight tables --------------------------------------------------------------------------
+struct Names {
+    std::vector<std::string> v;
+    int add(const std::string& s) { v.push_back(s); return (int)v.size() - 1; }
+};
+
+void convnext_names(Names& n, const std::string& p, bool adaptive) {
+    n.add(p + ".dw_w"); n.add(p + ".dw_b");
+    if (!adaptive) { n.add(p + ".norm_gain"); n.add(p + ".norm_offset"); }
+    n.add(p + ".pw1.W"); n.add(p + ".pw1.b"); n.add(p + ".pw2.W"); n.add(p + ".pw2.b"); n.add(p + ".scale");
+}
+
+const Names& names_of(int model) {
+    static Names ce, pe, dec;
+    static bool init = false;
+    if (!init) {
+        ce.add("input.W"); ce.add("input.b");
+        for (int i = 0; i < 4; ++i) convnext_names(ce, "mid" + std::to_string(i), false);
+        ce.add("output.W"); ce.add("output.b");
+        pe.add("input.W"); pe.add("input.b");
+        for (int i = 0; i < 4; ++i) convnext_names(pe, "mid" + std::to_string(i), false);
+        pe.add("last_norm.gain"); pe.add("last_norm.offset"); pe.add("output.W"); pe.add("output.b");
+        dec.add("fe.input.W"); dec.add("fe.input.b");
+        dec.add("fe.f0c1.W"); dec.add("fe.f0c1.b"); dec.add("fe.f0c2.W"); dec.add("fe.f0c2.b");
+        dec.add("fe.normfilm.W"); dec.add("fe.normfilm.b");
+        for (int i = 0; i < 4; ++i) convnext_names(dec, "fe.mid" + std::to_string(i), true);
+        dec.add("osc.amps.W"); dec.add("osc.amps.b");
+        dec.add("flt.film.W"); dec.add("flt.film.b"); dec.add("flt.film.post");
+        dec.add("flt.in.W"); dec.add("flt.in.b");
+        for (int i = 0; i < 4; ++i) { dec.add("flt.down" + std::to_string(i) + ".W"); dec.add("flt.down" + std::to_string(i) + ".b"); }
+        dec.add("flt.mid.W"); dec.add("flt.mid.b");
+        for (int i = 0; i < 4; ++i) { dec.add("flt.up" + std::to_string(i) + ".W"); dec.add("flt.up" + std::to_string(i) + ".b"); }
+        for (int s = 0; s < 4; ++s) {
+            std::string b = "flt.blk" + std::to_string(s);
+            dec.add(b + ".in.W"); dec.add(b + ".in.b");
+            for (int j = 0; j < 3; ++j)
+                for (int c = 1; c <= 2; ++c) {
+                    std::string q = b + "." + std::to_string(j) + ".c" + std::to_string(c);
+                    dec.add(q + ".W"); dec.add(q + ".b");
+                }
+        }
+        dec.add("flt.out.W"); dec.add("flt.out.b");
+        init = true;
+    }
+    return model == 0 ? ce : (model == 1 ? pe : dec);
+}
+
+struct Table {
+    const float* const* w;
+    int pos;
+    explicit Table(const float* const* p) : w(p), pos(0) {}
+    const float* next() { return w[pos++]; }
+};
+
+// ---- conv helpers ----------------------------------------------------------------------------
+AliveConv conv_desc(const float* W, const float* b, const float* X, int N, int Ci, int Tin, int Co, int KW, int stride,
+                    int dil, int pad_left, int pad_mode, int Tout, float* Y) {
+    AliveConv d;
+    memset(&d, 0, sizeof(d));
+    d.W = W; d.bias = b; d.X = X; d.N = N; d.Ci = Ci; d.Tin = Tin; d.Co = Co; d.K_pad = pad16(Ci * KW);
+    d.KW = KW; d.stride = stride; d.dil = dil; d.pad_left = pad_left; d.pad_mode = pad_mode; d.Tout = Tout;
+    d.up = 1; d.Y = Y;
+    return d;
+}
+AliveConv pw_desc(const float* W, const float* b, const float* X, int N, int Ci, int T, int Co, float* Y) {
+    return conv_desc(W, b, X, N, Ci, T, Co, 1, 1, 1, 0, 0, T, Y);
+}
+
+#define RUN(expr)                     \
+    do {                              \
+        int rc_ = (expr);             \
+        if (rc_ != ALIVE_OK) return rc_; \
+    } while (0)
+
+struct ConvNeXtW {
+    const float *dw_w, *dw_b, *gain, *offset, *pw1W, *pw1b, *pw2W, *pw2b, *scale;
+    ConvNeXtW(Table& t, bool adaptive) {
+        dw_w = t.next(); dw_b = t.next();
+        gain = offset = nullptr;
+        if (!adaptive) { gain = t.next(); offset = t.next(); }
+        pw1W = t.next(); pw1b = t.next(); pw2W = t.next(); pw2b = t.next(); scale = t.next();
+    }
+};
+
+// x <- x + scale * pw2(gelu(pw1(norm(dw(x)))))      (common.py:54-62 / 74-82)
+int convnext_layer(const ConvNeXtW& w, float* x, float* ybuf, float* hbuf, int N, int C, int H, int T, const float* cond,
+                   int cond_rows, int scale_row, int shift_row, void* s) {
+    RUN(alive_dwconv_norm(x, N, C, T, w.dw_w, w.dw_b, cond ? 1 : 0, w.gain, w.offset, cond, cond_rows, scale_row,
+                          shift_row, NORM_EPS, ybuf, s));
+    AliveConv d1 = pw_desc(w.pw1W, w.pw1b, ybuf, N, C, T, H, hbuf);
+    d1.act = 1;
+    RUN(alive_conv1d(&d1, s));
+    AliveConv d2 = pw_desc(w.pw2W, w.pw2b, hbuf, N, H, T, C, x);
+    d2.ch_scale = w.scale;
+    d2.residual = x;
+    RUN(alive_conv1d(&d2, s));
+    return ALIVE_OK;
+}
+
+__global__ void dft_basis_kernel(float* basis) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= DFT_ROWS * NFFT) return;
+    int row = i / NFFT, j = i % NFFT;
+    float v = 0.0f;
+    if (row < 2 * BINS) {
+        int f = row < BINS ? row : row - BINS;
+        int ph = (int)(((long long)f * j) % NFFT);
+        double sn, cs;
+        sincospi(2.0 * (double)ph / (double)NFFT, &sn, &cs);
+        v = row < BINS ? (float)cs : (float)(-sn);
+    }
+    basis[i] = v;
+}
+
+}  // namespace
+
+extern "C" int alive_weight_count(int model) { return (model >= 0 && model <= 2) ? (int)names_of(model).v.size() : -1; }
+extern "C" const char* alive_weight_name(int model, int index) {
+    if (model < 0 || model > 2) return nullptr;
+    const Names& n = names_of(model);
+    return (index >= 0 && index < (int)n.v.size()) ? n.v[index].c_str() : nullptr;
+}
+
+// ---- spectrogram -------------------------------------------------------------------------------
+extern "C" size_t alive_dft_basis_bytes(void) { return (size_t)DFT_ROWS * NFFT * sizeof(float); }
+extern "C" int alive_dft_basis(float* basis, void* stream) {
+    ALIVE_CHECK_ARG(basis, "alive_dft_basis: null");
+    dft_basis_kernel<<<cdiv((int64_t)DFT_ROWS * NFFT, 256), 256, 0, (hipStream_t)stream>>>(basis);
+    ALIVE_CHECK_LAUNCH("alive_dft_basis");
+    return ALIVE_OK;
+}
+extern "C" size_t alive_spectrogram_workspace_bytes(int N, int L) {
+    return align_up((size_t)N * 2 * BINS * (L / HOP) * sizeof(float), 256) + 256;
+}
+extern "C" int alive_spectrogram(const float* basis, const float* wav, int N, int L, float* spec, void* ws, void* stream) {
+    ALIVE_CHECK_ARG(basis && wav && spec && ws, "alive_spectrogram: null pointer");
+    ALIVE_CHECK_ARG(N > 0 && L > NFFT / 2 && L >= HOP, "alive_spectrogram: needs L > %d samples (reflect pad), got %d", NFFT / 2, L);
+    const int T = L / HOP;
+    Arena a(ws);
+    float* ri = a.take<float>((size_t)N * 2 * BINS * T);
+    AliveConv d = conv_desc(basis, nullptr, wav, N, 1, L, 2 * BINS, NFFT, HOP, 1, NFFT / 2, 2, T, ri);
+    RUN(alive_conv1d(&d, stream));
+    return alive_magnitude(ri, N, BINS, T, spec, (hipStream_t)stream);
+}
+
+// ---- content encoder -------------------------------------------------------------------------
+extern "C" size_t alive_content_encoder_workspace_bytes(int N, int T) {
+    size_t f = (size_t)N * T;
+    return align_up(f * CE_C * 4, 256) * 2 + align_up(f * CE_H * 4, 256) + 1024;
+}
+extern "C" int alive_content_encoder(const float* const* w, const float* spec, int N, int T, float* out, void* ws, void* stream) {
+    ALIVE_CHECK_ARG(w && spec && out && ws && N > 0 && T > 0, "alive_content_encoder: bad args");
+    Table t(w);
+    Arena a(ws);
+    float* x = a.take<float>((size_t)N * CE_C * T);
+    float* y = a.take<float>((size_t)N * CE_C * T);
+    float* h = a.take<float>((size_t)N * CE_H * T);
+    const float* inW = t.next(); const float* inb = t.next();
+    AliveConv d = pw_desc(inW, inb, spec, N, BINS, T, CE_C, x);
+    RUN(alive_conv1d(&d, stream));
+    for (int i = 0; i < 4; ++i) {
+        ConvNeXtW cw(t, false);
+        RUN(convnext_layer(cw, x, y, h, N, CE_C, CE_H, T, nullptr, 0, 0, 0, stream));
+    }
+    const float* oW = t.next(); const float* ob = t.next();
+    AliveConv o = pw_desc(oW, ob, x, N, CE_C, T, CE_OUT, out);
+    RUN(alive_conv1d(&o, stream));
+    return ALIVE_OK;
+}
+
+// ---- f0 estimator ----------------------------------------------------------------------------
+extern "C" size_t alive_f0_estimate_workspace_bytes(int N, int T) {
+    size_t f = (size_t)N * T;
+    return align_up(f * PE_C * 4, 256) * 2 + align_up(f * PE_H * 4, 256) + align_up(f * PE_OUT * 4, 256) + 1024;
+}
+extern "C" int alive_f0_estimate(const float* const* w, const float* spec, int N, int T, float* f0, void* ws, void* stream) {
+    ALIVE_CHECK_ARG(w && spec && f0 && ws && N > 0 && T > 0, "alive_f0_estimate: bad args");
+    Table t(w);
+    Arena a(ws);
+    float* x = a.take<float>((size_t)N * PE_C * T);
+    float* y = a.take<float>((size_t)N * PE_C * T);
+    float* h = a.take<float>((size_t)N * PE_H * T);
+    float* lg = a.take<float>((size_t)N * PE_OUT * T);
+    const float* inW = t.next(); const float* inb = t.next();
+    AliveConv d = pw_desc(inW, inb, spec, N, BINS, T, PE_C, x);
+    RUN(alive_conv1d(&d, stream));
+    for (int i = 0; i < 4; ++i) {
+        ConvNeXtW cw(t, false);
+        RUN(convnext_layer(cw, x, y, h, N, PE_C, PE_H, T, nullptr, 0, 0, 0, stream));
+    }
+    const float* g = t.next(); const float* of = t.next();
+    RUN(alive_channel_norm(x, N, PE_C, T, g, of, NORM_EPS, y, stream));
+    const float* oW = t.next(); const float* ob = t.next();
+    AliveConv o = pw_desc(oW, ob, y, N, PE_C, T, PE_OUT, lg);
+    RUN(alive_conv1d(&o, stream));
+    return alive_argmax_channels(lg, N, PE_OUT, T, f0, stream);
+}
+
+// ---- decoder ---------------------------------------------------------------------------------
+namespace {
+struct DecBuffers {
+    float *x, *y, *h, *sinb, *cond, *normfilm, *amps, *src, *film, *x0, *d0, *d1, *d2, *d3, *m, *U, *Hh, *Zz, *Z2;
+    void* osc_ws;
+    size_t bytes;
+};
+DecBuffers dec_layout(void* ws, int N, int Lf) {
+    Arena a(ws);
+    DecBuffers b;
+    const size_t f = (size_t)N * Lf, Lw = (size_t)Lf * SEG;
+    b.x = a.take<float>(f * DEC_C);
+    b.y = a.take<float>(f * DEC_C);
+    b.h = a.take<float>(f * DEC_H);
+    b.sinb = a.take<float>(f * DEC_C);
+    b.cond = a.take<float>(f * DEC_C);
+    b.normfilm = a.take<float>(f * 4096);
+    b.amps = a.take<float>(f * NH);
+    b.src = a.take<float>((size_t)N * Lw);
+    b.film = a.take<float>(f * FILM_ROWS);
+    b.x0 = a.take<float>((size_t)N * 8 * Lw);
+    b.d0 = a.take<float>((size_t)N * 16 * (Lw / 2));
+    b.d1 = a.take<float>((size_t)N * 64 * (Lw / 4));
+    b.d2 = a.take<float>((size_t)N * 256 * (Lw / 32));
+    b.d3 = a.take<float>(f * 256);
+    b.m = a.take<float>(f * 256);
+    const size_t big = (size_t)N * 64 * (Lw / 4);      // largest filter-scale tensor (64 x 36000 per window)
+    b.U = a.take<float>(big);
+    b.Hh = a.take<float>(big);
+    b.Zz = a.take<float>(big);
+    b.Z2 = a.take<float>(big);
+    b.osc_ws = a.take<char>(alive_oscillator_workspace_bytes(N, NH, Lf));
+    b.bytes = a.used() + 1024;
+    return b;
+}
+}  // namespace
+
+extern "C" size_t alive_decoder_workspace_bytes(int N, int Lf) { return dec_layout(nullptr, N, Lf).bytes; }
+
+extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, const float* f0, const float* phi_in, int crop0,
+                                     int phi_col, int N, int Lf, float* wave, float* phi_out, void* ws, void* stream) {
+    ALIVE_CHECK_ARG(w && x_in && f0 && wave && ws && N > 0, "alive_decoder_forward: bad args");
+    ALIVE_CHECK_ARG(Lf >= 5, "alive_decoder_forward: needs at least 5 frames (reflect pad 4 on the bottleneck), got %d", Lf);
+    Table t(w);
+    DecBuffers b = dec_layout(ws, N, Lf);
+    const int Lw = Lf * SEG;
+    // -- FeatureExtractor (decoder.py:43-48)
+    const float* inW = t.next(); const float* inb = t.next();
+    { AliveConv d = pw_desc(inW, inb, x_in, N, 768, Lf, DEC_C, b.x); RUN(alive_conv1d(&d, stream)); }
+    const float* c1W = t.next(); const float* c1b = t.next(); const float* c2W = t.next(); const float* c2b = t.next();
+    { AliveConv d = pw_desc(c1W, c1b, f0, N, 1, Lf, DEC_C, b.sinb); d.act = 3; RUN(alive_conv1d(&d, stream)); }
+    { AliveConv d = pw_desc(c2W, c2b, b.sinb, N, DEC_C, Lf, DEC_C, b.cond); RUN(alive_conv1d(&d, stream)); }
+    const float* nfW = t.next(); const float* nfb = t.next();
+    { AliveConv d = pw_desc(nfW, nfb, b.cond, N, DEC_C, Lf, 4096, b.normfilm); RUN(alive_conv1d(&d, stream)); }
+    for (int i = 0; i < 4; ++i) {
+        ConvNeXtW cw(t, true);
+        RUN(convnext_layer(cw, b.x, b.y, b.h, N, DEC_C, DEC_H, Lf, b.normfilm, 4096, i * 1024, i * 1024 + 512, stream));
+    }
+    // -- HarmonicOscillator (decoder.py:66-102)
+    const float* aW = t.next(); const float* ab = t.next();
+    { AliveConv d = pw_desc(aW, ab, b.x, N, DEC_C, Lf, NH, b.amps); d.act = 2; RUN(alive_conv1d(&d, stream)); }
+    RUN(alive_oscillator(b.amps, f0, phi_in, N, NH, Lf, SEG, SR, crop0, phi_col, b.src, phi_out, b.osc_ws, stream));
+    // -- Filter (decoder.py:184-195); FiLM scale(+1)/shift of all 24 modulated convs in one GEMM
+    const float* fW = t.next(); const float* fb = t.next(); const float* fpost = t.next();
+    { AliveConv d = pw_desc(fW, fb, b.x, N, DEC_C, Lf, FILM_ROWS, b.film); d.post_add = fpost; RUN(alive_conv1d(&d, stream)); }
+    const float* siW = t.next(); const float* sib = t.next();
+    { AliveConv d = conv_desc(siW, sib, b.src, N, 1, Lw, 8, 7, 1, 1, 3, 0, Lw, b.x0); RUN(alive_conv1d(&d, stream)); }
+    const int dch[5] = {8, 16, 64, 256, 256};
+    const int drate[4] = {2, 2, 8, 10};
+    float* dbuf[5] = {b.x0, b.d0, b.d1, b.d2, b.d3};
+    int len = Lw;
+    for (int i = 0; i < 4; ++i) {
+        const float* W = t.next(); const float* bb = t.next();
+        AliveConv d = conv_desc(W, bb, dbuf[i], N, dch[i], len, dch[i + 1], drate[i], drate[i], 1, 0, 0, len / drate[i], dbuf[i + 1]);
+        RUN(alive_conv1d(&d, stream));
+        len /= drate[i];
+    }
+    const float* mW = t.next(); const float* mb = t.next();
+    {   // mid CausalConv1d(256,256,5) + skips[3]   (decoder.py:190-191)
+        AliveConv d = conv_desc(mW, mb, b.d3, N, 256, Lf, 256, 5, 1, 1, 4, 1, Lf, b.m);
+        d.skip = b.d3;
+        RUN(alive_conv1d(&d, stream));
+    }
+    const float* upW[4]; const float* upb[4];
+    for (int i = 0; i < 4; ++i) { upW[i] = t.next(); upb[i] = t.next(); }
+    const float* skips[4] = {b.d2, b.d1, b.d0, nullptr};
+    const float* cur = b.m;
+    int cin = 256, L = Lf, film_off = 0;
+    for (int s = 0; s < 4; ++s) {
+        const int C = F_CH[s], r = F_UP[s];
+        {   // ConvTranspose1d(cin, C, r, r): rows = (co, j)
+            AliveConv d = conv_desc(upW[s], upb[s], cur, N, cin, L, C * r, 1, 1, 1, 0, 0, L, b.U);
+            d.up = r;
+            RUN(alive_conv1d(&d, stream));
+        }
+        L *= r;
+        const float* iW = t.next(); const float* ib = t.next();
+        {   // FilterBlock.input_conv; second output feeds blocks[0].c1 (gelu + FiLM)
+            AliveConv d = pw_desc(iW, ib, b.U, N, C, L, C, b.Hh);
+            d.Z = b.Zz; d.film = b.film; d.film_rows = FILM_ROWS; d.Lf = Lf;
+            d.film_scale_row = film_off; d.film_shift_row = film_off + C;
+            RUN(alive_conv1d(&d, stream));
+        }
+        for (int j = 0; j < 3; ++j) {
+            const int dil = 1 << j;
+            const float* W1 = t.next(); const float* b1 = t.next(); const float* W2 = t.next(); const float* b2 = t.next();
+            const int f1 = film_off + (j * 2) * 2 * C, f2 = film_off + (j * 2 + 1) * 2 * C;
+            (void)f1;
+            {   // c1: conv(Zz) -> only the modulated input of c2 is kept
+                AliveConv d = conv_desc(W1, b1, b.Zz, N, C, L, C, 5, 1, dil, 4 * dil, 1, L, nullptr);
+                d.Z = b.Z2; d.film = b.film; d.film_rows = FILM_ROWS; d.Lf = Lf;
+                d.film_scale_row = f2; d.film_shift_row = f2 + C;
+                RUN(alive_conv1d(&d, stream));
+            }
+            {   // c2: conv(Z2) + residual (+ U-Net skip after the last block) ; next block's c1 input
+                AliveConv d = conv_desc(W2, b2, b.Z2, N, C, L, C, 5, 1, dil, 4 * dil, 1, L, b.Hh);
+                d.residual = b.Hh;
+                if (j == 2) d.skip = skips[s];
+                if (j < 2) {
+                    const int fn = film_off + ((j + 1) * 2) * 2 * C;
+                    d.Z = b.Zz; d.film = b.film; d.film_rows = FILM_ROWS; d.Lf = Lf;
+                    d.film_scale_row = fn; d.film_shift_row = fn + C;
+                }
+                RUN(alive_conv1d(&d, stream));
+            }
+        }
+        film_off += 6 * 2 * C;
+        cur = b.Hh;
+        cin = C;
+    }
+    const float* oW = t.next(); const float* ob = t.next();
+    { AliveConv d = conv_desc(oW, ob, b.Hh, N, 8, Lw, 1, 7, 1, 1, 3, 0, Lw, wave); RUN(alive_conv1d(&d, stream)); }
+    return ALIVE_OK;
+}

@@ -1,0 +1,122 @@
+"""Re-pack reference state_dicts into the GEMM-ready tables of libalive_vc.so.
+
+One-time host/device plumbing at checkpoint-load time (torch ops, no kernels
+of our own): every conv weight becomes A[Co_pad16][K_pad16] with K = ci*KW + j
+(zero padded), transposed convs become rows (co, j), and the per-layer FiLM /
+adaptive-norm projections that share an input are concatenated into one GEMM.
+Table names are the ones `alive_weight_name()` reports.
+"""
+import torch
+
+
+def _pad16(n):
+    return (n + 15) // 16 * 16
+
+
+def pack_matrix(w2d):
+    """[rows, K] -> zero-padded [rows_pad16, K_pad16] fp32 contiguous."""
+    r, k = w2d.shape
+    out = torch.zeros(_pad16(r), _pad16(k), dtype=torch.float32, device=w2d.device)
+    out[:r, :k] = w2d
+    return out.contiguous()
+
+
+def pack_conv(w):
+    """Conv1d weight [Co, Ci, KW] -> [Co_pad, (Ci*KW)_pad]."""
+    return pack_matrix(w.reshape(w.shape[0], -1).float())
+
+
+def pack_convT(w, b):
+    """ConvTranspose1d(k == stride) weight [Ci, Co, r] -> rows (co, j): [Co*r, Ci]; bias repeated per j."""
+    ci, co, r = w.shape
+    a = w.permute(1, 2, 0).reshape(co * r, ci).float()
+    return pack_matrix(a), b.float().repeat_interleave(r).contiguous()
+
+
+def _vec(t):
+    return t.reshape(-1).float().contiguous()
+
+
+def _convnext(out, sd, src, dst, adaptive):
+    out[dst + ".dw_w"] = _vec(sd[src + ".dw_conv.weight"])
+    out[dst + ".dw_b"] = _vec(sd[src + ".dw_conv.bias"])
+    if not adaptive:
+        out[dst + ".norm_gain"] = _vec(sd[src + ".norm.scale"])
+        out[dst + ".norm_offset"] = _vec(sd[src + ".norm.shift"])
+    out[dst + ".pw1.W"] = pack_conv(sd[src + ".pw_conv1.weight"])
+    out[dst + ".pw1.b"] = _vec(sd[src + ".pw_conv1.bias"])
+    out[dst + ".pw2.W"] = pack_conv(sd[src + ".pw_conv2.weight"])
+    out[dst + ".pw2.b"] = _vec(sd[src + ".pw_conv2.bias"])
+    out[dst + ".scale"] = _vec(sd[src + ".scale"])
+
+
+def pack_content_encoder(sd):
+    out = {"input.W": pack_conv(sd["input_layer.weight"]), "input.b": _vec(sd["input_layer.bias"])}
+    for i in range(4):
+        _convnext(out, sd, f"mid_layers.{i}", f"mid{i}", False)
+    out["output.W"] = pack_conv(sd["output_layer.weight"])
+    out["output.b"] = _vec(sd["output_layer.bias"])
+    return out
+
+
+def pack_f0_estimator(sd):
+    out = pack_content_encoder(sd)
+    out["last_norm.gain"] = _vec(sd["last_norm.scale"])
+    out["last_norm.offset"] = _vec(sd["last_norm.shift"])
+    return out
+
+
+FILTER_CH = [256, 64, 16, 8]
+
+
+def pack_decoder(sd):
+    out = {}
+    fe = "feature_extractor"
+    out["fe.input.W"] = pack_conv(sd[fe + ".input_layer.weight"])
+    out["fe.input.b"] = _vec(sd[fe + ".input_layer.bias"])
+    out["fe.f0c1.W"] = pack_conv(sd[fe + ".f0_enc.c1.weight"])
+    out["fe.f0c1.b"] = _vec(sd[fe + ".f0_enc.c1.bias"])
+    out["fe.f0c2.W"] = pack_conv(sd[fe + ".f0_enc.c2.weight"])
+    out["fe.f0c2.b"] = _vec(sd[fe + ".f0_enc.c2.bias"])
+    ws, bs = [], []
+    for i in range(4):
+        p = f"{fe}.mid_layers.{i}.norm"
+        ws += [sd[p + ".scale.weight"].reshape(512, 512), sd[p + ".shift.weight"].reshape(512, 512)]
+        bs += [sd[p + ".scale.bias"], sd[p + ".shift.bias"]]
+        _convnext(out, sd, f"{fe}.mid_layers.{i}", f"fe.mid{i}", True)
+    out["fe.normfilm.W"] = pack_matrix(torch.cat(ws, 0).float())
+    out["fe.normfilm.b"] = _vec(torch.cat(bs, 0))
+    out["osc.amps.W"] = pack_conv(sd["harmonic_oscillator.to_amps.weight"])
+    out["osc.amps.b"] = _vec(sd["harmonic_oscillator.to_amps.bias"])
+    f = "filter"
+    ws, bs, post = [], [], []
+    for s, c in enumerate(FILTER_CH):
+        for j in range(3):
+            for cc in ("c1", "c2"):
+                p = f"{f}.blocks.{s}.blocks.{j}.{cc}"
+                ws += [sd[p + ".to_scale.weight"].reshape(c, 512), sd[p + ".to_shift.weight"].reshape(c, 512)]
+                bs += [sd[p + ".to_scale.bias"], sd[p + ".to_shift.bias"]]
+                post += [torch.ones(c, device=ws[0].device), torch.zeros(c, device=ws[0].device)]
+    out["flt.film.W"] = pack_matrix(torch.cat(ws, 0).float())
+    out["flt.film.b"] = _vec(torch.cat(bs, 0))
+    out["flt.film.post"] = _vec(torch.cat(post, 0))
+    out["flt.in.W"] = pack_conv(sd[f + ".source_in.weight"])
+    out["flt.in.b"] = _vec(sd[f + ".source_in.bias"])
+    for i in range(4):
+        out[f"flt.down{i}.W"] = pack_conv(sd[f"{f}.downs.{i}.weight"])
+        out[f"flt.down{i}.b"] = _vec(sd[f"{f}.downs.{i}.bias"])
+    out["flt.mid.W"] = pack_conv(sd[f + ".mid_conv.conv.weight"])
+    out["flt.mid.b"] = _vec(sd[f + ".mid_conv.conv.bias"])
+    for i in range(4):
+        out[f"flt.up{i}.W"], out[f"flt.up{i}.b"] = pack_convT(sd[f"{f}.ups.{i}.weight"], sd[f"{f}.ups.{i}.bias"])
+    for s in range(4):
+        b = f"{f}.blocks.{s}"
+        out[f"flt.blk{s}.in.W"] = pack_conv(sd[b + ".input_conv.weight"])
+        out[f"flt.blk{s}.in.b"] = _vec(sd[b + ".input_conv.bias"])
+        for j in range(3):
+            for cc in ("c1", "c2"):
+                out[f"flt.blk{s}.{j}.{cc}.W"] = pack_conv(sd[f"{b}.blocks.{j}.{cc}.conv.conv.weight"])
+                out[f"flt.blk{s}.{j}.{cc}.b"] = _vec(sd[f"{b}.blocks.{j}.{cc}.conv.conv.bias"])
+    out["flt.out.W"] = pack_conv(sd[f + ".source_out.weight"])
+    out["flt.out.b"] = _vec(sd[f + ".source_out.bias"])
+    return out

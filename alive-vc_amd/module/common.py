@@ -1,0 +1,101 @@
+"""Drop-in for the inference-time surface of the reference's module/common.py.
+
+  match_features(source, reference, k=4, alpha=0.0)   <- /root/reference/module/common.py:96-109
+
+runs on the MI355X through libalive_vc.so: bf16-MFMA candidate scoring with
+LDS-staged top-k' lists, exact fp32 rescoring, gather-mean-blend.  The library
+is packed (normalised bf16 rows + fp32 rows + norms) once per reference tensor
+and cached, so the per-window calls of inference.py:129 only pay for the search.
+"""
+import torch
+
+from . import _native as nat
+
+DIM = 768
+
+
+class PackedLibrary:
+    """Device-resident search form of a voice library tokens[768, M] (one shard).
+
+    lib_bf16[M_pad,768] normalised rows (MFMA operand), rows[M,768] fp32 raw rows,
+    norms[M].  `idx_base` is the global index of row 0 when the library is sharded."""
+
+    def __init__(self, tokens_DxM: torch.Tensor, idx_base: int = 0):
+        if tokens_DxM.dim() != 2 or tokens_DxM.shape[0] != DIM:
+            raise ValueError(f"library must be [768, M], got {tuple(tokens_DxM.shape)}")
+        t = tokens_DxM.contiguous().float()
+        L = nat.lib()
+        self.M = int(t.shape[1])
+        self.idx_base = int(idx_base)
+        m_pad = L.alive_library_padded_rows(self.M)
+        dev = t.device
+        self.lib_bf16 = torch.empty(m_pad, DIM, dtype=torch.bfloat16, device=dev)
+        self.rows = torch.empty(self.M, DIM, dtype=torch.float32, device=dev)
+        self.norms = torch.empty(self.M, dtype=torch.float32, device=dev)
+        nat.check(L.alive_library_pack(nat.ptr(t), self.M, DIM, nat.ptr(self.lib_bf16), nat.ptr(self.rows),
+                                       nat.ptr(self.norms), nat.stream()), "alive_library_pack")
+        self._ws = nat.Workspace()
+
+    def search(self, source, k):
+        """exact top-k of this shard: (val[Tt,k] fp32 desc, idx[Tt,k] int32 global)."""
+        n, d, t = source.shape
+        L = nat.lib()
+        val = torch.empty(n * t, k, dtype=torch.float32, device=source.device)
+        idx = torch.empty(n * t, k, dtype=torch.int32, device=source.device)
+        ws = self._ws.get(L.alive_knn_workspace_bytes(n * t, self.M), source.device)
+        nat.check(L.alive_knn_search(nat.ptr(source), n, t, nat.ptr(self.lib_bf16), nat.ptr(self.rows),
+                                     nat.ptr(self.norms), self.M, self.idx_base, k, nat.ptr(val), nat.ptr(idx),
+                                     nat.ptr(ws), nat.stream()), "alive_knn_search")
+        return val, idx
+
+
+def merge_gather(cand_val, cand_idx, n_shards, k, alpha, rows_full, source, return_indices=False):
+    """merge [S, Tt, k] exact lists, gather rows, mean over k, alpha-blend (common.py:107-109)."""
+    n, d, t = source.shape
+    out = torch.empty_like(source)
+    fin = torch.empty(n * t, k, dtype=torch.int32, device=source.device) if return_indices else None
+    nat.check(nat.lib().alive_knn_merge_gather(nat.ptr(cand_val), nat.ptr(cand_idx), n_shards, k, float(alpha),
+                                               nat.ptr(rows_full), nat.ptr(source), n, t, nat.ptr(out), nat.ptr(fin),
+                                               nat.stream()), "alive_knn_merge_gather")
+    return (out, fin) if return_indices else out
+
+
+_cache = {}
+
+
+def _packed_for(reference_DxM):
+    key = (reference_DxM.data_ptr(), tuple(reference_DxM.shape), reference_DxM._version, str(reference_DxM.device))
+    hit = _cache.get(key)
+    if hit is None:
+        if len(_cache) >= 4:
+            _cache.pop(next(iter(_cache)))
+        hit = PackedLibrary(reference_DxM)
+        _cache[key] = hit
+    return hit
+
+
+def match_features(source, reference, k=4, alpha=0.0, return_indices=False):
+    """source [N,768,T], reference [N or 1,768,M] -> [N,768,T].  Same contract as the reference function;
+    shape errors surface as ValueError (the reference raises RuntimeError from torch.bmm / topk)."""
+    if source.dim() != 3 or reference.dim() != 3 or source.shape[1] != DIM or reference.shape[1] != DIM:
+        raise ValueError("match_features expects source [N,768,T] and reference [N,768,M]")
+    if reference.shape[0] not in (1, source.shape[0]):
+        raise ValueError("match_features: batch of reference must be 1 or equal to the batch of source")
+    if reference.shape[2] < k:
+        raise ValueError(f"match_features: library has {reference.shape[2]} vectors, fewer than k={k}")
+    source = source.contiguous().float()
+    if reference.shape[0] == 1:
+        lib = _packed_for(reference[0])
+        val, idx = lib.search(source, k)
+        return merge_gather(val, idx, 1, k, alpha, lib.rows, source, return_indices)
+    outs, idxs = [], []
+    for n in range(source.shape[0]):
+        lib = _packed_for(reference[n])
+        s = source[n:n + 1].contiguous()
+        val, idx = lib.search(s, k)
+        r = merge_gather(val, idx, 1, k, alpha, lib.rows, s, return_indices)
+        outs.append(r[0] if return_indices else r)
+        if return_indices:
+            idxs.append(r[1])
+    out = torch.cat(outs, 0)
+    return (out, torch.cat(idxs, 0)) if return_indices else out

@@ -1,0 +1,27 @@
+"""Drop-in for /root/reference/module/f0_estimator.py:8-34 (`estimate`: argmax class index as float Hz)."""
+import torch
+
+from . import _native as nat
+from . import schema
+from ._netbase import PackedNet
+from ._pack import pack_f0_estimator
+
+
+class F0Estimator(PackedNet):
+    MODEL_ID = 1
+    PREFIX = "pe."
+    _schema = staticmethod(schema.f0_estimator_schema)
+    _pack = staticmethod(pack_f0_estimator)
+
+    def estimate(self, x, downsample_factor=1):
+        """x [N, 641, T] -> f0 [N, 1, T]"""
+        x = x.contiguous().float()
+        n, c, t = x.shape
+        if c != schema.N_BINS:
+            raise ValueError(f"F0Estimator expects 641 spectrogram bins, got {c}")
+        L = nat.lib()
+        f0 = torch.empty(n, 1, t, device=x.device)
+        ws = self._ws.get(L.alive_f0_estimate_workspace_bytes(n, t), x.device)
+        nat.check(L.alive_f0_estimate(self.table().array, nat.ptr(x), n, t, nat.ptr(f0), nat.ptr(ws), nat.stream()),
+                  "alive_f0_estimate")
+        return f0

@@ -1,0 +1,114 @@
+"""Operator-level Python wrappers over the C ABI (one per exported kernel family).
+
+Used by the module classes and by the per-kernel parity tests.  All tensors are
+fp32 contiguous HIP tensors; weights here are in the REFERENCE layout and are
+packed on the fly (the network classes pack once at load time instead).
+"""
+import ctypes as C
+
+import torch
+
+from . import _native as nat
+from ._pack import pack_conv, pack_convT
+
+ACT = {None: 0, "gelu": 1, "exp": 2, "sin": 3}
+_ws = nat.Workspace()
+
+
+def _f(t):
+    return None if t is None else t.contiguous().float()
+
+
+def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, out_len=None, act=None,
+           post_add=None, ch_scale=None, residual=None, skip=None, film=None, film_scale_row=0, film_shift_row=0,
+           want_raw=True, transposed=False):
+    """Generic Conv1d / ConvTranspose1d(k == stride) through alive_conv1d.
+    Returns (Y, Z): raw output (or None) and the gelu+FiLM modulated second output (or None)."""
+    x = _f(x)
+    n, ci, tin = x.shape
+    keep = []
+    if transposed:
+        r = weight.shape[2]
+        W, b = pack_convT(weight, bias)
+        co_rows, kw, up = weight.shape[1] * r, 1, r
+        stride_, tout = 1, tin
+        co_out = weight.shape[1]
+    else:
+        W = pack_conv(weight)
+        b = _f(bias)
+        co_rows, kw, up = weight.shape[0], weight.shape[2], 1
+        stride_ = stride
+        tout = out_len if out_len is not None else (tin + pad_left - dilation * (kw - 1) - 1) // stride + 1
+        co_out = co_rows
+    d = nat.AliveConv()
+    d.W, d.bias, d.X = nat.ptr(W), nat.ptr(b), nat.ptr(x)
+    d.N, d.Ci, d.Tin, d.Co, d.K_pad = n, ci, tin, co_rows, W.shape[1]
+    d.KW, d.stride, d.dil, d.pad_left, d.pad_mode = kw, stride_, dilation, pad_left, pad_mode
+    d.Tout, d.up, d.act = tout, up, ACT[act]
+    post_add, ch_scale, residual, skip, film = map(_f, (post_add, ch_scale, residual, skip, film))
+    keep += [W, b, x, post_add, ch_scale, residual, skip, film]
+    d.post_add, d.ch_scale, d.residual, d.skip = map(nat.ptr, (post_add, ch_scale, residual, skip))
+    Y = torch.empty(n, co_out, tout * up, device=x.device) if want_raw else None
+    Z = None
+    if film is not None:
+        Z = torch.empty(n, co_out, tout, device=x.device)
+        d.film, d.film_rows, d.Lf = nat.ptr(film), film.shape[1], film.shape[2]
+        d.film_scale_row, d.film_shift_row = film_scale_row, film_shift_row
+    d.Y, d.Z = nat.ptr(Y), nat.ptr(Z)
+    nat.check(nat.lib().alive_conv1d(C.byref(d), nat.stream()), "alive_conv1d")
+    return Y, Z
+
+
+def dwconv_norm(x, dw_w, dw_b, gain=None, offset=None, cond=None, scale_row=0, shift_row=0, eps=1e-4):
+    x = _f(x)
+    n, c, t = x.shape
+    y = torch.empty_like(x)
+    dw_w, dw_b, gain, offset, cond = map(_f, (dw_w.reshape(-1), dw_b, None if gain is None else gain.reshape(-1),
+                                              None if offset is None else offset.reshape(-1), cond))
+    rc = nat.lib().alive_dwconv_norm(nat.ptr(x), n, c, t, nat.ptr(dw_w), nat.ptr(dw_b), 0 if cond is None else 1,
+                                     nat.ptr(gain), nat.ptr(offset), nat.ptr(cond),
+                                     0 if cond is None else cond.shape[1], scale_row, shift_row, eps, nat.ptr(y),
+                                     nat.stream())
+    nat.check(rc, "alive_dwconv_norm")
+    return y
+
+
+def channel_norm(x, gain, offset, eps=1e-4):
+    x = _f(x)
+    n, c, t = x.shape
+    y = torch.empty_like(x)
+    g, o = _f(gain.reshape(-1)), _f(offset.reshape(-1))
+    nat.check(nat.lib().alive_channel_norm(nat.ptr(x), n, c, t, nat.ptr(g), nat.ptr(o), eps, nat.ptr(y), nat.stream()),
+              "alive_channel_norm")
+    return y
+
+
+def argmax_channels(x):
+    x = _f(x)
+    n, c, t = x.shape
+    out = torch.empty(n, 1, t, device=x.device)
+    nat.check(nat.lib().alive_argmax_channels(nat.ptr(x), n, c, t, nat.ptr(out), nat.stream()), "alive_argmax_channels")
+    return out
+
+
+def oscillator(amps, f0, phi=None, crop0=0, phi_col=None, seg=320, sample_rate=16000.0):
+    """amps[N,H,Lf] (already exp'd), f0[N,1,Lf] -> wave[N,1,Lf*seg], phi_out[N,H] at phi_col (or None)."""
+    amps, f0 = _f(amps), _f(f0)
+    n, h, lf = amps.shape
+    wave = torch.empty(n, 1, lf * seg, device=amps.device)
+    phi_in = None if phi is None else _f(phi.reshape(n, h))
+    phi_out = None if phi_col is None else torch.empty(n, h, device=amps.device)
+    L = nat.lib()
+    ws = _ws.get(L.alive_oscillator_workspace_bytes(n, h, lf), amps.device)
+    rc = L.alive_oscillator(nat.ptr(amps), nat.ptr(f0), nat.ptr(phi_in), n, h, lf, seg, sample_rate, crop0,
+                            0 if phi_col is None else phi_col, nat.ptr(wave), nat.ptr(phi_out), nat.ptr(ws), nat.stream())
+    nat.check(rc, "alive_oscillator")
+    return wave, phi_out
+
+
+def pitch_transform_(f0, mode, f0_rate=1.0, pitch_shift=0.0, intonation=1.0):
+    """in place on f0[N,1,T]; mode 0 = inference.py:119-130, mode 1 = realtime_inference.py:156-163"""
+    n, _, t = f0.shape
+    nat.check(nat.lib().alive_pitch_transform(nat.ptr(f0), n, t, mode, f0_rate, pitch_shift, intonation, nat.stream()),
+              "alive_pitch_transform")
+    return f0

@@ -1,0 +1,175 @@
+/*
+ * alive_vc.h -- C ABI of libalive_vc.so (MI355X / gfx950 voice-conversion hot path).
+ *
+ * The reference (uthree/ALiVE-VC) is pure PyTorch and has no FFI of its own;
+ * its boundary is the Python call surface of its module package.  This header is the
+ * native surface that the alive-vc_amd/module package binds with ctypes to implement
+ * that Python surface.  Each entry point names the reference function it
+ * replaces.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer (tensor.data_ptr()); fp32 unless noted
+ *   - activations are [N][C][T], T contiguous (the reference's layout)
+ *   - `stream` is a hipStream_t passed as void*
+ *   - no allocation, no synchronisation, no host<->device copy inside: any
+ *     call sequence can be captured into a hipGraph.  Scratch comes from the
+ *     caller via the *_workspace_bytes queries.
+ *   - return 0 on success, negative on error; alive_last_error() gives a
+ *     thread-local message.
+ */
+#ifndef ALIVE_VC_H
+#define ALIVE_VC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALIVE_OK 0
+#define ALIVE_ERR_ARG (-1)
+#define ALIVE_ERR_LAUNCH (-2)
+
+#define ALIVE_DIM 768          /* content feature width (voice_library.py:7) */
+#define ALIVE_KPRIME 16        /* bf16 candidates kept per partial list       */
+#define ALIVE_MAX_K 16         /* largest k accepted by the kNN entry points  */
+
+const char* alive_last_error(void);
+int alive_version(void);
+
+/* ---------------------------------------------------------------- kNN ----
+ * Replaces match_features (module/common.py:96-109) and VoiceLibrary.match
+ * (module/voice_library.py:15-33).
+ *
+ * alive_library_pack: tokens[D][M] (the on-disk layout of voice_library.pt,
+ *   generate_voice_library.py:42, batch dim dropped) ->
+ *     lib_bf16[M_pad][D]  L2-normalised rows, bf16 (MFMA scoring operand;
+ *                         M_pad = alive_library_padded_rows(M), pad rows zero)
+ *     rows_f32[M][D]      raw rows, fp32 (exact rescoring + gather)
+ *     norms[M]            fp32 L2 norm of each row
+ */
+int64_t alive_library_padded_rows(int64_t M);
+int alive_library_pack(const float* tokens_DxM, int64_t M, int D,
+                       void* lib_bf16, float* rows_f32, float* norms, void* stream);
+
+/* alive_knn_search: exact top-k of one library shard.
+ *   src[N][D][T] fp32 source frames; frames are flattened to Tt = N*T.
+ *   bf16 MFMA cosine scoring with per-wave top-k' lists in LDS, then exact
+ *   fp32 rescoring (normalise-then-dot, as the reference) of every candidate.
+ *   out_val[Tt][k] fp32 cosine, descending; out_idx[Tt][k] = idx_base + row.
+ *   ws: alive_knn_workspace_bytes(Tt, M) bytes.
+ */
+size_t alive_knn_workspace_bytes(int64_t Tt, int64_t M);
+int alive_knn_search(const float* src, int N, int T,
+                     const void* lib_bf16, const float* rows_f32, const float* norms,
+                     int64_t M, int64_t idx_base, int k,
+                     float* out_val, int32_t* out_idx, void* ws, void* stream);
+
+/* alive_knn_merge_gather: merge n_shards exact top-k lists ([S][Tt][k], e.g.
+ * after an RCCL all-gather), pick the global top-k, gather those rows from the
+ * full fp32 row table, mean over k, alpha-blend with the source.
+ *   out[N][D][T];  final_idx[Tt][k] (may be NULL).
+ */
+int alive_knn_merge_gather(const float* cand_val, const int32_t* cand_idx, int n_shards, int k,
+                           double alpha, const float* rows_f32_full, const float* src,
+                           int N, int T, float* out, int32_t* final_idx, void* stream);
+
+/* ----------------------------------------------------------- operators ----
+ * Building blocks, exported so that every kernel has its own parity test.
+ *
+ * alive_conv1d: Conv1d / ConvTranspose1d(k == stride) as an f32-MFMA implicit
+ * GEMM with fused epilogue.  Replaces every nn.Conv1d / nn.ConvTranspose1d on
+ * the path (common.py:48-51,88-92; decoder.py:16-17,41,61,108-110,141,164-182).
+ */
+typedef struct AliveConv {
+    const float* W;        /* packed [Co_pad][K_pad], K = Ci*KW (k-major within ci), zero padded to x16 */
+    const float* bias;     /* [rows] or NULL (rows = Co, or Co*up for transposed) */
+    const float* X;        /* [N][Ci][Tin] */
+    int N, Ci, Tin;
+    int Co;                /* GEMM rows (Co, or Co*up for transposed convs) */
+    int K_pad;             /* padded K (multiple of 16) */
+    int KW, stride, dil;   /* input index = t*stride + j*dil - pad_left */
+    int pad_left;
+    int pad_mode;          /* 0 zero; 1 reflect left, zero right; 2 reflect both (STFT centre pad) */
+    int Tout;              /* GEMM columns per batch item */
+    int up;                /* 1, or r for ConvTranspose1d(k=r, stride=r): row -> (co=row/r, j=row%r), t -> t*r+j */
+    int act;               /* 0 none, 1 gelu(erf), 2 exp, 3 sin */
+    const float* post_add; /* [rows] added after act (FiLM "+1"), or NULL */
+    const float* ch_scale; /* [rows] multiplied after act (ConvNeXt layer scale), or NULL */
+    const float* residual; /* [N][Co][Tout] added after ch_scale, or NULL */
+    const float* skip;     /* [N][Co][Tout] added after residual, or NULL */
+    float* Y;              /* raw output [N][Co_out][Tout*up], or NULL */
+    /* optional second output: Z = gelu(v) * interp(film[fs]) + interp(film[fh])  (decoder.py:112-117,130-132) */
+    float* Z;
+    const float* film;     /* [N][film_rows][Lf] */
+    int film_rows, Lf, film_scale_row, film_shift_row;
+} AliveConv;
+int alive_conv1d(const AliveConv* desc, void* stream);
+
+/* depthwise k7 conv + (Adaptive)ChannelNorm (common.py:20-26,35-41,55-56,75-76)
+ *   affine_mode 0: gain[C], offset[C];  1: per-sample scale/shift rows in cond[N][cond_rows][T] */
+int alive_dwconv_norm(const float* X, int N, int C, int T, const float* dw_w, const float* dw_b,
+                      int affine_mode, const float* gain, const float* offset,
+                      const float* cond, int cond_rows, int scale_row, int shift_row,
+                      float eps, float* Y, void* stream);
+/* ChannelNorm alone (f0_estimator.py:25) */
+int alive_channel_norm(const float* X, int N, int C, int T, const float* gain, const float* offset,
+                       float eps, float* Y, void* stream);
+/* argmax over channels -> float (f0_estimator.py:33) */
+int alive_argmax_channels(const float* X, int N, int C, int T, float* out, void* stream);
+
+/* HarmonicOscillator.forward after to_amps/exp (decoder.py:79-100).
+ *   amps[N][H][Lf] (already exp'd), f0[N][Lf], phi_in[N][H] or NULL, crop0,
+ *   wave[N][Lf*seg], phi_out[N][H] = asin(sin(theta)) at column phi_col (or NULL).
+ *   ws: alive_oscillator_workspace_bytes(N, H, Lf). */
+size_t alive_oscillator_workspace_bytes(int N, int H, int Lf);
+int alive_oscillator(const float* amps, const float* f0, const float* phi_in, int N, int H, int Lf,
+                     int seg, float sample_rate, int crop0, int phi_col,
+                     float* wave, float* phi_out, void* ws, void* stream);
+
+/* magnitude STFT 1280/320, rect window, reflect centre pad, last frame dropped
+ * (module/spectrogram.py:5-10): wav[N][L] -> spec[N][641][L/320], as a DFT GEMM on the
+ * f32 MFMA.  basis: [1296][1280] fp32 filled once by alive_dft_basis (rows 0..640 cos,
+ * 641..1281 -sin, rest zero); ws: alive_spectrogram_workspace_bytes(N, L). */
+size_t alive_dft_basis_bytes(void);
+int alive_dft_basis(float* basis, void* stream);
+size_t alive_spectrogram_workspace_bytes(int N, int L);
+int alive_spectrogram(const float* basis, const float* wav, int N, int L, float* spec, void* ws, void* stream);
+
+/* ------------------------------------------------------------ networks ----
+ * Weight tables are arrays of device pointers in the order given by
+ * alive_weight_name(model, i), i < alive_weight_count(model); tensors are the
+ * packed forms produced by module/_pack.py from a reference state_dict.
+ * model: 0 content encoder, 1 f0 estimator, 2 decoder.
+ */
+int alive_weight_count(int model);
+const char* alive_weight_name(int model, int index);
+
+/* ContentEncoder.forward (content_encoder.py:21-25): spec[N][641][T] -> out[N][768][T] */
+size_t alive_content_encoder_workspace_bytes(int N, int T);
+int alive_content_encoder(const float* const* w, const float* spec, int N, int T,
+                          float* out, void* ws, void* stream);
+
+/* F0Estimator.estimate (f0_estimator.py:29-34): spec -> f0[N][T] (class index as float) */
+size_t alive_f0_estimate_workspace_bytes(int N, int T);
+int alive_f0_estimate(const float* const* w, const float* spec, int N, int T,
+                      float* f0, void* ws, void* stream);
+
+/* Decoder.forward (decoder.py:205-210) at harmonics_scale == 1:
+ *   x[N][768][Lf], f0[N][Lf], phi_in[N][64] or NULL (phi = 0), crop0,
+ *   wave[N][320*Lf], phi_out[N][64] at column phi_col, or NULL. */
+size_t alive_decoder_workspace_bytes(int N, int Lf);
+int alive_decoder_forward(const float* const* w, const float* x, const float* f0,
+                          const float* phi_in, int crop0, int phi_col, int N, int Lf,
+                          float* wave, float* phi_out, void* ws, void* stream);
+
+/* pitch transform of inference.py:119-126,130 (mode 0, per-window mean pitch)
+ * and realtime_inference.py:156-163 (mode 1); in place on f0[N][T]. */
+int alive_pitch_transform(float* f0, int N, int T, int mode, float f0_rate, float pitch_shift,
+                          float intonation, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALIVE_VC_H */

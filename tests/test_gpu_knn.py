@@ -1,0 +1,124 @@
+"""kNN parity through the C ABI: index sets identical to the reference's outside near-ties
+(gap(k, k+1) < 1e-5), outputs within 1e-6, golden fixtures from the reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import alive_oracle as O
+from module import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def inputs_for(tag, d):
+    T, M = int(d["T"]), int(d["M"])
+    lib = synthetic.make_library(M, 12)
+    src = torch.from_numpy(d["src"]) if "src" in d else synthetic.gaussian(f"knn.src.{tag}", 11, (1, 768, T))
+    if str(d["kind"]) == "clustered":
+        base = synthetic.gaussian("knn.base", 13, (1, 768, 1))
+        lib = base + 0.35 * lib
+        src = base + 0.35 * synthetic.gaussian(f"knn.src.{tag}", 11, (1, 768, T))
+    return src, lib
+
+
+@pytest.mark.parametrize("tag", list("abcdef"))
+def test_knn_golden(golden_dir, tag):
+    from module.common import match_features
+    d = np.load(os.path.join(golden_dir, f"knn_{tag}.npz"))
+    k, alpha = int(d["k"]), float(d["alpha"])
+    src, lib = inputs_for(tag, d)
+    out, idx = match_features(src.to(DEV), lib.to(DEV), k=k, alpha=alpha, return_indices=True)
+    safe = d["gap"] > 1e-5
+    got = np.sort(idx.cpu().numpy(), axis=1)[safe]
+    want = np.sort(d["idx"], axis=1)[safe]
+    bad = (got != want).any(axis=1).sum()
+    assert bad == 0, f"{bad} of {safe.sum()} frames have a different top-{k} set"
+    ref = torch.from_numpy(d["out"])
+    o = out.cpu() if ref.shape[1] == 768 else out.cpu()[:, ::16, :]
+    torch.testing.assert_close(o[:, :, torch.from_numpy(safe)], ref[:, :, torch.from_numpy(safe)], rtol=1e-5, atol=1e-6)
+
+
+def test_knn_values_are_exact_fp32_cosines():
+    from module.common import PackedLibrary
+    src = synthetic.gaussian("kv.src", 3, (2, 768, 70))
+    lib = synthetic.make_library(3000, 4)
+    pl = PackedLibrary(lib[0].to(DEV))
+    val, idx = pl.search(src.to(DEV), 4)
+    _, oidx, cos = O.match_features(src, lib.expand(2, 768, 3000), 4, 0.0, return_indices=True)
+    top = torch.topk(cos, 4, dim=2).values.reshape(-1, 4)
+    torch.testing.assert_close(val.cpu(), top, rtol=0, atol=2e-6)
+    assert (val.cpu()[:, :-1] >= val.cpu()[:, 1:]).all()
+
+
+def test_knn_batched_windows_equal_per_window_calls():
+    """throughput mode flattens windows x frames into one problem; must equal per-window calls."""
+    from module.common import match_features
+    src = synthetic.gaussian("kb.src", 5, (5, 768, 33)).to(DEV)
+    lib = synthetic.make_library(2000, 6).to(DEV)
+    whole = match_features(src, lib, k=4, alpha=0.2)
+    parts = torch.cat([match_features(src[i:i + 1].contiguous(), lib, k=4, alpha=0.2) for i in range(5)], 0)
+    assert torch.equal(whole, parts)
+
+
+def test_knn_edge_cases():
+    from module.common import match_features
+    lib3 = synthetic.make_library(3, 1).to(DEV)
+    with pytest.raises(ValueError):
+        match_features(synthetic.gaussian("x", 1, (1, 768, 3)).to(DEV), lib3, k=4)
+    # M == k: every row is selected, output is the library mean
+    lib4 = synthetic.make_library(4, 1)
+    src = synthetic.gaussian("x", 1, (1, 768, 1))            # single frame
+    out = match_features(src.to(DEV), lib4.to(DEV), k=4)
+    torch.testing.assert_close(out.cpu(), O.match_features(src, lib4, 4), rtol=1e-6, atol=1e-6)
+    # ragged sizes around the 128-wide tiles
+    for T, M in [(127, 129), (129, 255), (1, 1000)]:
+        s = synthetic.gaussian(f"rag{T}", 2, (1, 768, T))
+        l = synthetic.make_library(M, 3)
+        got, gi = match_features(s.to(DEV), l.to(DEV), k=4, return_indices=True)
+        ref, ri, cos = O.match_features(s, l, 4, 0.0, return_indices=True)
+        top = torch.topk(cos, 5, dim=2).values[0]
+        safe = (top[:, 3] - top[:, 4]) > 1e-5
+        assert np.array_equal(np.sort(gi.cpu().numpy(), 1)[safe.numpy()], np.sort(ri[0].numpy(), 1)[safe.numpy()])
+        torch.testing.assert_close(got.cpu()[:, :, safe], ref[:, :, safe], rtol=1e-5, atol=1e-6)
+
+
+def test_knn_sharded_merge_equals_single_shard():
+    """library split into 4 contiguous shards, per-shard exact top-k, merged: same as unsharded."""
+    from module.common import PackedLibrary, merge_gather
+    src = synthetic.gaussian("ks.src", 8, (2, 768, 45)).to(DEV)
+    lib = synthetic.make_library(4100, 9)[0].to(DEV)
+    full = PackedLibrary(lib)
+    v0, i0 = full.search(src, 4)
+    ref, fin_ref = merge_gather(v0, i0, 1, 4, 0.0, full.rows, src, return_indices=True)
+    vs, is_ = [], []
+    bounds = [0, 1000, 2050, 3075, 4100]
+    for s in range(4):
+        sh = PackedLibrary(lib[:, bounds[s]:bounds[s + 1]].contiguous(), idx_base=bounds[s])
+        v, i = sh.search(src, 4)
+        vs.append(v)
+        is_.append(i)
+    out, fin = merge_gather(torch.stack(vs).contiguous(), torch.stack(is_).contiguous(), 4, 4, 0.0, full.rows, src,
+                            return_indices=True)
+    assert torch.equal(fin, fin_ref)
+    assert torch.equal(out, ref)
+
+
+def test_voice_library_format_and_match(golden_dir, tmp_path):
+    from module.voice_library import VoiceLibrary
+    d = np.load(os.path.join(golden_dir, "voice_library_match.npz"))
+    vl = VoiceLibrary()
+    vl.load_state_dict({"tokens": synthetic.make_library(512, int(d["seed"]))})
+    p = tmp_path / "voice_library.pt"
+    torch.save(vl.state_dict(), p)
+    sd = torch.load(p)
+    assert list(sd.keys()) == ["tokens"] and tuple(sd["tokens"].shape) == (1, 768, 512)
+    vl2 = VoiceLibrary().to(DEV)
+    vl2.load_state_dict(sd)
+    out = vl2.match(torch.from_numpy(d["src"]).to(DEV), k=4, alpha=0.25)
+    torch.testing.assert_close(out.cpu(), torch.from_numpy(d["out"]), rtol=1e-5, atol=1e-6)
+    big = VoiceLibrary().to(DEV)
+    big.load_state_dict({"tokens": synthetic.make_library(1000, 3)})     # M != 512 loads too
+    assert big.tokens.shape == (1, 768, 1000)

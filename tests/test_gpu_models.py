@@ -1,0 +1,109 @@
+"""Full-size networks on seeded synthetic weights against fixtures captured from the reference and
+against the CPU oracle: waveform RMS error <= 1e-3 (north-star bar), f0 argmax exact outside near-ties."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import alive_oracle as O
+from module import schema, synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+RMS_BAR = 1e-3
+
+
+@pytest.fixture(scope="module")
+def nets():
+    from module.content_encoder import ContentEncoder
+    from module.decoder import Decoder
+    from module.f0_estimator import F0Estimator
+    ce, pe, dec = ContentEncoder(seed=2).to(DEV), F0Estimator(seed=2).to(DEV), Decoder(seed=2).to(DEV)
+    cpu = (synthetic.make_state_dict(schema.content_encoder_schema(), 2, "ce."),
+           synthetic.make_state_dict(schema.f0_estimator_schema(), 2, "pe."),
+           synthetic.make_state_dict(schema.decoder_schema(), 2, "dec."))
+    return ce, pe, dec, cpu
+
+
+def rms(a, b):
+    return (a.double().cpu() - b.double().cpu()).pow(2).mean().sqrt().item()
+
+
+@pytest.mark.parametrize("T", [5, 8, 24, 450])
+def test_networks_against_reference_fixtures(golden_dir, nets, T):
+    ce, pe, dec, cpu = nets
+    z = np.load(os.path.join(golden_dir, f"full_T{T}.npz"))
+    wav = torch.from_numpy(z["wav"])
+    spec = torch.from_numpy(z["spec"]) if "spec" in z.files else O.spectrogram(wav)
+    feat = ce(spec.to(DEV)).cpu()
+    ref_feat = torch.from_numpy(z["feat"])
+    f = feat if ref_feat.shape[1] == 768 else feat[:, ::8, :]
+    assert rms(f, ref_feat) < 1e-5 * max(1.0, ref_feat.pow(2).mean().sqrt().item()), rms(f, ref_feat)
+    f0 = pe.estimate(spec.to(DEV)).cpu()
+    safe = torch.from_numpy(z["f0_margin"])[0] > 1e-4
+    assert torch.equal(f0[0, 0][safe], torch.from_numpy(z["f0"])[0, 0][safe])
+    assert safe.float().mean() > 0.9
+    full_feat = O.content_encoder(cpu[0], spec)
+    wave, phi = dec(full_feat.to(DEV), torch.from_numpy(z["f0_dec"]).to(DEV))
+    err = rms(wave, torch.from_numpy(z["wave"]))
+    assert err < RMS_BAR, f"waveform RMS error {err:.3e} vs reference fixture"
+    torch.testing.assert_close(phi[:, :, -1].cpu(), torch.from_numpy(z["phi_last"]), rtol=0, atol=5e-2)
+
+
+def test_decoder_stage_errors_are_small(nets):
+    """same decoder inputs on both sides, batch of 3 windows of 40 frames: tight bound."""
+    ce, pe, dec, cpu = nets
+    x = synthetic.gaussian("dx", 4, (3, 768, 40))
+    f0 = (100 + 300 * torch.from_numpy(synthetic.uniform01("df0", 4, 120)).float()).view(3, 1, 40)
+    f0[1, 0, 10:14] = 0
+    wave, _ = dec(x.to(DEV), f0.to(DEV))
+    ref, _ = O.decoder(cpu[2], x, f0)
+    assert rms(wave, ref) < 2e-4, rms(wave, ref)
+
+
+def test_realtime_two_steps(golden_dir, nets):
+    """realtime_inference.py:146-167: phase carried through phi[:, :, end_of_output]."""
+    from module.common import match_features
+    from module.spectrogram import spectrogram
+    from module import ops
+    ce, pe, dec, cpu = nets
+    z = np.load(os.path.join(golden_dir, "realtime_two_steps.npz"))
+    stream = torch.from_numpy(z["stream"]).to(DEV)
+    lib = synthetic.make_library(int(z["lib_M"]), int(z["lib_seed"])).to(DEV)
+    c, bs, begin, end = int(z["chunk"]), int(z["buffersize"]), int(z["begin"]), int(z["end"])
+    phi = 0
+    for step in range(2):
+        ring = stream[:, step * c: step * c + bs * c].contiguous()
+        spec = spectrogram(ring)
+        content = ce(spec)
+        f0 = pe.estimate(spec)
+        f0 = ops.pitch_transform_(f0, 1, f0_rate=float(z["f0_rate"]), pitch_shift=0.0)
+        content = match_features(content, lib, k=4, alpha=0.0)
+        data, phi_out = dec(content, f0=f0, phi=phi, crop=(begin, end))
+        phi = phi_out[:, :, end].unsqueeze(2)
+        assert rms(data, torch.from_numpy(z[f"wave{step}"])) < RMS_BAR
+        torch.testing.assert_close(phi.cpu(), torch.from_numpy(z[f"phi{step}"]), rtol=0, atol=2e-2)
+
+
+def test_decoder_rejects_short_input_and_bad_scale(nets):
+    ce, pe, dec, cpu = nets
+    x = torch.zeros(1, 768, 4, device=DEV)
+    with pytest.raises(ValueError):
+        dec(x, torch.zeros(1, 1, 4, device=DEV))
+    with pytest.raises(ValueError):
+        dec(torch.zeros(1, 768, 8, device=DEV), torch.zeros(1, 1, 8, device=DEV), harmonics_scale=0.5)
+
+
+def test_checkpoint_roundtrip(tmp_path, nets):
+    from module.decoder import Decoder
+    ce, pe, dec, cpu = nets
+    p = tmp_path / "decoder.pt"
+    torch.save(dec.state_dict(), p)
+    sd = torch.load(p, map_location="cpu")
+    assert list(sd.keys()) == list(schema.decoder_schema().keys())
+    d2 = Decoder().to(DEV)
+    d2.load_state_dict(sd)
+    x = synthetic.gaussian("rt", 1, (1, 768, 6)).to(DEV)
+    f0 = torch.full((1, 1, 6), 200.0, device=DEV)
+    assert torch.equal(d2(x, f0)[0], dec(x, f0)[0])

@@ -1,0 +1,228 @@
+"""Per-kernel parity: every exported operator of libalive_vc.so (through the C ABI) against the
+CPU oracle / plain torch fp32 on the same seeded inputs.  Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import alive_oracle as O
+from module import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def g(name, shape, seed=7, scale=1.0):
+    return synthetic.gaussian(name, seed, shape, scale)
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("co,ci,kw,stride,dil,pad,mode,t", [
+    (512, 641, 1, 1, 1, 0, 0, 450),      # CE input layer
+    (1536, 512, 1, 1, 1, 0, 0, 37),      # pw1, ragged T
+    (64, 512, 1, 1, 1, 0, 0, 24),        # to_amps
+    (8, 1, 7, 1, 1, 3, 0, 2000),         # source_in (zero pad both sides)
+    (1, 8, 7, 1, 1, 3, 0, 1999),         # source_out
+    (16, 8, 2, 2, 1, 0, 0, 3200),        # down 0
+    (256, 64, 8, 8, 1, 0, 0, 1600),      # down 2
+    (256, 256, 10, 10, 1, 0, 0, 500),    # down 3
+    (256, 256, 5, 1, 1, 4, 1, 50),       # mid causal conv (reflect)
+    (64, 64, 5, 1, 2, 8, 1, 700),        # dilated causal
+    (16, 16, 5, 1, 4, 16, 1, 1400),      # dilated causal, small C
+    (8, 8, 5, 1, 4, 16, 1, 333),
+    (24, 20, 3, 1, 1, 0, 0, 100),        # odd sizes
+])
+def test_conv1d_matches_torch(co, ci, kw, stride, dil, pad, mode, t):
+    from module import ops
+    x = g(f"cx{co}{ci}{kw}", (2, ci, t))
+    w = g(f"cw{co}{ci}{kw}", (co, ci, kw), scale=1.0 / np.sqrt(ci * kw))
+    b = g(f"cb{co}{ci}{kw}", (co,), scale=0.1)
+    if mode == 1:
+        ref = F.conv1d(F.pad(x, (pad, 0), mode="reflect"), w, b, stride=stride, dilation=dil)
+    else:
+        ref = F.conv1d(x, w, b, stride=stride, dilation=dil, padding=pad)
+    y, _ = ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), stride=stride, dilation=dil, pad_left=pad, pad_mode=mode,
+                      out_len=ref.shape[2])
+    assert y.shape == ref.shape
+    assert relerr(y, ref) < 2e-6, relerr(y, ref)
+
+
+def test_conv1d_k1_is_single_fma():
+    """F0Encoder.c1 (decoder.py:16,21): K == 1 conv must be fma(w, x, b) bit for bit (it feeds sin)."""
+    from module import ops
+    f0 = (torch.arange(0, 4096, dtype=torch.float32) * 0.97).view(1, 1, -1)
+    w = g("k1w", (512, 1, 1), scale=0.3)
+    b = g("k1b", (512,), scale=0.5)
+    ref = F.conv1d(f0, w, b)
+    y, _ = ops.conv1d(f0.to(DEV), w.to(DEV), b.to(DEV))
+    assert torch.equal(y.cpu(), ref)
+
+
+@pytest.mark.parametrize("act", ["gelu", "exp", "sin"])
+def test_conv1d_activations(act):
+    from module import ops
+    x = g("ax", (1, 40, 129))
+    w = g("aw", (48, 40, 1), scale=0.15)
+    b = g("ab", (48,), scale=0.1)
+    ref = F.conv1d(x, w, b)
+    ref = {"gelu": F.gelu, "exp": torch.exp, "sin": torch.sin}[act](ref)
+    y, _ = ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), act=act)
+    torch.testing.assert_close(y.cpu(), ref, rtol=2e-5, atol=2e-6)
+
+
+def test_conv1d_epilogue_scale_residual_skip():
+    from module import ops
+    x = g("ex", (2, 96, 77))
+    w = g("ew", (32, 96, 1), scale=0.1)
+    b = g("eb", (32,), scale=0.1)
+    sc = g("es", (32,), scale=0.5)
+    res = g("er", (2, 32, 77))
+    sk = g("ek", (2, 32, 77))
+    ref = F.conv1d(x, w, b) * sc.view(1, -1, 1) + res + sk
+    y, _ = ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), ch_scale=sc.to(DEV), residual=res.to(DEV), skip=sk.to(DEV))
+    torch.testing.assert_close(y.cpu(), ref, rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("ci,co,r,t", [(256, 256, 10, 45), (256, 64, 8, 450), (64, 16, 2, 999), (16, 8, 2, 2000)])
+def test_conv_transpose(ci, co, r, t):
+    from module import ops
+    x = g(f"tx{ci}{r}", (2, ci, t))
+    w = g(f"tw{ci}{r}", (ci, co, r), scale=1.0 / np.sqrt(ci))
+    b = g(f"tb{ci}{r}", (co,), scale=0.1)
+    ref = F.conv_transpose1d(x, w, b, stride=r)
+    y, _ = ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), transposed=True)
+    assert y.shape == ref.shape
+    assert relerr(y, ref) < 2e-6
+
+
+def test_modulated_chain_matches_oracle(golden_dir):
+    """input_conv -> (gelu, FiLM, causal conv) x2 + residual, i.e. FilterBlock with one res block,
+    through the dual-output epilogue (decoder.py:112-134,146-150)."""
+    from module import ops
+    z = np.load(os.path.join(golden_dir, "blk_filter_block.npz"))
+    sd = {"n." + k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w::")}
+    x, c = torch.from_numpy(z["x"]), torch.from_numpy(z["c"])
+    ref = torch.from_numpy(z["y"])
+    C = x.shape[1]
+    ws, bs, post = [], [], []
+    for j in range(3):
+        for cc in ("c1", "c2"):
+            p = f"n.blocks.{j}.{cc}"
+            ws += [sd[p + ".to_scale.weight"], sd[p + ".to_shift.weight"]]
+            bs += [sd[p + ".to_scale.bias"], sd[p + ".to_shift.bias"]]
+            post += [torch.ones(C), torch.zeros(C)]
+    film, _ = ops.conv1d(c.to(DEV), torch.cat(ws, 0).to(DEV), torch.cat(bs, 0).to(DEV), post_add=torch.cat(post).to(DEV))
+    h, zz = ops.conv1d(x.to(DEV), sd["n.input_conv.weight"].to(DEV), sd["n.input_conv.bias"].to(DEV), film=film,
+                       film_scale_row=0, film_shift_row=C)
+    for j in range(3):
+        d = 2 ** j
+        p = f"n.blocks.{j}"
+        _, z2 = ops.conv1d(zz, sd[p + ".c1.conv.conv.weight"].to(DEV), sd[p + ".c1.conv.conv.bias"].to(DEV), dilation=d,
+                           pad_left=4 * d, pad_mode=1, out_len=x.shape[2], film=film, want_raw=False,
+                           film_scale_row=(2 * j + 1) * 2 * C, film_shift_row=(2 * j + 1) * 2 * C + C)
+        nxt = (2 * j + 2) * 2 * C
+        h, zz = ops.conv1d(z2, sd[p + ".c2.conv.conv.weight"].to(DEV), sd[p + ".c2.conv.conv.bias"].to(DEV), dilation=d,
+                           pad_left=4 * d, pad_mode=1, out_len=x.shape[2], residual=h,
+                           film=film if j < 2 else None, film_scale_row=nxt, film_shift_row=nxt + C)
+    assert relerr(h, ref) < 5e-6, relerr(h, ref)
+    sdo = dict(sd)
+    torch.testing.assert_close(h.cpu(), O.filter_block(sdo, "n", x, c), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("c,t,adaptive", [(512, 450, False), (256, 37, False), (512, 24, True), (32, 19, True)])
+def test_dwconv_norm(c, t, adaptive):
+    from module import ops
+    x = g(f"nx{c}{t}", (2, c, t))
+    sd = {"n.dw_conv.weight": g("ndw", (c, 1, 7), scale=0.3), "n.dw_conv.bias": g("ndb", (c,), scale=0.1)}
+    y0 = F.conv1d(x, sd["n.dw_conv.weight"], sd["n.dw_conv.bias"], padding=3, groups=c)
+    if adaptive:
+        cond = g("ncond", (2, 2 * c + 5, t))
+        ref = O.channel_stats_normalise(y0) * cond[:, 3:3 + c] + cond[:, 3 + c:3 + 2 * c]
+        y = ops.dwconv_norm(x.to(DEV), sd["n.dw_conv.weight"].to(DEV), sd["n.dw_conv.bias"].to(DEV), cond=cond.to(DEV),
+                            scale_row=3, shift_row=3 + c)
+    else:
+        gain, off = 1 + g("ng", (1, c, 1), scale=0.1), g("no", (1, c, 1), scale=0.1)
+        ref = O.channel_stats_normalise(y0) * gain + off
+        y = ops.dwconv_norm(x.to(DEV), sd["n.dw_conv.weight"].to(DEV), sd["n.dw_conv.bias"].to(DEV), gain=gain.to(DEV),
+                            offset=off.to(DEV))
+    torch.testing.assert_close(y.cpu(), ref, rtol=2e-5, atol=2e-5)
+
+
+def test_channel_norm_and_argmax():
+    from module import ops
+    x = g("cnx", (3, 256, 101))
+    gain, off = 1 + g("cng", (1, 256, 1), scale=0.1), g("cno", (1, 256, 1), scale=0.1)
+    ref = O.channel_stats_normalise(x) * gain + off
+    torch.testing.assert_close(ops.channel_norm(x.to(DEV), gain.to(DEV), off.to(DEV)).cpu(), ref, rtol=2e-5, atol=2e-5)
+    lg = g("amx", (2, 4096, 77))
+    lg[0, 100, 5] = lg[0, 900, 5] = 50.0          # tie -> first index
+    am = ops.argmax_channels(lg.to(DEV)).cpu()
+    assert torch.equal(am, torch.argmax(lg, dim=1).float().unsqueeze(1))
+
+
+@pytest.mark.parametrize("name", ["blk_oscillator", "blk_oscillator_carry"])
+def test_oscillator_golden(golden_dir, name):
+    from module import ops
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    sd = {"n." + k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w::")}
+    x, f0 = torch.from_numpy(z["x"]), torch.from_numpy(z["f0"])
+    amps = torch.exp(F.conv1d(x, sd["n.to_amps.weight"], sd["n.to_amps.bias"]))
+    carry = name.endswith("carry")
+    phi = torch.from_numpy(z["phi_in"]) if carry else None
+    crop0 = int(z["crop0"]) if carry else 0
+    col = 4000 if carry else 3000
+    wave, phi_out = ops.oscillator(amps.to(DEV), f0.to(DEV), phi=None if phi is None else phi.to(DEV), crop0=crop0,
+                                   phi_col=col)
+    ow, oph, dbg = O.harmonic_oscillator(sd, "n", x, f0, phi=0 if phi is None else phi, crop0=crop0, return_debug=True)
+    err = (wave.cpu() - ow).abs().max().item()
+    assert err < 2e-6, err
+    torch.testing.assert_close(wave.cpu(), torch.from_numpy(z["wave"]), rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(phi_out.cpu(), oph[:, :, col], rtol=1e-4, atol=2e-5)
+
+
+def test_oscillator_long_window_phase_exact():
+    """450-frame window, 64 harmonics: the fp64-accumulate / fp32-round phase of every sample must
+    reproduce the CPU cumsum; compared through the waveform at 1e-5."""
+    from module import ops
+    lf = 450
+    f0 = (80.0 + 400.0 * torch.from_numpy(synthetic.uniform01("f0long", 3, lf)).float()).view(1, 1, lf)
+    f0[0, 0, 100:120] = 0.0
+    amps = torch.exp(g("ampl", (1, 64, lf), scale=0.5))
+    wave, _ = ops.oscillator(amps.to(DEV), f0.to(DEV))
+    formants = F.interpolate(f0 * (torch.arange(64) + 1).view(1, 64, 1), lf * 320, mode="linear")
+    dt = torch.cumsum(formants / 16000, dim=2)
+    dt = dt - dt[:, :, 0].unsqueeze(2)
+    ref = (torch.sin(2 * np.pi * dt) * F.interpolate(amps, lf * 320, mode="linear")).mean(dim=1, keepdim=True)
+    err = (wave.cpu() - ref).abs().max().item()
+    assert err < 1e-5, err
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_pitch_transform(mode):
+    from module import ops
+    f0 = torch.from_numpy(np.round(synthetic.uniform01("pf0", 5, 2 * 450) * 600).astype(np.float32)).view(2, 1, 450)
+    f0[0, 0, :40] = 0.0
+    if mode == 0:
+        ref = torch.cat([O.pitch_transform_offline(f0[i:i + 1].clone(), -3.0, 0.8, 0.5) for i in range(2)], 0)
+        got = ops.pitch_transform_(f0.clone().to(DEV), 0, f0_rate=0.5, pitch_shift=-3.0, intonation=0.8)
+    else:
+        ref = O.pitch_transform_realtime(f0.clone() * 0.5, 2.0)
+        got = ops.pitch_transform_(f0.clone().to(DEV), 1, f0_rate=0.5, pitch_shift=2.0)
+    torch.testing.assert_close(got.cpu(), ref, rtol=3e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("L", [1600, 2560, 144000])
+def test_spectrogram(L):
+    from module.spectrogram import spectrogram
+    wav = torch.cat([synthetic.make_waveform(L, 9), synthetic.make_waveform(L, 10)], 0)
+    ref = O.spectrogram(wav)
+    got = spectrogram(wav.to(DEV)).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 2e-3 * ref.abs().max().item() * 1e-2 + 1e-3
+    assert relerr(got, ref) < 1e-5
