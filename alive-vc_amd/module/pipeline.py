@@ -1,0 +1,68 @@
+"""The conversion loop of the reference's inference.py:94-135 as a batched device pipeline.
+
+The reference walks the overlapping windows of one utterance serially (N = 1, two host syncs per
+window).  Windows are independent units (each has its own mean pitch, oscillator phase origin
+and reflect pads), so here all windows of all utterances go through the networks as one batch
+[n_windows, ...]; results are identical to per-window calls.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .common import PackedLibrary, merge_gather
+from .content_encoder import ContentEncoder
+from .decoder import Decoder
+from .f0_estimator import F0Estimator
+from .spectrogram import spectrogram
+
+
+def make_windows(wf, chunk=48000):
+    """inference.py:94-101: wf [1, L] -> windows [n, 3*chunk] (hop = chunk), total length."""
+    total = wf.shape[1]
+    wf = torch.cat([wf, torch.zeros(1, chunk * 3, device=wf.device, dtype=wf.dtype)], dim=1)
+    wf = F.pad(wf, (chunk, chunk))
+    n = (wf.shape[1] - 3 * chunk) // chunk + 1
+    return wf.unfold(1, 3 * chunk, chunk)[0, :n].contiguous(), total
+
+
+def stitch(window_out, total, chunk=48000):
+    """inference.py:132-135: keep the centre third of every window, concatenate, trim."""
+    return window_out[:, chunk:2 * chunk].reshape(1, -1)[:, :total]
+
+
+class Converter:
+    def __init__(self, content_encoder: ContentEncoder, f0_estimator: F0Estimator, decoder: Decoder, device="cuda"):
+        self.device = torch.device(device)
+        self.ce, self.pe, self.dec = content_encoder.to(device), f0_estimator.to(device), decoder.to(device)
+        self.library = None
+
+    def set_library(self, tokens):
+        """tokens [1, 768, M] (voice_library.pt layout) or an already packed PackedLibrary."""
+        self.library = tokens if isinstance(tokens, PackedLibrary) else PackedLibrary(tokens[0].to(self.device))
+        return self
+
+    def features(self, windows, pitch_shift=0.0, intonation=1.0, f0_rate=1.0):
+        """spectrogram -> f0 (+ per-window pitch transform) and content features   (inference.py:112-128)"""
+        spec = spectrogram(windows)
+        f0 = self.pe.estimate(spec)
+        f0 = ops.pitch_transform_(f0, 0, f0_rate=f0_rate, pitch_shift=pitch_shift, intonation=intonation)
+        return self.ce(spec), f0
+
+    def match(self, feat, k=4, alpha=0.0):
+        val, idx = self.library.search(feat, k)
+        return merge_gather(val, idx, 1, k, alpha, self.library.rows, feat)
+
+    def convert_windows(self, windows, k=4, alpha=0.0, pitch_shift=0.0, intonation=1.0, f0_rate=1.0, window_batch=64):
+        """windows [n, L] on the device -> waveforms [n, L]; L a multiple of 320."""
+        out = torch.empty_like(windows)
+        for i in range(0, windows.shape[0], window_batch):
+            w = windows[i:i + window_batch]
+            feat, f0 = self.features(w, pitch_shift, intonation, f0_rate)
+            feat = self.match(feat, k, alpha)
+            out[i:i + window_batch], _ = self.dec(feat, f0)
+        return out
+
+    def convert(self, wf, chunk=48000, **kw):
+        """one utterance: wf [1, L] at 16 kHz (already normalised / mono) -> [1, L]"""
+        windows, total = make_windows(wf.to(self.device), chunk)
+        return stitch(self.convert_windows(windows, **kw), total, chunk)

@@ -107,3 +107,34 @@ def test_checkpoint_roundtrip(tmp_path, nets):
     x = synthetic.gaussian("rt", 1, (1, 768, 6)).to(DEV)
     f0 = torch.full((1, 1, 6), 200.0, device=DEV)
     assert torch.equal(d2(x, f0)[0], dec(x, f0)[0])
+
+
+def test_utterance_end_to_end(golden_dir, nets):
+    """windowing + per-window pitch transform + kNN + decoder vs the reference's loop (inference.py:94-135)."""
+    from module.pipeline import Converter, make_windows
+    ce, pe, dec, cpu = nets
+    z = np.load(os.path.join(golden_dir, "utterance_small.npz"))
+    conv = Converter(ce, pe, dec).set_library(synthetic.make_library(int(z["lib_M"]), int(z["lib_seed"])))
+    wf = torch.from_numpy(z["wf"])
+    w_gpu, total = make_windows(wf.to(DEV), int(z["chunk"]))
+    w_cpu, total_cpu = O.make_windows(wf, int(z["chunk"]))
+    assert total == total_cpu and torch.equal(w_gpu.cpu(), w_cpu)
+    out = conv.convert(wf, chunk=int(z["chunk"]), k=int(z["k"]), alpha=float(z["alpha"]), pitch_shift=float(z["pitch"]),
+                       intonation=float(z["intonation"]), f0_rate=float(z["f0_rate"]))
+    err = rms(out, torch.from_numpy(z["out"]))
+    assert err < RMS_BAR, err
+
+
+def test_default_window_end_to_end(nets):
+    """one default 144000-sample window (450 frames), default CLI parameters, 5 k-vector library:
+    the full device path against the CPU oracle on the same input."""
+    from module.pipeline import Converter
+    ce, pe, dec, cpu = nets
+    lib = synthetic.make_library(5000, 21)
+    wav = synthetic.make_waveform(144000, 77)
+    conv = Converter(ce, pe, dec).set_library(lib)
+    out = conv.convert_windows(wav.to(DEV), f0_rate=0.5)
+    ref = O.convert_window(cpu[0], cpu[1], cpu[2], wav, lib, f0_rate=0.5)
+    full, mid = rms(out, ref), rms(out[:, 48000:96000], ref[:, 48000:96000])
+    print(f"450-frame window: rms error full {full:.3e}, kept centre third {mid:.3e}, signal rms {ref.pow(2).mean().sqrt():.3f}")
+    assert mid < RMS_BAR, (full, mid)

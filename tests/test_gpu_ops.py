@@ -59,9 +59,12 @@ def test_conv1d_k1_is_single_fma():
     f0 = (torch.arange(0, 4096, dtype=torch.float32) * 0.97).view(1, 1, -1)
     w = g("k1w", (512, 1, 1), scale=0.3)
     b = g("k1b", (512,), scale=0.5)
-    ref = F.conv1d(f0, w, b)
     y, _ = ops.conv1d(f0.to(DEV), w.to(DEV), b.to(DEV))
-    assert torch.equal(y.cpu(), ref)
+    fma = (w[:, 0].double() * f0[0].double() + b.double().view(-1, 1)).float().unsqueeze(0)   # fma(w, x, b), one rounding
+    assert torch.equal(y.cpu(), fma)
+    # ATen's CPU conv gives the same single-rounding result on the build host; other hosts may round the
+    # product first, so against the host's F.conv1d only closeness is required
+    torch.testing.assert_close(y.cpu(), F.conv1d(f0, w, b), rtol=3e-7, atol=1e-6)
 
 
 @pytest.mark.parametrize("act", ["gelu", "exp", "sin"])
@@ -131,8 +134,7 @@ def test_modulated_chain_matches_oracle(golden_dir):
                            pad_left=4 * d, pad_mode=1, out_len=x.shape[2], residual=h,
                            film=film if j < 2 else None, film_scale_row=nxt, film_shift_row=nxt + C)
     assert relerr(h, ref) < 5e-6, relerr(h, ref)
-    sdo = dict(sd)
-    torch.testing.assert_close(h.cpu(), O.filter_block(sdo, "n", x, c), rtol=1e-4, atol=1e-5)
+    assert relerr(h, O.filter_block(dict(sd), "n", x, c)) < 5e-6
 
 
 @pytest.mark.parametrize("c,t,adaptive", [(512, 450, False), (256, 37, False), (512, 24, True), (32, 19, True)])
