@@ -461,6 +461,9 @@ __global__ __launch_bounds__(256) void knn_merge_gather_kernel(const float* __re
     }
 }
 
+// optional instrumentation: events recorded on the search stream around the scoring kernel only
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+
 static int choose_split(int64_t Tt_pad, int tiles_total) {
     int64_t frame_tiles = Tt_pad / TILE;
     int64_t want = (1024 + frame_tiles - 1) / frame_tiles;
@@ -517,11 +520,19 @@ extern "C" int alive_knn_search(const float* src, int N, int T, const void* lib_
     int* ci = a.take<int>((size_t)Tt_pad * P * KP);
     hipStream_t s = (hipStream_t)stream;
     src_prep_kernel<<<(unsigned)(Tt_pad / 64), 256, 0, s>>>(src, T, Tt, Tt_pad, s_f32, s_bf16);
+    if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
     knn_score_kernel<<<dim3((unsigned)(Tt_pad / TILE), split), 256, 0, s>>>(s_bf16, (const unsigned short*)lib_bf16, M,
                                                                            tiles_total, tiles_per_split, P, cv, ci);
+    if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
     knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(cv, ci, P, s_f32, rows_f32, norms, Tt, idx_base, k, out_val,
                                                                out_idx);
     ALIVE_CHECK_LAUNCH("alive_knn_search");
+    return ALIVE_OK;
+}
+
+extern "C" int alive_knn_set_timing_events(void* ev_start, void* ev_stop) {
+    g_ev_start = (hipEvent_t)ev_start;
+    g_ev_stop = (hipEvent_t)ev_stop;
     return ALIVE_OK;
 }
 

@@ -66,6 +66,11 @@ int alive_knn_search(const float* src, int N, int T,
                      int64_t M, int64_t idx_base, int k,
                      float* out_val, int32_t* out_idx, void* ws, void* stream);
 
+/* Measurement hook (bench.py): when both are non-NULL hipEvent_t handles, every following
+ * alive_knn_search on this host thread records them on its stream immediately before / after the
+ * bf16 scoring kernel (the dominant kernel).  Pass NULLs to switch off. */
+int alive_knn_set_timing_events(void* ev_start, void* ev_stop);
+
 /* alive_knn_merge_gather: merge n_shards exact top-k lists ([S][Tt][k], e.g.
  * after an RCCL all-gather), pick the global top-k, gather those rows from the
  * full fp32 row table, mean over k, alpha-blend with the source.
