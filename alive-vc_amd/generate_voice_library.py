@@ -1,0 +1,83 @@
+"""Voice-library builder -- same positional/flags and on-disk format as the reference's
+generate_voice_library.py:13-43 (torch.save({'tokens': float32[1, 768, M]})).
+
+The reference fills 512 fixed slots with one random content frame from each of up to 513 random
+7680-sample clips (unseeded).  This build batches the content encoder over all clips on the
+MI355X, takes --frames-per-clip frames per clip, is seedable, and writes any M (--num-tokens,
+default 512 so the file stays loadable by the reference's VoiceLibrary()).
+"""
+import argparse
+import glob
+import os
+import random
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from module import audio_io                                     # noqa: E402
+from module.content_encoder import ContentEncoder                # noqa: E402
+from module.spectrogram import spectrogram                       # noqa: E402
+from module.voice_library import VoiceLibrary                    # noqa: E402
+
+CLIP = 7680          # WaveFileDirectory(length=7680): 24 content frames per clip
+
+
+def collect_clips(root, max_clips, rng):
+    """all non-overlapping 7680-sample clips of every wav under `root`, 16 kHz mono, peak-normalised per file
+    (module/dataset.py:25-40 of the reference)."""
+    clips = []
+    for path in sorted(glob.glob(os.path.join(root, "**", "*.wav"), recursive=True)):
+        wf, sr = audio_io.load(path)
+        wf = audio_io.resample(wf, sr, 16000)
+        wf = wf / wf.abs().max().clamp(min=1e-8)
+        wf = wf.mean(dim=0)
+        n = wf.shape[0] // CLIP
+        if n:
+            clips.append(wf[: n * CLIP].view(n, CLIP))
+    if not clips:
+        raise SystemExit(f"no usable .wav files under {root}")
+    clips = torch.cat(clips, 0)
+    order = list(range(clips.shape[0]))
+    rng.shuffle(order)
+    return clips[order[:max_clips]]
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description="Generate voice library from wave files")
+    parser.add_argument("dataset")
+    parser.add_argument("-lib", "--voice-library-path", default="voice_library.pt")
+    parser.add_argument('-cep', '--content-encoder-path', default="content_encoder.pt")
+    parser.add_argument('--num-tokens', default=512, type=int)
+    parser.add_argument('--frames-per-clip', default=1, type=int)
+    parser.add_argument('--seed', default=None, type=int)
+    parser.add_argument('-d', '--device', default='cuda')
+    args = parser.parse_args(argv)
+    rng = random.Random(args.seed)
+    device = torch.device(args.device)
+    CE = ContentEncoder().to(device)
+    CE.load_state_dict(torch.load(args.content_encoder_path, map_location=device))
+    VL = VoiceLibrary(args.num_tokens)
+    if args.seed is not None:
+        VL.tokens = torch.randn(1, 768, args.num_tokens, generator=torch.Generator().manual_seed(args.seed))
+    print("Generating Library...")
+    need = (args.num_tokens + args.frames_per_clip - 1) // args.frames_per_clip
+    clips = collect_clips(args.dataset, need, rng)
+    filled = 0
+    for s in range(0, clips.shape[0], 256):
+        feats = CE(spectrogram(clips[s:s + 256].to(device))).cpu()          # [B, 768, 24]
+        for b in range(feats.shape[0]):
+            # the reference draws frame randint(0, 7) of each clip (generate_voice_library.py:37)
+            frames = rng.sample(range(0, 8), min(args.frames_per_clip, 8))
+            for fr in frames:
+                if filled < args.num_tokens:
+                    VL.tokens[0, :, filled] = feats[b, :, fr]
+                    filled += 1
+    print(f"Writing file... ({filled} of {args.num_tokens} slots from data)")
+    torch.save(VL.state_dict(), args.voice_library_path)
+    print("Complete!")
+
+
+if __name__ == "__main__":
+    main()

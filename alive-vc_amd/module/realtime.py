@@ -1,0 +1,62 @@
+"""Streaming conversion step of the reference's realtime_inference.py:122-191 as a reusable class.
+
+int16 chunk in -> ring of `buffersize` chunks -> spectrogram / content encoder / f0 / kNN /
+decoder over the whole ring (exactly what the reference recomputes per step) -> centre chunk out
+as int16, with the oscillator phase carried through phi[:, :, end_of_output].
+"""
+import numpy as np
+import torch
+
+from . import audio_io, ops
+from .common import PackedLibrary, merge_gather
+from .spectrogram import spectrogram
+
+
+class RealtimeConverter:
+    def __init__(self, content_encoder, f0_estimator, decoder, library_tokens, device="cuda", chunk=960, buffersize=8,
+                 input_sr=16000, output_sr=16000, f0_rate=1.0, pitch=0.0, k=4, alpha=0.0, gain=0.0, input_gain=0.0):
+        self.device = torch.device(device)
+        self.ce, self.pe, self.dec = content_encoder.to(device), f0_estimator.to(device), decoder.to(device)
+        self.lib = library_tokens if isinstance(library_tokens, PackedLibrary) else PackedLibrary(library_tokens[0].to(device))
+        self.chunk, self.buffersize = chunk, buffersize
+        self.input_sr, self.output_sr = input_sr, output_sr
+        self.f0_rate, self.pitch, self.k, self.alpha, self.gain, self.input_gain = f0_rate, pitch, k, alpha, gain, input_gain
+        # realtime_inference.py:122-126
+        internal_chunk = int(chunk * (16000 / output_sr))
+        center = int(internal_chunk * buffersize) // 2
+        self.end_of_output = center + internal_chunk // 2
+        self.begin_of_output = center - internal_chunk // 2
+        frames = (chunk * buffersize * 16000 // input_sr) // 320
+        if frames < 5:
+            raise ValueError(f"ring of {buffersize} x {chunk} samples is {frames} frames; the decoder needs >= 5 "
+                             "(reflection pad 4 on the bottleneck: module/decoder.py:165 of the reference)")
+        self.ring = []
+        self.phi = 0
+        self.last_f0 = None
+
+    def step(self, data_int16: np.ndarray):
+        """one chunk of int16 samples -> converted centre chunk (int16), or None while the ring fills
+        (the reference's loop emits nothing until it holds more than `buffersize` chunks: :133-137)."""
+        self.ring.append(np.asarray(data_int16, dtype=np.int16))
+        if len(self.ring) > self.buffersize:
+            del self.ring[0]
+        else:
+            return None
+        data = np.concatenate(self.ring, 0).astype(np.float32) / 32768
+        data = torch.from_numpy(data).to(self.device).unsqueeze(0)
+        data = audio_io.resample(data, self.input_sr, 16000)
+        data = audio_io.gain(data, self.input_gain)
+        spec = spectrogram(data)
+        content = self.ce(spec)
+        f0 = self.pe.estimate(spec)
+        f0 = ops.pitch_transform_(f0, 1, f0_rate=self.f0_rate, pitch_shift=self.pitch)
+        val, idx = self.lib.search(content, self.k)
+        content = merge_gather(val, idx, 1, self.k, self.alpha, self.lib.rows, content)
+        wave, phi_out = self.dec(content, f0=f0, phi=self.phi, crop=(self.begin_of_output, self.end_of_output))
+        self.phi = phi_out[:, :, self.end_of_output].unsqueeze(2)
+        self.last_f0 = f0
+        wave = audio_io.gain(wave, self.gain)
+        wave = audio_io.resample(wave, 16000, self.output_sr)[0]
+        out = (wave.cpu().numpy() * 32768).astype(np.int16)          # C cast, no clipping (:180-183)
+        center = self.buffersize * self.chunk // 2
+        return out[center - self.chunk // 2: center + self.chunk // 2]

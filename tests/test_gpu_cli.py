@@ -1,0 +1,110 @@
+"""The drop-in CLI surface on the MI355X: inference.py / realtime_inference.py / generate_voice_library.py
+with the reference's flags, checkpoint files and library format, checked against the CPU oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import alive_oracle as O
+from module import audio_io, schema, synthetic
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "alive-vc_amd"))
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory):
+    d = tmp_path_factory.mktemp("cli")
+    sds = {"content_encoder.pt": synthetic.make_state_dict(schema.content_encoder_schema(), 2, "ce."),
+           "f0_estimator.pt": synthetic.make_state_dict(schema.f0_estimator_schema(), 2, "pe."),
+           "decoder.pt": synthetic.make_state_dict(schema.decoder_schema(), 2, "dec.")}
+    for name, sd in sds.items():
+        torch.save(sd, d / name)
+    torch.save({"tokens": synthetic.make_library(512, 5)}, d / "voice_library.pt")     # reference M = 512 file
+    os.makedirs(d / "inputs")
+    wav24 = synthetic.make_waveform(24000, 91) * 0.5            # 1 s mono at 24 kHz (BASELINE config 1 shape)
+    audio_io.save(str(d / "inputs" / "utt.wav"), wav24, 24000)
+    return d, sds, wav24
+
+
+def test_inference_cli_matches_oracle(workdir):
+    import inference
+    d, sds, wav24 = workdir
+    inference.main(["-i", str(d / "inputs"), "-o", str(d / "outputs"), "-dep", str(d / "decoder.pt"),
+                    "-cep", str(d / "content_encoder.pt"), "-f0ep", str(d / "f0_estimator.pt"),
+                    "-lib", str(d / "voice_library.pt"), "-d", "cuda", "-c", "4800", "-f0", "0.5", "-p", "2", "-a", "0.1"])
+    out, sr = audio_io.load(str(d / "outputs" / "0_utt.wav"))
+    assert sr == 24000 and out.shape == (1, 24000)
+    # oracle: same edges (this package's resampler/gain on CPU), reference loop in between
+    wf = audio_io.resample(wav24, 24000, 16000)
+    wf = (wf / wf.abs().max()).mean(dim=0, keepdim=True)
+    ref = O.convert_utterance(sds["content_encoder.pt"], sds["f0_estimator.pt"], sds["decoder.pt"], wf,
+                              synthetic.make_library(512, 5), chunk=4800, k=4, alpha=0.1, pitch_shift=2.0, f0_rate=0.5)
+    ref = audio_io.gain(audio_io.resample(ref, 16000, 24000), 1.0)
+    err = (out - ref).pow(2).mean().sqrt().item()
+    assert err < 1e-3, err
+
+
+def test_realtime_converter_matches_oracle(workdir):
+    from module.content_encoder import ContentEncoder
+    from module.decoder import Decoder
+    from module.f0_estimator import F0Estimator
+    from module.realtime import RealtimeConverter
+    d, sds, _ = workdir
+    lib = synthetic.make_library(1000, 1)
+    chunk, bs = 320, 8
+    rt = RealtimeConverter(ContentEncoder(seed=2), F0Estimator(seed=2), Decoder(seed=2), lib, "cuda", chunk=chunk,
+                           buffersize=bs, f0_rate=0.5)
+    pcm = (synthetic.make_waveform(chunk * (bs + 3), 62)[0].numpy() * 20000).astype(np.int16)
+    begin, end = O.realtime_geometry(chunk, bs)
+    assert (begin, end) == (rt.begin_of_output, rt.end_of_output)
+    phi, outs, refs = 0, [], []
+    for s in range(bs + 3):
+        o = rt.step(pcm[s * chunk:(s + 1) * chunk])
+        if s < bs:
+            assert o is None            # the reference emits nothing until the ring holds > buffersize chunks
+            continue
+        ring = torch.from_numpy(pcm[(s - bs + 1) * chunk:(s + 1) * chunk].astype(np.float32) / 32768)[None]
+        wave, phi = O.realtime_step(sds["content_encoder.pt"], sds["f0_estimator.pt"], sds["decoder.pt"], ring, lib, phi,
+                                    begin, end, f0_rate=0.5)
+        ref = (wave[0].numpy() * 32768).astype(np.int16)
+        c = bs * chunk // 2
+        refs.append(ref[c - chunk // 2: c + chunk // 2])
+        outs.append(o)
+    got, want = np.concatenate(outs).astype(np.float64), np.concatenate(refs).astype(np.float64)
+    assert got.shape == want.shape == (3 * chunk,)
+    assert np.sqrt(np.mean((got - want) ** 2)) / 32768 < 1e-3
+
+
+def test_realtime_rejects_rings_shorter_than_five_frames(workdir):
+    from module.content_encoder import ContentEncoder
+    from module.decoder import Decoder
+    from module.f0_estimator import F0Estimator
+    from module.realtime import RealtimeConverter
+    with pytest.raises(ValueError):
+        RealtimeConverter(ContentEncoder(seed=2), F0Estimator(seed=2), Decoder(seed=2), synthetic.make_library(16, 1), "cuda",
+                          chunk=160, buffersize=8)
+
+
+def test_generate_voice_library_writes_reference_format(workdir):
+    import generate_voice_library as gvl
+    from module.voice_library import VoiceLibrary
+    d, sds, _ = workdir
+    os.makedirs(d / "corpus", exist_ok=True)
+    audio_io.save(str(d / "corpus" / "a.wav"), synthetic.make_waveform(16000 * 6, 7) * 0.4, 16000)
+    gvl.main([str(d / "corpus"), "-lib", str(d / "vl_out.pt"), "-cep", str(d / "content_encoder.pt"), "--seed", "3",
+              "--num-tokens", "512", "--frames-per-clip", "4"])
+    sd = torch.load(d / "vl_out.pt")
+    assert list(sd.keys()) == ["tokens"] and tuple(sd["tokens"].shape) == (1, 768, 512) and sd["tokens"].dtype == torch.float32
+    # the first slots hold content-encoder frames of the corpus
+    wf = synthetic.make_waveform(16000 * 6, 7) * 0.4
+    wf = wf / wf.abs().max()
+    clips = wf[0, : (wf.shape[1] // 7680) * 7680].view(-1, 7680)
+    feats = O.content_encoder(sds["content_encoder.pt"], O.spectrogram(clips))        # [n, 768, 24]
+    tok = sd["tokens"][0, :, 0]
+    d2 = (feats[:, :, :8] - tok.view(1, 768, 1)).pow(2).sum(dim=1)
+    assert d2.min().item() < 1e-4 * tok.pow(2).sum().item()
+    VoiceLibrary().load_state_dict(sd)

@@ -1,0 +1,188 @@
+"""CPU tests: C-ABI exports, host-side logic (windowing, packing, WAV I/O, resampler, CLI flags) and the
+multi-GPU protocol on a world_size-2 gloo group.  No GPU compute is called."""
+import ctypes
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import alive_oracle as O
+from module import _native as nat
+from module import _pack, audio_io, schema, synthetic
+from module.pipeline import make_windows, stitch
+from module.sharded import ShardedLibrary, partition_windows, shard_bounds
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    import __graft_entry__
+    __graft_entry__.build()
+    hdr = open(os.path.join(ROOT, "include", "alive_vc.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(alive_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    L = ctypes.CDLL(nat.LIB_PATH)
+    missing = [n for n in declared if not hasattr(L, n)]
+    assert not missing, missing
+    assert declared == set(nat.PROTOTYPES), declared ^ set(nat.PROTOTYPES)
+    assert nat.lib().alive_version() == 1
+    assert nat.lib().alive_library_padded_rows(1000) == 1024
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    L = nat.lib()
+    assert L.alive_library_pack(None, 10, 768, None, None, None, None) == -1
+    assert b"null" in L.alive_last_error()
+    rc = L.alive_knn_search(1, 1, 5, 1, 1, 1, 3, 0, 4, 1, 1, 1, None)     # M < k
+    assert rc == -1 and b"fewer than k" in L.alive_last_error()
+    rc = L.alive_decoder_forward(1, 1, 1, None, 0, 0, 1, 4, 1, None, 1, None)    # Lf < 5
+    assert rc == -1 and b"at least 5 frames" in L.alive_last_error()
+
+
+def test_product_path_refuses_cpu_tensors():
+    from module.common import match_features
+    from module.content_encoder import ContentEncoder
+    with pytest.raises(RuntimeError):
+        match_features(torch.zeros(1, 768, 4), torch.zeros(1, 768, 8))
+    with pytest.raises(RuntimeError):
+        ContentEncoder(seed=2)(torch.zeros(1, 641, 4))
+    assert "oracle" not in " ".join(sys.modules[m].__file__ or "" for m in list(sys.modules)
+                                    if m.startswith("module.") and hasattr(sys.modules[m], "__file__"))
+
+
+def test_weight_tables_cover_the_schema():
+    for mid, (sch, pk) in enumerate([(schema.content_encoder_schema(), _pack.pack_content_encoder),
+                                     (schema.f0_estimator_schema(), _pack.pack_f0_estimator),
+                                     (schema.decoder_schema(), _pack.pack_decoder)]):
+        packed = pk(synthetic.make_state_dict(sch, 2))
+        assert set(packed) == set(nat.weight_names(mid))
+        for k, v in packed.items():
+            assert v.dtype == torch.float32 and v.is_contiguous()
+            if k.endswith(".W"):
+                assert v.shape[0] % 16 == 0 and v.shape[1] % 16 == 0
+    p = _pack.pack_decoder(synthetic.make_state_dict(schema.decoder_schema(), 2))
+    assert p["flt.film.W"].shape == (4128, 512) and p["flt.film.post"].sum().item() == 2064
+    w = torch.arange(2 * 3 * 4, dtype=torch.float32).view(2, 3, 4)            # ConvT [Ci=2, Co=3, r=4]
+    W, b = _pack.pack_convT(w, torch.tensor([1.0, 2.0, 3.0]))
+    assert W[1 * 4 + 2, 1].item() == w[1, 1, 2].item() and b.tolist() == [1.0] * 4 + [2.0] * 4 + [3.0] * 4
+
+
+@pytest.mark.parametrize("L", [1, 15999, 16000, 48000, 100001])
+def test_windowing_equals_oracle(L):
+    wf = synthetic.make_waveform(L, 60)
+    w, total = make_windows(wf, 48000)
+    ow, ot = O.make_windows(wf, 48000)
+    assert total == ot and torch.equal(w, ow)
+    assert stitch(w, total, 48000).shape == (1, L)
+    assert torch.equal(stitch(w, total, 48000), wf)          # centre thirds tile the input exactly
+
+
+def test_wav_roundtrip_and_resampler(tmp_path):
+    x = synthetic.make_waveform(24000, 5) * 0.3
+    for enc, tol in (("float32", 0.0), ("pcm16", 1.0 / 32768)):
+        p = str(tmp_path / f"a_{enc}.wav")
+        audio_io.save(p, x, 24000, enc)
+        y, sr = audio_io.load(p)
+        assert sr == 24000 and y.shape == x.shape and (y - x).abs().max().item() <= tol
+    assert audio_io.resample(x, 16000, 16000) is x
+    t = torch.arange(24000, dtype=torch.float64) / 24000
+    tone = torch.sin(2 * np.pi * 440 * t).float()[None]
+    down = audio_io.resample(tone, 24000, 16000)
+    assert down.shape == (1, 16000)
+    ref = torch.sin(2 * np.pi * 440 * torch.arange(16000, dtype=torch.float64) / 16000).float()[None]
+    assert (down - ref)[:, 200:-200].abs().max().item() < 2e-3
+    up = audio_io.resample(down, 16000, 24000)
+    assert up.shape == (1, 24000) and (up - tone)[:, 300:-300].abs().max().item() < 4e-3
+    assert abs(audio_io.gain(torch.ones(1), 1.0).item() - 10 ** 0.05) < 1e-6
+
+
+def test_cli_flags_match_the_reference():
+    sys.path.insert(0, os.path.join(ROOT, "alive-vc_amd"))
+    import importlib
+    inf = importlib.import_module("inference").build_parser()
+    d = vars(inf.parse_args([]))
+    assert (d["inputs"], d["outputs"], d["decoder_path"], d["chunk"], d["k"], d["gain"], d["alpha"], d["f0_rate"],
+            d["intonation"], d["pitch"], d["voice_library_path"], d["target"]) == \
+        ("./inputs/", "./outputs/", "decoder.pt", 48000, 4, 1.0, 0.0, 1.0, 1.0, 0, "NONE", "NONE")
+    rt = importlib.import_module("realtime_inference").build_parser()
+    d = vars(rt.parse_args([]))
+    assert (d["buffersize"], d["chunk"], d["input_sr"], d["output_sr"], d["gain"], d["k"]) == (8, 960, 16000, 16000, 0.0, 4)
+    for flag in ("-dep", "-cep", "-f0ep", "-f0", "-p", "-t", "-a", "-lib", "-wpe", "-isr", "-osr", "-lsr", "-ic", "-oc", "-lc",
+                 "-ig", "-b", "-c", "-l", "-fp16"):
+        assert flag in rt._option_string_actions, flag
+
+
+def test_shard_bounds_and_window_partition():
+    assert shard_bounds(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert shard_bounds(1_000_000, 8)[7] == (875000, 1000000)
+    cover = []
+    for r in range(3):
+        s = partition_windows(384, 3, r)
+        cover += list(range(384))[s]
+    assert cover == list(range(384))
+
+
+def _cpu_search_factory(lib_DxM, begin, end):
+    """oracle-arithmetic stand-in for the HIP search of one slab (test only)."""
+    slab = lib_DxM[:, begin:end]
+
+    def search(source, k):
+        s = source.transpose(1, 2)
+        r = slab.t().unsqueeze(0).expand(s.shape[0], -1, -1)
+        cos = torch.bmm(s / torch.norm(s, dim=2, keepdim=True), (r / torch.norm(r, dim=2, keepdim=True)).transpose(1, 2))
+        top = torch.topk(cos, k, dim=2)
+        return top.values.reshape(-1, k).contiguous(), (top.indices.reshape(-1, k) + begin).to(torch.int32).contiguous()
+    return search
+
+
+def _cpu_merge_factory(lib_DxM):
+    def merge(gv, gi, S, k, alpha, source):
+        n, d, t = source.shape
+        v = gv.permute(1, 0, 2).reshape(n * t, S * k)
+        i = gi.permute(1, 0, 2).reshape(n * t, S * k).long()
+        best = torch.topk(v, k, dim=1).indices
+        sel = torch.gather(i, 1, best)                                    # [Tt, k]
+        picked = lib_DxM.t()[sel].mean(dim=1).view(n, t, d).transpose(1, 2)
+        return picked * (1 - alpha) + source * alpha
+    return merge
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lib = synthetic.make_library(777, 31)[0]
+        src = synthetic.gaussian("sh.src", 32, (2, 768, 21))
+        b, e = shard_bounds(777, world)[rank]
+        sl = ShardedLibrary(_cpu_search_factory(lib, b, e), _cpu_merge_factory(lib))
+        out = sl.match(src, k=4, alpha=0.25)
+        ref = O.match_features(src, lib.unsqueeze(0).expand(2, -1, -1), 4, 0.25)
+        # data-parallel windows: every rank converts its own slice; gather on rank 0 reproduces the whole
+        mine = partition_windows(2, world, rank)
+        parts = [None] * world
+        dist.all_gather_object(parts, out[mine])
+        whole = torch.cat(parts, 0)
+        q.put((rank, float((out - ref).abs().max()), float((whole - ref).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_knn_protocol_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, e1, e2 in res:
+        assert e1 < 1e-5 and e2 < 1e-5, res
