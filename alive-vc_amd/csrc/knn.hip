@@ -23,10 +23,8 @@ namespace {
 
 constexpr int D = ALIVE_DIM;          // 768
 constexpr int KP = ALIVE_KPRIME;      // 16
-constexpr int TILE = 128;             // frames per block == library rows per tile
-constexpr int BK = 64;                // bf16 k per stage (128-B rows in LDS)
-constexpr int NKS = D / BK;           // 12
-constexpr int MAX_SPLIT = 32;         // max library splits (grid.y); candidates/frame = split*2*KP <= 1024
+constexpr int TILE = 128;             // library row padding granule
+constexpr int MAX_SPLIT = 64;         // max library splits (grid.y); candidates/frame = split*KP <= 1024
 
 // ----------------------------------------------------------------------------------------------
 // packing
@@ -109,8 +107,16 @@ __global__ __launch_bounds__(256) void src_prep_kernel(const float* __restrict__
 }
 
 // ----------------------------------------------------------------------------------------------
-// scoring
+// scoring: frames stationary in registers, library streamed through LDS by LDS-DMA
 // ----------------------------------------------------------------------------------------------
+// One block = 4 waves = 256 source frames (64 per wave).  A wave keeps the bf16 B-operand fragments of
+// its 64 frames for ALL of K = 768 in registers (2 x 48 x 4 = 384 VGPRs; one wave per SIMD, 512-register
+// budget), so the only operand that moves in the main loop is the library: tiles of 32 rows x 768 k
+// (48 KB) are copied global -> LDS by `global_load_lds_dwordx4` (no VGPR round trip, no ds_write) into
+// a double buffer while the previous tile is consumed; one barrier per tile (96 MFMAs per wave).
+// DMA pieces are 8 rows x 128 B (full lines from L2); the 16-B chunk order inside a line is XOR-swizzled
+// on the SOURCE address (the LDS image of an LDS-DMA is lane-linear) and pieces sit at a 1152-B stride,
+// which together make every ds_read_b128 of an A fragment conflict-free.
 struct ListRef {
     float* v;
     int* i;
@@ -135,146 +141,132 @@ __device__ __forceinline__ float list_insert(ListRef L, float val, int idx) {
     return mn;
 }
 
-__global__ __launch_bounds__(256) void knn_score_kernel(const unsigned short* __restrict__ s_bf16,
-                                                        const unsigned short* __restrict__ lib, int64_t M, int tiles_total,
-                                                        int tiles_per_split, int P, float* __restrict__ cand_val,
-                                                        int* __restrict__ cand_idx) {
-    // one LDS array: [A tile 16 KB][B tile 16 KB][lists: 256 x KP x (val,idx) 32 KB]
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE * BK * 2 + 2 * TILE * KP * 8];
-    unsigned char* As = smem;
-    unsigned char* Bs = smem + TILE * BK * 2;
-    float* Lv = (float*)(smem + 2 * TILE * BK * 2);
-    int* Li = (int*)(Lv + 2 * TILE * KP);
+constexpr int FT = 256;                  // frames per block
+constexpr int LT = 32;                   // library rows per tile
+constexpr int NK16 = D / 16;             // 48 MFMA k-steps
+constexpr int PIECE = 1152;              // LDS bytes reserved per 1-KB DMA piece (stagger of 128 B per odd piece)
+constexpr int NPIECE = 4 * (D / 64);     // 4 row groups x 12 k-segments = 48
+constexpr int ABUF = NPIECE * PIECE;     // 55296 B per tile buffer
+constexpr int SCORE_LDS = 2 * ABUF + FT * KP * 8;   // 143360 B
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;              // wave tile: 64 library rows (wm) x 64 frames (wn)
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short* __restrict__ s_bf16,
+                                                           const unsigned short* __restrict__ lib, int64_t M, int tiles_total,
+                                                           int tiles_per_split, int P, float* __restrict__ cand_val,
+                                                           int* __restrict__ cand_idx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* Lv = (float*)(smem + 2 * ABUF);
+    int* Li = (int*)(Lv + FT * KP);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
-    const int64_t frame0 = (int64_t)blockIdx.x * TILE;
+    const int64_t frame0 = (int64_t)blockIdx.x * FT;
     const int split = blockIdx.y;
     const int tile_begin = split * tiles_per_split;
     int tile_end = tile_begin + tiles_per_split;
     if (tile_end > tiles_total) tile_end = tiles_total;
 
-    for (int e = tid; e < 2 * TILE * KP; e += 256) { Lv[e] = -INFINITY; Li[e] = -1; }
+    for (int e = tid; e < FT * KP; e += 256) { Lv[e] = -INFINITY; Li[e] = -1; }
 
-    // staging map: 1024 16-B chunks per operand tile -> 4 per thread; chunk (row, c) lands at c ^ (row & 7)
-    const int st_row = tid >> 3, st_c = tid & 7;        // rows st_row + 32*i
-    const unsigned short* gB = s_bf16 + (size_t)(frame0 + st_row) * D + st_c * 8;
+    // DMA source of this lane inside a piece: row (lane>>3) of the wave's 8-row group, chunk (lane&7)^(lane>>3)
+    const int dma_row = 8 * w + (lane >> 3);
+    const int dma_chunk = (lane & 7) ^ (lane >> 3);
+    auto issue_tile = [&](int tile, int buf) {
+        const unsigned short* g = lib + ((size_t)tile * LT + dma_row) * D + dma_chunk * 8;
+        unsigned char* l = smem + buf * ABUF + w * PIECE;
+#pragma unroll
+        for (int sg = 0; sg < D / 64; ++sg)
+            __builtin_amdgcn_global_load_lds((gptr_t)(g + sg * 64), (lptr_t)(l + sg * 4 * PIECE), 16, 0, 0);
+    };
+    if (tile_begin < tile_end) issue_tile(tile_begin, 0);
 
-    // this lane's two list slots (frame columns) inside the wm half
+    // stationary B fragments: frame = frame0 + 64 w + 32 ni + lr, k = 16 ks + 8 lh .. +7
+    bf16x8 bq[2][NK16];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const unsigned short* fp = s_bf16 + (size_t)(frame0 + 64 * w + 32 * ni + lr) * D + 8 * lh;
+#pragma unroll
+        for (int ks = 0; ks < NK16; ++ks) bq[ni][ks] = *(const bf16x8*)(fp + 16 * ks);
+    }
+
+    // A-fragment read addresses: row lr -> piece group q = lr>>3, line rr = lr&7; chunk ((ks&3)*2+lh) ^ rr
+    const int rr = lr & 7;
+    int a_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_off[j] = (lr >> 3) * PIECE + rr * 128 + ((((j * 2 + lh) ^ rr)) << 4);
+
     ListRef lists[2];
     float thr[2];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-        int col = wn * 64 + ni * 32 + lr;
-        lists[ni].v = Lv + (size_t)(wm * TILE + col) * KP;
-        lists[ni].i = Li + (size_t)(wm * TILE + col) * KP;
+        int col = 64 * w + 32 * ni + lr;
+        lists[ni].v = Lv + (size_t)col * KP;
+        lists[ni].i = Li + (size_t)col * KP;
         thr[ni] = -INFINITY;
     }
-    __syncthreads();
+    __syncthreads();                                   // lists initialised, tile_begin landed (vmcnt(0) + barrier)
 
     for (int tile = tile_begin; tile < tile_end; ++tile) {
-        const int64_t row0 = (int64_t)tile * TILE;
-        const unsigned short* gA = lib + (size_t)(row0 + st_row) * D + st_c * 8;
-        f32x16 acc[2][2];
+        const int buf = (tile - tile_begin) & 1;
+        if (tile + 1 < tile_end) issue_tile(tile + 1, buf ^ 1);
+        const unsigned char* Ab = smem + buf * ABUF;
+        f32x16 acc0, acc1;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+        // A fragments are read two k-steps ahead of their MFMAs (three rotating registers)
+        bf16x8 a[3];
+        a[0] = *(const bf16x8*)(Ab + a_off[0]);
+        a[1] = *(const bf16x8*)(Ab + a_off[1]);
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-
-        u32x4 ra[4], rb[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *(const u32x4*)(gA + (size_t)i * 32 * D);
-            rb[i] = *(const u32x4*)(gB + (size_t)i * 32 * D);
-        }
-        for (int ks = 0; ks < NKS; ++ks) {
-            __syncthreads();                            // previous stage fully consumed
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int row = st_row + 32 * i;
-                int off = row * (BK * 2) + ((st_c ^ (row & 7)) << 4);
-                *(u32x4*)(As + off) = ra[i];
-                *(u32x4*)(Bs + off) = rb[i];
-            }
-            __syncthreads();
-            if (ks + 1 < NKS) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    ra[i] = *(const u32x4*)(gA + (size_t)i * 32 * D + (ks + 1) * BK);
-                    rb[i] = *(const u32x4*)(gB + (size_t)i * 32 * D + (ks + 1) * BK);
-                }
-            }
-#pragma unroll
-            for (int k16 = 0; k16 < 4; ++k16) {
-                const int c = k16 * 2 + lh;             // 16-B chunk holding k = 16*k16 + 8*lh .. +7
-                bf16x8 fa[2], fb[2];
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    int row = wm * 64 + a * 32 + lr;
-                    fa[a] = *(const bf16x8*)(As + row * (BK * 2) + ((c ^ (row & 7)) << 4));
-                }
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    int row = wn * 64 + b * 32 + lr;
-                    fb[b] = *(const bf16x8*)(Bs + row * (BK * 2) + ((c ^ (row & 7)) << 4));
-                }
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
-            }
+        for (int ks = 0; ks < NK16; ++ks) {
+            if (ks + 2 < NK16) a[(ks + 2) % 3] = *(const bf16x8*)(Ab + a_off[(ks + 2) & 3] + ((ks + 2) >> 2) * 4 * PIECE);
+            __builtin_amdgcn_sched_barrier(0);          // keep the read ahead of this step's MFMAs (hipcc otherwise
+                                                        // sinks it next to its use and waits lgkmcnt(0) every step)
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % 3], bq[0][ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % 3], bq[1][ks], acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
-        // ---- fold the 64x64 wave tile into the per-frame candidate lists ----
-        // acc[a][b][r]: library row = row0 + wm*64 + a*32 + (r&3) + 8*(r>>2) + 4*lh, frame col = wn*64 + b*32 + lr
-        const bool ragged = row0 + TILE > M;
+        // ---- fold the 32 x 64 wave tile into the per-frame candidate lists ----
+        // acc{ni}[r]: library row = row0 + (r&3) + 8*(r>>2) + 4*lh, frame column = 64 w + 32 ni + lr
+        const int64_t row0 = (int64_t)tile * LT;
+        const bool ragged = row0 + LT > M;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int ni = 0; ni < 2; ++ni) {
+            f32x16& acc = ni == 0 ? acc0 : acc1;
             float mx = -INFINITY;
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (ragged) {
-                        int64_t row = row0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (row >= M) acc[a][b][r] = -INFINITY;
-                    }
-                    mx = fmaxf(mx, acc[a][b][r]);
-                }
-            if (mx > thr[b]) {
+            for (int r = 0; r < 16; ++r) {
+                if (ragged && row0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= M) acc[r] = -INFINITY;
+                mx = fmaxf(mx, acc[r]);
+            }
+            if (mx > thr[ni]) {
                 // the two half-waves share a list: serialise them (LDS ops of one wave execute in order)
 #pragma unroll 1
                 for (int half = 0; half < 2; ++half) {
                     if (lh == half) {
-                        float t = thr[b];
+                        float t = list_insert(lists[ni], -INFINITY, -1);       // refresh the threshold
 #pragma unroll
-                        for (int a = 0; a < 2; ++a)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                float v = acc[a][b][r];
-                                if (v > t) {
-                                    int row = (int)(row0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
-                                    t = list_insert(lists[b], v, row);
-                                }
-                            }
-                        thr[b] = t;
+                        for (int r = 0; r < 16; ++r) {
+                            float v = acc[r];
+                            if (v > t) t = list_insert(lists[ni], v, (int)(row0 + (r & 3) + 8 * (r >> 2) + 4 * lh));
+                        }
+                        thr[ni] = t;
                     }
                 }
             }
         }
+        __syncthreads();                               // next tile landed (vmcnt(0)), this buffer free for tile+2
     }
 
-    // ---- write this block's lists: cand[frame][P][KP], list id = split*2 + wm ----
-    __syncthreads();
-    for (int e = tid; e < 2 * TILE * KP; e += 256) {
+    // ---- write this block's lists: cand[frame][P][KP], list id = split ----
+    for (int e = tid; e < FT * KP; e += 256) {
         int k = e % KP;
-        int col = (e / KP) % TILE;
-        int w = e / (KP * TILE);
-        size_t o = (((size_t)(frame0 + col)) * P + split * 2 + w) * KP + k;
+        int col = e / KP;
+        size_t o = (((size_t)(frame0 + col)) * P + split) * KP + k;
         cand_val[o] = Lv[e];
         cand_idx[o] = Li[e];
     }
@@ -464,13 +456,34 @@ __global__ __launch_bounds__(256) void knn_merge_gather_kernel(const float* __re
 // optional instrumentation: events recorded on the search stream around the scoring kernel only
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 
-static int choose_split(int64_t Tt_pad, int tiles_total) {
-    int64_t frame_tiles = Tt_pad / TILE;
-    int64_t want = (1024 + frame_tiles - 1) / frame_tiles;
-    if (want > MAX_SPLIT) want = MAX_SPLIT;
-    if (want > tiles_total) want = tiles_total;
-    if (want < 1) want = 1;
-    return (int)want;
+struct SearchPlan {
+    int64_t Tt, Tt_pad;
+    int tiles_total, split, tiles_per_split, P;
+};
+
+// Grid = (Tt_pad / 256 frame blocks) x (split library ranges), one block per CU at a time (1 wave / SIMD).
+// The split is chosen so that the last round of blocks over the 256 CUs is as full as possible.
+static SearchPlan make_plan(int64_t Tt, int64_t M) {
+    SearchPlan p;
+    p.Tt = Tt;
+    p.Tt_pad = (Tt + FT - 1) / FT * FT;
+    p.tiles_total = (int)(((M + TILE - 1) / TILE * TILE) / LT);
+    const int64_t fb = p.Tt_pad / FT;
+    int max_split = p.tiles_total / 8;                 // at least 8 tiles (256 rows) per block
+    if (max_split > MAX_SPLIT) max_split = MAX_SPLIT;
+    if (max_split < 1) max_split = 1;
+    int best = 1;
+    double best_eff = -1.0;
+    for (int sp = 1; sp <= max_split; ++sp) {
+        int64_t blocks = fb * sp;
+        int64_t rounds = (blocks + 255) / 256;
+        double eff = (double)blocks / (double)(rounds * 256);
+        if (eff > best_eff + 0.02) { best_eff = eff; best = sp; }
+    }
+    p.split = best;
+    p.tiles_per_split = (p.tiles_total + best - 1) / best;
+    p.P = best;
+    return p;
 }
 
 }  // namespace
@@ -490,13 +503,11 @@ extern "C" int alive_library_pack(const float* tokens, int64_t M, int Dd, void* 
 }
 
 extern "C" size_t alive_knn_workspace_bytes(int64_t Tt, int64_t M) {
-    int64_t Tt_pad = (Tt + TILE - 1) / TILE * TILE;
-    int tiles_total = (int)(alive_library_padded_rows(M) / TILE);
-    int split = choose_split(Tt_pad, tiles_total);
+    SearchPlan p = make_plan(Tt, M);
     size_t b = 0;
-    b += align_up((size_t)Tt * D * 4, 256);                 // s_f32
-    b += align_up((size_t)Tt_pad * D * 2, 256);             // s_bf16
-    b += 2 * align_up((size_t)Tt_pad * split * 2 * KP * 4, 256);   // candidate lists
+    b += align_up((size_t)Tt * D * 4, 256);                        // s_f32
+    b += align_up((size_t)p.Tt_pad * D * 2, 256);                  // s_bf16
+    b += 2 * align_up((size_t)p.Tt_pad * p.P * KP * 4, 256);       // candidate lists
     return b + 1024;
 }
 
@@ -507,25 +518,29 @@ extern "C" int alive_knn_search(const float* src, int N, int T, const void* lib_
     ALIVE_CHECK_ARG(N > 0 && T > 0, "alive_knn_search: empty source");
     ALIVE_CHECK_ARG(k >= 1 && k <= ALIVE_MAX_K, "alive_knn_search: k=%d outside [1,%d]", k, ALIVE_MAX_K);
     ALIVE_CHECK_ARG(M >= k, "alive_knn_search: library shard has %lld vectors, fewer than k=%d", (long long)M, k);
-    const int64_t Tt = (int64_t)N * T;
-    const int64_t Tt_pad = (Tt + TILE - 1) / TILE * TILE;
-    const int tiles_total = (int)(alive_library_padded_rows(M) / TILE);
-    const int split = choose_split(Tt_pad, tiles_total);
-    const int tiles_per_split = (tiles_total + split - 1) / split;
-    const int P = split * 2;
+    const SearchPlan p = make_plan((int64_t)N * T, M);
     Arena a(ws);
-    float* s_f32 = a.take<float>((size_t)Tt * D);
-    unsigned short* s_bf16 = a.take<unsigned short>((size_t)Tt_pad * D);
-    float* cv = a.take<float>((size_t)Tt_pad * P * KP);
-    int* ci = a.take<int>((size_t)Tt_pad * P * KP);
+    float* s_f32 = a.take<float>((size_t)p.Tt * D);
+    unsigned short* s_bf16 = a.take<unsigned short>((size_t)p.Tt_pad * D);
+    float* cv = a.take<float>((size_t)p.Tt_pad * p.P * KP);
+    int* ci = a.take<int>((size_t)p.Tt_pad * p.P * KP);
     hipStream_t s = (hipStream_t)stream;
-    src_prep_kernel<<<(unsigned)(Tt_pad / 64), 256, 0, s>>>(src, T, Tt, Tt_pad, s_f32, s_bf16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)knn_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_LDS);
+        if (e != hipSuccess) {
+            alive_set_error("alive_knn_search: cannot reserve %d B of LDS: %s", SCORE_LDS, hipGetErrorString(e));
+            return ALIVE_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    src_prep_kernel<<<(unsigned)(p.Tt_pad / 64), 256, 0, s>>>(src, T, p.Tt, p.Tt_pad, s_f32, s_bf16);
     if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
-    knn_score_kernel<<<dim3((unsigned)(Tt_pad / TILE), split), 256, 0, s>>>(s_bf16, (const unsigned short*)lib_bf16, M,
-                                                                           tiles_total, tiles_per_split, P, cv, ci);
+    knn_score_kernel<<<dim3((unsigned)(p.Tt_pad / FT), p.split), 256, SCORE_LDS, s>>>(
+        s_bf16, (const unsigned short*)lib_bf16, M, p.tiles_total, p.tiles_per_split, p.P, cv, ci);
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
-    knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(cv, ci, P, s_f32, rows_f32, norms, Tt, idx_base, k, out_val,
-                                                               out_idx);
+    knn_rescore_kernel<<<(unsigned)((p.Tt + 3) / 4), 256, 0, s>>>(cv, ci, p.P, s_f32, rows_f32, norms, p.Tt, idx_base, k,
+                                                                 out_val, out_idx);
     ALIVE_CHECK_LAUNCH("alive_knn_search");
     return ALIVE_OK;
 }
