@@ -16,20 +16,12 @@
 // Reference call sites replaced: every nn.Conv1d / nn.ConvTranspose1d of
 // module/common.py:48-51,88-92, content_encoder.py:15-19, f0_estimator.py:15-20,
 // decoder.py:16-17,41,61,108-110,141,164-182.
-#include "common.h"
+#include "conv_epilogue.h"
 
 namespace {
 
 constexpr int BK = 16;
 constexpr int A_LD = BK + 4;   // 20 floats = 80 B rows: keeps b128 reads 16-B aligned, spreads banks
-
-// Kept out of line: 64 inlined copies of erff/expf/sinf (one per accumulator element) blow the unrolled
-// epilogue past the point where the accumulators stay in registers.
-__device__ __attribute__((noinline)) float apply_act(float v, int act) {
-    if (act == 1) return gelu_erf(v);
-    if (act == 2) return expf(v);
-    return sinf(v);
-}
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(AliveConv p, unsigned kw_magic, float film_ratio) {
@@ -147,8 +139,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(AliveConv p, unsigned kw
     }
 
     // ---- epilogue ----
-    const int Tfull = p.Tout * p.up;
-    const int co_out = p.Co / p.up;
 #pragma unroll
     for (int nn = 0; nn < NR; ++nn) {
         const int t = t0 + wn * TN + nn * 16 + lr;
@@ -161,27 +151,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(AliveConv p, unsigned kw
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm * TM + m * 16 + lq * 4 + r;
                 if (row >= p.Co) continue;
-                float v = acc[m][nn][r];
-                if (p.act != 0) v = apply_act(v, p.act);
-                if (p.post_add != nullptr) v = v + p.post_add[row];
-                if (p.ch_scale != nullptr) v = v * p.ch_scale[row];
-                if (p.up == 1) {
-                    const size_t o = ((size_t)n * p.Co + row) * p.Tout + t;
-                    if (p.residual != nullptr) v = v + p.residual[o];
-                    if (p.skip != nullptr) v = v + p.skip[o];
-                    if (p.Y != nullptr) p.Y[o] = v;
-                    if (p.Z != nullptr) {
-                        const float* fs = p.film + ((size_t)n * p.film_rows + p.film_scale_row + row) * p.Lf;
-                        const float* fh = p.film + ((size_t)n * p.film_rows + p.film_shift_row + row) * p.Lf;
-                        float sc = lerp_apply(lp, fs[lp.i0], fs[lp.i1]);
-                        float sh = lerp_apply(lp, fh[lp.i0], fh[lp.i1]);
-                        float g = apply_act(v, 1);
-                        p.Z[o] = g * sc + sh;
-                    }
-                } else {
-                    const int co = row / p.up, jj = row - co * p.up;
-                    p.Y[((size_t)n * co_out + co) * Tfull + (size_t)t * p.up + jj] = v;
-                }
+                conv_epilogue_store(p, n, row, t, acc[m][nn][r], lp);
             }
         }
     }
@@ -189,11 +159,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(AliveConv p, unsigned kw
 
 }  // namespace
 
+int alive_conv_split_launch(const AliveConv* d, float ratio, hipStream_t s);
+
 extern "C" int alive_conv1d(const AliveConv* d, void* stream) {
     ALIVE_CHECK_ARG(d && d->W && d->X, "alive_conv1d: null W/X");
     ALIVE_CHECK_ARG(d->N > 0 && d->Ci > 0 && d->Co > 0 && d->Tin > 0 && d->Tout > 0, "alive_conv1d: bad sizes");
     ALIVE_CHECK_ARG(d->KW >= 1 && (d->KW <= 16 || d->Ci == 1) && d->stride >= 1 && d->dil >= 1 && d->up >= 1, "alive_conv1d: bad geometry");
-    ALIVE_CHECK_ARG(d->K_pad % 16 == 0 && d->K_pad >= d->Ci * d->KW, "alive_conv1d: K_pad %d for K %d", d->K_pad, d->Ci * d->KW);
+    ALIVE_CHECK_ARG(d->precision == 1 || (d->K_pad % 16 == 0 && d->K_pad >= d->Ci * d->KW), "alive_conv1d: K_pad %d for K %d", d->K_pad, d->Ci * d->KW);
+    ALIVE_CHECK_ARG(d->precision == 0 || d->precision == 1, "alive_conv1d: precision");
     ALIVE_CHECK_ARG(d->Ci * d->KW < 32768, "alive_conv1d: K too large");
     ALIVE_CHECK_ARG(d->Y || d->Z, "alive_conv1d: no output");
     if (d->up > 1) {
@@ -202,6 +175,7 @@ extern "C" int alive_conv1d(const AliveConv* d, void* stream) {
     ALIVE_CHECK_ARG(d->pad_mode >= 0 && d->pad_mode <= 2, "alive_conv1d: pad_mode");
     if (d->pad_mode != 0) ALIVE_CHECK_ARG(d->pad_left < d->Tin, "alive_conv1d: reflect pad %d needs Tin > pad (Tin %d)", d->pad_left, d->Tin);
     if (d->Z) ALIVE_CHECK_ARG(d->film && d->Lf > 0, "alive_conv1d: Z needs film");
+    if (d->precision == 1) return alive_conv_split_launch(d, d->Z ? (float)d->Lf / (float)d->Tout : 0.0f, (hipStream_t)stream);
     const unsigned magic = d->Ci == 1 ? 0u : (unsigned)(((1u << 20) + d->KW - 1) / d->KW);
     const float ratio = d->Z ? (float)d->Lf / (float)d->Tout : 0.0f;
     hipStream_t s = (hipStream_t)stream;

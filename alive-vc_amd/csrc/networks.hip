@@ -97,6 +97,14 @@ AliveConv pw_desc(const float* W, const float* b, const float* X, int N, int Ci,
     return conv_desc(W, b, X, N, Ci, T, Co, 1, 1, 1, 0, 0, T, Y);
 }
 
+// route a conv to the split-bf16 MFMA kernel (weights packed by module/_pack.py::pack_conv_split)
+AliveConv split(AliveConv d) {
+    d.precision = 1;
+    d.Ci_pad = (d.Ci + 31) & ~31;
+    return d;
+}
+constexpr bool F_SPLIT[4] = {true, true, false, false};   // filter scales on the split kernel (C = 256, 64)
+
 #define RUN(expr)                     \
     do {                              \
         int rc_ = (expr);             \
@@ -115,15 +123,17 @@ struct ConvNeXtW {
 
 // x <- x + scale * pw2(gelu(pw1(norm(dw(x)))))      (common.py:54-62 / 74-82)
 int convnext_layer(const ConvNeXtW& w, float* x, float* ybuf, float* hbuf, int N, int C, int H, int T, const float* cond,
-                   int cond_rows, int scale_row, int shift_row, void* s) {
+                   int cond_rows, int scale_row, int shift_row, bool use_split, void* s) {
     RUN(alive_dwconv_norm(x, N, C, T, w.dw_w, w.dw_b, cond ? 1 : 0, w.gain, w.offset, cond, cond_rows, scale_row,
                           shift_row, NORM_EPS, ybuf, s));
     AliveConv d1 = pw_desc(w.pw1W, w.pw1b, ybuf, N, C, T, H, hbuf);
     d1.act = 1;
+    if (use_split) d1 = split(d1);
     RUN(alive_conv1d(&d1, s));
     AliveConv d2 = pw_desc(w.pw2W, w.pw2b, hbuf, N, H, T, C, x);
     d2.ch_scale = w.scale;
     d2.residual = x;
+    if (use_split) d2 = split(d2);
     RUN(alive_conv1d(&d2, s));
     return ALIVE_OK;
 }
@@ -191,7 +201,7 @@ extern "C" int alive_content_encoder(const float* const* w, const float* spec, i
     RUN(alive_conv1d(&d, stream));
     for (int i = 0; i < 4; ++i) {
         ConvNeXtW cw(t, false);
-        RUN(convnext_layer(cw, x, y, h, N, CE_C, CE_H, T, nullptr, 0, 0, 0, stream));
+        RUN(convnext_layer(cw, x, y, h, N, CE_C, CE_H, T, nullptr, 0, 0, 0, false, stream));
     }
     const float* oW = t.next(); const float* ob = t.next();
     AliveConv o = pw_desc(oW, ob, x, N, CE_C, T, CE_OUT, out);
@@ -217,7 +227,7 @@ extern "C" int alive_f0_estimate(const float* const* w, const float* spec, int N
     RUN(alive_conv1d(&d, stream));
     for (int i = 0; i < 4; ++i) {
         ConvNeXtW cw(t, false);
-        RUN(convnext_layer(cw, x, y, h, N, PE_C, PE_H, T, nullptr, 0, 0, 0, stream));
+        RUN(convnext_layer(cw, x, y, h, N, PE_C, PE_H, T, nullptr, 0, 0, 0, false, stream));
     }
     const float* g = t.next(); const float* of = t.next();
     RUN(alive_channel_norm(x, N, PE_C, T, g, of, NORM_EPS, y, stream));
@@ -275,23 +285,23 @@ extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, c
     const int Lw = Lf * SEG;
     // -- FeatureExtractor (decoder.py:43-48)
     const float* inW = t.next(); const float* inb = t.next();
-    { AliveConv d = pw_desc(inW, inb, x_in, N, 768, Lf, DEC_C, b.x); RUN(alive_conv1d(&d, stream)); }
+    { AliveConv d = split(pw_desc(inW, inb, x_in, N, 768, Lf, DEC_C, b.x)); RUN(alive_conv1d(&d, stream)); }
     const float* c1W = t.next(); const float* c1b = t.next(); const float* c2W = t.next(); const float* c2b = t.next();
     { AliveConv d = pw_desc(c1W, c1b, f0, N, 1, Lf, DEC_C, b.sinb); d.act = 3; RUN(alive_conv1d(&d, stream)); }
-    { AliveConv d = pw_desc(c2W, c2b, b.sinb, N, DEC_C, Lf, DEC_C, b.cond); RUN(alive_conv1d(&d, stream)); }
+    { AliveConv d = split(pw_desc(c2W, c2b, b.sinb, N, DEC_C, Lf, DEC_C, b.cond)); RUN(alive_conv1d(&d, stream)); }
     const float* nfW = t.next(); const float* nfb = t.next();
-    { AliveConv d = pw_desc(nfW, nfb, b.cond, N, DEC_C, Lf, 4096, b.normfilm); RUN(alive_conv1d(&d, stream)); }
+    { AliveConv d = split(pw_desc(nfW, nfb, b.cond, N, DEC_C, Lf, 4096, b.normfilm)); RUN(alive_conv1d(&d, stream)); }
     for (int i = 0; i < 4; ++i) {
         ConvNeXtW cw(t, true);
-        RUN(convnext_layer(cw, b.x, b.y, b.h, N, DEC_C, DEC_H, Lf, b.normfilm, 4096, i * 1024, i * 1024 + 512, stream));
+        RUN(convnext_layer(cw, b.x, b.y, b.h, N, DEC_C, DEC_H, Lf, b.normfilm, 4096, i * 1024, i * 1024 + 512, true, stream));
     }
     // -- HarmonicOscillator (decoder.py:66-102)
     const float* aW = t.next(); const float* ab = t.next();
-    { AliveConv d = pw_desc(aW, ab, b.x, N, DEC_C, Lf, NH, b.amps); d.act = 2; RUN(alive_conv1d(&d, stream)); }
+    { AliveConv d = split(pw_desc(aW, ab, b.x, N, DEC_C, Lf, NH, b.amps)); d.act = 2; RUN(alive_conv1d(&d, stream)); }
     RUN(alive_oscillator(b.amps, f0, phi_in, N, NH, Lf, SEG, SR, crop0, phi_col, b.src, phi_out, b.osc_ws, stream));
     // -- Filter (decoder.py:184-195); FiLM scale(+1)/shift of all 24 modulated convs in one GEMM
     const float* fW = t.next(); const float* fb = t.next(); const float* fpost = t.next();
-    { AliveConv d = pw_desc(fW, fb, b.x, N, DEC_C, Lf, FILM_ROWS, b.film); d.post_add = fpost; RUN(alive_conv1d(&d, stream)); }
+    { AliveConv d = split(pw_desc(fW, fb, b.x, N, DEC_C, Lf, FILM_ROWS, b.film)); d.post_add = fpost; RUN(alive_conv1d(&d, stream)); }
     const float* siW = t.next(); const float* sib = t.next();
     { AliveConv d = conv_desc(siW, sib, b.src, N, 1, Lw, 8, 7, 1, 1, 3, 0, Lw, b.x0); RUN(alive_conv1d(&d, stream)); }
     const int dch[5] = {8, 16, 64, 256, 256};
@@ -306,7 +316,7 @@ extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, c
     }
     const float* mW = t.next(); const float* mb = t.next();
     {   // mid CausalConv1d(256,256,5) + skips[3]   (decoder.py:190-191)
-        AliveConv d = conv_desc(mW, mb, b.d3, N, 256, Lf, 256, 5, 1, 1, 4, 1, Lf, b.m);
+        AliveConv d = split(conv_desc(mW, mb, b.d3, N, 256, Lf, 256, 5, 1, 1, 4, 1, Lf, b.m));
         d.skip = b.d3;
         RUN(alive_conv1d(&d, stream));
     }
@@ -320,6 +330,7 @@ extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, c
         {   // ConvTranspose1d(cin, C, r, r): rows = (co, j)
             AliveConv d = conv_desc(upW[s], upb[s], cur, N, cin, L, C * r, 1, 1, 1, 0, 0, L, b.U);
             d.up = r;
+            if (F_SPLIT[s]) d = split(d);
             RUN(alive_conv1d(&d, stream));
         }
         L *= r;
@@ -328,6 +339,7 @@ extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, c
             AliveConv d = pw_desc(iW, ib, b.U, N, C, L, C, b.Hh);
             d.Z = b.Zz; d.film = b.film; d.film_rows = FILM_ROWS; d.Lf = Lf;
             d.film_scale_row = film_off; d.film_shift_row = film_off + C;
+            if (F_SPLIT[s]) d = split(d);
             RUN(alive_conv1d(&d, stream));
         }
         for (int j = 0; j < 3; ++j) {
@@ -339,6 +351,7 @@ extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, c
                 AliveConv d = conv_desc(W1, b1, b.Zz, N, C, L, C, 5, 1, dil, 4 * dil, 1, L, nullptr);
                 d.Z = b.Z2; d.film = b.film; d.film_rows = FILM_ROWS; d.Lf = Lf;
                 d.film_scale_row = f2; d.film_shift_row = f2 + C;
+                if (F_SPLIT[s]) d = split(d);
                 RUN(alive_conv1d(&d, stream));
             }
             {   // c2: conv(Z2) + residual (+ U-Net skip after the last block) ; next block's c1 input
@@ -350,6 +363,7 @@ extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, c
                     d.Z = b.Zz; d.film = b.film; d.film_rows = FILM_ROWS; d.Lf = Lf;
                     d.film_scale_row = fn; d.film_shift_row = fn + C;
                 }
+                if (F_SPLIT[s]) d = split(d);
                 RUN(alive_conv1d(&d, stream));
             }
         }

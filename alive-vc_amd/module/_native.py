@@ -23,6 +23,7 @@ class AliveConv(C.Structure):
         ("post_add", C.c_void_p), ("ch_scale", C.c_void_p), ("residual", C.c_void_p), ("skip", C.c_void_p),
         ("Y", C.c_void_p), ("Z", C.c_void_p), ("film", C.c_void_p),
         ("film_rows", C.c_int), ("Lf", C.c_int), ("film_scale_row", C.c_int), ("film_shift_row", C.c_int),
+        ("precision", C.c_int), ("Ci_pad", C.c_int),
     ]
 
 
@@ -126,6 +127,6 @@ class WeightTable:
             raise KeyError(f"packed weights missing {missing[:4]}...")
         self.tensors = [packed[n] for n in names]
         for n, t in zip(names, self.tensors):
-            if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
-                raise RuntimeError(f"packed weight {n} must be a contiguous fp32 HIP tensor")
+            if t.dtype not in (torch.float32, torch.bfloat16) or not t.is_contiguous() or not t.is_cuda:
+                raise RuntimeError(f"packed weight {n} must be a contiguous fp32 / bf16 HIP tensor")
         self.array = (C.c_void_p * len(names))(*[t.data_ptr() for t in self.tensors])

@@ -33,19 +33,43 @@ def pack_convT(w, b):
     return pack_matrix(a), b.float().repeat_interleave(r).contiguous()
 
 
+def split_bf16(w):
+    """fp32 -> (hi, lo) bf16 planes with hi + lo ~= w to 16 mantissa bits (round-to-nearest both steps)."""
+    hi = w.float().bfloat16()
+    lo = (w.float() - hi.float()).bfloat16()
+    return hi, lo
+
+
+def pack_conv_split(w):
+    """Conv1d weight [Co, Ci, KW] -> bf16 [2, Co_pad16, KW * Ci_pad32], tap-major k = j * Ci_pad + ci."""
+    co, ci, kw = w.shape
+    co_pad, ci_pad = _pad16(co), (ci + 31) // 32 * 32
+    a = torch.zeros(co_pad, kw, ci_pad, dtype=torch.float32, device=w.device)
+    a[:co, :, :ci] = w.float().permute(0, 2, 1)
+    hi, lo = split_bf16(a.reshape(co_pad, kw * ci_pad))
+    return torch.stack([hi, lo], 0).contiguous()
+
+
+def pack_convT_split(w, b):
+    """ConvTranspose1d(k == stride) weight [Ci, Co, r] -> rows (co, j) as a split 1x1 conv; bias repeated per j."""
+    ci, co, r = w.shape
+    a = w.permute(1, 2, 0).reshape(co * r, ci, 1)
+    return pack_conv_split(a), b.float().repeat_interleave(r).contiguous()
+
+
 def _vec(t):
     return t.reshape(-1).float().contiguous()
 
 
-def _convnext(out, sd, src, dst, adaptive):
+def _convnext(out, sd, src, dst, adaptive, pc=pack_conv):
     out[dst + ".dw_w"] = _vec(sd[src + ".dw_conv.weight"])
     out[dst + ".dw_b"] = _vec(sd[src + ".dw_conv.bias"])
     if not adaptive:
         out[dst + ".norm_gain"] = _vec(sd[src + ".norm.scale"])
         out[dst + ".norm_offset"] = _vec(sd[src + ".norm.shift"])
-    out[dst + ".pw1.W"] = pack_conv(sd[src + ".pw_conv1.weight"])
+    out[dst + ".pw1.W"] = pc(sd[src + ".pw_conv1.weight"])
     out[dst + ".pw1.b"] = _vec(sd[src + ".pw_conv1.bias"])
-    out[dst + ".pw2.W"] = pack_conv(sd[src + ".pw_conv2.weight"])
+    out[dst + ".pw2.W"] = pc(sd[src + ".pw_conv2.weight"])
     out[dst + ".pw2.b"] = _vec(sd[src + ".pw_conv2.bias"])
     out[dst + ".scale"] = _vec(sd[src + ".scale"])
 
@@ -67,26 +91,29 @@ def pack_f0_estimator(sd):
 
 
 FILTER_CH = [256, 64, 16, 8]
+# filter scales whose convs run on the split-bf16 MFMA kernel (C = 256, 64); the 16- and 8-channel scales are
+# HBM-bound and stay on the fp32 kernel.  Must match F_SPLIT in csrc/networks.hip.
+SPLIT_SCALE = [True, True, False, False]
 
 
 def pack_decoder(sd):
     out = {}
     fe = "feature_extractor"
-    out["fe.input.W"] = pack_conv(sd[fe + ".input_layer.weight"])
+    out["fe.input.W"] = pack_conv_split(sd[fe + ".input_layer.weight"])
     out["fe.input.b"] = _vec(sd[fe + ".input_layer.bias"])
     out["fe.f0c1.W"] = pack_conv(sd[fe + ".f0_enc.c1.weight"])
     out["fe.f0c1.b"] = _vec(sd[fe + ".f0_enc.c1.bias"])
-    out["fe.f0c2.W"] = pack_conv(sd[fe + ".f0_enc.c2.weight"])
+    out["fe.f0c2.W"] = pack_conv_split(sd[fe + ".f0_enc.c2.weight"])
     out["fe.f0c2.b"] = _vec(sd[fe + ".f0_enc.c2.bias"])
     ws, bs = [], []
     for i in range(4):
         p = f"{fe}.mid_layers.{i}.norm"
         ws += [sd[p + ".scale.weight"].reshape(512, 512), sd[p + ".shift.weight"].reshape(512, 512)]
         bs += [sd[p + ".scale.bias"], sd[p + ".shift.bias"]]
-        _convnext(out, sd, f"{fe}.mid_layers.{i}", f"fe.mid{i}", True)
-    out["fe.normfilm.W"] = pack_matrix(torch.cat(ws, 0).float())
+        _convnext(out, sd, f"{fe}.mid_layers.{i}", f"fe.mid{i}", True, pack_conv_split)
+    out["fe.normfilm.W"] = pack_conv_split(torch.cat(ws, 0).float().unsqueeze(2))
     out["fe.normfilm.b"] = _vec(torch.cat(bs, 0))
-    out["osc.amps.W"] = pack_conv(sd["harmonic_oscillator.to_amps.weight"])
+    out["osc.amps.W"] = pack_conv_split(sd["harmonic_oscillator.to_amps.weight"])
     out["osc.amps.b"] = _vec(sd["harmonic_oscillator.to_amps.bias"])
     f = "filter"
     ws, bs, post = [], [], []
@@ -97,7 +124,7 @@ def pack_decoder(sd):
                 ws += [sd[p + ".to_scale.weight"].reshape(c, 512), sd[p + ".to_shift.weight"].reshape(c, 512)]
                 bs += [sd[p + ".to_scale.bias"], sd[p + ".to_shift.bias"]]
                 post += [torch.ones(c, device=ws[0].device), torch.zeros(c, device=ws[0].device)]
-    out["flt.film.W"] = pack_matrix(torch.cat(ws, 0).float())
+    out["flt.film.W"] = pack_conv_split(torch.cat(ws, 0).float().unsqueeze(2))
     out["flt.film.b"] = _vec(torch.cat(bs, 0))
     out["flt.film.post"] = _vec(torch.cat(post, 0))
     out["flt.in.W"] = pack_conv(sd[f + ".source_in.weight"])
@@ -105,17 +132,19 @@ def pack_decoder(sd):
     for i in range(4):
         out[f"flt.down{i}.W"] = pack_conv(sd[f"{f}.downs.{i}.weight"])
         out[f"flt.down{i}.b"] = _vec(sd[f"{f}.downs.{i}.bias"])
-    out["flt.mid.W"] = pack_conv(sd[f + ".mid_conv.conv.weight"])
+    out["flt.mid.W"] = pack_conv_split(sd[f + ".mid_conv.conv.weight"])
     out["flt.mid.b"] = _vec(sd[f + ".mid_conv.conv.bias"])
     for i in range(4):
-        out[f"flt.up{i}.W"], out[f"flt.up{i}.b"] = pack_convT(sd[f"{f}.ups.{i}.weight"], sd[f"{f}.ups.{i}.bias"])
+        pt = pack_convT_split if SPLIT_SCALE[i] else pack_convT
+        out[f"flt.up{i}.W"], out[f"flt.up{i}.b"] = pt(sd[f"{f}.ups.{i}.weight"], sd[f"{f}.ups.{i}.bias"])
     for s in range(4):
         b = f"{f}.blocks.{s}"
-        out[f"flt.blk{s}.in.W"] = pack_conv(sd[b + ".input_conv.weight"])
+        pc = pack_conv_split if SPLIT_SCALE[s] else pack_conv
+        out[f"flt.blk{s}.in.W"] = pc(sd[b + ".input_conv.weight"])
         out[f"flt.blk{s}.in.b"] = _vec(sd[b + ".input_conv.bias"])
         for j in range(3):
             for cc in ("c1", "c2"):
-                out[f"flt.blk{s}.{j}.{cc}.W"] = pack_conv(sd[f"{b}.blocks.{j}.{cc}.conv.conv.weight"])
+                out[f"flt.blk{s}.{j}.{cc}.W"] = pc(sd[f"{b}.blocks.{j}.{cc}.conv.conv.weight"])
                 out[f"flt.blk{s}.{j}.{cc}.b"] = _vec(sd[f"{b}.blocks.{j}.{cc}.conv.conv.bias"])
     out["flt.out.W"] = pack_conv(sd[f + ".source_out.weight"])
     out["flt.out.b"] = _vec(sd[f + ".source_out.bias"])

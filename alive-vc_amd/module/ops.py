@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _native as nat
-from ._pack import pack_conv, pack_convT
+from ._pack import pack_conv, pack_conv_split, pack_convT, pack_convT_split
 
 ACT = {None: 0, "gelu": 1, "exp": 2, "sin": 3}
 _ws = nat.Workspace()
@@ -21,13 +21,27 @@ def _f(t):
 
 def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, out_len=None, act=None,
            post_add=None, ch_scale=None, residual=None, skip=None, film=None, film_scale_row=0, film_shift_row=0,
-           want_raw=True, transposed=False):
+           want_raw=True, transposed=False, precision="fp32"):
     """Generic Conv1d / ConvTranspose1d(k == stride) through alive_conv1d.
     Returns (Y, Z): raw output (or None) and the gelu+FiLM modulated second output (or None)."""
     x = _f(x)
     n, ci, tin = x.shape
     keep = []
-    if transposed:
+    split = precision == "bf16x3"
+    if split and transposed:
+        r = weight.shape[2]
+        W, b = pack_convT_split(weight, bias)
+        co_rows, kw, up = weight.shape[1] * r, 1, r
+        stride_, tout = 1, tin
+        co_out = weight.shape[1]
+    elif split:
+        W = pack_conv_split(weight)
+        b = _f(bias)
+        co_rows, kw, up = weight.shape[0], weight.shape[2], 1
+        stride_ = stride
+        tout = out_len if out_len is not None else (tin + pad_left - dilation * (kw - 1) - 1) // stride + 1
+        co_out = co_rows
+    elif transposed:
         r = weight.shape[2]
         W, b = pack_convT(weight, bias)
         co_rows, kw, up = weight.shape[1] * r, 1, r
@@ -42,7 +56,8 @@ def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, o
         co_out = co_rows
     d = nat.AliveConv()
     d.W, d.bias, d.X = nat.ptr(W), nat.ptr(b), nat.ptr(x)
-    d.N, d.Ci, d.Tin, d.Co, d.K_pad = n, ci, tin, co_rows, W.shape[1]
+    d.N, d.Ci, d.Tin, d.Co, d.K_pad = n, ci, tin, co_rows, W.shape[-1]
+    d.precision, d.Ci_pad = (1, (ci + 31) // 32 * 32) if split else (0, 0)
     d.KW, d.stride, d.dil, d.pad_left, d.pad_mode = kw, stride_, dilation, pad_left, pad_mode
     d.Tout, d.up, d.act = tout, up, ACT[act]
     post_add, ch_scale, residual, skip, film = map(_f, (post_add, ch_scale, residual, skip, film))

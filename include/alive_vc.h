@@ -109,6 +109,11 @@ typedef struct AliveConv {
     float* Z;
     const float* film;     /* [N][film_rows][Lf] */
     int film_rows, Lf, film_scale_row, film_shift_row;
+    /* arithmetic: 0 = exact fp32 (f32-input MFMA), W as above;
+     *             1 = 2-term split bf16 ("bf16x3": hi*hi + hi*lo + lo*hi on the bf16 MFMA, ~2^-16 per product),
+     *                 W = bf16 [2][Co_pad][KW*Ci_pad] (plane 0 hi, plane 1 lo), tap-major k = j*Ci_pad + ci,
+     *                 Ci_pad a multiple of 32; stride must be 1. */
+    int precision, Ci_pad;
 } AliveConv;
 int alive_conv1d(const AliveConv* desc, void* stream);
 

@@ -228,3 +228,73 @@ def test_spectrogram(L):
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() < 2e-3 * ref.abs().max().item() * 1e-2 + 1e-3
     assert relerr(got, ref) < 1e-5
+
+
+# ---- split-bf16 ("bf16x3") MFMA conv kernel: decoder GEMMs ----------------------------------------------
+@pytest.mark.parametrize("co,ci,kw,dil,pad,mode,t", [
+    (512, 768, 1, 1, 0, 0, 450),       # fe.input
+    (1536, 512, 1, 1, 0, 0, 37),       # pw1, ragged T
+    (64, 512, 1, 1, 0, 0, 24),         # to_amps (BM = 64 tile)
+    (4128, 512, 1, 1, 0, 0, 130),      # FiLM projections, ragged Co
+    (256, 256, 5, 1, 4, 1, 50),        # mid causal conv (reflect)
+    (256, 256, 5, 4, 16, 1, 700),      # dilated causal, C = 256
+    (64, 64, 5, 2, 8, 1, 1000),        # dilated causal, C = 64
+    (40, 24, 3, 1, 2, 0, 100),         # odd sizes, zero pad
+])
+def test_conv1d_split_bf16(co, ci, kw, dil, pad, mode, t):
+    from module import ops
+    x = g(f"sx{co}{ci}{kw}", (2, ci, t))
+    w = g(f"sw{co}{ci}{kw}", (co, ci, kw), scale=1.0 / np.sqrt(ci * kw))
+    b = g(f"sb{co}{ci}{kw}", (co,), scale=0.1)
+    if mode == 1:
+        ref = F.conv1d(F.pad(x, (pad, 0), mode="reflect").double(), w.double(), b.double(), dilation=dil)
+    else:
+        ref = F.conv1d(F.pad(x, (pad, 0)).double(), w.double(), b.double(), dilation=dil)
+    ref = ref[:, :, :t]
+    y, _ = ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), dilation=dil, pad_left=pad, pad_mode=mode, out_len=t,
+                      precision="bf16x3")
+    assert y.shape == ref.shape
+    e = relerr(y, ref)
+    assert e < 2e-5, e          # 2-term split: ~2^-16 per product; fp32 kernel is ~1e-7, plain bf16 would be ~3e-3
+
+
+@pytest.mark.parametrize("ci,co,r,t", [(256, 256, 10, 45), (256, 64, 8, 450)])
+def test_conv_transpose_split_bf16(ci, co, r, t):
+    from module import ops
+    x = g(f"tsx{ci}{r}", (2, ci, t))
+    w = g(f"tsw{ci}{r}", (ci, co, r), scale=1.0 / np.sqrt(ci))
+    b = g(f"tsb{ci}{r}", (co,), scale=0.1)
+    ref = F.conv_transpose1d(x.double(), w.double(), b.double(), stride=r)
+    y, _ = ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), transposed=True, precision="bf16x3")
+    assert y.shape == ref.shape and relerr(y, ref) < 2e-5
+
+
+def test_modulated_chain_split_bf16(golden_dir):
+    """same FilterBlock chain as above on the split kernel (dual-output epilogue included)."""
+    from module import ops
+    z = np.load(os.path.join(golden_dir, "blk_filter_block.npz"))
+    sd = {"n." + k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w::")}
+    x, c, ref = torch.from_numpy(z["x"]), torch.from_numpy(z["c"]), torch.from_numpy(z["y"])
+    C = x.shape[1]
+    ws, bs, post = [], [], []
+    for j in range(3):
+        for cc in ("c1", "c2"):
+            p = f"n.blocks.{j}.{cc}"
+            ws += [sd[p + ".to_scale.weight"], sd[p + ".to_shift.weight"]]
+            bs += [sd[p + ".to_scale.bias"], sd[p + ".to_shift.bias"]]
+            post += [torch.ones(C), torch.zeros(C)]
+    kw = dict(precision="bf16x3")
+    film, _ = ops.conv1d(c.to(DEV), torch.cat(ws, 0).to(DEV), torch.cat(bs, 0).to(DEV), post_add=torch.cat(post).to(DEV), **kw)
+    h, zz = ops.conv1d(x.to(DEV), sd["n.input_conv.weight"].to(DEV), sd["n.input_conv.bias"].to(DEV), film=film,
+                       film_scale_row=0, film_shift_row=C, **kw)
+    for j in range(3):
+        d = 2 ** j
+        p = f"n.blocks.{j}"
+        _, z2 = ops.conv1d(zz, sd[p + ".c1.conv.conv.weight"].to(DEV), sd[p + ".c1.conv.conv.bias"].to(DEV), dilation=d,
+                           pad_left=4 * d, pad_mode=1, out_len=x.shape[2], film=film, want_raw=False,
+                           film_scale_row=(2 * j + 1) * 2 * C, film_shift_row=(2 * j + 1) * 2 * C + C, **kw)
+        nxt = (2 * j + 2) * 2 * C
+        h, zz = ops.conv1d(z2, sd[p + ".c2.conv.conv.weight"].to(DEV), sd[p + ".c2.conv.conv.bias"].to(DEV), dilation=d,
+                           pad_left=4 * d, pad_mode=1, out_len=x.shape[2], residual=h,
+                           film=film if j < 2 else None, film_scale_row=nxt, film_shift_row=nxt + C, **kw)
+    assert relerr(h, ref) < 1e-4, relerr(h, ref)
