@@ -139,6 +139,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(AliveConv p, unsigned kw
     }
 
     // ---- epilogue ----
+    FilmTile ft{nullptr, 0};
+    if (p.Z != nullptr) {                    // block-uniform: FiLM rows of this tile -> LDS (reuses the A buffers)
+        int f_lo, nf;
+        if (film_tile_range(p, film_ratio, t0, BN, f_lo, nf)) {
+            static_assert(sizeof(As) >= BM * 2 * FILM_NF * sizeof(float), "film tile fits the A buffers");
+            film_tile_load(p, n, m0, BM, f_lo, nf, &As[0][0][0]);
+            __syncthreads();
+            ft.lds = &As[0][0][0];
+            ft.f_lo = f_lo;
+        }
+    }
 #pragma unroll
     for (int nn = 0; nn < NR; ++nn) {
         const int t = t0 + wn * TN + nn * 16 + lr;
@@ -149,9 +160,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(AliveConv p, unsigned kw
         for (int m = 0; m < MR; ++m) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * TM + m * 16 + lq * 4 + r;
-                if (row >= p.Co) continue;
-                conv_epilogue_store(p, n, row, t, acc[m][nn][r], lp);
+                const int row_local = wm * TM + m * 16 + lq * 4 + r;
+                if (m0 + row_local >= p.Co) continue;
+                conv_epilogue_store<false>(p, n, m0 + row_local, row_local, t, acc[m][nn][r], lp, ft);
             }
         }
     }

@@ -5,16 +5,71 @@
 #pragma once
 #include "common.h"
 
-// Kept out of line: dozens of inlined copies of erff/expf/sinf (one per accumulator element) blow the
-// unrolled epilogue past the point where the accumulators stay in registers.
+// exact activations, kept out of line: dozens of inlined copies of erff/expf/sinf (one per accumulator
+// element) blow the unrolled epilogue past the point where the accumulators stay in registers.
 __device__ __attribute__((noinline)) static float apply_act(float v, int act) {
     if (act == 1) return gelu_erf(v);
     if (act == 2) return expf(v);
     return sinf(v);
 }
 
-__device__ __forceinline__ void conv_epilogue_store(const AliveConv& p, int n, int row, int t, float v, const Lerp& lp) {
-    if (p.act != 0) v = apply_act(v, p.act);
+// Branch-free GELU for the decoder's FiLM path: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7) on
+// v_rcp/v_exp; ~16 VALU, inlined.  Only used next to the split-bf16 GEMMs and the FiLM second output,
+// whose own error (~1e-5 relative) is two orders above it; the encoder / f0 paths keep erff.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float ax = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p = p * t;
+    const float e = __expf(-ax * ax);
+    const float erf_abs = fmaf(-p, e, 1.0f);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
+// FiLM slab of one block in LDS: [row_local][2 (scale, shift)][FILM_NF frames]
+constexpr int FILM_NF = 20;
+
+struct FilmTile {
+    const float* lds;     // nullptr -> read film from global memory
+    int f_lo;
+};
+
+// frames [f_lo, f_lo + nf) cover every interpolation tap of output columns [t0, t0 + ncols)
+__device__ __forceinline__ bool film_tile_range(const AliveConv& p, float ratio, int t0, int ncols, int& f_lo, int& nf) {
+    int t1 = t0 + ncols - 1;
+    if (t1 > p.Tout - 1) t1 = p.Tout - 1;
+    Lerp a = lerp_coord(t0, ratio, p.Lf), b = lerp_coord(t1, ratio, p.Lf);
+    f_lo = a.i0;
+    nf = b.i1 - a.i0 + 1;
+    return nf <= FILM_NF;
+}
+
+// cooperative load by the whole block (256 threads); call between two __syncthreads()
+__device__ __forceinline__ void film_tile_load(const AliveConv& p, int n, int m0, int rows, int f_lo, int nf, float* lds) {
+    for (int e = threadIdx.x; e < rows * 2 * FILM_NF; e += 256) {
+        int f = e % FILM_NF, sel = (e / FILM_NF) & 1, r = e / (2 * FILM_NF);
+        int row = m0 + r;
+        float v = 0.0f;
+        if (row < p.Co && f < nf) {
+            int base = sel == 0 ? p.film_scale_row : p.film_shift_row;
+            v = p.film[((size_t)n * p.film_rows + base + row) * p.Lf + f_lo + f];
+        }
+        lds[e] = v;
+    }
+}
+
+template <bool FAST>
+__device__ __forceinline__ void conv_epilogue_store(const AliveConv& p, int n, int row, int row_local, int t, float v,
+                                                    const Lerp& lp, const FilmTile& ft) {
+    if (FAST) {               // split-bf16 kernel: everything inline (a call would spill the accumulators); no sin
+        if (p.act == 1) v = gelu_fast(v);
+        else if (p.act == 2) v = expf(v);
+    } else if (p.act != 0) {
+        v = apply_act(v, p.act);
+    }
     if (p.post_add != nullptr) v = v + p.post_add[row];
     if (p.ch_scale != nullptr) v = v * p.ch_scale[row];
     if (p.up == 1) {
@@ -23,11 +78,18 @@ __device__ __forceinline__ void conv_epilogue_store(const AliveConv& p, int n, i
         if (p.skip != nullptr) v = v + p.skip[o];
         if (p.Y != nullptr) p.Y[o] = v;
         if (p.Z != nullptr) {
-            const float* fs = p.film + ((size_t)n * p.film_rows + p.film_scale_row + row) * p.Lf;
-            const float* fh = p.film + ((size_t)n * p.film_rows + p.film_shift_row + row) * p.Lf;
-            float sc = lerp_apply(lp, fs[lp.i0], fs[lp.i1]);
-            float sh = lerp_apply(lp, fh[lp.i0], fh[lp.i1]);
-            float g = apply_act(v, 1);
+            float s0, s1, h0, h1;
+            if (ft.lds != nullptr) {
+                const float* fs = ft.lds + row_local * 2 * FILM_NF - ft.f_lo;
+                s0 = fs[lp.i0]; s1 = fs[lp.i1]; h0 = fs[FILM_NF + lp.i0]; h1 = fs[FILM_NF + lp.i1];
+            } else {
+                const float* fs = p.film + ((size_t)n * p.film_rows + p.film_scale_row + row) * p.Lf;
+                const float* fh = p.film + ((size_t)n * p.film_rows + p.film_shift_row + row) * p.Lf;
+                s0 = fs[lp.i0]; s1 = fs[lp.i1]; h0 = fh[lp.i0]; h1 = fh[lp.i1];
+            }
+            float sc = lerp_apply(lp, s0, s1);
+            float sh = lerp_apply(lp, h0, h1);
+            float g = gelu_fast(v);
             p.Z[o] = g * sc + sh;
         }
     } else {

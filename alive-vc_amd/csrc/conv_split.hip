@@ -164,22 +164,96 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
         if (++j == p.KW) { j = 0; ++cb; }
     }
 
-    // ---- epilogue: lane = time column, 16 rows per (mm, nn) tile ----
+    // ---- epilogue: accumulators -> LDS -> cooperative row-wise pass ----
+    // Staging the tile through LDS turns the MFMA layout (a lane owns 16 scattered rows of one column) into
+    // whole rows: every global access of the epilogue (residual, skip, Y, Z) is a 16-B vector per thread on
+    // 512-B contiguous row segments, and the element code exists once in a rolled loop instead of 64 times.
+    constexpr int PR = BM == 128 ? 64 : 32;          // rows per pass (two passes: mm = 0, 1)
+    constexpr int CP = BN + 4;                       // fp32 pitch of the staged tile
+    float* Ct = (float*)smem;                        // [PR][CP]
+    float* Ft = Ct + PR * CP;                        // [PR][2][FILM_NF]
+    static_assert((PR * CP + PR * 2 * FILM_NF) * 4 <= (int)sizeof(smem), "epilogue staging fits");
+    int f_lo = 0, nf = 0;
+    if (p.Z != nullptr) film_tile_range(p, film_ratio, t0, BN, f_lo, nf);       // fit is checked on the host
+    const bool vec = (p.up == 1) && ((p.Tout & 3) == 0);
 #pragma unroll
-    for (int nn = 0; nn < NR; ++nn) {
-        const int t = t0 + wn * TN + nn * 32 + lr;
-        if (t >= p.Tout) continue;
-        Lerp lp;
-        if (p.Z != nullptr) lp = lerp_coord(t, film_ratio, p.Lf);
+    for (int mm = 0; mm < MR; ++mm) {
 #pragma unroll
-        for (int mm = 0; mm < MR; ++mm) {
+        for (int nn = 0; nn < NR; ++nn)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + mm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row >= p.Co) continue;
-                conv_epilogue_store(p, n, row, t, acc[mm][nn][r], lp);
+            for (int r = 0; r < 16; ++r)
+                Ct[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CP + wn * TN + nn * 32 + lr] = acc[mm][nn][r];
+        if (p.Z != nullptr) {
+            for (int e = tid; e < PR * 2 * FILM_NF; e += 256) {
+                int f = e % FILM_NF, sel = (e / FILM_NF) & 1, pr = e / (2 * FILM_NF);
+                int row = m0 + (pr >> 5) * 64 + mm * 32 + (pr & 31);
+                float v = 0.0f;
+                if (row < p.Co && f < nf)
+                    v = p.film[((size_t)n * p.film_rows + (sel == 0 ? p.film_scale_row : p.film_shift_row) + row) * p.Lf + f_lo + f];
+                Ft[e] = v;
             }
         }
+        __syncthreads();
+        if (vec) {
+#pragma unroll 1
+            for (int g = tid; g < PR * (BN / 4); g += 256) {
+                const int pr = g >> 5, c4 = (g & 31) * 4;
+                const int row = m0 + (pr >> 5) * 64 + mm * 32 + (pr & 31);
+                const int t = t0 + c4;
+                if (row >= p.Co || t >= p.Tout) continue;
+                f32x4 v = *(const f32x4*)&Ct[pr * CP + c4];
+                if (p.act == 1) { for (int q = 0; q < 4; ++q) v[q] = gelu_fast(v[q]); }
+                else if (p.act == 2) { for (int q = 0; q < 4; ++q) v[q] = expf(v[q]); }
+                if (p.post_add != nullptr) v = v + p.post_add[row];
+                if (p.ch_scale != nullptr) v = v * p.ch_scale[row];
+                const size_t o = ((size_t)n * p.Co + row) * p.Tout + t;
+                if (p.residual != nullptr) v = v + *(const f32x4*)(p.residual + o);
+                if (p.skip != nullptr) v = v + *(const f32x4*)(p.skip + o);
+                if (p.Y != nullptr) *(f32x4*)(p.Y + o) = v;
+                if (p.Z != nullptr) {
+                    const float* fs = Ft + pr * 2 * FILM_NF - f_lo;
+                    f32x4 z;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        Lerp lp = lerp_coord(t + q, film_ratio, p.Lf);
+                        float sc = lerp_apply(lp, fs[lp.i0], fs[lp.i1]);
+                        float sh = lerp_apply(lp, fs[FILM_NF + lp.i0], fs[FILM_NF + lp.i1]);
+                        z[q] = gelu_fast(v[q]) * sc + sh;
+                    }
+                    *(f32x4*)(p.Z + o) = z;
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int g = tid; g < PR * BN; g += 256) {
+                const int pr = g >> 7, c = g & 127;
+                const int row = m0 + (pr >> 5) * 64 + mm * 32 + (pr & 31);
+                const int t = t0 + c;
+                if (row >= p.Co || t >= p.Tout) continue;
+                float v = Ct[pr * CP + c];
+                if (p.act == 1) v = gelu_fast(v);
+                else if (p.act == 2) v = expf(v);
+                if (p.post_add != nullptr) v = v + p.post_add[row];
+                if (p.ch_scale != nullptr) v = v * p.ch_scale[row];
+                if (p.up == 1) {
+                    const size_t o = ((size_t)n * p.Co + row) * p.Tout + t;
+                    if (p.residual != nullptr) v = v + p.residual[o];
+                    if (p.skip != nullptr) v = v + p.skip[o];
+                    if (p.Y != nullptr) p.Y[o] = v;
+                    if (p.Z != nullptr) {
+                        const float* fs = Ft + pr * 2 * FILM_NF - f_lo;
+                        Lerp lp = lerp_coord(t, film_ratio, p.Lf);
+                        float sc = lerp_apply(lp, fs[lp.i0], fs[lp.i1]);
+                        float sh = lerp_apply(lp, fs[FILM_NF + lp.i0], fs[FILM_NF + lp.i1]);
+                        p.Z[o] = gelu_fast(v) * sc + sh;
+                    }
+                } else {
+                    const int co = row / p.up, jj = row - co * p.up;
+                    p.Y[((size_t)n * (p.Co / p.up) + co) * ((size_t)p.Tout * p.up) + (size_t)t * p.up + jj] = v;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -191,6 +265,13 @@ int alive_conv_split_launch(const AliveConv* d, float ratio, hipStream_t s) {
     ALIVE_CHECK_ARG(d->KW <= 8 && (d->KW - 1) * d->dil <= XROWS - BN, "alive_conv1d(split): halo (KW-1)*dil = %d exceeds %d",
                     (d->KW - 1) * d->dil, XROWS - BN);
     ALIVE_CHECK_ARG(d->pad_mode == 0 || d->pad_mode == 1, "alive_conv1d(split): pad_mode");
+    ALIVE_CHECK_ARG(((((uintptr_t)d->Y) | ((uintptr_t)d->Z) | ((uintptr_t)d->residual) | ((uintptr_t)d->skip)) & 15) == 0,
+                    "alive_conv1d(split): Y / Z / residual / skip must be 16-byte aligned");
+    if (d->Z) {
+        const double span = (double)d->Lf / (double)d->Tout * BN + 3.0;
+        ALIVE_CHECK_ARG(span <= FILM_NF, "alive_conv1d(split): FiLM second output needs Tout >= ~8 Lf (got Lf %d, Tout %d)", d->Lf, d->Tout);
+    }
+    ALIVE_CHECK_ARG(d->act >= 0 && d->act <= 2, "alive_conv1d(split): activation %d not available on the split kernel", d->act);
     ALIVE_CHECK_ARG(d->Tout <= d->Tin + d->pad_left, "alive_conv1d(split): Tout");
     if (d->Co > 64) {
         dim3 g(cdiv(d->Tout, BN), cdiv(d->Co, 128), d->N);
