@@ -117,30 +117,8 @@ __global__ __launch_bounds__(256) void src_prep_kernel(const float* __restrict__
 // DMA pieces are 8 rows x 128 B (full lines from L2); the 16-B chunk order inside a line is XOR-swizzled
 // on the SOURCE address (the LDS image of an LDS-DMA is lane-linear) and pieces sit at a 1152-B stride,
 // which together make every ds_read_b128 of an A fragment conflict-free.
-struct ListRef {
-    float* v;
-    int* i;
-};
-
-// insert (val, idx) into an unsorted KP-entry list if it beats the list minimum; returns the new minimum
-__device__ __forceinline__ float list_insert(ListRef L, float val, int idx) {
-    float mn = L.v[0];
-    int mp = 0;
-#pragma unroll 1
-    for (int e = 1; e < KP; ++e) {
-        float x = L.v[e];
-        if (x < mn) { mn = x; mp = e; }
-    }
-    if (val > mn) {
-        L.v[mp] = val;
-        L.i[mp] = idx;
-        mn = L.v[0];
-#pragma unroll 1
-        for (int e = 1; e < KP; ++e) mn = fminf(mn, L.v[e]);
-    }
-    return mn;
-}
-
+constexpr int KH = KP / 2;                // entries per half-list: each lane keeps its own list per frame column (the two
+                                          // half-waves of a column see disjoint library rows), so updates are lane-private
 constexpr int FT = 256;                  // frames per block
 constexpr int LT = 32;                   // library rows per tile
 constexpr int NK16 = D / 16;             // 48 MFMA k-steps
@@ -158,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
                                                            int* __restrict__ cand_idx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Lv = (float*)(smem + 2 * ABUF);
-    int* Li = (int*)(Lv + FT * KP);
+    int* Li = (int*)(Lv + FT * KP);            // both entry-major: [KH][512 lane-columns] -> wave-wide conflict-free access
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -198,20 +176,19 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
 #pragma unroll
     for (int j = 0; j < 4; ++j) a_off[j] = (lr >> 3) * PIECE + rr * 128 + ((((j * 2 + lh) ^ rr)) << 4);
 
-    ListRef lists[2];
-    float thr[2];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        int col = 64 * w + 32 * ni + lr;
-        lists[ni].v = Lv + (size_t)col * KP;
-        lists[ni].i = Li + (size_t)col * KP;
-        thr[ni] = -INFINITY;
-    }
+    // lane-column id = w*128 + ni*64 + lane; entry e of its list lives at [e*512 + id]
+    float thr[2] = {-INFINITY, -INFINITY};
+    const int lc0 = w * 128 + lane;
     __syncthreads();                                   // lists initialised, tile_begin landed (vmcnt(0) + barrier)
 
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int buf = (tile - tile_begin) & 1;
-        if (tile + 1 < tile_end) issue_tile(tile + 1, buf ^ 1);
+        // The 12 DMA pieces of the next tile are issued one per four k-steps INSIDE the MFMA stream (an LDS-DMA
+        // costs the issuing wave ~60-180 cycles when issued back to back, almost nothing in an MFMA shadow).
+        // On the last tile the same tile is fetched again into the idle buffer: no branch in the stream.
+        const int next_tile = tile + 1 < tile_end ? tile + 1 : tile;
+        const unsigned short* gnext = lib + ((size_t)next_tile * LT + dma_row) * D + dma_chunk * 8;
+        unsigned char* lnext = smem + (buf ^ 1) * ABUF + w * PIECE;
         const unsigned char* Ab = smem + buf * ABUF;
         f32x16 acc0, acc1;
 #pragma unroll
@@ -223,6 +200,8 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
 #pragma unroll
         for (int ks = 0; ks < NK16; ++ks) {
             if (ks + 2 < NK16) a[(ks + 2) % 3] = *(const bf16x8*)(Ab + a_off[(ks + 2) & 3] + ((ks + 2) >> 2) * 4 * PIECE);
+            if ((ks & 3) == 1)
+                __builtin_amdgcn_global_load_lds((gptr_t)(gnext + (ks >> 2) * 64), (lptr_t)(lnext + (ks >> 2) * 4 * PIECE), 16, 0, 0);
             __builtin_amdgcn_sched_barrier(0);          // keep the read ahead of this step's MFMAs (hipcc otherwise
                                                         // sinks it next to its use and waits lgkmcnt(0) every step)
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % 3], bq[0][ks], acc0, 0, 0, 0);
@@ -243,32 +222,51 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
                 if (ragged && row0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= M) acc[r] = -INFINITY;
                 mx = fmaxf(mx, acc[r]);
             }
-            if (mx > thr[ni]) {
-                // the two half-waves share a list: serialise them (LDS ops of one wave execute in order)
-#pragma unroll 1
-                for (int half = 0; half < 2; ++half) {
-                    if (lh == half) {
-                        float t = list_insert(lists[ni], -INFINITY, -1);       // refresh the threshold
+            // Rare path (wave-uniform branch): some lane's best new score beats its list minimum.  The whole wave
+            // runs it converged: every lane scans its own 8-entry list (entry-major LDS: conflict-free), lanes with a
+            // candidate replace their minimum; repeated while any lane still holds a second candidate in this tile.
+            while (__builtin_amdgcn_ballot_w64(mx > thr[ni]) != 0) {
+                const bool has = mx > thr[ni];
+                int rsel = 0;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            float v = acc[r];
-                            if (v > t) t = list_insert(lists[ni], v, (int)(row0 + (r & 3) + 8 * (r >> 2) + 4 * lh));
-                        }
-                        thr[ni] = t;
-                    }
+                for (int r = 1; r < 16; ++r) rsel = (acc[r] == mx) ? r : rsel;
+                float* lv = Lv + lc0 + ni * 64;
+                int* li = Li + lc0 + ni * 64;
+                float m1 = lv[0], m2 = INFINITY;          // smallest and second smallest entry
+                int pos = 0;
+#pragma unroll
+                for (int e = 1; e < KH; ++e) {
+                    float x = lv[e * 512];
+                    bool lt = x < m1;
+                    m2 = lt ? m1 : fminf(m2, x);
+                    pos = lt ? e : pos;
+                    m1 = lt ? x : m1;
                 }
+                if (has) {
+                    lv[pos * 512] = mx;
+                    li[pos * 512] = (int)(row0 + (rsel & 3) + 8 * (rsel >> 2) + 4 * lh);
+                    thr[ni] = fminf(m2, mx);
+                }
+                // retire the inserted value and look for the next candidate of this lane
+                float nmx = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (has && r == rsel) acc[r] = -INFINITY;
+                    nmx = fmaxf(nmx, acc[r]);
+                }
+                mx = nmx;
             }
         }
         __syncthreads();                               // next tile landed (vmcnt(0)), this buffer free for tile+2
     }
 
-    // ---- write this block's lists: cand[frame][P][KP], list id = split ----
+    // ---- write this block's lists: cand[frame][P][KP]; entries 0..7 from the lower half-wave, 8..15 from the upper ----
     for (int e = tid; e < FT * KP; e += 256) {
-        int k = e % KP;
-        int col = e / KP;
-        size_t o = (((size_t)(frame0 + col)) * P + split) * KP + k;
-        cand_val[o] = Lv[e];
-        cand_idx[o] = Li[e];
+        const int k = e % KP, col = e / KP;
+        const int lc = (col >> 6) * 128 + ((col >> 5) & 1) * 64 + (k / KH) * 32 + (col & 31);
+        const size_t o = (((size_t)(frame0 + col)) * P + split) * KP + k;
+        cand_val[o] = Lv[(k % KH) * 512 + lc];
+        cand_idx[o] = Li[(k % KH) * 512 + lc];
     }
 }
 
