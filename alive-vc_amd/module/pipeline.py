@@ -53,13 +53,20 @@ class Converter:
         return merge_gather(val, idx, 1, k, alpha, self.library.rows, feat)
 
     def convert_windows(self, windows, k=4, alpha=0.0, pitch_shift=0.0, intonation=1.0, f0_rate=1.0, window_batch=64):
-        """windows [n, L] on the device -> waveforms [n, L]; L a multiple of 320."""
+        """windows [n, L] on the device -> waveforms [n, L]; L a multiple of 320.
+        Networks run in batches of `window_batch` windows (bounded scratch); the kNN match runs ONCE over the frames
+        of all windows, so every library tile streamed from L2 is used by as many frames as possible."""
+        n, L = windows.shape
+        lf = L // 320
+        feat = torch.empty(n, 768, lf, device=windows.device)
+        f0 = torch.empty(n, 1, lf, device=windows.device)
+        for i in range(0, n, window_batch):
+            feat[i:i + window_batch], f0[i:i + window_batch] = self.features(windows[i:i + window_batch], pitch_shift,
+                                                                           intonation, f0_rate)
+        feat = self.match(feat, k, alpha)
         out = torch.empty_like(windows)
-        for i in range(0, windows.shape[0], window_batch):
-            w = windows[i:i + window_batch]
-            feat, f0 = self.features(w, pitch_shift, intonation, f0_rate)
-            feat = self.match(feat, k, alpha)
-            out[i:i + window_batch], _ = self.dec(feat, f0)
+        for i in range(0, n, window_batch):
+            out[i:i + window_batch], _ = self.dec(feat[i:i + window_batch], f0[i:i + window_batch])
         return out
 
     def convert(self, wf, chunk=48000, **kw):
