@@ -208,7 +208,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 scoring + f32 rescoring/networks (f32 MFMA), f64 phase scan",
+            "dtype": "bf16 MFMA scoring + exact f32 rescoring; f32-MFMA encoders; split-bf16 (bf16x3) decoder GEMMs; f64 phase scan",
             "data": "synthetic",
             "config": {"workload": f"{args.utterances} utterances x {args.seconds:g} s per GPU -> {n_win} windows x "
                                    f"{L // FRAME} frames per step, {M}-vector library (BASELINE config 3/4 shape)",
