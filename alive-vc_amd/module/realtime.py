@@ -32,7 +32,57 @@ class RealtimeConverter:
                              "(reflection pad 4 on the bottleneck: module/decoder.py:165 of the reference)")
         self.ring = []
         self.phi = 0
+        self._graph = None
         self.last_f0 = None
+
+    # ------------------------------------------------------------------ device part of one step
+    def _device_step(self, data, phi):
+        """data float32 [1, ring samples at input_sr] on the device, phi [1, 64] -> (wave at output_sr [L], phi_next [1, 64])"""
+        data = audio_io.resample(data, self.input_sr, 16000)
+        data = audio_io.gain(data, self.input_gain)
+        spec = spectrogram(data)
+        content = self.ce(spec)
+        f0 = self.pe.estimate(spec)
+        f0 = ops.pitch_transform_(f0, 1, f0_rate=self.f0_rate, pitch_shift=self.pitch)
+        val, idx = self.lib.search(content, self.k)
+        content = merge_gather(val, idx, 1, self.k, self.alpha, self.lib.rows, content)
+        wave, phi_out = self.dec(content, f0=f0, phi=phi, crop=(self.begin_of_output, self.end_of_output))
+        self.last_f0 = f0
+        wave = audio_io.gain(wave, self.gain)
+        wave = audio_io.resample(wave, 16000, self.output_sr)[0]
+        return wave, phi_out[:, :, self.end_of_output]
+
+    def enable_graph(self):
+        """Capture the whole per-step device pipeline (~150 launches) into one hipGraph: the C ABI never allocates or
+        synchronises, and every scratch buffer reaches its steady-state size during the warm-up steps below."""
+        n = self.chunk * self.buffersize
+        self._g_in = torch.zeros(1, n, device=self.device)
+        self._g_phi = torch.zeros(1, 64, device=self.device)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._device_step(self._g_in, self._g_phi)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            wave, phi_next = self._device_step(self._g_in, self._g_phi)
+            self._g_phi.copy_(phi_next)
+            self._g_out = wave
+        self._g_phi.zero_()
+        return self
+
+    def step_device(self, ring_f32):
+        """ring float32 [1, buffersize*chunk] already on the device -> wave [L] (device); phase carried internally."""
+        if getattr(self, "_graph", None) is not None:
+            self._g_in.copy_(ring_f32)
+            self._graph.replay()
+            return self._g_out
+        phi = self.phi if isinstance(self.phi, torch.Tensor) else torch.zeros(1, 64, device=self.device)
+        wave, phi_next = self._device_step(ring_f32, phi)
+        self.phi = phi_next
+        return wave
 
     def step(self, data_int16: np.ndarray):
         """one chunk of int16 samples -> converted centre chunk (int16), or None while the ring fills
@@ -44,19 +94,7 @@ class RealtimeConverter:
             return None
         data = np.concatenate(self.ring, 0).astype(np.float32) / 32768
         data = torch.from_numpy(data).to(self.device).unsqueeze(0)
-        data = audio_io.resample(data, self.input_sr, 16000)
-        data = audio_io.gain(data, self.input_gain)
-        spec = spectrogram(data)
-        content = self.ce(spec)
-        f0 = self.pe.estimate(spec)
-        f0 = ops.pitch_transform_(f0, 1, f0_rate=self.f0_rate, pitch_shift=self.pitch)
-        val, idx = self.lib.search(content, self.k)
-        content = merge_gather(val, idx, 1, self.k, self.alpha, self.lib.rows, content)
-        wave, phi_out = self.dec(content, f0=f0, phi=self.phi, crop=(self.begin_of_output, self.end_of_output))
-        self.phi = phi_out[:, :, self.end_of_output].unsqueeze(2)
-        self.last_f0 = f0
-        wave = audio_io.gain(wave, self.gain)
-        wave = audio_io.resample(wave, 16000, self.output_sr)[0]
+        wave = self.step_device(data)
         out = (wave.cpu().numpy() * 32768).astype(np.int16)          # C cast, no clipping (:180-183)
         center = self.buffersize * self.chunk // 2
         return out[center - self.chunk // 2: center + self.chunk // 2]

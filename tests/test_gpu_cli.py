@@ -108,3 +108,24 @@ def test_generate_voice_library_writes_reference_format(workdir):
     d2 = (feats[:, :, :8] - tok.view(1, 768, 1)).pow(2).sum(dim=1)
     assert d2.min().item() < 1e-4 * tok.pow(2).sum().item()
     VoiceLibrary().load_state_dict(sd)
+
+
+def test_realtime_graph_capture_equals_eager(workdir):
+    """the whole per-step device pipeline captured into one hipGraph replays to the same samples as eager execution"""
+    from module.content_encoder import ContentEncoder
+    from module.decoder import Decoder
+    from module.f0_estimator import F0Estimator
+    from module.realtime import RealtimeConverter
+    lib = synthetic.make_library(2000, 1)
+    chunk, bs = 160, 16                      # 10 ms chunks, 8-frame ring (BASELINE config 5)
+    pcm = (synthetic.make_waveform(chunk * (bs + 6), 63)[0].numpy() * 20000).astype(np.int16)
+    outs = {}
+    for mode in ("eager", "graph"):
+        rt = RealtimeConverter(ContentEncoder(seed=2), F0Estimator(seed=2), Decoder(seed=2), lib, "cuda", chunk=chunk,
+                               buffersize=bs, f0_rate=0.5)
+        if mode == "graph":
+            rt.enable_graph()
+        got = [rt.step(pcm[s * chunk:(s + 1) * chunk]) for s in range(bs + 6)]
+        outs[mode] = np.concatenate([o for o in got if o is not None])
+    assert outs["eager"].shape == (6 * chunk,)
+    assert np.array_equal(outs["eager"], outs["graph"])
