@@ -36,6 +36,9 @@ def partition_windows(n_windows, world, rank):
 def allgather_candidates(val, idx, group=None):
     """[Tt, k] per rank -> ([S, Tt, k], [S, Tt, k]) in rank order (the layout alive_knn_merge_gather reads)."""
     world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo" and val.is_cuda:      # test-only path (1-GPU box): gloo moves host memory
+        gv, gi = allgather_candidates(val.cpu(), idx.cpu(), group)
+        return gv.to(val.device), gi.to(val.device)
     tt, k = val.shape
     gv = torch.empty((world * tt, k), dtype=val.dtype, device=val.device)
     gi = torch.empty((world * tt, k), dtype=idx.dtype, device=idx.device)
@@ -85,7 +88,7 @@ def bench_sharded_knn(conv, windows, M, k, world, rank, dev, steps=3):
         lib.match(feat, k)
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    tt = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     frames = feat.shape[0] * feat.shape[2]
     return {"frames": frames, "ms": round(tt.item() * 1e3, 3), "frames_per_s": round(frames / tt.item(), 1),

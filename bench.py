@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--window-batch", type=int, default=64)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-oracle leg (0 = skip)")
     ap.add_argument("--shard-library", action="store_true", help="also time the library-sharded kNN + all-gather")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the real thing); gloo + --same-device only exercise the multi-rank code path on a 1-GPU box")
+    ap.add_argument("--same-device", action="store_true", help="test only: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -109,10 +112,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", 0 if args.same_device else local)
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from module import _native as nat
     from module.common import PackedLibrary
@@ -168,7 +174,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     assert torch.isfinite(out).all(), "non-finite waveform"

@@ -63,11 +63,18 @@ def test_weight_tables_cover_the_schema():
         packed = pk(synthetic.make_state_dict(sch, 2))
         assert set(packed) == set(nat.weight_names(mid))
         for k, v in packed.items():
-            assert v.dtype == torch.float32 and v.is_contiguous()
-            if k.endswith(".W"):
+            assert v.dtype in (torch.float32, torch.bfloat16) and v.is_contiguous()
+            if k.endswith(".W") and v.dtype == torch.float32:          # exact-fp32 kernel: [Co_pad16][K_pad16]
                 assert v.shape[0] % 16 == 0 and v.shape[1] % 16 == 0
-    p = _pack.pack_decoder(synthetic.make_state_dict(schema.decoder_schema(), 2))
-    assert p["flt.film.W"].shape == (4128, 512) and p["flt.film.post"].sum().item() == 2064
+            if k.endswith(".W") and v.dtype == torch.bfloat16:         # split kernel: [2][Co_pad16][KW * Ci_pad32]
+                assert v.shape[0] == 2 and v.shape[1] % 16 == 0 and v.shape[2] % 32 == 0
+    sd = synthetic.make_state_dict(schema.decoder_schema(), 2)
+    p = _pack.pack_decoder(sd)
+    assert p["flt.film.W"].shape == (2, 4128, 512) and p["flt.film.post"].sum().item() == 2064
+    w = sd["filter.blocks.0.blocks.1.c2.conv.conv.weight"]                 # [256, 256, 5]
+    hi, lo = p["flt.blk0.1.c2.W"][0].float(), p["flt.blk0.1.c2.W"][1].float()
+    back = (hi + lo).view(256, 5, 256).permute(0, 2, 1)                    # tap-major -> [co, ci, j]
+    assert (back - w).abs().max().item() <= 2.0 ** -16 * w.abs().max().item()
     w = torch.arange(2 * 3 * 4, dtype=torch.float32).view(2, 3, 4)            # ConvT [Ci=2, Co=3, r=4]
     W, b = _pack.pack_convT(w, torch.tensor([1.0, 2.0, 3.0]))
     assert W[1 * 4 + 2, 1].item() == w[1, 1, 2].item() and b.tolist() == [1.0] * 4 + [2.0] * 4 + [3.0] * 4
