@@ -26,6 +26,8 @@ constexpr float NORM_EPS = 1e-4f;
 constexpr int F_CH[4] = {256, 64, 16, 8};            // filter channels, coarse -> fine (decoder.py:157,171)
 constexpr int F_UP[4] = {10, 8, 2, 2};               // upsampling rates, coarse -> fine
 constexpr int FILM_ROWS = 6 * 2 * (256 + 64 + 16 + 8);   // 4128
+constexpr bool F_SPLIT[4] = {true, true, false, false};   // filter scales on the split-bf16 MFMA kernel (C = 256, 64);
+                                                          // the 16- / 8-channel scales run the fused VALU FilterBlock kernel
 
 inline int pad16(int x) { return (x + 15) & ~15; }
 
@@ -63,6 +65,7 @@ const Names& names_of(int model) {
         for (int i = 0; i < 4; ++i) { dec.add("flt.up" + std::to_string(i) + ".W"); dec.add("flt.up" + std::to_string(i) + ".b"); }
         for (int s = 0; s < 4; ++s) {
             std::string b = "flt.blk" + std::to_string(s);
+            if (!F_SPLIT[s]) { dec.add(b + ".pack"); continue; }        // fused 16- / 8-channel FilterBlock
             dec.add(b + ".in.W"); dec.add(b + ".in.b");
             for (int j = 0; j < 3; ++j)
                 for (int c = 1; c <= 2; ++c) {
@@ -103,7 +106,6 @@ AliveConv split(AliveConv d) {
     d.Ci_pad = (d.Ci + 31) & ~31;
     return d;
 }
-constexpr bool F_SPLIT[4] = {true, true, false, false};   // filter scales on the split kernel (C = 256, 64)
 
 #define RUN(expr)                     \
     do {                              \
@@ -334,6 +336,14 @@ extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, c
             RUN(alive_conv1d(&d, stream));
         }
         L *= r;
+        if (!F_SPLIT[s]) {      // whole FilterBlock (+ skip) in one kernel: U -> Hh
+            const float* wpack = t.next();
+            RUN(alive_filter_block_small(b.U, N, C, L, wpack, b.film, FILM_ROWS, Lf, film_off, skips[s], b.Hh, stream));
+            film_off += 6 * 2 * C;
+            cur = b.Hh;
+            cin = C;
+            continue;
+        }
         const float* iW = t.next(); const float* ib = t.next();
         {   // FilterBlock.input_conv; second output feeds blocks[0].c1 (gelu + FiLM)
             AliveConv d = pw_desc(iW, ib, b.U, N, C, L, C, b.Hh);

@@ -40,6 +40,8 @@ PROTOTYPES = {
     "alive_knn_set_timing_events": (_I, [_VP, _VP]),
     "alive_knn_merge_gather": (_I, [_VP, _VP, _I, _I, _D, _VP, _VP, _I, _I, _VP, _VP, _VP]),
     "alive_conv1d": (_I, [C.POINTER(AliveConv), _VP]),
+    "alive_filter_block_small_weights": (_I, [_I]),
+    "alive_filter_block_small": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
     "alive_dwconv_norm": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP]),
     "alive_channel_norm": (_I, [_VP, _I, _I, _I, _VP, _VP, _F, _VP, _VP]),
     "alive_argmax_channels": (_I, [_VP, _I, _I, _I, _VP, _VP]),

@@ -96,6 +96,16 @@ FILTER_CH = [256, 64, 16, 8]
 SPLIT_SCALE = [True, True, False, False]
 
 
+def pack_filter_small(sd, prefix):
+    """FilterBlock weights for the fused 8/16-channel kernel: Win[ci][co], bin, then per conv W[ci][j][co], b."""
+    parts = [sd[prefix + ".input_conv.weight"][:, :, 0].t().reshape(-1), sd[prefix + ".input_conv.bias"].reshape(-1)]
+    for j in range(3):
+        for cc in ("c1", "c2"):
+            w = sd[f"{prefix}.blocks.{j}.{cc}.conv.conv.weight"]            # [co, ci, 5]
+            parts += [w.permute(1, 2, 0).reshape(-1), sd[f"{prefix}.blocks.{j}.{cc}.conv.conv.bias"].reshape(-1)]
+    return torch.cat([p.float() for p in parts]).contiguous()
+
+
 def pack_decoder(sd):
     out = {}
     fe = "feature_extractor"
@@ -139,12 +149,14 @@ def pack_decoder(sd):
         out[f"flt.up{i}.W"], out[f"flt.up{i}.b"] = pt(sd[f"{f}.ups.{i}.weight"], sd[f"{f}.ups.{i}.bias"])
     for s in range(4):
         b = f"{f}.blocks.{s}"
-        pc = pack_conv_split if SPLIT_SCALE[s] else pack_conv
-        out[f"flt.blk{s}.in.W"] = pc(sd[b + ".input_conv.weight"])
+        if not SPLIT_SCALE[s]:                       # 16- / 8-channel scales: one fused kernel per FilterBlock
+            out[f"flt.blk{s}.pack"] = pack_filter_small(sd, b)
+            continue
+        out[f"flt.blk{s}.in.W"] = pack_conv_split(sd[b + ".input_conv.weight"])
         out[f"flt.blk{s}.in.b"] = _vec(sd[b + ".input_conv.bias"])
         for j in range(3):
             for cc in ("c1", "c2"):
-                out[f"flt.blk{s}.{j}.{cc}.W"] = pc(sd[f"{b}.blocks.{j}.{cc}.conv.conv.weight"])
+                out[f"flt.blk{s}.{j}.{cc}.W"] = pack_conv_split(sd[f"{b}.blocks.{j}.{cc}.conv.conv.weight"])
                 out[f"flt.blk{s}.{j}.{cc}.b"] = _vec(sd[f"{b}.blocks.{j}.{cc}.conv.conv.bias"])
     out["flt.out.W"] = pack_conv(sd[f + ".source_out.weight"])
     out["flt.out.b"] = _vec(sd[f + ".source_out.bias"])

@@ -127,3 +127,16 @@ def pitch_transform_(f0, mode, f0_rate=1.0, pitch_shift=0.0, intonation=1.0):
     nat.check(nat.lib().alive_pitch_transform(nat.ptr(f0), n, t, mode, f0_rate, pitch_shift, intonation, nat.stream()),
               "alive_pitch_transform")
     return f0
+
+
+def filter_block_small(x, sd, prefix, film, film_off, skip=None):
+    """fused FilterBlock for C in (8, 16): x[N,C,L], reference-layout weights sd[prefix + ...], film[N,rows,Lf]."""
+    from ._pack import pack_filter_small
+    x, film, skip = _f(x), _f(film), _f(skip)
+    n, c, l = x.shape
+    w = pack_filter_small(sd, prefix).to(x.device)
+    assert w.numel() == nat.lib().alive_filter_block_small_weights(c)
+    out = torch.empty_like(x)
+    nat.check(nat.lib().alive_filter_block_small(nat.ptr(x), n, c, l, nat.ptr(w), nat.ptr(film), film.shape[1], film.shape[2],
+                                                 film_off, nat.ptr(skip), nat.ptr(out), nat.stream()), "alive_filter_block_small")
+    return out

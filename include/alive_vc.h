@@ -117,6 +117,16 @@ typedef struct AliveConv {
 } AliveConv;
 int alive_conv1d(const AliveConv* desc, void* stream);
 
+/* FilterBlock.forward (decoder.py:137-150) for C = 8 or 16 fused into one kernel: input_conv 1x1 + three
+ * FilterResBlocks (six GELU -> FiLM -> reflect-left causal k5 convs, dilations 1,1,2,2,4,4), optional U-Net skip
+ * added to the result.  U[N][C][L] -> out[N][C][L] (not in place).
+ *   wpack: alive_filter_block_small_weights(C) floats = Win[ci][co], bin[co], then per conv q = 0..5
+ *          W[ci][j][co], b[co]   (module/_pack.py::pack_filter_small)
+ *   film[N][film_rows][Lf]; conv q reads its scale rows at film_off + q*2C and shift rows at film_off + q*2C + C. */
+int alive_filter_block_small_weights(int C);
+int alive_filter_block_small(const float* U, int N, int C, int L, const float* wpack, const float* film,
+                             int film_rows, int Lf, int film_off, const float* skip, float* out, void* stream);
+
 /* depthwise k7 conv + (Adaptive)ChannelNorm (common.py:20-26,35-41,55-56,75-76)
  *   affine_mode 0: gain[C], offset[C];  1: per-sample scale/shift rows in cond[N][cond_rows][T] */
 int alive_dwconv_norm(const float* X, int N, int C, int T, const float* dw_w, const float* dw_b,

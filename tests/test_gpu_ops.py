@@ -298,3 +298,35 @@ def test_modulated_chain_split_bf16(golden_dir):
                            pad_left=4 * d, pad_mode=1, out_len=x.shape[2], residual=h,
                            film=film if j < 2 else None, film_scale_row=nxt, film_shift_row=nxt + C, **kw)
     assert relerr(h, ref) < 1e-4, relerr(h, ref)
+
+
+@pytest.mark.parametrize("c,l,lf", [(8, 4800, 15), (16, 2400, 15), (8, 144000, 450), (16, 1000, 5)])
+def test_fused_filter_block_small(c, l, lf):
+    """whole FilterBlock (input_conv + 3 res blocks, FiLM, reflect pads, halo recompute across tiles) in one kernel
+    against the oracle's conv-by-conv evaluation (decoder.py:105-150)."""
+    from module import ops
+    cond_ch = 24
+    x = g(f"fbx{c}{l}", (2, c, l))
+    cnd = g(f"fbc{c}{l}", (2, cond_ch, lf))
+    skip = g(f"fbs{c}{l}", (2, c, l))
+    sd = {"n.input_conv.weight": g("fbiw", (c, c, 1), scale=0.4), "n.input_conv.bias": g("fbib", (c,), scale=0.1)}
+    ws, bs, post = [], [], []
+    for j in range(3):
+        for cc in ("c1", "c2"):
+            p = f"n.blocks.{j}.{cc}"
+            sd[p + ".conv.conv.weight"] = g(p + "w", (c, c, 5), scale=0.5 / np.sqrt(c))
+            sd[p + ".conv.conv.bias"] = g(p + "b", (c,), scale=0.1)
+            sd[p + ".to_scale.weight"] = g(p + "sw", (c, cond_ch, 1), scale=0.1)
+            sd[p + ".to_scale.bias"] = g(p + "sb", (c,), scale=0.1)
+            sd[p + ".to_shift.weight"] = g(p + "hw", (c, cond_ch, 1), scale=0.1)
+            sd[p + ".to_shift.bias"] = g(p + "hb", (c,), scale=0.1)
+            ws += [sd[p + ".to_scale.weight"], sd[p + ".to_shift.weight"]]
+            bs += [sd[p + ".to_scale.bias"], sd[p + ".to_shift.bias"]]
+            post += [torch.ones(c), torch.zeros(c)]
+    ref = O.filter_block(sd, "n", x, cnd) + skip
+    pad_rows = 5                                     # FiLM rows start at an offset inside a larger table, as in the decoder
+    film, _ = ops.conv1d(cnd.to(DEV), torch.cat([torch.zeros(pad_rows, cond_ch, 1)] + ws, 0).to(DEV),
+                         torch.cat([torch.zeros(pad_rows)] + bs, 0).to(DEV), post_add=torch.cat([torch.zeros(pad_rows)] + post).to(DEV))
+    out = ops.filter_block_small(x.to(DEV), {k: v.to(DEV) for k, v in sd.items()}, "n", film, pad_rows, skip=skip.to(DEV))
+    e = relerr(out, ref)
+    assert e < 5e-6, e
