@@ -3,189 +3,195 @@
 // reflect-left causal k5 convs with dilations 1,1,2,2,4,4 and three residual adds, fused into ONE kernel.
 //
 // At 72 000 / 144 000 samples x 16 / 8 channels these layers are HBM-bound when run conv by conv (each conv
-// reads and writes 1-2 full tensors: ~14 tensor passes per scale).  Here a block owns a time tile, keeps the
-// three live tensors (residual stream h, modulated conv input z, intermediate y) of that tile in LDS, and
-// recomputes the 56-sample causal halo (4 x (1+1+2+2+4+4)) instead of exchanging it: HBM traffic drops to the
-// input, the U-Net skip and the output.  Arithmetic is plain fp32 FMA on the VALU (C <= 16 makes an MFMA
-// tile at least half empty); every thread owns fixed time columns through all seven convs, weights and the
-// FiLM rows of the tile are broadcast from LDS.
+// reads and writes 1-2 full tensors: ~14 tensor passes per scale).  Here a block owns a time tile and keeps it on
+// chip through all seven convs: the modulated conv input z and the intermediate y live in two LDS buffers, the
+// residual stream h in registers; the 56-sample causal halo (4 x (1+1+2+2+4+4)) is recomputed instead of
+// exchanged, so HBM traffic drops to the input, the U-Net skip and the output.
+//
+// Arithmetic: exact fp32 on v_mfma_f32_16x16x4_f32 with the WEIGHTS stationary in registers: a conv has
+// K = 5*C <= 80, i.e. at most 20 MFMA k-steps, so the A fragments of all seven convs are 124 VGPRs per lane for
+// the whole kernel, and the only per-MFMA operand traffic is one ds_read_b32 of the B fragment (16 time columns x
+// 4 k).  (A first VALU version streamed the weights through SGPRs / LDS and was bound by those fetches: 4.6 ms vs
+// the ~0.6 ms of MFMA work.)  A wave owns fixed 16-column groups through all convs, so the epilogue of a group
+// (residual add, GELU, FiLM) is register-local and only the modulated result goes back to LDS.
 #include "conv_epilogue.h"
 
 namespace {
 
 constexpr int HALO = 56;
 constexpr int NCONV = 6;
-constexpr int NFP = 8;          // FiLM frames staged per tile (tile span / 160 or / 320 + 2 taps)
+constexpr int NFP = 10;         // FiLM frames staged per tile (tile span / 160 or / 320 + 2 taps + slack)
+constexpr int NT = 512;         // 8 waves: two per SIMD
 
 template <int C>
 struct SmallCfg {
-    static constexpr int SPT = C == 8 ? 4 : 2;          // columns per thread
-    static constexpr int BL = 256 * SPT;                // columns per tile incl. halo
+    static constexpr int BL = 1024;                     // columns per tile incl. halo
     static constexpr int TT = BL - HALO;                // output columns per tile
-    static constexpr int WFLOATS = C * C + C + NCONV * (5 * C * C + C);
+    static constexpr int P = BL + 16;                   // LDS row pitch: the four k-rows of a B fragment land on disjoint banks
+    static constexpr int NG = BL / 16;                  // 16-column groups per tile
+    static constexpr int G = NG / 8;                    // groups per wave
+    static constexpr int KS = 5 * C / 4;                // MFMA k-steps of a k5 conv (20 / 10)
+    static constexpr int KS_IN = C / 4;                 // k-steps of the 1x1 input conv
+    static constexpr int WFLOATS = (C + NCONV * 5 * C) * 16 + (1 + NCONV) * 16;   // [k][16 co] per conv, then 7 x bias[16]
 };
 
 template <int C>
-__global__ __launch_bounds__(256, 1) void filter_block_small_kernel(const float* __restrict__ U, int L,
-                                                                    const float* __restrict__ wpack,
-                                                                    const float* __restrict__ film, int film_rows, int Lf,
-                                                                    int film_off, float ratio, const float* __restrict__ skip,
-                                                                    float* __restrict__ out) {
+__global__ __launch_bounds__(NT, 2) void filter_block_small_kernel(const float* __restrict__ U, int L,
+                                                                   const float* __restrict__ wpack,
+                                                                   const float* __restrict__ film, int film_rows, int Lf,
+                                                                   int film_off, float ratio, const float* __restrict__ skip,
+                                                                   float* __restrict__ out) {
     using Cfg = SmallCfg<C>;
-    constexpr int SPT = Cfg::SPT, BL = Cfg::BL, TT = Cfg::TT;
+    constexpr int BL = Cfg::BL, TT = Cfg::TT, P = Cfg::P, G = Cfg::G, KS = Cfg::KS, KS_IN = Cfg::KS_IN;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* bufH = sm;                       // [C][BL]
-    float* bufZ = bufH + C * BL;            // [C][BL]
-    float* bufY = bufZ + C * BL;            // [C][BL]
-    float* W = bufY + C * BL;               // packed weights
-    float* Fs = W + Cfg::WFLOATS;           // [NCONV][2][C][NFP]
+    float* bufZ = sm;                       // [C][P]
+    float* bufY = bufZ + C * P;             // [C][P]
+    float* Fs = bufY + C * P;               // [NCONV][2][C][NFP]
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ln = lane & 15, lq = lane >> 4;
     const int n = blockIdx.y;
     const int t0 = blockIdx.x * TT;
     const int tbase = t0 - HALO;
     const float* Un = U + (size_t)n * C * L;
 
-    for (int e = tid; e < Cfg::WFLOATS; e += 256) W[e] = wpack[e];
-    // FiLM rows of the tile: frames covering columns [max(tbase,0), t0+TT)
-    int f_lo;
-    {
-        int ta = tbase < 0 ? 0 : tbase;
-        f_lo = lerp_coord(ta, ratio, Lf).i0;
-    }
-    for (int e = tid; e < NCONV * 2 * C * NFP; e += 256) {
+    // ---- stationary A fragments: lane (co = ln, k-slot lq) of k-step s holds W[k = 4s + lq][co] ----
+    // (the input conv's here; each k5 conv reloads its 20 / 10 values from L2 at the top of its pass, which keeps the
+    //  register footprint at two waves per SIMD and the conv loop rolled)
+    float a_in[KS_IN], bias_in[4];
+#pragma unroll
+    for (int s = 0; s < KS_IN; ++s) a_in[s] = wpack[(4 * s + lq) * 16 + ln];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias_in[r] = wpack[(C + NCONV * 5 * C) * 16 + lq * 4 + r];
+
+    // ---- FiLM rows of the tile ----
+    const int f_lo = lerp_coord(tbase < 0 ? 0 : tbase, ratio, Lf).i0;
+    for (int e = tid; e < NCONV * 2 * C * NFP; e += NT) {
         int f = e % NFP, c = (e / NFP) % C, sel = (e / (NFP * C)) & 1, q = e / (NFP * C * 2);
         int fr = f_lo + f;
         fr = fr < Lf ? fr : Lf - 1;
         Fs[e] = film[((size_t)n * film_rows + film_off + q * 2 * C + sel * C + c) * Lf + fr];
     }
-    // per-column interpolation taps (same for every conv): column i = tid + 256*s, t = tbase + i
-    int li0[SPT], li1[SPT];
-    float lw0[SPT], lw1[SPT];
-#pragma unroll
-    for (int s = 0; s < SPT; ++s) {
-        int t = tbase + tid + 256 * s;
-        t = t < 0 ? 0 : (t < L ? t : L - 1);
-        Lerp lp = lerp_coord(t, ratio, Lf);
-        li0[s] = lp.i0 - f_lo;
-        li1[s] = lp.i1 - f_lo;
-        if (li0[s] > NFP - 1) li0[s] = NFP - 1;
-        if (li1[s] > NFP - 1) li1[s] = NFP - 1;
-        lw0[s] = lp.w0;
-        lw1[s] = lp.w1;
-    }
-    // stage the input tile
-#pragma unroll
-    for (int s = 0; s < SPT; ++s) {
-        const int i = tid + 256 * s, t = tbase + i;
-        const bool ok = t >= 0 && t < L;
-#pragma unroll
-        for (int c = 0; c < C; ++c) bufZ[c * BL + i] = ok ? Un[(size_t)c * L + t] : 0.0f;
+    // ---- stage the input tile (raw U) into bufZ ----
+    for (int e = tid; e < C * BL; e += NT) {
+        int c = e / BL, i = e - c * BL;
+        int t = tbase + i;
+        bufZ[c * P + i] = (t >= 0 && t < L) ? Un[(size_t)c * L + t] : 0.0f;
     }
     __syncthreads();
 
-    auto modulate = [&](int q, int c, int s, float v) {       // gelu -> FiLM of conv q's input
-        const float* f = Fs + ((q * 2) * C + c) * NFP;
-        float sc = fmaf(lw0[s], f[li0[s]], lw1[s] * f[li1[s]]);
-        float sh = fmaf(lw0[s], f[C * NFP + li0[s]], lw1[s] * f[C * NFP + li1[s]]);
-        return gelu_fast(v) * sc + sh;
-    };
-
-    // ---- input_conv (1x1): h = Win * U + b ; z0 = mod_0(h)     (decoder.py:147) ----
-    {
-        const float* Win = W;               // [ci][co]
-        const float* bin = W + C * C;
-        float acc[C][SPT];
+    // gelu -> FiLM of conv q's input, for channel rows lq*4 + r of column `col`
+    auto modulate_store = [&](int q, float* dst, int col, const f32x4& v) {
+        int t = tbase + col;
+        t = t < 0 ? 0 : (t < L ? t : L - 1);
+        Lerp lp = lerp_coord(t, ratio, Lf);
+        int i0 = lp.i0 - f_lo, i1 = lp.i1 - f_lo;
+        i0 = i0 < NFP - 1 ? i0 : NFP - 1;
+        i1 = i1 < NFP - 1 ? i1 : NFP - 1;
 #pragma unroll
-        for (int co = 0; co < C; ++co)
-#pragma unroll
-            for (int s = 0; s < SPT; ++s) acc[co][s] = bin[co];
-#pragma unroll
-        for (int ci = 0; ci < C; ++ci) {
-            float x[SPT];
-#pragma unroll
-            for (int s = 0; s < SPT; ++s) x[s] = bufZ[ci * BL + tid + 256 * s];
-#pragma unroll
-            for (int co = 0; co < C; ++co) {
-                float w = Win[ci * C + co];
-#pragma unroll
-                for (int s = 0; s < SPT; ++s) acc[co][s] = fmaf(w, x[s], acc[co][s]);
+        for (int r = 0; r < 4; ++r) {
+            const int co = lq * 4 + r;
+            if (co < C) {
+                const float* f = Fs + ((q * 2) * C + co) * NFP;
+                float sc = fmaf(lp.w0, f[i0], lp.w1 * f[i1]);
+                float sh = fmaf(lp.w0, f[C * NFP + i0], lp.w1 * f[C * NFP + i1]);
+                dst[co * P + col] = gelu_fast(v[r]) * sc + sh;
             }
         }
+    };
+
+    // B-fragment row offsets: k = 4s + lq -> ci = (4s + lq) % C = 4*(s % (C/4)) + lq
+    int rowoff[C / 4];
 #pragma unroll
-        for (int co = 0; co < C; ++co)
+    for (int u = 0; u < C / 4; ++u) rowoff[u] = (4 * u + lq) * P;
+
+    // residual stream of this wave's column groups (group g = wv + 8*i, column = 16 g + ln), MFMA C layout
+    f32x4 h[G];
+
+    // ---- input_conv (1x1): h = Win * U + b ; z0 = mod_0(h), written back over the same columns ----
 #pragma unroll
-            for (int s = 0; s < SPT; ++s) {
-                const int i = tid + 256 * s;
-                bufH[co * BL + i] = acc[co][s];
-                bufZ[co * BL + i] = modulate(0, co, s, acc[co][s]);      // same column, all ci already consumed
-            }
+    for (int i = 0; i < G; ++i) {
+        const int col = (wv + 8 * i) * 16 + ln;
+        f32x4 acc = {bias_in[0], bias_in[1], bias_in[2], bias_in[3]};
+#pragma unroll
+        for (int s = 0; s < KS_IN; ++s)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_in[s], bufZ[rowoff[s] + col], acc, 0, 0, 0);
+        h[i] = acc;
     }
+    __syncthreads();            // every wave has read its raw columns (a group's rows are read by that group only, but
+                                // the A x B product of one MFMA gathers all 16 lanes' columns: keep it simple and safe)
+#pragma unroll
+    for (int i = 0; i < G; ++i) modulate_store(0, bufZ, (wv + 8 * i) * 16 + ln, h[i]);
     __syncthreads();
 
     // ---- three FilterResBlocks: q = 2j (c1), 2j+1 (c2), dilation 2^j    (decoder.py:128-134) ----
-    const float* Wq = W + C * C + C;
 #pragma unroll 1
     for (int q = 0; q < NCONV; ++q) {
+        float a_q[KS], bias_q[4];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a_q[s] = wpack[(C + q * 5 * C + 4 * s + lq) * 16 + ln];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias_q[r] = wpack[(C + NCONV * 5 * C) * 16 + (1 + q) * 16 + lq * 4 + r];
         const int d = 1 << (q >> 1);
         const bool second = q & 1;
         const float* in = second ? bufY : bufZ;
-        const float* wq = Wq + q * (5 * C * C + C);       // [ci][j][co]
-        const float* bq = wq + 5 * C * C;
-        float acc[C][SPT];
-#pragma unroll
-        for (int co = 0; co < C; ++co)
-#pragma unroll
-            for (int s = 0; s < SPT; ++s) acc[co][s] = bq[co];
-#pragma unroll 1
-        for (int ci = 0; ci < C; ++ci) {
+        float* dst = second ? bufZ : bufY;
+        // B fragments of a group (KS values per lane) are read one group AHEAD of their MFMAs: with the weights in
+        // registers the ds_read latency is the only thing an MFMA could wait for.
+        auto load_group = [&](int i, float (&bv)[KS]) {
+            const int col = (wv + 8 * i) * 16 + ln;
+            int idx[5];
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
-                float x[SPT];
-#pragma unroll
-                for (int s = 0; s < SPT; ++s) {
-                    int t = tbase + tid + 256 * s + (j - 4) * d;
-                    t = t < 0 ? -t : t;                                  // ReflectionPad1d on the left (common.py:88)
-                    int i = t - tbase;
-                    i = i < BL ? i : BL - 1;                             // only garbage columns can get here
-                    x[s] = in[ci * BL + i];
-                }
-                const float* w = wq + (ci * 5 + j) * C;
-#pragma unroll
-                for (int co = 0; co < C; ++co) {
-                    float wv = w[co];
-#pragma unroll
-                    for (int s = 0; s < SPT; ++s) acc[co][s] = fmaf(wv, x[s], acc[co][s]);
-                }
+                int ta = tbase + col + (j - 4) * d;
+                ta = ta < 0 ? -ta : ta;                      // ReflectionPad1d on the left (common.py:88)
+                int ia = ta - tbase;
+                ia = ia < 0 ? 0 : ia;                        // only never-stored halo columns can be clamped
+                idx[j] = ia < BL ? ia : BL - 1;
             }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) bv[s] = in[rowoff[s % (C / 4)] + idx[(4 * s) / C]];
+        };
+        float bcur[KS], bnxt[KS];
+        load_group(0, bcur);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            if (i + 1 < G) load_group(i + 1, bnxt);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc0 = {bias_q[0], bias_q[1], bias_q[2], bias_q[3]};
+            f32x4 acc1 = {0.0f, 0.0f, 0.0f, 0.0f};           // two chains: the 16x16x4 MFMA has a 40-cycle dependent latency
+#pragma unroll
+            for (int s = 0; s < KS; s += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_q[s], bcur[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_q[s + 1], bcur[s + 1], acc1, 0, 0, 0);
+            }
+            acc0 = acc0 + acc1;
+            if (second) {
+                acc0 = acc0 + h[i];
+                h[i] = acc0;
+            }
+            if (q + 1 < NCONV) modulate_store(q + 1, dst, (wv + 8 * i) * 16 + ln, acc0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) bcur[s] = bnxt[s];
         }
-        float* dst = second ? bufZ : bufY;
-#pragma unroll
-        for (int co = 0; co < C; ++co)
-#pragma unroll
-            for (int s = 0; s < SPT; ++s) {
-                const int i = tid + 256 * s;
-                float v = acc[co][s];
-                if (second) {
-                    v = v + bufH[co * BL + i];
-                    bufH[co * BL + i] = v;
-                }
-                if (q + 1 < NCONV) dst[co * BL + i] = modulate(q + 1, co, s, v);
-            }
         __syncthreads();
     }
 
     // ---- store the tile (+ U-Net skip, decoder.py:191) ----
 #pragma unroll
-    for (int s = 0; s < SPT; ++s) {
-        const int i = tid + 256 * s, t = tbase + i;
-        if (i >= HALO && t < L) {
+    for (int i = 0; i < G; ++i) {
+        const int col = (wv + 8 * i) * 16 + ln, t = tbase + col;
+        if (col >= HALO && t < L) {
 #pragma unroll
-            for (int co = 0; co < C; ++co) {
-                const size_t o = ((size_t)n * C + co) * L + t;
-                float v = bufH[co * BL + i];
-                if (skip != nullptr) v = v + skip[o];
-                out[o] = v;
+            for (int r = 0; r < 4; ++r) {
+                const int co = lq * 4 + r;
+                if (co < C) {
+                    const size_t o = ((size_t)n * C + co) * L + t;
+                    float v = h[i][r];
+                    if (skip != nullptr) v = v + skip[o];
+                    out[o] = v;
+                }
             }
         }
     }
@@ -195,7 +201,7 @@ template <int C>
 int launch_small(const float* U, int N, int L, const float* wpack, const float* film, int film_rows, int Lf, int film_off,
                  const float* skip, float* out, hipStream_t s) {
     using Cfg = SmallCfg<C>;
-    const int lds = (3 * C * Cfg::BL + Cfg::WFLOATS + NCONV * 2 * C * NFP) * (int)sizeof(float);
+    const int lds = (2 * C * Cfg::P + NCONV * 2 * C * NFP) * (int)sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)filter_block_small_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -208,7 +214,7 @@ int launch_small(const float* U, int N, int L, const float* wpack, const float* 
     const float ratio = (float)Lf / (float)L;
     ALIVE_CHECK_ARG((double)Cfg::BL * Lf / L + 3.0 <= NFP, "alive_filter_block_small: tile spans more than %d frames (L %d, Lf %d)", NFP, L, Lf);
     dim3 g(cdiv(L, Cfg::TT), N);
-    filter_block_small_kernel<C><<<g, 256, lds, s>>>(U, L, wpack, film, film_rows, Lf, film_off, ratio, skip, out);
+    filter_block_small_kernel<C><<<g, NT, lds, s>>>(U, L, wpack, film, film_rows, Lf, film_off, ratio, skip, out);
     ALIVE_CHECK_LAUNCH("alive_filter_block_small");
     return ALIVE_OK;
 }

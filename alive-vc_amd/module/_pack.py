@@ -97,13 +97,24 @@ SPLIT_SCALE = [True, True, False, False]
 
 
 def pack_filter_small(sd, prefix):
-    """FilterBlock weights for the fused 8/16-channel kernel: Win[ci][co], bin, then per conv W[ci][j][co], b."""
-    parts = [sd[prefix + ".input_conv.weight"][:, :, 0].t().reshape(-1), sd[prefix + ".input_conv.bias"].reshape(-1)]
+    """FilterBlock weights for the fused 8/16-channel kernel (csrc/filter_small.hip): MFMA A-operand order.
+    [k = ci][16] input conv, then per conv q [k = j*C + ci][16] (output channel padded to 16), then 7 x bias[16]."""
+    def pad_co(m):                       # [K, C] -> [K, 16]
+        out = torch.zeros(m.shape[0], 16, dtype=torch.float32, device=m.device)
+        out[:, :m.shape[1]] = m
+        return out
+    w_in = sd[prefix + ".input_conv.weight"].float()                           # [co, ci, 1]
+    mats, biases = [pad_co(w_in[:, :, 0].t())], [sd[prefix + ".input_conv.bias"].float()]
     for j in range(3):
         for cc in ("c1", "c2"):
-            w = sd[f"{prefix}.blocks.{j}.{cc}.conv.conv.weight"]            # [co, ci, 5]
-            parts += [w.permute(1, 2, 0).reshape(-1), sd[f"{prefix}.blocks.{j}.{cc}.conv.conv.bias"].reshape(-1)]
-    return torch.cat([p.float() for p in parts]).contiguous()
+            w = sd[f"{prefix}.blocks.{j}.{cc}.conv.conv.weight"].float()         # [co, ci, 5]
+            c = w.shape[0]
+            mats.append(pad_co(w.permute(2, 1, 0).reshape(5 * c, c)))            # k = tap*C + ci
+            biases.append(sd[f"{prefix}.blocks.{j}.{cc}.conv.conv.bias"].float())
+    bvec = torch.zeros(len(biases), 16, dtype=torch.float32, device=w_in.device)
+    for i, b in enumerate(biases):
+        bvec[i, :b.numel()] = b
+    return torch.cat([m.reshape(-1) for m in mats] + [bvec.reshape(-1)]).contiguous()
 
 
 def pack_decoder(sd):
