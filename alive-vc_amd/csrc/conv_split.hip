@@ -25,150 +25,156 @@ constexpr int XROWS = 144;        // BN + max halo (4 taps x dilation 4)
 constexpr int PITCH = 80;         // bytes per LDS row (32 bf16 + 16 B pad): 16-B aligned rows, conflict-free ds_read_b128
 constexpr int XPLANE = XROWS * PITCH;
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p) { return *(const bf16x8*)p; }
 
 template <int BM>
 __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float film_ratio) {
-    constexpr int WN = BM == 128 ? 2 : 4;         // waves along time
-    constexpr int TN = BN / WN;                   // 64 or 32
-    constexpr int NR = TN / 32;                   // 2 or 1
-    constexpr int MR = 2;                         // 64 rows per wave
-    constexpr int APLANE = BM * PITCH;
-    constexpr int A_ITEMS = 2 * BM * 4 / 256;     // 16-B chunks per thread per k-step (4 or 2)
+    // wave tile: 32 rows x (128 | 64) columns.  BM = 128: four waves stacked along the rows; BM = 64: 2 x 2.
+    constexpr int NR = BM == 128 ? 4 : 2;         // 32-column MFMA tiles per wave
+    constexpr int MR = 1;
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * XPLANE + 2 * 2 * APLANE];
-    unsigned char* Xs = smem;
-    unsigned char* As = smem + 2 * XPLANE;
+    // X tile, double buffered: [2 buffers][2 planes][XROWS][PITCH]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * XPLANE];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = BM == 128 ? (wid >> 1) : 0, wn = BM == 128 ? (wid & 1) : wid;
+    const int wrow = BM == 128 ? wid : (wid >> 1);          // 32-row block of this wave
+    const int wcol = BM == 128 ? 0 : (wid & 1) * 64;        // first column of this wave
     const int lr = lane & 31, lh = lane >> 5;
     const int n = blockIdx.z, m0 = blockIdx.y * BM, t0 = blockIdx.x * BN;
     const int co_pad = (p.Co + 15) & ~15;
     const int K2 = p.KW * p.Ci_pad;
     const int ncb = p.Ci_pad / BKC;
-    const int nsteps = ncb * p.KW;
     const int xrows = BN + (p.KW - 1) * p.dil;
     const unsigned short* W16 = (const unsigned short*)p.W;
     const float* Xn = p.X + (size_t)n * p.Ci * p.Tin;
 
-    // ---- staging registers ----
-    u32x4 a_reg[A_ITEMS];
-    float x_reg[9][2];
-
-    auto load_A = [&](int step) {
-        const int cb = step / p.KW, j = step - cb * p.KW;
+    // ---- A fragments come STRAIGHT from global memory (the weights are L2-resident and each wave owns its 32 rows):
+    // lane (row lr, half lh) loads the 16 B of k-step s, plane pl it feeds to the MFMA.  No LDS staging of the weights,
+    // hence no block barrier per k-step: the only barrier left is the one that publishes the next X tile, once per
+    // 32-channel block (KW taps x 24 MFMAs per wave).  One k-step is prefetched in registers.
+    int grow = m0 + wrow * 32 + lr;
+    grow = grow < co_pad ? grow : co_pad - 1;
+    const unsigned short* Wrow[2] = {W16 + (size_t)grow * K2 + lh * 8, W16 + ((size_t)co_pad + grow) * K2 + lh * 8};
+    bf16x8 a_cur[2][2], a_nxt[2][2];              // [k16 step][plane]
+    auto load_A = [&](int cb, int j, bf16x8 (&a)[2][2]) {
         const int kcol = j * p.Ci_pad + cb * BKC;
 #pragma unroll
-        for (int v = 0; v < A_ITEMS; ++v) {
-            int i = v * 256 + tid;
-            int c = i & 3, r = (i >> 2) % BM, pl = i / (4 * BM);
-            int grow = m0 + r;
-            grow = grow < co_pad ? grow : co_pad - 1;
-            a_reg[v] = *(const u32x4*)(W16 + ((size_t)pl * co_pad + grow) * K2 + kcol + c * 8);
-        }
-    };
-    auto store_A = [&](int buf) {
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int v = 0; v < A_ITEMS; ++v) {
-            int i = v * 256 + tid;
-            int c = i & 3, r = (i >> 2) % BM, pl = i / (4 * BM);
-            *(u32x4*)(As + (buf * 2 + pl) * APLANE + r * PITCH + c * 16) = a_reg[v];
-        }
+            for (int pl = 0; pl < 2; ++pl) a[s2][pl] = *(const bf16x8*)(Wrow[pl] + kcol + s2 * 16);
     };
+
+    // ---- X staging: 9 (row, channel-pair) items per thread per 32-channel block.  Everything that does not depend on
+    // the channel block is hoisted: the clamped row offset, the validity mask, the LDS address.  Loads are
+    // unconditional on clamped addresses (no branch per element), the split uses the hardware f32->bf16 pack
+    // (v_cvt_pk_bf16_f32): ~16 VALU per item instead of ~120, which matters because at KW = 1 this staging is the only
+    // work between two rounds of 24 MFMAs.
+    float x_reg[9][2];
+    int x_off[9];                 // pair*2*Tin + clamped tin  (element offset inside the channel block)
+    unsigned x_ok = 0;            // bit it: row inside the tile and inside the signal
+#pragma unroll
+    for (int it = 0; it < 9; ++it) {
+        int i = it * 256 + tid;
+        int r = i % XROWS, pair = i / XROWS;
+        int tin = t0 - p.pad_left + r;
+        if (tin < 0 && p.pad_mode != 0) tin = -tin;
+        bool ok = r < xrows && tin >= 0 && tin < p.Tin;
+        tin = tin < 0 ? 0 : (tin < p.Tin ? tin : p.Tin - 1);
+        x_off[it] = pair * 2 * p.Tin + tin;
+        x_ok |= (ok ? 1u : 0u) << it;
+    }
+    const bool ragged_ci = (p.Ci % BKC) != 0;
     auto load_X = [&](int cb) {
+        const float* Xc = Xn + (size_t)cb * BKC * p.Tin;
+        const bool tail = ragged_ci && (cb + 1) * BKC > p.Ci;          // block-uniform
 #pragma unroll
         for (int it = 0; it < 9; ++it) {
-            int i = it * 256 + tid;
-            int r = i % XROWS, pair = i / XROWS;
-            int tin = t0 - p.pad_left + r;
-            if (tin < 0 && p.pad_mode != 0) tin = -tin;
-            bool ok = r < xrows && tin >= 0 && tin < p.Tin;
-            int ci = cb * BKC + pair * 2;
-            x_reg[it][0] = (ok && ci < p.Ci) ? Xn[(size_t)ci * p.Tin + tin] : 0.0f;
-            x_reg[it][1] = (ok && ci + 1 < p.Ci) ? Xn[(size_t)(ci + 1) * p.Tin + tin] : 0.0f;
+            if (!tail) {
+                x_reg[it][0] = Xc[x_off[it]];
+                x_reg[it][1] = Xc[x_off[it] + p.Tin];
+            } else {
+                int pair = (it * 256 + tid) / XROWS;
+                int ci = cb * BKC + pair * 2;
+                x_reg[it][0] = ci < p.Ci ? Xc[x_off[it]] : 0.0f;
+                x_reg[it][1] = ci + 1 < p.Ci ? Xc[x_off[it] + p.Tin] : 0.0f;
+            }
         }
     };
-    auto store_X = [&]() {
+    auto store_X = [&](int buf) {
+        unsigned char* Xs = smem + buf * 2 * XPLANE;
 #pragma unroll
         for (int it = 0; it < 9; ++it) {
             int i = it * 256 + tid;
             int r = i % XROWS, pair = i / XROWS;
-            float x0 = x_reg[it][0], x1 = x_reg[it][1];
-            unsigned h0 = f32_to_bf16_rn(x0), h1 = f32_to_bf16_rn(x1);
-            unsigned l0 = f32_to_bf16_rn(x0 - __uint_as_float(h0 << 16));
-            unsigned l1 = f32_to_bf16_rn(x1 - __uint_as_float(h1 << 16));
-            *(unsigned*)(Xs + r * PITCH + pair * 4) = h0 | (h1 << 16);
-            *(unsigned*)(Xs + XPLANE + r * PITCH + pair * 4) = l0 | (l1 << 16);
+            const bool ok = (x_ok >> it) & 1u;
+            float x0 = ok ? x_reg[it][0] : 0.0f, x1 = ok ? x_reg[it][1] : 0.0f;
+            bf16x2_t hp = {(__bf16)x0, (__bf16)x1};
+            unsigned h = __builtin_bit_cast(unsigned, hp);
+            float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+            bf16x2_t lp = {(__bf16)r0, (__bf16)r1};
+            *(unsigned*)(Xs + r * PITCH + pair * 4) = h;
+            *(unsigned*)(Xs + XPLANE + r * PITCH + pair * 4) = __builtin_bit_cast(unsigned, lp);
         }
     };
 
     // ---- accumulators start at the bias ----
     f32x16 acc[MR][NR];
-#pragma unroll
-    for (int mm = 0; mm < MR; ++mm) {
+    {
         f32x16 b16;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            int row = m0 + wm * 64 + mm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            int row = m0 + wrow * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             b16[r] = (p.bias != nullptr && row < p.Co) ? p.bias[row] : 0.0f;
         }
 #pragma unroll
-        for (int nn = 0; nn < NR; ++nn) acc[mm][nn] = b16;
+        for (int nn = 0; nn < NR; ++nn) acc[0][nn] = b16;
     }
 
-    load_A(0);
     load_X(0);
-    store_A(0);
-    store_X();
+    load_A(0, 0, a_cur);
+    store_X(0);
     __syncthreads();
-    int cb = 0, j = 0;
-    for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
-        const bool more = step + 1 < nsteps;
-        const bool next_cb = more && (j + 1 == p.KW);
-        if (more) load_A(step + 1);
-        if (next_cb) load_X(cb + 1);
-
-        const unsigned char* Ab = As + buf * 2 * APLANE;
+    for (int cb = 0; cb < ncb; ++cb) {
+        const bool more_cb = cb + 1 < ncb;
+        if (more_cb) load_X(cb + 1);                           // in flight under this block's taps
+        const unsigned char* Xs = smem + (cb & 1) * 2 * XPLANE;
+        for (int j = 0; j < p.KW; ++j) {
+            const bool last_tap = j + 1 == p.KW;
+            if (!last_tap) load_A(cb, j + 1, a_nxt);
+            else if (more_cb) load_A(cb + 1, 0, a_nxt);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 ah[MR], al[MR], bh[NR], bl[NR];
-#pragma unroll
-            for (int mm = 0; mm < MR; ++mm) {
-                const unsigned char* a = Ab + (wm * 64 + mm * 32 + lr) * PITCH + s * 32 + lh * 16;
-                ah[mm] = lds_frag(a);
-                al[mm] = lds_frag(a + APLANE);
-            }
-#pragma unroll
-            for (int nn = 0; nn < NR; ++nn) {
-                const unsigned char* b = Xs + (wn * TN + nn * 32 + lr + j * p.dil) * PITCH + s * 32 + lh * 16;
-                bh[nn] = lds_frag(b);
-                bl[nn] = lds_frag(b + XPLANE);
-            }
-#pragma unroll
-            for (int mm = 0; mm < MR; ++mm)
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 bh[NR], bl[NR];
 #pragma unroll
                 for (int nn = 0; nn < NR; ++nn) {
-                    acc[mm][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mm], bh[nn], acc[mm][nn], 0, 0, 0);
-                    acc[mm][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mm], bl[nn], acc[mm][nn], 0, 0, 0);
-                    acc[mm][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mm], bh[nn], acc[mm][nn], 0, 0, 0);
+                    const unsigned char* b = Xs + (wcol + nn * 32 + lr + j * p.dil) * PITCH + s2 * 32 + lh * 16;
+                    bh[nn] = lds_frag(b);
+                    bl[nn] = lds_frag(b + XPLANE);
                 }
+#pragma unroll
+                for (int nn = 0; nn < NR; ++nn) {
+                    acc[0][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[s2][1], bh[nn], acc[0][nn], 0, 0, 0);
+                    acc[0][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[s2][0], bl[nn], acc[0][nn], 0, 0, 0);
+                    acc[0][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[s2][0], bh[nn], acc[0][nn], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) a_cur[s2][pl] = a_nxt[s2][pl];
         }
-        if (next_cb) {
-            __syncthreads();                // every wave is done with the X tile of this ci-block
-            store_X();
-        }
-        if (more) store_A(buf ^ 1);
-        __syncthreads();
-        if (++j == p.KW) { j = 0; ++cb; }
+        if (more_cb) store_X((cb + 1) & 1);
+        __syncthreads();          // next X tile visible; this one is free to be overwritten one block later
     }
 
     // ---- epilogue: accumulators -> LDS -> cooperative row-wise pass ----
     // Staging the tile through LDS turns the MFMA layout (a lane owns 16 scattered rows of one column) into
     // whole rows: every global access of the epilogue (residual, skip, Y, Z) is a 16-B vector per thread on
     // 512-B contiguous row segments, and the element code exists once in a rolled loop instead of 64 times.
-    constexpr int PR = BM == 128 ? 64 : 32;          // rows per pass (two passes: mm = 0, 1)
+    constexpr int PR = 64;                           // rows per pass
+    constexpr int NP = BM / 64;                      // passes
     constexpr int CP = BN + 4;                       // fp32 pitch of the staged tile
     float* Ct = (float*)smem;                        // [PR][CP]
     float* Ft = Ct + PR * CP;                        // [PR][2][FILM_NF]
@@ -177,16 +183,18 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
     if (p.Z != nullptr) film_tile_range(p, film_ratio, t0, BN, f_lo, nf);       // fit is checked on the host
     const bool vec = (p.up == 1) && ((p.Tout & 3) == 0);
 #pragma unroll
-    for (int mm = 0; mm < MR; ++mm) {
+    for (int ps = 0; ps < NP; ++ps) {
+        if ((wrow >> 1) == ps) {                     // wave-uniform: the two 32-row waves of this pass deposit their tiles
 #pragma unroll
-        for (int nn = 0; nn < NR; ++nn)
+            for (int nn = 0; nn < NR; ++nn)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Ct[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CP + wn * TN + nn * 32 + lr] = acc[mm][nn][r];
+                for (int r = 0; r < 16; ++r)
+                    Ct[((wrow & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CP + wcol + nn * 32 + lr] = acc[0][nn][r];
+        }
         if (p.Z != nullptr) {
             for (int e = tid; e < PR * 2 * FILM_NF; e += 256) {
                 int f = e % FILM_NF, sel = (e / FILM_NF) & 1, pr = e / (2 * FILM_NF);
-                int row = m0 + (pr >> 5) * 64 + mm * 32 + (pr & 31);
+                int row = m0 + ps * 64 + pr;
                 float v = 0.0f;
                 if (row < p.Co && f < nf)
                     v = p.film[((size_t)n * p.film_rows + (sel == 0 ? p.film_scale_row : p.film_shift_row) + row) * p.Lf + f_lo + f];
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
 #pragma unroll 1
             for (int g = tid; g < PR * (BN / 4); g += 256) {
                 const int pr = g >> 5, c4 = (g & 31) * 4;
-                const int row = m0 + (pr >> 5) * 64 + mm * 32 + (pr & 31);
+                const int row = m0 + ps * 64 + pr;
                 const int t = t0 + c4;
                 if (row >= p.Co || t >= p.Tout) continue;
                 f32x4 v = *(const f32x4*)&Ct[pr * CP + c4];
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
 #pragma unroll 1
             for (int g = tid; g < PR * BN; g += 256) {
                 const int pr = g >> 7, c = g & 127;
-                const int row = m0 + (pr >> 5) * 64 + mm * 32 + (pr & 31);
+                const int row = m0 + ps * 64 + pr;
                 const int t = t0 + c;
                 if (row >= p.Co || t >= p.Tout) continue;
                 float v = Ct[pr * CP + c];
