@@ -132,8 +132,15 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
         for (int nn = 0; nn < NR; ++nn) acc[0][nn] = b16;
     }
 
+    // weights are prefetched TWO k-steps ahead (fragment-shaped L2 reads have a long tail under load)
+    bf16x8 a_nx2[2][2];
+    int pcb = 0, pj = 0;                                       // (block, tap) of the next fragment set to fetch
+    auto advance = [&]() { if (++pj == p.KW) { pj = 0; ++pcb; } };
     load_X(0);
     load_A(0, 0, a_cur);
+    advance();
+    if (pcb < ncb) load_A(pcb, pj, a_nxt);
+    advance();
     store_X(0);
     __syncthreads();
     for (int cb = 0; cb < ncb; ++cb) {
@@ -141,9 +148,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
         if (more_cb) load_X(cb + 1);                           // in flight under this block's taps
         const unsigned char* Xs = smem + (cb & 1) * 2 * XPLANE;
         for (int j = 0; j < p.KW; ++j) {
-            const bool last_tap = j + 1 == p.KW;
-            if (!last_tap) load_A(cb, j + 1, a_nxt);
-            else if (more_cb) load_A(cb + 1, 0, a_nxt);
+            if (pcb < ncb) load_A(pcb, pj, a_nx2);
+            advance();
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 bf16x8 bh[NR], bl[NR];
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) a_cur[s2][pl] = a_nxt[s2][pl];
+                for (int pl = 0; pl < 2; ++pl) { a_cur[s2][pl] = a_nxt[s2][pl]; a_nxt[s2][pl] = a_nx2[s2][pl]; }
         }
         if (more_cb) store_X((cb + 1) & 1);
         __syncthreads();          // next X tile visible; this one is free to be overwritten one block later
@@ -203,7 +209,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
         }
         __syncthreads();
         if (vec) {
-#pragma unroll 1
+            // PR*BN/4/256 = 8 iterations, fully unrolled: the residual / skip loads of all eight 16-B groups are in flight
+            // together (rolled, each iteration exposed a full L2 round trip and the epilogue cost as much as the GEMM)
+#pragma unroll
             for (int g = tid; g < PR * (BN / 4); g += 256) {
                 const int pr = g >> 5, c4 = (g & 31) * 4;
                 const int row = m0 + ps * 64 + pr;
