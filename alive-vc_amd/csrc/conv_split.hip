@@ -29,14 +29,15 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p) { return *(const bf16x8*)p; }
 
-template <int BM>
+// NP = number of bf16 planes per operand: 2 -> 3 MFMAs per product (~2^-16), 3 -> 6 MFMAs per product (~2^-24, fp32-grade)
+template <int BM, int NP>
 __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float film_ratio) {
     // wave tile: 32 rows x (128 | 64) columns.  BM = 128: four waves stacked along the rows; BM = 64: 2 x 2.
     constexpr int NR = BM == 128 ? 4 : 2;         // 32-column MFMA tiles per wave
     constexpr int MR = 1;
 
     // X tile, double buffered: [2 buffers][2 planes][XROWS][PITCH]
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * XPLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NP * XPLANE];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wrow = BM == 128 ? wid : (wid >> 1);          // 32-row block of this wave
@@ -56,14 +57,16 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
     // 32-channel block (KW taps x 24 MFMAs per wave).  One k-step is prefetched in registers.
     int grow = m0 + wrow * 32 + lr;
     grow = grow < co_pad ? grow : co_pad - 1;
-    const unsigned short* Wrow[2] = {W16 + (size_t)grow * K2 + lh * 8, W16 + ((size_t)co_pad + grow) * K2 + lh * 8};
-    bf16x8 a_cur[2][2], a_nxt[2][2];              // [k16 step][plane]
-    auto load_A = [&](int cb, int j, bf16x8 (&a)[2][2]) {
+    const unsigned short* Wrow[NP];
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) Wrow[pl] = W16 + ((size_t)pl * co_pad + grow) * K2 + lh * 8;
+    bf16x8 a_cur[2][NP], a_nxt[2][NP];            // [k16 step][plane]
+    auto load_A = [&](int cb, int j, bf16x8 (&a)[2][NP]) {
         const int kcol = j * p.Ci_pad + cb * BKC;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) a[s2][pl] = *(const bf16x8*)(Wrow[pl] + kcol + s2 * 16);
+            for (int pl = 0; pl < NP; ++pl) a[s2][pl] = *(const bf16x8*)(Wrow[pl] + kcol + s2 * 16);
     };
 
     // ---- X staging: 9 (row, channel-pair) items per thread per 32-channel block.  Everything that does not depend on
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
         }
     };
     auto store_X = [&](int buf) {
-        unsigned char* Xs = smem + buf * 2 * XPLANE;
+        unsigned char* Xs = smem + buf * NP * XPLANE;
 #pragma unroll
         for (int it = 0; it < 9; ++it) {
             int i = it * 256 + tid;
@@ -115,7 +118,13 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
             float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
             bf16x2_t lp = {(__bf16)r0, (__bf16)r1};
             *(unsigned*)(Xs + r * PITCH + pair * 4) = h;
-            *(unsigned*)(Xs + XPLANE + r * PITCH + pair * 4) = __builtin_bit_cast(unsigned, lp);
+            const unsigned l = __builtin_bit_cast(unsigned, lp);
+            *(unsigned*)(Xs + XPLANE + r * PITCH + pair * 4) = l;
+            if (NP == 3) {
+                float q0 = r0 - __uint_as_float(l << 16), q1 = r1 - __uint_as_float(l & 0xffff0000u);
+                bf16x2_t tp = {(__bf16)q0, (__bf16)q1};
+                *(unsigned*)(Xs + 2 * XPLANE + r * PITCH + pair * 4) = __builtin_bit_cast(unsigned, tp);
+            }
         }
     };
 
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
     }
 
     // weights are prefetched TWO k-steps ahead (fragment-shaped L2 reads have a long tail under load)
-    bf16x8 a_nx2[2][2];
+    bf16x8 a_nx2[2][NP];
     int pcb = 0, pj = 0;                                       // (block, tap) of the next fragment set to fetch
     auto advance = [&]() { if (++pj == p.KW) { pj = 0; ++pcb; } };
     load_X(0);
@@ -146,30 +155,33 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
     for (int cb = 0; cb < ncb; ++cb) {
         const bool more_cb = cb + 1 < ncb;
         if (more_cb) load_X(cb + 1);                           // in flight under this block's taps
-        const unsigned char* Xs = smem + (cb & 1) * 2 * XPLANE;
+        const unsigned char* Xs = smem + (cb & 1) * NP * XPLANE;
         for (int j = 0; j < p.KW; ++j) {
             if (pcb < ncb) load_A(pcb, pj, a_nx2);
             advance();
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 bh[NR], bl[NR];
+                bf16x8 bf[NP][NR];
 #pragma unroll
                 for (int nn = 0; nn < NR; ++nn) {
                     const unsigned char* b = Xs + (wcol + nn * 32 + lr + j * p.dil) * PITCH + s2 * 32 + lh * 16;
-                    bh[nn] = lds_frag(b);
-                    bl[nn] = lds_frag(b + XPLANE);
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) bf[pl][nn] = lds_frag(b + pl * XPLANE);
                 }
+                // all plane products (i, j) with i + j <= NP - 1, smallest terms first
 #pragma unroll
                 for (int nn = 0; nn < NR; ++nn) {
-                    acc[0][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[s2][1], bh[nn], acc[0][nn], 0, 0, 0);
-                    acc[0][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[s2][0], bl[nn], acc[0][nn], 0, 0, 0);
-                    acc[0][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[s2][0], bh[nn], acc[0][nn], 0, 0, 0);
+#pragma unroll
+                    for (int sum = NP - 1; sum >= 0; --sum)
+#pragma unroll
+                        for (int i = 0; i <= sum; ++i)
+                            acc[0][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[s2][i], bf[sum - i][nn], acc[0][nn], 0, 0, 0);
                 }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) { a_cur[s2][pl] = a_nxt[s2][pl]; a_nxt[s2][pl] = a_nx2[s2][pl]; }
+                for (int pl = 0; pl < NP; ++pl) { a_cur[s2][pl] = a_nxt[s2][pl]; a_nxt[s2][pl] = a_nx2[s2][pl]; }
         }
         if (more_cb) store_X((cb + 1) & 1);
         __syncthreads();          // next X tile visible; this one is free to be overwritten one block later
@@ -180,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
     // whole rows: every global access of the epilogue (residual, skip, Y, Z) is a 16-B vector per thread on
     // 512-B contiguous row segments, and the element code exists once in a rolled loop instead of 64 times.
     constexpr int PR = 64;                           // rows per pass
-    constexpr int NP = BM / 64;                      // passes
+    constexpr int NPASS = BM / 64;                   // passes
     constexpr int CP = BN + 4;                       // fp32 pitch of the staged tile
     float* Ct = (float*)smem;                        // [PR][CP]
     float* Ft = Ct + PR * CP;                        // [PR][2][FILM_NF]
@@ -189,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
     if (p.Z != nullptr) film_tile_range(p, film_ratio, t0, BN, f_lo, nf);       // fit is checked on the host
     const bool vec = (p.up == 1) && ((p.Tout & 3) == 0);
 #pragma unroll
-    for (int ps = 0; ps < NP; ++ps) {
+    for (int ps = 0; ps < NPASS; ++ps) {
         if ((wrow >> 1) == ps) {                     // wave-uniform: the two 32-row waves of this pass deposit their tiles
 #pragma unroll
             for (int nn = 0; nn < NR; ++nn)
@@ -291,10 +303,12 @@ int alive_conv_split_launch(const AliveConv* d, float ratio, hipStream_t s) {
     ALIVE_CHECK_ARG(d->Tout <= d->Tin + d->pad_left, "alive_conv1d(split): Tout");
     if (d->Co > 64) {
         dim3 g(cdiv(d->Tout, BN), cdiv(d->Co, 128), d->N);
-        conv_split_kernel<128><<<g, 256, 0, s>>>(*d, ratio);
+        if (d->precision == 2) conv_split_kernel<128, 3><<<g, 256, 0, s>>>(*d, ratio);
+        else conv_split_kernel<128, 2><<<g, 256, 0, s>>>(*d, ratio);
     } else {
         dim3 g(cdiv(d->Tout, BN), 1, d->N);
-        conv_split_kernel<64><<<g, 256, 0, s>>>(*d, ratio);
+        if (d->precision == 2) conv_split_kernel<64, 3><<<g, 256, 0, s>>>(*d, ratio);
+        else conv_split_kernel<64, 2><<<g, 256, 0, s>>>(*d, ratio);
     }
     ALIVE_CHECK_LAUNCH("alive_conv1d(split)");
     return ALIVE_OK;

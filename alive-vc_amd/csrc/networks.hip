@@ -107,6 +107,12 @@ AliveConv split(AliveConv d) {
     return d;
 }
 
+AliveConv split3(AliveConv d) {      // 3-plane split ("bf16x6"): fp32-grade, used by the encoders (argmax / top-k downstream)
+    d = split(d);
+    d.precision = 2;
+    return d;
+}
+
 #define RUN(expr)                     \
     do {                              \
         int rc_ = (expr);             \
@@ -125,17 +131,17 @@ struct ConvNeXtW {
 
 // x <- x + scale * pw2(gelu(pw1(norm(dw(x)))))      (common.py:54-62 / 74-82)
 int convnext_layer(const ConvNeXtW& w, float* x, float* ybuf, float* hbuf, int N, int C, int H, int T, const float* cond,
-                   int cond_rows, int scale_row, int shift_row, bool use_split, void* s) {
+                   int cond_rows, int scale_row, int shift_row, int planes, void* s) {
     RUN(alive_dwconv_norm(x, N, C, T, w.dw_w, w.dw_b, cond ? 1 : 0, w.gain, w.offset, cond, cond_rows, scale_row,
                           shift_row, NORM_EPS, ybuf, s));
     AliveConv d1 = pw_desc(w.pw1W, w.pw1b, ybuf, N, C, T, H, hbuf);
     d1.act = 1;
-    if (use_split) d1 = split(d1);
+    d1 = planes == 3 ? split3(d1) : split(d1);
     RUN(alive_conv1d(&d1, s));
     AliveConv d2 = pw_desc(w.pw2W, w.pw2b, hbuf, N, H, T, C, x);
     d2.ch_scale = w.scale;
     d2.residual = x;
-    if (use_split) d2 = split(d2);
+    d2 = planes == 3 ? split3(d2) : split(d2);
     RUN(alive_conv1d(&d2, s));
     return ALIVE_OK;
 }
@@ -199,14 +205,14 @@ extern "C" int alive_content_encoder(const float* const* w, const float* spec, i
     float* y = a.take<float>((size_t)N * CE_C * T);
     float* h = a.take<float>((size_t)N * CE_H * T);
     const float* inW = t.next(); const float* inb = t.next();
-    AliveConv d = pw_desc(inW, inb, spec, N, BINS, T, CE_C, x);
+    AliveConv d = split3(pw_desc(inW, inb, spec, N, BINS, T, CE_C, x));
     RUN(alive_conv1d(&d, stream));
     for (int i = 0; i < 4; ++i) {
         ConvNeXtW cw(t, false);
-        RUN(convnext_layer(cw, x, y, h, N, CE_C, CE_H, T, nullptr, 0, 0, 0, false, stream));
+        RUN(convnext_layer(cw, x, y, h, N, CE_C, CE_H, T, nullptr, 0, 0, 0, 3, stream));
     }
     const float* oW = t.next(); const float* ob = t.next();
-    AliveConv o = pw_desc(oW, ob, x, N, CE_C, T, CE_OUT, out);
+    AliveConv o = split3(pw_desc(oW, ob, x, N, CE_C, T, CE_OUT, out));
     RUN(alive_conv1d(&o, stream));
     return ALIVE_OK;
 }
@@ -225,16 +231,16 @@ extern "C" int alive_f0_estimate(const float* const* w, const float* spec, int N
     float* h = a.take<float>((size_t)N * PE_H * T);
     float* lg = a.take<float>((size_t)N * PE_OUT * T);
     const float* inW = t.next(); const float* inb = t.next();
-    AliveConv d = pw_desc(inW, inb, spec, N, BINS, T, PE_C, x);
+    AliveConv d = split3(pw_desc(inW, inb, spec, N, BINS, T, PE_C, x));
     RUN(alive_conv1d(&d, stream));
     for (int i = 0; i < 4; ++i) {
         ConvNeXtW cw(t, false);
-        RUN(convnext_layer(cw, x, y, h, N, PE_C, PE_H, T, nullptr, 0, 0, 0, false, stream));
+        RUN(convnext_layer(cw, x, y, h, N, PE_C, PE_H, T, nullptr, 0, 0, 0, 3, stream));
     }
     const float* g = t.next(); const float* of = t.next();
     RUN(alive_channel_norm(x, N, PE_C, T, g, of, NORM_EPS, y, stream));
     const float* oW = t.next(); const float* ob = t.next();
-    AliveConv o = pw_desc(oW, ob, y, N, PE_C, T, PE_OUT, lg);
+    AliveConv o = split3(pw_desc(oW, ob, y, N, PE_C, T, PE_OUT, lg));
     RUN(alive_conv1d(&o, stream));
     return alive_argmax_channels(lg, N, PE_OUT, T, f0, stream);
 }
@@ -295,7 +301,7 @@ extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, c
     { AliveConv d = split(pw_desc(nfW, nfb, b.cond, N, DEC_C, Lf, 4096, b.normfilm)); RUN(alive_conv1d(&d, stream)); }
     for (int i = 0; i < 4; ++i) {
         ConvNeXtW cw(t, true);
-        RUN(convnext_layer(cw, b.x, b.y, b.h, N, DEC_C, DEC_H, Lf, b.normfilm, 4096, i * 1024, i * 1024 + 512, true, stream));
+        RUN(convnext_layer(cw, b.x, b.y, b.h, N, DEC_C, DEC_H, Lf, b.normfilm, 4096, i * 1024, i * 1024 + 512, 2, stream));
     }
     // -- HarmonicOscillator (decoder.py:66-102)
     const float* aW = t.next(); const float* ab = t.next();

@@ -33,21 +33,28 @@ def pack_convT(w, b):
     return pack_matrix(a), b.float().repeat_interleave(r).contiguous()
 
 
-def split_bf16(w):
-    """fp32 -> (hi, lo) bf16 planes with hi + lo ~= w to 16 mantissa bits (round-to-nearest both steps)."""
-    hi = w.float().bfloat16()
-    lo = (w.float() - hi.float()).bfloat16()
-    return hi, lo
+def split_bf16(w, planes=2):
+    """fp32 -> `planes` bf16 tensors whose sum reproduces w to 8*planes mantissa bits (round-to-nearest each step)."""
+    out, r = [], w.float()
+    for _ in range(planes):
+        h = r.bfloat16()
+        out.append(h)
+        r = r - h.float()
+    return out
 
 
-def pack_conv_split(w):
-    """Conv1d weight [Co, Ci, KW] -> bf16 [2, Co_pad16, KW * Ci_pad32], tap-major k = j * Ci_pad + ci."""
+def pack_conv_split(w, planes=2):
+    """Conv1d weight [Co, Ci, KW] -> bf16 [planes, Co_pad16, KW * Ci_pad32], tap-major k = j * Ci_pad + ci.
+    planes = 2: "bf16x3" (3 MFMAs per product, ~2^-16); planes = 3: "bf16x6" (6 MFMAs, ~2^-24, fp32-grade)."""
     co, ci, kw = w.shape
     co_pad, ci_pad = _pad16(co), (ci + 31) // 32 * 32
     a = torch.zeros(co_pad, kw, ci_pad, dtype=torch.float32, device=w.device)
     a[:co, :, :ci] = w.float().permute(0, 2, 1)
-    hi, lo = split_bf16(a.reshape(co_pad, kw * ci_pad))
-    return torch.stack([hi, lo], 0).contiguous()
+    return torch.stack(split_bf16(a.reshape(co_pad, kw * ci_pad), planes), 0).contiguous()
+
+
+def pack_conv_split3(w):
+    return pack_conv_split(w, 3)
 
 
 def pack_convT_split(w, b):
@@ -75,10 +82,11 @@ def _convnext(out, sd, src, dst, adaptive, pc=pack_conv):
 
 
 def pack_content_encoder(sd):
-    out = {"input.W": pack_conv(sd["input_layer.weight"]), "input.b": _vec(sd["input_layer.bias"])}
+    """encoders: 3-plane split ("bf16x6", fp32-grade) -- a top-k / an argmax sit downstream of these GEMMs"""
+    out = {"input.W": pack_conv_split3(sd["input_layer.weight"]), "input.b": _vec(sd["input_layer.bias"])}
     for i in range(4):
-        _convnext(out, sd, f"mid_layers.{i}", f"mid{i}", False)
-    out["output.W"] = pack_conv(sd["output_layer.weight"])
+        _convnext(out, sd, f"mid_layers.{i}", f"mid{i}", False, pack_conv_split3)
+    out["output.W"] = pack_conv_split3(sd["output_layer.weight"])
     out["output.b"] = _vec(sd["output_layer.bias"])
     return out
 

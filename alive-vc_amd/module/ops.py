@@ -27,7 +27,8 @@ def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, o
     x = _f(x)
     n, ci, tin = x.shape
     keep = []
-    split = precision == "bf16x3"
+    split = precision in ("bf16x3", "bf16x6")
+    planes = 3 if precision == "bf16x6" else 2
     if split and transposed:
         r = weight.shape[2]
         W, b = pack_convT_split(weight, bias)
@@ -35,7 +36,7 @@ def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, o
         stride_, tout = 1, tin
         co_out = weight.shape[1]
     elif split:
-        W = pack_conv_split(weight)
+        W = pack_conv_split(weight, planes)
         b = _f(bias)
         co_rows, kw, up = weight.shape[0], weight.shape[2], 1
         stride_ = stride
@@ -57,7 +58,7 @@ def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, o
     d = nat.AliveConv()
     d.W, d.bias, d.X = nat.ptr(W), nat.ptr(b), nat.ptr(x)
     d.N, d.Ci, d.Tin, d.Co, d.K_pad = n, ci, tin, co_rows, W.shape[-1]
-    d.precision, d.Ci_pad = (1, (ci + 31) // 32 * 32) if split else (0, 0)
+    d.precision, d.Ci_pad = (planes - 1, (ci + 31) // 32 * 32) if split else (0, 0)
     d.KW, d.stride, d.dil, d.pad_left, d.pad_mode = kw, stride_, dilation, pad_left, pad_mode
     d.Tout, d.up, d.act = tout, up, ACT[act]
     post_add, ch_scale, residual, skip, film = map(_f, (post_add, ch_scale, residual, skip, film))

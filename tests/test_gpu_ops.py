@@ -330,3 +330,19 @@ def test_fused_filter_block_small(c, l, lf):
     out = ops.filter_block_small(x.to(DEV), {k: v.to(DEV) for k, v in sd.items()}, "n", film, pad_rows, skip=skip.to(DEV))
     e = relerr(out, ref)
     assert e < 5e-6, e
+
+
+@pytest.mark.parametrize("co,ci,t", [(512, 641, 450), (1536, 512, 37), (4096, 256, 130), (768, 512, 450)])
+def test_conv1d_split_bf16x6_is_fp32_grade(co, ci, t):
+    """3-plane split (6 MFMAs per product): error at the level of fp32 rounding, so it may sit in front of the
+    argmax of the f0 estimator and the top-k of the kNN like the exact fp32 kernel."""
+    from module import ops
+    x = g(f"s6x{co}{ci}", (2, ci, t))
+    w = g(f"s6w{co}{ci}", (co, ci, 1), scale=1.0 / np.sqrt(ci))
+    b = g(f"s6b{co}{ci}", (co,), scale=0.1)
+    ref = F.conv1d(x.double(), w.double(), b.double())
+    y6, _ = ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), precision="bf16x6")
+    y32, _ = ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV))
+    e6, e32 = relerr(y6, ref), relerr(y32, ref)
+    print(f"bf16x6 {e6:.2e}  fp32-MFMA {e32:.2e}  torch-cpu-fp32 {relerr(F.conv1d(x, w, b), ref):.2e}")
+    assert e6 < 4e-7 and e6 < 4 * e32 + 1e-8, (e6, e32)
