@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libalive_vc.so")
+LIB_PATH = os.environ.get("ALIVE_VC_LIB", os.path.join(os.path.dirname(_HERE), "libalive_vc.so"))   # override: kernel A/B builds
 
 _lib = None
 
