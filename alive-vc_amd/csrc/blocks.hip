@@ -79,6 +79,89 @@ __global__ __launch_bounds__(256) void dwconv_norm_kernel(
     }
 }
 
+// ---- small-T variants (streaming: a handful of frames): one block per (frame, window), threads along the channels ----
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+template <bool DW>
+__global__ __launch_bounds__(256) void dwconv_norm_small_kernel(
+    const float* __restrict__ X, int C, int T, const float* __restrict__ dw_w, const float* __restrict__ dw_b,
+    int affine_mode, const float* __restrict__ gain, const float* __restrict__ offset,
+    const float* __restrict__ cond, int cond_rows, int scale_row, int shift_row, float eps, float* __restrict__ Y) {
+    __shared__ float sh[4];
+    const int t = blockIdx.x, n = blockIdx.y;
+    const float* Xn = X + (size_t)n * C * T;
+    float* Yn = Y + (size_t)n * C * T;
+    float s = 0.0f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float* xc = Xn + (size_t)c * T;
+        float y;
+        if (DW) {
+            y = dw_b[c];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                int ti = t + j - 3;
+                float xv = (ti >= 0 && ti < T) ? xc[ti] : 0.0f;
+                y = fmaf(dw_w[c * 7 + j], xv, y);
+            }
+            Yn[(size_t)c * T + t] = y;
+        } else {
+            y = xc[t];
+        }
+        s += y;
+    }
+    const float mean = block_sum(s, sh) / (float)C;
+    const float* src = DW ? Yn : Xn;
+    float ss = 0.0f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float d = src[(size_t)c * T + t] - mean;
+        ss = fmaf(d, d, ss);
+    }
+    const float sigma = sqrtf(block_sum(ss, sh) / (float)(C - 1)) + eps;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float v = (src[(size_t)c * T + t] - mean) / sigma;
+        float g, o;
+        if (affine_mode == 0) { g = gain[c]; o = offset[c]; }
+        else {
+            g = cond[((size_t)n * cond_rows + scale_row + c) * T + t];
+            o = cond[((size_t)n * cond_rows + shift_row + c) * T + t];
+        }
+        Yn[(size_t)c * T + t] = v * g + o;
+    }
+}
+
+__global__ __launch_bounds__(256) void argmax_small_kernel(const float* __restrict__ X, int C, int T, float* __restrict__ out) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    const int t = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const float* Xn = X + (size_t)n * C * T + t;
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int c = tid; c < C; c += 256) {
+        float v = Xn[(size_t)c * T];
+        if (v > best || (v != v && best == best)) { best = v; besti = c; }
+    }
+    bv[tid] = best;
+    bi[tid] = besti;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            float v = bv[tid + o];
+            int vi = bi[tid + o];
+            bool take = (v > bv[tid]) || (v == bv[tid] && vi < bi[tid]) || (v != v && bv[tid] == bv[tid]);
+            if (take) { bv[tid] = v; bi[tid] = vi; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out[(size_t)n * T + t] = (float)bi[0];
+}
+
 __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ X, int C, int T, float* __restrict__ out) {
     __shared__ float bv[4][TT];
     __shared__ int bi[4][TT];
@@ -170,6 +253,12 @@ extern "C" int alive_dwconv_norm(const float* X, int N, int C, int T, const floa
     ALIVE_CHECK_ARG(X && Y && dw_w && dw_b && N > 0 && C > 1 && T > 0, "alive_dwconv_norm: bad args");
     ALIVE_CHECK_ARG(X != Y, "alive_dwconv_norm: in-place not supported");
     ALIVE_CHECK_ARG(affine_mode == 0 ? (gain && offset) : (cond != nullptr), "alive_dwconv_norm: affine params");
+    if (T <= 32) {      // streaming: one block per frame, threads along the channels
+        dwconv_norm_small_kernel<true><<<dim3(T, N), 256, 0, (hipStream_t)stream>>>(X, C, T, dw_w, dw_b, affine_mode, gain, offset,
+                                                                                   cond, cond_rows, scale_row, shift_row, eps, Y);
+        ALIVE_CHECK_LAUNCH("alive_dwconv_norm");
+        return ALIVE_OK;
+    }
     dim3 g(cdiv(T, TT), N);
     dwconv_norm_kernel<true><<<g, 256, 0, (hipStream_t)stream>>>(X, C, T, dw_w, dw_b, affine_mode, gain, offset, cond,
                                                                 cond_rows, scale_row, shift_row, eps, Y);
@@ -180,6 +269,12 @@ extern "C" int alive_dwconv_norm(const float* X, int N, int C, int T, const floa
 extern "C" int alive_channel_norm(const float* X, int N, int C, int T, const float* gain, const float* offset, float eps,
                                   float* Y, void* stream) {
     ALIVE_CHECK_ARG(X && Y && gain && offset && N > 0 && C > 1 && T > 0, "alive_channel_norm: bad args");
+    if (T <= 32) {
+        dwconv_norm_small_kernel<false><<<dim3(T, N), 256, 0, (hipStream_t)stream>>>(X, C, T, nullptr, nullptr, 0, gain, offset,
+                                                                                    nullptr, 0, 0, 0, eps, Y);
+        ALIVE_CHECK_LAUNCH("alive_channel_norm");
+        return ALIVE_OK;
+    }
     dim3 g(cdiv(T, TT), N);
     dwconv_norm_kernel<false><<<g, 256, 0, (hipStream_t)stream>>>(X, C, T, nullptr, nullptr, 0, gain, offset, nullptr, 0, 0,
                                                                  0, eps, Y);
@@ -189,6 +284,11 @@ extern "C" int alive_channel_norm(const float* X, int N, int C, int T, const flo
 
 extern "C" int alive_argmax_channels(const float* X, int N, int C, int T, float* out, void* stream) {
     ALIVE_CHECK_ARG(X && out && N > 0 && C > 0 && T > 0, "alive_argmax_channels: bad args");
+    if (T <= 32) {
+        argmax_small_kernel<<<dim3(T, N), 256, 0, (hipStream_t)stream>>>(X, C, T, out);
+        ALIVE_CHECK_LAUNCH("alive_argmax_channels");
+        return ALIVE_OK;
+    }
     dim3 g(cdiv(T, TT), N);
     argmax_kernel<<<g, 256, 0, (hipStream_t)stream>>>(X, C, T, out);
     ALIVE_CHECK_LAUNCH("alive_argmax_channels");

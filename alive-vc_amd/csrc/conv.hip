@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(AliveConv p, unsigned kw
 }  // namespace
 
 int alive_conv_split_launch(const AliveConv* d, float ratio, hipStream_t s);
+bool alive_conv_skinny_try(const AliveConv* d, hipStream_t s, int* rc);
 
 extern "C" int alive_conv1d(const AliveConv* d, void* stream) {
     ALIVE_CHECK_ARG(d && d->W && d->X, "alive_conv1d: null W/X");
@@ -186,6 +187,10 @@ extern "C" int alive_conv1d(const AliveConv* d, void* stream) {
     ALIVE_CHECK_ARG(d->pad_mode >= 0 && d->pad_mode <= 2, "alive_conv1d: pad_mode");
     if (d->pad_mode != 0) ALIVE_CHECK_ARG(d->pad_left < d->Tin, "alive_conv1d: reflect pad %d needs Tin > pad (Tin %d)", d->pad_left, d->Tin);
     if (d->Z) ALIVE_CHECK_ARG(d->film && d->Lf > 0, "alive_conv1d: Z needs film");
+    {
+        int rc;
+        if (alive_conv_skinny_try(d, (hipStream_t)stream, &rc)) return rc;      // <= 32 columns (streaming)
+    }
     if (d->precision >= 1) return alive_conv_split_launch(d, d->Z ? (float)d->Lf / (float)d->Tout : 0.0f, (hipStream_t)stream);
     const unsigned magic = d->Ci == 1 ? 0u : (unsigned)(((1u << 20) + d->KW - 1) / d->KW);
     const float ratio = d->Z ? (float)d->Lf / (float)d->Tout : 0.0f;

@@ -346,3 +346,35 @@ def test_conv1d_split_bf16x6_is_fp32_grade(co, ci, t):
     e6, e32 = relerr(y6, ref), relerr(y32, ref)
     print(f"bf16x6 {e6:.2e}  fp32-MFMA {e32:.2e}  torch-cpu-fp32 {relerr(F.conv1d(x, w, b), ref):.2e}")
     assert e6 < 4e-7 and e6 < 4 * e32 + 1e-8, (e6, e32)
+
+
+@pytest.mark.parametrize("co,ci,n,t,prec", [(512, 641, 1, 8, "fp32"), (1536, 512, 1, 8, "bf16x6"), (4128, 512, 1, 24, "bf16x3"),
+                                             (64, 512, 2, 5, "bf16x3"), (4096, 256, 1, 13, "bf16x6"), (40, 20, 3, 7, "fp32")])
+def test_conv1d_skinny_streaming_shapes(co, ci, n, t, prec):
+    """N*T <= 32 columns: the K-split skinny kernel (streaming path) for every weight format"""
+    from module import ops
+    x = g(f"kx{co}{ci}{t}", (n, ci, t))
+    w = g(f"kw{co}{ci}{t}", (co, ci, 1), scale=1.0 / np.sqrt(ci))
+    b = g(f"kb{co}{ci}{t}", (co,), scale=0.1)
+    res = g(f"kr{co}{ci}{t}", (n, co, t))
+    ref = F.gelu(F.conv1d(x.double(), w.double(), b.double())) + res.double()
+    y, _ = ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), act="gelu", residual=res.to(DEV), precision=prec)
+    e = relerr(y, ref)
+    assert e < (2e-5 if prec == "bf16x3" else 5e-7), e
+
+
+def test_small_t_norm_and_argmax():
+    """T <= 32: one block per frame (streaming variants of dwconv+norm, ChannelNorm, argmax)"""
+    from module import ops
+    for c, t in ((512, 8), (256, 5), (512, 24)):
+        x = g(f"snx{c}{t}", (2, c, t))
+        dw_w, dw_b = g("sndw", (c, 1, 7), scale=0.3), g("sndb", (c,), scale=0.1)
+        gain, off = 1 + g("sng", (1, c, 1), scale=0.1), g("sno", (1, c, 1), scale=0.1)
+        ref = O.channel_stats_normalise(F.conv1d(x, dw_w, dw_b, padding=3, groups=c)) * gain + off
+        y = ops.dwconv_norm(x.to(DEV), dw_w.to(DEV), dw_b.to(DEV), gain=gain.to(DEV), offset=off.to(DEV))
+        torch.testing.assert_close(y.cpu(), ref, rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(ops.channel_norm(x.to(DEV), gain.to(DEV), off.to(DEV)).cpu(),
+                                   O.channel_stats_normalise(x) * gain + off, rtol=2e-5, atol=2e-5)
+    lg = g("samx", (2, 4096, 8))
+    lg[1, 77, 3] = lg[1, 3000, 3] = 60.0
+    assert torch.equal(ops.argmax_channels(lg.to(DEV)).cpu(), torch.argmax(lg, dim=1).float().unsqueeze(1))
