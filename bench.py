@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--chunk", type=int, default=48000)
     ap.add_argument("-k", type=int, default=4)
-    ap.add_argument("--window-batch", type=int, default=64)
+    ap.add_argument("--window-batch", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-oracle leg (0 = skip)")
     ap.add_argument("--shard-library", action="store_true", help="also time the library-sharded kNN + all-gather")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -194,6 +194,17 @@ def main():
                 "launches": len(ev_pairs), "avg_launch_ms": round(ms / max(1, len(ev_pairs)), 3),
                 "kernel_share_of_step": round(ms * 1e-3 / dt, 3)}
 
+    # Data dependence of the scoring kernel: the candidate-list path is taken more often when the frames of a wave
+    # are uncorrelated.  The batch above comes from one synthetic signal family (correlated frames); time the same
+    # kernel once on i.i.d. Gaussian frames so both ends are on record (real speech lies in between).
+    ev_pairs.clear()
+    rnd = torch.randn(n_win, 768, L // FRAME, device=dev, generator=torch.Generator(device=dev).manual_seed(77 + rank))
+    library.search(rnd, args.k)
+    torch.cuda.synchronize()
+    a, b, tt_frames = ev_pairs[-1]
+    roofline["achieved_uncorrelated_frames"] = round(2.0 * 768 * M * tt_frames / (a.elapsed_time(b) * 1e-3) / 1e12, 1)
+    del rnd
+
     sharded = None
     if args.shard_library and world > 1:
         from module.sharded import bench_sharded_knn
@@ -214,7 +225,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 MFMA scoring + exact f32 rescoring; f32-MFMA encoders; split-bf16 (bf16x3) decoder GEMMs; f64 phase scan",
+            "dtype": "bf16 MFMA scoring + exact f32 rescoring; 3-plane split-bf16 (fp32-grade) encoder GEMMs; 2-plane split-bf16 decoder GEMMs; f32 MFMA DFT / strided / small-channel convs; f64 phase scan",
             "data": "synthetic",
             "config": {"workload": f"{args.utterances} utterances x {args.seconds:g} s per GPU -> {n_win} windows x "
                                    f"{L // FRAME} frames per step, {M}-vector library (BASELINE config 3/4 shape)",
