@@ -1,0 +1,387 @@
+// Frame-rate GEMMs of the ConvNeXt stacks on plane-packed operands (include/alive_vc.h "plane-packed activations").
+//
+//   D[co][col] = bias[co] + sum_k W[co][k] * X[col][k]          co < Co, col = n*T + t < N*T, k < Ci
+//
+// Both operands are stored as NP bf16 planes (v = p0 + p1 (+ p2)) with k contiguous, so a tile of either is a set of
+// 64-byte row segments that LDS-DMA (`global_load_lds_dwordx4`) copies straight into LDS: no VGPR round trip, no
+// conversion and no ds_write in the loop, which is what bound conv_split.hip on these shapes (one 32-channel block of a
+// 1x1 conv is only 24 MFMAs per wave between two barriers, and the fp32 activations had to be loaded, split and stored
+// behind them).  The product of two split values keeps the plane pairs (i, j) with i + j <= NP - 1:
+//   NP = 2: 3 MFMAs ("bf16x3", ~2^-16 per product)    NP = 3: 6 MFMAs ("bf16x6", fp32-grade)
+//
+// Block = 4 waves (2 x 2), tile 128 (co) x 128 (col), wave tile 64 x 64 = 2 x 2 v_mfma_f32_32x32x16_bf16 tiles.
+// K advances 32 per step; a step's operands (2 x NP x 8 KB) live in one slot of an NS-slot LDS ring.  After the
+// barrier of step s the slot of step s is free and the DMA of step s + NS goes into it, so NS - 2 steps are always in
+// flight behind the one that must have landed (counted vmcnt, never 0 in the steady state).
+// LDS image of a tile plane: [128 rows][64 B], filled in 1-KB pieces of 16 rows; the LDS side of an LDS-DMA is
+// lane-linear, so the bank swizzle sits on the SOURCE address: 16-B chunk c of row r is stored at chunk
+// c ^ ((r >> 2) & 3), which makes every ds_read_b128 of an MFMA fragment conflict-free (16-lane groups, 256-B bank rows).
+#include "conv_epilogue.h"
+
+namespace {
+
+constexpr int GM = 128, GN = 128, GK = 32;
+constexpr int PLANE_BYTES = GM * GK * 2;          // 8 KB: one operand plane of one step
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    // gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14 ; unused counters at their maximum
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+__device__ __forceinline__ void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14)); }
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t h = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+
+template <int NP, int NS, int MINB, int ACT>
+__global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int n_mt, int ntiles, int64_t cols,
+                                                             int64_t cols_pad, int co_pad, int co_pad32, int kpad, int dbg,
+                                                             long long* stamps) {
+    const long long ts0 = wall_clock64();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int SLOT = 2 * NP * PLANE_BYTES;
+    constexpr int NI = 4 * NP;                    // DMA pieces per wave per step
+    constexpr int NPROD = NP * (NP + 1) / 2;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    // XCD-aware tile order: the blocks an XCD runs together share column tiles (and the L2 copy of their X rows)
+    int v;
+    {
+        const int L = blockIdx.x, xcd = L & 7, j = L >> 3, q = ntiles >> 3, r = ntiles & 7;
+        v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int mt = v % n_mt, ct = (dbg & 1) ? 0 : v / n_mt;
+    const int m0 = mt * GM;
+    const int64_t c0 = (int64_t)ct * GN;
+    const int nsteps = (dbg & 8) ? 1 : kpad / GK;
+
+    // ---- DMA geometry: piece q = w + 4 i  ->  (operand, plane, 16-row group) ----
+    const int prow = lane >> 2;
+    const int pchunk = (lane & 3) ^ ((prow >> 2) & 3);
+    const unsigned short* src[NI];
+    int ldst[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int q = w + 4 * i;
+        const int op = q / (8 * NP), pl = (q % (8 * NP)) / 8, g = q % 8;
+        const int r = g * 16 + prow;
+        if (op == 0) {
+            int row = m0 + r;
+            row = row < co_pad ? row : co_pad - 1;
+            src[i] = (const unsigned short*)p.W + ((size_t)pl * co_pad + row) * kpad + pchunk * 8;
+        } else {
+            int64_t col = c0 + r;
+            col = col < cols_pad ? col : cols_pad - 1;
+            src[i] = (const unsigned short*)p.P + ((size_t)pl * cols_pad + col) * kpad + pchunk * 8;
+        }
+        ldst[i] = (op * NP + pl) * PLANE_BYTES + g * 1024;
+    }
+    auto issue = [&](int step, int i) {
+        if (((dbg & 2) && ldst[i] < NP * PLANE_BYTES) || ((dbg & 4) && ldst[i] >= NP * PLANE_BYTES)) return;
+        __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + step * GK), (lptr_t)(smem + (step % NS) * SLOT + ldst[i]), 16, 0, 0);
+    };
+
+    // the bias joins in the epilogue: nothing but the DMA issue stands between the launch and the first MFMA
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0.0f; acc[i][1][r] = 0.0f; }
+
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        if (s < nsteps) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) issue(s, i);
+        }
+
+    // fragment byte offsets inside a plane: row * 64 + ((2 ks + lh) ^ ((row >> 2) & 3)) * 16 ; ks = 1 flips bit 5
+    const int sw = (lr >> 2) & 3;
+    const int a_off = (wr * 64 + lr) * 64 + ((lh ^ sw) << 4);
+    const int b_off = NP * PLANE_BYTES + (wc * 64 + lr) * 64 + ((lh ^ sw) << 4);
+
+    bf16x8 fa[2][2][NP], fb[2][2][NP];            // [ks parity][tile][plane]
+    auto load_frags = [&](int step, int ks, bf16x8 (&a)[2][NP], bf16x8 (&b)[2][NP]) {
+        const unsigned char* S = smem + (step % NS) * SLOT;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                a[t][pl] = *(const bf16x8*)(S + ((a_off + t * 2048) ^ (ks << 5)) + pl * PLANE_BYTES);
+                b[t][pl] = *(const bf16x8*)(S + ((b_off + t * 2048) ^ (ks << 5)) + pl * PLANE_BYTES);
+            }
+    };
+    // all plane products (i, j), i + j <= NP - 1, smallest terms first; the four accumulator tiles are interleaved so
+    // that dependent MFMAs are four issues apart.  `hook(n)` runs after the n-th group of four (DMA issue slots).
+    auto mma = [&](bf16x8 (&a)[2][NP], bf16x8 (&b)[2][NP], auto&& hook) {
+        int n = 0;
+#pragma unroll
+        for (int sum = NP - 1; sum >= 0; --sum)
+#pragma unroll
+            for (int i = 0; i <= sum; ++i) {
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj)
+                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][i], b[tj][sum - i], acc[ti][tj], 0, 0, 0);
+                hook(n++);
+            }
+    };
+
+    const long long ts1 = wall_clock64();
+    // stage 0 landed?  (NS - 1 younger stages may still be in flight)
+    if (nsteps >= NS) wait_vmcnt<(NS - 1) * NI>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, 0, fa[0], fb[0]);
+    const long long ts2 = wall_clock64();
+
+    for (int s = 0; s < nsteps; ++s) {
+        // the second half's fragments are requested behind the first MFMA group (a request in front of it would be
+        // waited for together with the first half's: lgkmcnt is in order and the loop edge hides the count)
+        mma(fa[0], fb[0], [&](int n) {
+            if (n == 0) load_frags(s, 1, fa[1], fb[1]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        // step s + 1 must have landed for every wave; steps s + 2 .. s + NS - 1 stay in flight
+        wait_lgkmcnt0();
+        if (s + NS - 1 < nsteps) wait_vmcnt<(NS - 2) * NI>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (s + 1 < nsteps) load_frags(s + 1, 0, fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        // slot of step s is free now: refill it with step s + NS, NI pieces spread over the NPROD MFMA groups
+        const bool refill = s + NS < nsteps;
+        mma(fa[1], fb[1], [&](int n) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                if (i * NPROD / NI == n && refill) issue(s + NS, i);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    wait_vmcnt<0>();
+    const long long ts3 = wall_clock64();
+
+    // ---- epilogue, straight from the accumulators ----
+    // A lane holds, per 32 x 32 tile, one column and 16 rows in 4 groups of 4 consecutive rows (8 g + 4 lh + e).
+    // Offsets are 32-bit (checked on the host) against uniform bases; per-row vectors (bias, post_add, ch_scale) come
+    // as clamped loads, and all residual values of a 32-row half are requested before its first store (Y may alias the
+    // residual, so the compiler may not hoist them).  Tiles that lie completely inside Co take the store path without
+    // per-row tests.
+    unsigned obase[2];
+    bool cok[2];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        const int64_t col = c0 + wc * 64 + tj * 32 + lr;
+        cok[tj] = col < cols;
+        const int64_t n = cok[tj] ? col / p.T : 0;
+        obase[tj] = (unsigned)(n * p.Co * p.T + (cok[tj] ? col - n * p.T : 0));
+    }
+    const bool full_rows = m0 + GM <= p.Co;            // block-uniform
+    const float* __restrict__ bias = p.bias;
+    const float* __restrict__ post_add = p.post_add;
+    const float* __restrict__ ch_scale = p.ch_scale;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int rbase = m0 + wr * 64 + ti * 32 + 4 * lh;
+        float bia[4][4], pad[4][4], scl[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int row = rbase + 8 * g + e;
+                row = row < p.Co ? row : p.Co - 1;
+                bia[g][e] = bias != nullptr ? bias[row] : 0.0f;
+                pad[g][e] = post_add != nullptr ? post_add[row] : 0.0f;
+                scl[g][e] = ch_scale != nullptr ? ch_scale[row] : 1.0f;
+            }
+        float res[2][16];
+        if (p.residual != nullptr) {
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = rbase + (r & 3) + 8 * (r >> 2);
+                    row = row < p.Co ? row : p.Co - 1;
+                    res[tj][r] = p.residual[obase[tj] + (unsigned)(row * p.T)];
+                }
+        }
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            float vv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = acc[ti][tj][r] + bia[r >> 2][r & 3];
+                if (ACT == 1) x = gelu_fast(x);
+                else if (ACT == 2) x = expf(x);
+                x = (x + pad[r >> 2][r & 3]) * scl[r >> 2][r & 3];
+                if (p.residual != nullptr) x += res[tj][r];
+                vv[r] = x;
+            }
+            if (p.Y != nullptr && cok[tj] && !(dbg & 32)) {
+                if (full_rows) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        p.Y[obase[tj] + (unsigned)((rbase + (r & 3) + 8 * (r >> 2)) * p.T)] = vv[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + (r & 3) + 8 * (r >> 2);
+                        if (row < p.Co) p.Y[obase[tj] + (unsigned)(row * p.T)] = vv[r];
+                    }
+                }
+            }
+            if (p.Pout != nullptr && cok[tj]) {
+                // plane-packed output for the next GEMM: 4 consecutive channels of one column -> 8 B per plane
+                unsigned short* Po = (unsigned short*)p.Pout;
+                const int64_t col = c0 + wc * 64 + tj * 32 + lr;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = rbase + 8 * g;
+                    if (row >= co_pad32) continue;
+                    float q[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) q[e] = (full_rows || row + e < p.Co) ? vv[4 * g + e] : 0.0f;
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) {
+                        const unsigned h01 = pack_bf16x2(q[0], q[1]), h23 = pack_bf16x2(q[2], q[3]);
+                        *(uint2*)(Po + ((size_t)pl * cols_pad + col) * co_pad32 + row) = make_uint2(h01, h23);
+                        q[0] -= __uint_as_float(h01 << 16);
+                        q[1] -= __uint_as_float(h01 & 0xffff0000u);
+                        q[2] -= __uint_as_float(h23 << 16);
+                        q[3] -= __uint_as_float(h23 & 0xffff0000u);
+                    }
+                }
+            }
+        }
+    }
+    if (stamps != nullptr && tid == 0) {
+        long long* o = stamps + (size_t)blockIdx.x * 8;
+        o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3; o[4] = wall_clock64();
+        o[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+    }
+}
+
+// fp32 [N][C][T] -> planes [NP][cols_pad][C_pad] (zero padded in both directions)
+template <int NP>
+__global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict__ X, int C, int T, int64_t cols, int64_t cols_pad,
+                                                        int c_pad, unsigned short* __restrict__ P) {
+    __shared__ float tile[64][65];                 // [channel][column]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t col0 = (int64_t)blockIdx.x * 64;
+    const int ch0 = blockIdx.y * 64;
+    {
+        const int64_t col = col0 + lane;
+        const bool ok = col < cols;
+        const int64_t n = ok ? col / T : 0;
+        const int t = ok ? (int)(col - n * T) : 0;
+        const float* xc = X + (size_t)n * C * T + t;
+        for (int r = wv; r < 64; r += 4) {
+            const int c = ch0 + r;
+            tile[r][lane] = (ok && c < C) ? xc[(size_t)c * T] : 0.0f;
+        }
+    }
+    __syncthreads();
+    // thread -> (column, 8-channel chunk): 64 columns x 8 chunks = 512 items, two per thread
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int item = it * 256 + threadIdx.x;
+        const int ck = item & 7, cl = item >> 3;
+        const int64_t col = col0 + cl;
+        const int c = ch0 + ck * 8;
+        if (col >= cols_pad || c >= c_pad) continue;
+        float vv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vv[e] = tile[ck * 8 + e][cl];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned h = pack_bf16x2(vv[2 * e], vv[2 * e + 1]);
+                o[e] = h;
+                vv[2 * e] -= __uint_as_float(h << 16);
+                vv[2 * e + 1] -= __uint_as_float(h & 0xffff0000u);
+            }
+            *(u32x4*)(P + ((size_t)pl * cols_pad + col) * c_pad + c) = o;
+        }
+    }
+}
+
+long long* g_stamps = nullptr;
+inline int64_t pad_cols(int64_t cols) { return (cols + GN - 1) / GN * GN; }
+inline int pad32(int c) { return (c + 31) & ~31; }
+
+template <int NP, int NS, int MINB, int ACT>
+int launch_gemm_act(const AliveGemm& d, hipStream_t s) {
+    constexpr int LDS = NS * 2 * NP * PLANE_BYTES;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_planes_kernel<NP, NS, MINB, ACT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            alive_set_error("alive_gemm_planes: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return ALIVE_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    const int64_t cols = (int64_t)d.N * d.T;
+    const int n_mt = cdiv(d.Co, GM), n_ct = cdiv(cols, GN);
+    const int ntiles = n_mt * n_ct;
+    gemm_planes_kernel<NP, NS, MINB, ACT><<<ntiles, 256, LDS, s>>>(
+        d, n_mt, ntiles, cols, pad_cols(cols), (d.Co + 15) & ~15, pad32(d.Co), pad32(d.Ci),
+        getenv("ALIVE_GEMM_DEBUG") ? atoi(getenv("ALIVE_GEMM_DEBUG")) : 0, g_stamps);
+    ALIVE_CHECK_LAUNCH("alive_gemm_planes");
+    return ALIVE_OK;
+}
+
+template <int NP, int NS, int MINB>
+int launch_gemm(const AliveGemm& d, hipStream_t s) {
+    if (d.act == 1) return launch_gemm_act<NP, NS, MINB, 1>(d, s);
+    if (d.act == 2) return launch_gemm_act<NP, NS, MINB, 2>(d, s);
+    return launch_gemm_act<NP, NS, MINB, 0>(d, s);
+}
+
+}  // namespace
+
+extern "C" void alive_debug_set_stamps(long long* p) { g_stamps = p; }
+
+extern "C" size_t alive_planes_bytes(int64_t cols, int C, int planes) {
+    return (size_t)planes * (size_t)pad_cols(cols) * pad32(C) * 2;
+}
+
+extern "C" int alive_to_planes(const float* X, int N, int C, int T, int planes, void* P, void* stream) {
+    ALIVE_CHECK_ARG(X && P && N > 0 && C > 0 && T > 0, "alive_to_planes: bad args");
+    ALIVE_CHECK_ARG(planes == 2 || planes == 3, "alive_to_planes: planes must be 2 or 3, got %d", planes);
+    ALIVE_CHECK_ARG((((uintptr_t)P) & 15) == 0, "alive_to_planes: P must be 16-byte aligned");
+    const int64_t cols = (int64_t)N * T, cp = pad_cols(cols);
+    const int c_pad = pad32(C);
+    dim3 g((unsigned)(cp / 64), cdiv(c_pad, 64));
+    if (planes == 2) to_planes_kernel<2><<<g, 256, 0, (hipStream_t)stream>>>(X, C, T, cols, cp, c_pad, (unsigned short*)P);
+    else to_planes_kernel<3><<<g, 256, 0, (hipStream_t)stream>>>(X, C, T, cols, cp, c_pad, (unsigned short*)P);
+    ALIVE_CHECK_LAUNCH("alive_to_planes");
+    return ALIVE_OK;
+}
+
+extern "C" int alive_gemm_planes(const AliveGemm* d, void* stream) {
+    ALIVE_CHECK_ARG(d && d->W && d->P && (d->Y || d->Pout), "alive_gemm_planes: null pointer");
+    ALIVE_CHECK_ARG(d->N > 0 && d->T > 0 && d->Ci > 0 && d->Co > 0, "alive_gemm_planes: bad shape");
+    ALIVE_CHECK_ARG(d->planes == 2 || d->planes == 3, "alive_gemm_planes: planes must be 2 or 3, got %d", d->planes);
+    ALIVE_CHECK_ARG(d->act >= 0 && d->act <= 2, "alive_gemm_planes: activation %d", d->act);
+    ALIVE_CHECK_ARG(((((uintptr_t)d->W) | ((uintptr_t)d->P) | ((uintptr_t)d->Pout)) & 15) == 0,
+                    "alive_gemm_planes: W / P / Pout must be 16-byte aligned");
+    ALIVE_CHECK_ARG((d->Y == nullptr) != (d->Pout == nullptr), "alive_gemm_planes: exactly one of Y / Pout");
+    ALIVE_CHECK_ARG((int64_t)d->N * d->Co * d->T < (1ll << 30), "alive_gemm_planes: fp32 tensor of %lld elements exceeds the 32-bit offsets",
+                    (long long)d->N * d->Co * d->T);
+    static const int variant = getenv("ALIVE_GEMM_VARIANT") ? atoi(getenv("ALIVE_GEMM_VARIANT")) : 0;
+    if (d->planes == 2) return variant == 1 ? launch_gemm<2, 4, 1>(*d, (hipStream_t)stream) : launch_gemm<2, 2, 2>(*d, (hipStream_t)stream);
+    return launch_gemm<3, 3, 1>(*d, (hipStream_t)stream);
+}

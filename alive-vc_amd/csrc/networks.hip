@@ -129,11 +129,34 @@ struct ConvNeXtW {
     }
 };
 
+// ---- frame-rate 1x1 convs ---------------------------------------------------------------------
+// With enough columns (N*T) they run as plane-packed GEMMs (gemm_planes.hip): the activation operand is split into
+// bf16 planes once, by its producer or by alive_to_planes, and both operands stream into LDS by LDS-DMA.  Below that
+// (the streaming path: a handful of frames per step) the fp32-activation kernels of alive_conv1d stay in charge.
+constexpr int64_t PLANES_MIN_COLS = 96;
+inline bool use_planes(int N, int T) { return (int64_t)N * T >= PLANES_MIN_COLS; }
+inline size_t planes_bytes(int N, int T, int C, int planes) { return align_up(alive_planes_bytes((int64_t)N * T, C, planes), 256); }
+
+int pw_gemm(const float* W, const float* b, const void* P, int N, int T, int Ci, int Co, int planes, int act,
+            const float* post_add, const float* ch_scale, const float* residual, float* Y, void* Pout, void* s) {
+    AliveGemm g;
+    memset(&g, 0, sizeof(g));
+    g.W = W; g.bias = b; g.P = P; g.N = N; g.T = T; g.Ci = Ci; g.Co = Co; g.planes = planes; g.act = act;
+    g.post_add = post_add; g.ch_scale = ch_scale; g.residual = residual; g.Y = Y; g.Pout = Pout;
+    return alive_gemm_planes(&g, s);
+}
+
 // x <- x + scale * pw2(gelu(pw1(norm(dw(x)))))      (common.py:54-62 / 74-82)
-int convnext_layer(const ConvNeXtW& w, float* x, float* ybuf, float* hbuf, int N, int C, int H, int T, const float* cond,
-                   int cond_rows, int scale_row, int shift_row, int planes, void* s) {
+// Pa / Ph: plane-packed scratch for the normalised input and the hidden layer (nullptr: fp32-activation path via hbuf)
+int convnext_layer(const ConvNeXtW& w, float* x, float* ybuf, float* hbuf, void* Pa, void* Ph, int N, int C, int H, int T,
+                   const float* cond, int cond_rows, int scale_row, int shift_row, int planes, void* s) {
     RUN(alive_dwconv_norm(x, N, C, T, w.dw_w, w.dw_b, cond ? 1 : 0, w.gain, w.offset, cond, cond_rows, scale_row,
                           shift_row, NORM_EPS, ybuf, s));
+    if (Pa != nullptr) {
+        RUN(alive_to_planes(ybuf, N, C, T, planes, Pa, s));
+        RUN(pw_gemm(w.pw1W, w.pw1b, Pa, N, T, C, H, planes, 1, nullptr, nullptr, nullptr, nullptr, Ph, s));
+        return pw_gemm(w.pw2W, w.pw2b, Ph, N, T, H, C, planes, 0, nullptr, w.scale, x, x, nullptr, s);
+    }
     AliveConv d1 = pw_desc(w.pw1W, w.pw1b, ybuf, N, C, T, H, hbuf);
     d1.act = 1;
     d1 = planes == 3 ? split3(d1) : split(d1);
@@ -144,6 +167,20 @@ int convnext_layer(const ConvNeXtW& w, float* x, float* ybuf, float* hbuf, int N
     d2 = planes == 3 ? split3(d2) : split(d2);
     RUN(alive_conv1d(&d2, s));
     return ALIVE_OK;
+}
+
+// one 1x1 conv from an fp32 [N][Ci][T] tensor: converts to planes (scratch Pa) when the plane path is on
+int pw_conv(const float* W, const float* b, const float* X, void* Pa, int N, int T, int Ci, int Co, int planes, int act,
+            const float* post_add, float* Y, void* s) {
+    if (Pa != nullptr) {
+        RUN(alive_to_planes(X, N, Ci, T, planes, Pa, s));
+        return pw_gemm(W, b, Pa, N, T, Ci, Co, planes, act, post_add, nullptr, nullptr, Y, nullptr, s);
+    }
+    AliveConv d = pw_desc(W, b, X, N, Ci, T, Co, Y);
+    d.act = act;
+    d.post_add = post_add;
+    d = planes == 3 ? split3(d) : split(d);
+    return alive_conv1d(&d, s);
 }
 
 __global__ void dft_basis_kernel(float* basis) {
@@ -193,62 +230,72 @@ extern "C" int alive_spectrogram(const float* basis, const float* wav, int N, in
 }
 
 // ---- content encoder -------------------------------------------------------------------------
-extern "C" size_t alive_content_encoder_workspace_bytes(int N, int T) {
-    size_t f = (size_t)N * T;
-    return align_up(f * CE_C * 4, 256) * 2 + align_up(f * CE_H * 4, 256) + 1024;
+namespace {
+struct EncBuffers {
+    float *x, *y, *h, *lg;
+    void *Pa, *Ph;
+    size_t bytes;
+};
+// C / H: ConvNeXt widths; logits: rows of the fp32 logits tensor of the f0 estimator (0 for the content encoder)
+EncBuffers enc_layout(void* ws, int N, int T, int C, int H, int logits) {
+    Arena a(ws);
+    EncBuffers b;
+    const size_t f = (size_t)N * T;
+    b.x = a.take<float>(f * C);
+    b.y = a.take<float>(f * C);
+    b.lg = logits ? a.take<float>(f * logits) : nullptr;
+    if (use_planes(N, T)) {
+        b.h = nullptr;
+        b.Pa = a.take<char>(planes_bytes(N, T, BINS, 3));          // widest plane-packed input: the 641 spectrogram bins
+        b.Ph = a.take<char>(planes_bytes(N, T, H, 3));
+    } else {
+        b.h = a.take<float>(f * H);
+        b.Pa = b.Ph = nullptr;
+    }
+    b.bytes = a.used() + 1024;
+    return b;
 }
+}  // namespace
+
+extern "C" size_t alive_content_encoder_workspace_bytes(int N, int T) { return enc_layout(nullptr, N, T, CE_C, CE_H, 0).bytes; }
 extern "C" int alive_content_encoder(const float* const* w, const float* spec, int N, int T, float* out, void* ws, void* stream) {
     ALIVE_CHECK_ARG(w && spec && out && ws && N > 0 && T > 0, "alive_content_encoder: bad args");
     Table t(w);
-    Arena a(ws);
-    float* x = a.take<float>((size_t)N * CE_C * T);
-    float* y = a.take<float>((size_t)N * CE_C * T);
-    float* h = a.take<float>((size_t)N * CE_H * T);
+    EncBuffers b = enc_layout(ws, N, T, CE_C, CE_H, 0);
     const float* inW = t.next(); const float* inb = t.next();
-    AliveConv d = split3(pw_desc(inW, inb, spec, N, BINS, T, CE_C, x));
-    RUN(alive_conv1d(&d, stream));
+    RUN(pw_conv(inW, inb, spec, b.Pa, N, T, BINS, CE_C, 3, 0, nullptr, b.x, stream));
     for (int i = 0; i < 4; ++i) {
         ConvNeXtW cw(t, false);
-        RUN(convnext_layer(cw, x, y, h, N, CE_C, CE_H, T, nullptr, 0, 0, 0, 3, stream));
+        RUN(convnext_layer(cw, b.x, b.y, b.h, b.Pa, b.Ph, N, CE_C, CE_H, T, nullptr, 0, 0, 0, 3, stream));
     }
     const float* oW = t.next(); const float* ob = t.next();
-    AliveConv o = split3(pw_desc(oW, ob, x, N, CE_C, T, CE_OUT, out));
-    RUN(alive_conv1d(&o, stream));
-    return ALIVE_OK;
+    return pw_conv(oW, ob, b.x, b.Pa, N, T, CE_C, CE_OUT, 3, 0, nullptr, out, stream);
 }
 
 // ---- f0 estimator ----------------------------------------------------------------------------
-extern "C" size_t alive_f0_estimate_workspace_bytes(int N, int T) {
-    size_t f = (size_t)N * T;
-    return align_up(f * PE_C * 4, 256) * 2 + align_up(f * PE_H * 4, 256) + align_up(f * PE_OUT * 4, 256) + 1024;
-}
+extern "C" size_t alive_f0_estimate_workspace_bytes(int N, int T) { return enc_layout(nullptr, N, T, PE_C, PE_H, PE_OUT).bytes; }
 extern "C" int alive_f0_estimate(const float* const* w, const float* spec, int N, int T, float* f0, void* ws, void* stream) {
     ALIVE_CHECK_ARG(w && spec && f0 && ws && N > 0 && T > 0, "alive_f0_estimate: bad args");
     Table t(w);
-    Arena a(ws);
-    float* x = a.take<float>((size_t)N * PE_C * T);
-    float* y = a.take<float>((size_t)N * PE_C * T);
-    float* h = a.take<float>((size_t)N * PE_H * T);
-    float* lg = a.take<float>((size_t)N * PE_OUT * T);
+    EncBuffers b = enc_layout(ws, N, T, PE_C, PE_H, PE_OUT);
     const float* inW = t.next(); const float* inb = t.next();
-    AliveConv d = split3(pw_desc(inW, inb, spec, N, BINS, T, PE_C, x));
-    RUN(alive_conv1d(&d, stream));
+    RUN(pw_conv(inW, inb, spec, b.Pa, N, T, BINS, PE_C, 3, 0, nullptr, b.x, stream));
     for (int i = 0; i < 4; ++i) {
         ConvNeXtW cw(t, false);
-        RUN(convnext_layer(cw, x, y, h, N, PE_C, PE_H, T, nullptr, 0, 0, 0, 3, stream));
+        RUN(convnext_layer(cw, b.x, b.y, b.h, b.Pa, b.Ph, N, PE_C, PE_H, T, nullptr, 0, 0, 0, 3, stream));
     }
     const float* g = t.next(); const float* of = t.next();
-    RUN(alive_channel_norm(x, N, PE_C, T, g, of, NORM_EPS, y, stream));
+    RUN(alive_channel_norm(b.x, N, PE_C, T, g, of, NORM_EPS, b.y, stream));
     const float* oW = t.next(); const float* ob = t.next();
-    AliveConv o = split3(pw_desc(oW, ob, y, N, PE_C, T, PE_OUT, lg));
-    RUN(alive_conv1d(&o, stream));
-    return alive_argmax_channels(lg, N, PE_OUT, T, f0, stream);
+    RUN(pw_conv(oW, ob, b.y, b.Pa, N, T, PE_C, PE_OUT, 3, 0, nullptr, b.lg, stream));
+    return alive_argmax_channels(b.lg, N, PE_OUT, T, f0, stream);
 }
 
 // ---- decoder ---------------------------------------------------------------------------------
 namespace {
 struct DecBuffers {
     float *x, *y, *h, *sinb, *cond, *normfilm, *amps, *src, *film, *x0, *d0, *d1, *d2, *d3, *m, *U, *Hh, *Zz, *Z2;
+    void *Pa, *Ph;          // plane-packed scratch of the FeatureExtractor GEMMs (nullptr on the streaming path)
     void* osc_ws;
     size_t bytes;
 };
@@ -258,7 +305,14 @@ DecBuffers dec_layout(void* ws, int N, int Lf) {
     const size_t f = (size_t)N * Lf, Lw = (size_t)Lf * SEG;
     b.x = a.take<float>(f * DEC_C);
     b.y = a.take<float>(f * DEC_C);
-    b.h = a.take<float>(f * DEC_H);
+    if (use_planes(N, Lf)) {
+        b.h = nullptr;
+        b.Pa = a.take<char>(planes_bytes(N, Lf, 768, 2));
+        b.Ph = a.take<char>(planes_bytes(N, Lf, DEC_H, 2));
+    } else {
+        b.h = a.take<float>(f * DEC_H);
+        b.Pa = b.Ph = nullptr;
+    }
     b.sinb = a.take<float>(f * DEC_C);
     b.cond = a.take<float>(f * DEC_C);
     b.normfilm = a.take<float>(f * 4096);
@@ -293,23 +347,27 @@ extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, c
     const int Lw = Lf * SEG;
     // -- FeatureExtractor (decoder.py:43-48)
     const float* inW = t.next(); const float* inb = t.next();
-    { AliveConv d = split(pw_desc(inW, inb, x_in, N, 768, Lf, DEC_C, b.x)); RUN(alive_conv1d(&d, stream)); }
+    RUN(pw_conv(inW, inb, x_in, b.Pa, N, Lf, 768, DEC_C, 2, 0, nullptr, b.x, stream));
     const float* c1W = t.next(); const float* c1b = t.next(); const float* c2W = t.next(); const float* c2b = t.next();
     { AliveConv d = pw_desc(c1W, c1b, f0, N, 1, Lf, DEC_C, b.sinb); d.act = 3; RUN(alive_conv1d(&d, stream)); }
-    { AliveConv d = split(pw_desc(c2W, c2b, b.sinb, N, DEC_C, Lf, DEC_C, b.cond)); RUN(alive_conv1d(&d, stream)); }
+    RUN(pw_conv(c2W, c2b, b.sinb, b.Pa, N, Lf, DEC_C, DEC_C, 2, 0, nullptr, b.cond, stream));
     const float* nfW = t.next(); const float* nfb = t.next();
-    { AliveConv d = split(pw_desc(nfW, nfb, b.cond, N, DEC_C, Lf, 4096, b.normfilm)); RUN(alive_conv1d(&d, stream)); }
+    RUN(pw_conv(nfW, nfb, b.cond, b.Pa, N, Lf, DEC_C, 4096, 2, 0, nullptr, b.normfilm, stream));
     for (int i = 0; i < 4; ++i) {
         ConvNeXtW cw(t, true);
-        RUN(convnext_layer(cw, b.x, b.y, b.h, N, DEC_C, DEC_H, Lf, b.normfilm, 4096, i * 1024, i * 1024 + 512, 2, stream));
+        RUN(convnext_layer(cw, b.x, b.y, b.h, b.Pa, b.Ph, N, DEC_C, DEC_H, Lf, b.normfilm, 4096, i * 1024, i * 1024 + 512, 2, stream));
     }
     // -- HarmonicOscillator (decoder.py:66-102)
     const float* aW = t.next(); const float* ab = t.next();
-    { AliveConv d = split(pw_desc(aW, ab, b.x, N, DEC_C, Lf, NH, b.amps)); d.act = 2; RUN(alive_conv1d(&d, stream)); }
+    RUN(pw_conv(aW, ab, b.x, b.Pa, N, Lf, DEC_C, NH, 2, 2, nullptr, b.amps, stream));
     RUN(alive_oscillator(b.amps, f0, phi_in, N, NH, Lf, SEG, SR, crop0, phi_col, b.src, phi_out, b.osc_ws, stream));
     // -- Filter (decoder.py:184-195); FiLM scale(+1)/shift of all 24 modulated convs in one GEMM
     const float* fW = t.next(); const float* fb = t.next(); const float* fpost = t.next();
-    { AliveConv d = split(pw_desc(fW, fb, b.x, N, DEC_C, Lf, FILM_ROWS, b.film)); d.post_add = fpost; RUN(alive_conv1d(&d, stream)); }
+    if (b.Pa != nullptr) {      // b.Pa still holds the planes of b.x (to_amps above)
+        RUN(pw_gemm(fW, fb, b.Pa, N, Lf, DEC_C, FILM_ROWS, 2, 0, fpost, nullptr, nullptr, b.film, nullptr, stream));
+    } else {
+        AliveConv d = split(pw_desc(fW, fb, b.x, N, DEC_C, Lf, FILM_ROWS, b.film)); d.post_add = fpost; RUN(alive_conv1d(&d, stream));
+    }
     const float* siW = t.next(); const float* sib = t.next();
     { AliveConv d = conv_desc(siW, sib, b.src, N, 1, Lw, 8, 7, 1, 1, 3, 0, Lw, b.x0); RUN(alive_conv1d(&d, stream)); }
     const int dch[5] = {8, 16, 64, 256, 256};

@@ -27,6 +27,15 @@ class AliveConv(C.Structure):
     ]
 
 
+class AliveGemm(C.Structure):
+    _fields_ = [
+        ("W", C.c_void_p), ("bias", C.c_void_p), ("P", C.c_void_p),
+        ("N", C.c_int), ("T", C.c_int), ("Ci", C.c_int), ("Co", C.c_int), ("planes", C.c_int), ("act", C.c_int),
+        ("post_add", C.c_void_p), ("ch_scale", C.c_void_p), ("residual", C.c_void_p),
+        ("Y", C.c_void_p), ("Pout", C.c_void_p),
+    ]
+
+
 _VP, _I, _I64, _F, _D, _SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
 
 # name -> (restype, argtypes); mirrors include/alive_vc.h one to one
@@ -40,6 +49,9 @@ PROTOTYPES = {
     "alive_knn_set_timing_events": (_I, [_VP, _VP]),
     "alive_knn_merge_gather": (_I, [_VP, _VP, _I, _I, _D, _VP, _VP, _I, _I, _VP, _VP, _VP]),
     "alive_conv1d": (_I, [C.POINTER(AliveConv), _VP]),
+    "alive_planes_bytes": (_SZ, [_I64, _I, _I]),
+    "alive_to_planes": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
+    "alive_gemm_planes": (_I, [C.POINTER(AliveGemm), _VP]),
     "alive_filter_block_small_weights": (_I, [_I]),
     "alive_filter_block_small": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
     "alive_dwconv_norm": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP]),

@@ -75,6 +75,40 @@ def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, o
     return Y, Z
 
 
+def to_planes(x, planes=2):
+    """fp32 [N][C][T] -> plane-packed bf16 buffer (uint8 tensor of alive_planes_bytes) for gemm_planes."""
+    x = _f(x)
+    n, c, t = x.shape
+    P = torch.empty(nat.lib().alive_planes_bytes(n * t, c, planes), dtype=torch.uint8, device=x.device)
+    nat.check(nat.lib().alive_to_planes(nat.ptr(x), n, c, t, planes, nat.ptr(P), nat.stream()), "alive_to_planes")
+    return P
+
+
+def planes_to_float(P, n, c, t, planes):
+    """inverse of to_planes (sum of the planes), for tests"""
+    cols, cp = n * t, (c + 31) // 32 * 32
+    cols_pad = (cols + 127) // 128 * 128
+    v = P.view(torch.bfloat16).view(planes, cols_pad, cp).float().sum(0)[:cols, :c]
+    return v.view(n, t, c).permute(0, 2, 1).contiguous()
+
+
+def gemm_planes(P, n, t, weight, bias=None, planes=2, act=None, post_add=None, ch_scale=None, residual=None,
+                want_fp32=True, want_planes=False):
+    """1x1 conv on a plane-packed input through alive_gemm_planes.  Returns (Y fp32 [n][co][t] or None, Pout or None)."""
+    co, ci = weight.shape[0], weight.shape[1]
+    W = pack_conv_split(weight, planes)
+    b, post_add, ch_scale, residual = map(_f, (bias, post_add, ch_scale, residual))
+    d = nat.AliveGemm()
+    d.W, d.bias, d.P = nat.ptr(W), nat.ptr(b), nat.ptr(P)
+    d.N, d.T, d.Ci, d.Co, d.planes, d.act = n, t, ci, co, planes, ACT[act]
+    d.post_add, d.ch_scale, d.residual = map(nat.ptr, (post_add, ch_scale, residual))
+    Y = torch.empty(n, co, t, device=P.device) if want_fp32 else None
+    Po = torch.empty(nat.lib().alive_planes_bytes(n * t, co, planes), dtype=torch.uint8, device=P.device) if want_planes else None
+    d.Y, d.Pout = nat.ptr(Y), nat.ptr(Po)
+    nat.check(nat.lib().alive_gemm_planes(C.byref(d), nat.stream()), "alive_gemm_planes")
+    return Y, Po
+
+
 def dwconv_norm(x, dw_w, dw_b, gain=None, offset=None, cond=None, scale_row=0, shift_row=0, eps=1e-4):
     x = _f(x)
     n, c, t = x.shape

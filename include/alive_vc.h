@@ -117,6 +117,33 @@ typedef struct AliveConv {
 } AliveConv;
 int alive_conv1d(const AliveConv* desc, void* stream);
 
+/* ---- plane-packed activations: the frame-rate GEMMs of the ConvNeXt stacks --------------------------
+ * The 1x1 convs of ContentEncoder / F0Estimator / FeatureExtractor (content_encoder.py:22-25,
+ * f0_estimator.py:23-27, decoder.py:43-48, common.py:57-61,77-81) run as plain GEMMs whose activation operand is
+ * already split into bf16 planes and stored K-contiguous, so that BOTH operands go global -> LDS by LDS-DMA and
+ * the inner loop is MFMAs only:
+ *   P[plane][col][C_pad] bf16, col = n*T + t, plane 0 = bf16(v), plane 1 = bf16(v - p0), plane 2 = bf16(v - p0 - p1);
+ *   C_pad a multiple of 32 (zero filled), plane stride = cols_pad * C_pad with cols_pad a multiple of 128.
+ * alive_to_planes converts an fp32 [N][C][T] tensor; alive_gemm_planes writes fp32 [N][Co][T] (same epilogue
+ * options as alive_conv1d) and / or plane-packed output (act applied first) for the next GEMM. */
+size_t alive_planes_bytes(int64_t cols, int C, int planes);        /* bytes of a plane-packed buffer */
+int alive_to_planes(const float* X, int N, int C, int T, int planes, void* P, void* stream);
+typedef struct AliveGemm {
+    const void* W;         /* bf16 [planes][Co_pad][Ci_pad] (module/_pack.py::pack_conv_split of a k=1 conv) */
+    const float* bias;     /* [Co] or NULL */
+    const void* P;         /* input planes [planes][cols_pad][Ci_pad] */
+    int N, T;              /* cols = N*T; fp32 outputs are [N][Co][T] */
+    int Ci, Co;
+    int planes;            /* 2: bf16x3, 3: bf16x6 (both operands) */
+    int act;               /* 0 none, 1 gelu, 2 exp */
+    const float* post_add; /* [Co] or NULL */
+    const float* ch_scale; /* [Co] or NULL */
+    const float* residual; /* [N][Co][T] or NULL */
+    float* Y;              /* fp32 output [N][Co][T] or NULL */
+    void* Pout;            /* plane-packed output [planes][cols_pad][Co_pad32] or NULL (Co_pad32 = Co rounded up to 32) */
+} AliveGemm;
+int alive_gemm_planes(const AliveGemm* desc, void* stream);
+
 /* FilterBlock.forward (decoder.py:137-150) for C = 8 or 16 fused into one kernel: input_conv 1x1 + three
  * FilterResBlocks (six GELU -> FiLM -> reflect-left causal k5 convs, dilations 1,1,2,2,4,4), optional U-Net skip
  * added to the result.  U[N][C][L] -> out[N][C][L] (not in place).

@@ -378,3 +378,76 @@ def test_small_t_norm_and_argmax():
     lg = g("samx", (2, 4096, 8))
     lg[1, 77, 3] = lg[1, 3000, 3] = 60.0
     assert torch.equal(ops.argmax_channels(lg.to(DEV)).cpu(), torch.argmax(lg, dim=1).float().unsqueeze(1))
+
+
+# ---- plane-packed GEMMs (frame-rate 1x1 convs of the ConvNeXt stacks) -----------------------------------
+@pytest.mark.parametrize("planes", [2, 3])
+@pytest.mark.parametrize("n,c,t", [(2, 641, 450), (1, 512, 37), (3, 40, 130)])
+def test_to_planes_roundtrip(planes, n, c, t):
+    from module import ops
+    x = g(f"tp{n}{c}{t}", (n, c, t))
+    P = ops.to_planes(x.to(DEV), planes)
+    back = ops.planes_to_float(P, n, c, t, planes).cpu()
+    # 2 planes carry 16 mantissa bits, 3 planes all 24
+    assert (back - x).abs().max().item() <= (2.0 ** -15 if planes == 2 else 2.0 ** -22) * x.abs().max().item()
+    cp, cols_pad = (c + 31) // 32 * 32, (n * t + 127) // 128 * 128
+    raw = P.view(torch.bfloat16).view(planes, cols_pad, cp).float()
+    assert raw[:, n * t:, :].abs().sum().item() == 0.0 and raw[:, :, c:].abs().sum().item() == 0.0      # zero padding
+
+
+@pytest.mark.parametrize("planes,tol", [(2, 2e-5), (3, 4e-7)])
+@pytest.mark.parametrize("co,ci,n,t", [
+    (512, 641, 2, 450),       # encoder input convs, ragged K (641 -> 672)
+    (1536, 512, 3, 37),       # pw1, ragged columns
+    (512, 1536, 2, 450),      # pw2
+    (4128, 512, 1, 130),      # FiLM projections, ragged Co
+    (64, 512, 2, 24),         # to_amps: one partial row tile
+    (4096, 256, 2, 200),      # f0 logits, K = 256 (8 steps)
+    (40, 24, 3, 50),          # K = 32: a single step, fewer than the ring depth
+    (256, 64, 1, 129),        # two steps
+])
+def test_gemm_planes_vs_float64(planes, tol, co, ci, n, t):
+    from module import ops
+    x = g(f"gpx{co}{ci}", (n, ci, t))
+    w = g(f"gpw{co}{ci}", (co, ci, 1), scale=1.0 / np.sqrt(ci))
+    b = g(f"gpb{co}{ci}", (co,), scale=0.1)
+    res = g(f"gpr{co}{ci}", (n, co, t))
+    sc = g(f"gps{co}{ci}", (co,), scale=0.5)
+    ref = F.conv1d(x.double(), w.double(), b.double()) * sc.double().view(1, -1, 1) + res.double()
+    P = ops.to_planes(x.to(DEV), planes)
+    y, _ = ops.gemm_planes(P, n, t, w.to(DEV), b.to(DEV), planes=planes, ch_scale=sc.to(DEV), residual=res.to(DEV))
+    assert y.shape == ref.shape
+    e = relerr(y, ref)
+    assert e < tol, e
+
+
+@pytest.mark.parametrize("planes,tol", [(2, 3e-5), (3, 1e-6)])
+def test_gemm_planes_chain_pw1_gelu_pw2(planes, tol):
+    """pw1 -> GELU -> plane-packed hidden -> pw2 (+ layer scale + residual): the ConvNeXt MLP of common.py:57-62"""
+    from module import ops
+    n, c, h, t = 2, 512, 1536, 450
+    x = g("gcx", (n, c, t))
+    w1, b1 = g("gcw1", (h, c, 1), scale=1.0 / np.sqrt(c)), g("gcb1", (h,), scale=0.1)
+    w2, b2 = g("gcw2", (c, h, 1), scale=1.0 / np.sqrt(h)), g("gcb2", (c,), scale=0.1)
+    sc, res = g("gcs", (c,), scale=0.25), g("gcr", (n, c, t))
+    hid = F.gelu(F.conv1d(x.double(), w1.double(), b1.double()))
+    ref = F.conv1d(hid, w2.double(), b2.double()) * sc.double().view(1, -1, 1) + res.double()
+    P = ops.to_planes(x.to(DEV), planes)
+    hy, _ = ops.gemm_planes(P, n, t, w1.to(DEV), b1.to(DEV), planes=planes, act="gelu")
+    _, Ph = ops.gemm_planes(P, n, t, w1.to(DEV), b1.to(DEV), planes=planes, act="gelu", want_fp32=False, want_planes=True)
+    assert relerr(hy, hid) < tol
+    assert relerr(ops.planes_to_float(Ph, n, h, t, planes), hid) < tol + (2e-5 if planes == 2 else 0.0)
+    y, _ = ops.gemm_planes(Ph, n, t, w2.to(DEV), b2.to(DEV), planes=planes, ch_scale=sc.to(DEV), residual=res.to(DEV))
+    e = relerr(y, ref)
+    assert e < tol, e
+
+
+def test_gemm_planes_argument_errors():
+    from module import ops
+    P = ops.to_planes(g("gex", (1, 32, 8)).to(DEV), 2)
+    with pytest.raises(ValueError):
+        ops.gemm_planes(P, 1, 8, torch.zeros(8, 32, 1, device=DEV), planes=4)
+    with pytest.raises(ValueError):
+        ops.gemm_planes(P, 1, 8, torch.zeros(8, 32, 1, device=DEV), want_fp32=False, want_planes=False)
+    with pytest.raises(ValueError):
+        ops.gemm_planes(P, 1, 8, torch.zeros(8, 32, 1, device=DEV), want_fp32=True, want_planes=True)
