@@ -30,7 +30,7 @@ def collect_clips(root, max_clips, rng):
     clips = []
     for path in sorted(glob.glob(os.path.join(root, "**", "*.wav"), recursive=True)):
         wf, sr = audio_io.load(path)
-        wf = audio_io.resample(wf, sr, 16000)
+        wf = audio_io.resample(wf.to("cuda"), sr, 16000).cpu()          # device resampler (csrc/audio.hip)
         wf = wf / wf.abs().max().clamp(min=1e-8)
         wf = wf.mean(dim=0)
         n = wf.shape[0] // CLIP

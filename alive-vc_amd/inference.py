@@ -86,14 +86,13 @@ def main(argv=None):
     paths = sorted(glob.glob(os.path.join(args.inputs, "*")))
     for i, path in enumerate(paths):
         wf, sr = audio_io.load(path)
-        wf = audio_io.resample(wf, sr, 16000)
+        wf = audio_io.resample(wf.to(device), sr, 16000)
         wf = wf / wf.abs().max()
         wf = wf.mean(dim=0, keepdim=True)
         print(f"converting {path}")
         out = conv.convert(wf, chunk=args.chunk, k=args.k, alpha=args.alpha, pitch_shift=args.pitch,
                            intonation=args.intonation, f0_rate=args.f0_rate, window_batch=args.window_batch)
-        out = audio_io.resample(out, 16000, sr)
-        out = audio_io.gain(out, args.gain).cpu()
+        out = audio_io.resample(out, 16000, sr, post_gain_db=args.gain).cpu()      # resample, then gain (:136-137)
         if args.normalize:
             out = out / out.abs().max()
         file_name = f"{i}_{os.path.splitext(os.path.basename(path))[0]}"

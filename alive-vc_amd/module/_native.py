@@ -63,6 +63,12 @@ PROTOTYPES = {
     "alive_dft_basis": (_I, [_VP, _VP]),
     "alive_spectrogram_workspace_bytes": (_SZ, [_I, _I]),
     "alive_spectrogram": (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP]),
+    "alive_resample_taps": (_I, [_I, _I]),
+    "alive_resample_length": (_I64, [_I64, _I, _I]),
+    "alive_resample_filter": (_I, [_I, _I, _VP, _VP]),
+    "alive_resample": (_I, [_VP, _I, _I, _I, _I, _VP, _F, _F, _VP, _I, _VP]),
+    "alive_pcm16_to_float": (_I, [_VP, _I64, _VP, _VP]),
+    "alive_float_to_pcm16": (_I, [_VP, _I64, _VP, _VP]),
     "alive_weight_count": (_I, [_I]),
     "alive_weight_name": (C.c_char_p, [_I, _I]),
     "alive_content_encoder_workspace_bytes": (_SZ, [_I, _I]),

@@ -2,9 +2,9 @@
 
 The reference uses torchaudio for these (inference.py:88-91,136-142; realtime_inference.py:146-147,
 173-175); torchaudio is not part of this image and none of its arithmetic is pinned by reference
-tests, so this file restates the PUBLIC algorithm of torchaudio.functional.resample
-(sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99) and documents its own file format choice:
-"parity unpinned" (DESIGN.md).  Reads PCM 8/16/24/32 and float32 WAV; writes float32 WAV by
+tests, so csrc/audio.hip restates the PUBLIC algorithm of torchaudio.functional.resample
+(sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99; checked against the torch formulation kept in
+oracle/alive_oracle.py) and this file documents its own file format choice: "parity unpinned" (DESIGN.md).  Reads PCM 8/16/24/32 and float32 WAV; writes float32 WAV by
 default (lossless w.r.t. the 1e-3 RMS comparison) or PCM16.
 """
 import math
@@ -12,7 +12,6 @@ import struct
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 
 def load(path):
@@ -71,41 +70,39 @@ def save(path, src, sample_rate, encoding="float32"):
         f.write(hdr + body)
 
 
-_kernels = {}
+_filters = {}
 
 
-def _sinc_kernel(orig, new, device, width_param=6, rolloff=0.99):
-    key = (orig, new, str(device))
-    if key not in _kernels:
-        base = min(orig, new) * rolloff
-        width = math.ceil(width_param * orig / base)
-        idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
-        t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
-        t = (t * base).clamp(-width_param, width_param)
-        window = torch.cos(t * math.pi / width_param / 2) ** 2
-        t = t * math.pi
-        scale = base / orig
-        k = torch.where(t == 0, torch.tensor(1.0, dtype=torch.float64), t.sin() / t) * window * scale
-        _kernels[key] = (k.float().to(device), width)
-    return _kernels[key]
+def _reduced(orig_freq, new_freq):
+    g = math.gcd(int(orig_freq), int(new_freq))
+    return int(orig_freq) // g, int(new_freq) // g
 
 
-def resample(waveform, orig_freq, new_freq):
-    """polyphase windowed-sinc resampling, waveform [..., time]; identity when the rates match."""
-    orig_freq, new_freq = int(orig_freq), int(new_freq)
-    if orig_freq == new_freq:
-        return waveform
-    g = math.gcd(orig_freq, new_freq)
-    orig, new = orig_freq // g, new_freq // g
-    kernel, width = _sinc_kernel(orig, new, waveform.device)
+def resample(waveform, orig_freq, new_freq, pre_gain_db=0.0, post_gain_db=0.0):
+    """torchaudio.functional.resample on the device (csrc/audio.hip: polyphase windowed sinc), waveform [..., time];
+    identity when the rates match.  The optional gains are torchaudio.functional.gain applied to the input / output
+    inside the same kernel (bitwise the same as separate multiplies)."""
+    from . import _native as nat
+    orig, new = _reduced(orig_freq, new_freq)
+    pre = float(10 ** (pre_gain_db / 20)) if pre_gain_db != 0 else 1.0
+    post = float(10 ** (post_gain_db / 20)) if post_gain_db != 0 else 1.0
+    if orig == new:
+        if pre * post == 1.0:
+            return waveform
+        return gain(gain(waveform, pre_gain_db), post_gain_db)
+    L_ = nat.lib()
+    key = (orig, new, str(waveform.device))
+    if key not in _filters:
+        f = torch.empty(new * L_.alive_resample_taps(orig, new), device=waveform.device)
+        nat.check(L_.alive_resample_filter(orig, new, nat.ptr(f), nat.stream()), "alive_resample_filter")
+        _filters[key] = f
     shape = waveform.shape
-    x = waveform.reshape(-1, shape[-1])
-    length = x.shape[1]
-    x = F.pad(x, (width, width + orig))
-    y = F.conv1d(x[:, None], kernel, stride=orig)            # [B, new, frames]
-    y = y.transpose(1, 2).reshape(x.shape[0], -1)
-    target = math.ceil(new * length / orig)
-    return y[..., :target].reshape(shape[:-1] + (target,))
+    x = waveform.reshape(-1, shape[-1]).contiguous().float()
+    lout = int(L_.alive_resample_length(x.shape[1], orig, new))
+    y = torch.empty(x.shape[0], lout, device=x.device)
+    nat.check(L_.alive_resample(nat.ptr(x), x.shape[0], x.shape[1], orig, new, nat.ptr(_filters[key]), pre, post,
+                                nat.ptr(y), lout, nat.stream()), "alive_resample")
+    return y.reshape(shape[:-1] + (lout,))
 
 
 def gain(waveform, gain_db=1.0):
@@ -113,3 +110,21 @@ def gain(waveform, gain_db=1.0):
     if gain_db == 0:
         return waveform
     return waveform * (10 ** (gain_db / 20))
+
+
+def pcm16_to_float(data_i16):
+    """int16 device tensor -> float32 / 32768 (realtime_inference.py:139-140)"""
+    from . import _native as nat
+    out = torch.empty(data_i16.shape, dtype=torch.float32, device=data_i16.device)
+    nat.check(nat.lib().alive_pcm16_to_float(nat.ptr(data_i16), data_i16.numel(), nat.ptr(out), nat.stream()), "alive_pcm16_to_float")
+    return out
+
+
+def float_to_pcm16(wave):
+    """float32 device tensor -> int16 by the C cast of numpy's astype: truncate toward zero, no clipping
+    (realtime_inference.py:180-183)"""
+    from . import _native as nat
+    wave = wave.contiguous()
+    out = torch.empty(wave.shape, dtype=torch.int16, device=wave.device)
+    nat.check(nat.lib().alive_float_to_pcm16(nat.ptr(wave), wave.numel(), nat.ptr(out), nat.stream()), "alive_float_to_pcm16")
+    return out

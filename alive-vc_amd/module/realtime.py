@@ -38,8 +38,7 @@ class RealtimeConverter:
     # ------------------------------------------------------------------ device part of one step
     def _device_step(self, data, phi):
         """data float32 [1, ring samples at input_sr] on the device, phi [1, 64] -> (wave at output_sr [L], phi_next [1, 64])"""
-        data = audio_io.resample(data, self.input_sr, 16000)
-        data = audio_io.gain(data, self.input_gain)
+        data = audio_io.resample(data, self.input_sr, 16000, post_gain_db=self.input_gain)     # resample, then gain (:146-147)
         spec = spectrogram(data)
         content = self.ce(spec)
         f0 = self.pe.estimate(spec)
@@ -48,8 +47,7 @@ class RealtimeConverter:
         content = merge_gather(val, idx, 1, self.k, self.alpha, self.lib.rows, content)
         wave, phi_out = self.dec(content, f0=f0, phi=phi, crop=(self.begin_of_output, self.end_of_output))
         self.last_f0 = f0
-        wave = audio_io.gain(wave, self.gain)
-        wave = audio_io.resample(wave, 16000, self.output_sr)[0]
+        wave = audio_io.resample(wave, 16000, self.output_sr, pre_gain_db=self.gain)[0]         # gain, then resample (:173-175)
         return wave, phi_out[:, :, self.end_of_output]
 
     def enable_graph(self):
@@ -92,9 +90,9 @@ class RealtimeConverter:
             del self.ring[0]
         else:
             return None
-        data = np.concatenate(self.ring, 0).astype(np.float32) / 32768
-        data = torch.from_numpy(data).to(self.device).unsqueeze(0)
+        data = torch.from_numpy(np.concatenate(self.ring, 0)).to(self.device)
+        data = audio_io.pcm16_to_float(data).unsqueeze(0)            # / 32768 on the device (:139-140)
         wave = self.step_device(data)
-        out = (wave.cpu().numpy() * 32768).astype(np.int16)          # C cast, no clipping (:180-183)
+        out = audio_io.float_to_pcm16(wave).cpu().numpy()            # C cast of numpy's astype, no clipping (:180-183)
         center = self.buffersize * self.chunk // 2
         return out[center - self.chunk // 2: center + self.chunk // 2]

@@ -87,7 +87,7 @@ def main(argv=None):
     print("converting voice...")
     if args.input_wav is not None:
         wf, sr = audio_io.load(args.input_wav)
-        wf = audio_io.resample(wf.mean(dim=0, keepdim=True), sr, args.input_sr)[0]
+        wf = audio_io.resample(wf.mean(dim=0, keepdim=True).to(device), sr, args.input_sr)[0].cpu()
         pcm = (wf.numpy() * 32767).astype(np.int16)
         outs = []
         for s in range(0, len(pcm) - args.chunk + 1, args.chunk):

@@ -184,6 +184,22 @@ int alive_dft_basis(float* basis, void* stream);
 size_t alive_spectrogram_workspace_bytes(int N, int L);
 int alive_spectrogram(const float* basis, const float* wav, int N, int L, float* spec, void* ws, void* stream);
 
+/* ------------------------------------------------------- audio edges (f2) ----
+ * torchaudio.functional.resample (sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99) as a polyphase filter bank,
+ * torchaudio.functional.gain folded in as a pre / post factor, and the int16 conversions of the streaming loop
+ * (inference.py:88-94,135-142; realtime_inference.py:139-147,173-183).  orig / new are the rates divided by their gcd.
+ *   filt: [new][alive_resample_taps(orig, new)] floats filled once by alive_resample_filter;
+ *   y[b][o] = post_scale * sum_j filt[o % new][j] * (pre_scale * x[b][(o / new) * orig + j - width]), zero outside x;
+ *   Lout <= alive_resample_length(L, orig, new) = ceil(new * L / orig).
+ *   alive_float_to_pcm16 truncates toward zero and keeps the low 16 bits (numpy astype, no clipping). */
+int alive_resample_taps(int orig, int new_rate);
+int64_t alive_resample_length(int64_t L, int orig, int new_rate);
+int alive_resample_filter(int orig, int new_rate, float* filt, void* stream);
+int alive_resample(const float* x, int B, int L, int orig, int new_rate, const float* filt, float pre_scale,
+                   float post_scale, float* y, int Lout, void* stream);
+int alive_pcm16_to_float(const int16_t* in, int64_t n, float* out, void* stream);
+int alive_float_to_pcm16(const float* in, int64_t n, int16_t* out, void* stream);
+
 /* ------------------------------------------------------------ networks ----
  * Weight tables are arrays of device pointers in the order given by
  * alive_weight_name(model, i), i < alive_weight_count(model); tensors are the

@@ -306,3 +306,43 @@ def realtime_step(ce, pe, dec, ring, tgt, phi, begin, end, k=4, alpha=0.0,
     content = match_features(content, tgt, k=k, alpha=alpha)
     wave, phi_out = decoder(dec, content, f0, phi=phi, crop0=begin)
     return wave, phi_out[:, :, end].unsqueeze(2)
+
+
+# ---- torchaudio.functional.resample / gain (Appendix C of SURVEY.md: restated from the public algorithm, torchaudio is
+# not in the reference tree -> "parity unpinned"; used to check csrc/audio.hip) ---------------------------------------
+def resample_filter(orig, new, width_param=6, rolloff=0.99):
+    """_get_sinc_resample_kernel(sinc_interp_hann): -> (kernel float32 [new, 1, 2*width + orig], width)"""
+    import math
+    base = min(orig, new) * rolloff
+    width = math.ceil(width_param * orig / base)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t = (t * base).clamp(-width_param, width_param)
+    window = torch.cos(t * math.pi / width_param / 2) ** 2
+    t = t * math.pi
+    scale = base / orig
+    k = torch.where(t == 0, torch.tensor(1.0, dtype=torch.float64), t.sin() / t) * window * scale
+    return k.float(), width
+
+
+def resample(waveform, orig_freq, new_freq):
+    """_apply_sinc_resample_kernel: pad, strided conv with the filter bank, interleave the phases, trim"""
+    import math
+    orig_freq, new_freq = int(orig_freq), int(new_freq)
+    if orig_freq == new_freq:
+        return waveform
+    g = math.gcd(orig_freq, new_freq)
+    orig, new = orig_freq // g, new_freq // g
+    kernel, width = resample_filter(orig, new)
+    shape = waveform.shape
+    x = waveform.reshape(-1, shape[-1])
+    length = x.shape[1]
+    x = F.pad(x, (width, width + orig))
+    y = F.conv1d(x[:, None], kernel, stride=orig)            # [B, new, frames]
+    y = y.transpose(1, 2).reshape(x.shape[0], -1)
+    target = math.ceil(new * length / orig)
+    return y[..., :target].reshape(shape[:-1] + (target,))
+
+
+def gain(waveform, gain_db=1.0):
+    return waveform if gain_db == 0 else waveform * (10 ** (gain_db / 20))

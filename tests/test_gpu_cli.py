@@ -38,12 +38,12 @@ def test_inference_cli_matches_oracle(workdir):
                     "-lib", str(d / "voice_library.pt"), "-d", "cuda", "-c", "4800", "-f0", "0.5", "-p", "2", "-a", "0.1"])
     out, sr = audio_io.load(str(d / "outputs" / "0_utt.wav"))
     assert sr == 24000 and out.shape == (1, 24000)
-    # oracle: same edges (this package's resampler/gain on CPU), reference loop in between
-    wf = audio_io.resample(wav24, 24000, 16000)
+    # oracle: torch formulation of the resampler / gain on CPU, reference loop in between
+    wf = O.resample(wav24, 24000, 16000)
     wf = (wf / wf.abs().max()).mean(dim=0, keepdim=True)
     ref = O.convert_utterance(sds["content_encoder.pt"], sds["f0_estimator.pt"], sds["decoder.pt"], wf,
                               synthetic.make_library(512, 5), chunk=4800, k=4, alpha=0.1, pitch_shift=2.0, f0_rate=0.5)
-    ref = audio_io.gain(audio_io.resample(ref, 16000, 24000), 1.0)
+    ref = O.gain(O.resample(ref, 16000, 24000), 1.0)
     err = (out - ref).pow(2).mean().sqrt().item()
     assert err < 1e-3, err
 

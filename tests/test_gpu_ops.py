@@ -451,3 +451,31 @@ def test_gemm_planes_argument_errors():
         ops.gemm_planes(P, 1, 8, torch.zeros(8, 32, 1, device=DEV), want_fp32=False, want_planes=False)
     with pytest.raises(ValueError):
         ops.gemm_planes(P, 1, 8, torch.zeros(8, 32, 1, device=DEV), want_fp32=True, want_planes=True)
+
+
+# ---- audio edges: resampler, gain, int16 conversions on the device -----------------------------------
+@pytest.mark.parametrize("orig,new,L", [(24000, 16000, 24000), (16000, 24000, 16001), (48000, 16000, 4803), (44100, 16000, 22050),
+                                        (16000, 22050, 3000)])
+def test_resample_matches_torch_formulation(orig, new, L):
+    from module import audio_io
+    x = synthetic.make_waveform(L, 3)
+    x = torch.cat([x, 0.5 * synthetic.make_waveform(L, 4)], 0)          # two channels
+    ref = O.resample(x, orig, new)
+    got = audio_io.resample(x.to(DEV), orig, new).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
+    g2 = audio_io.resample(x.to(DEV), orig, new, pre_gain_db=-3.0, post_gain_db=1.5).cpu()
+    ref2 = O.gain(O.resample(O.gain(x, -3.0), orig, new), 1.5)
+    assert (g2 - ref2).abs().max().item() < 2e-6 * max(1.0, ref2.abs().max().item())
+
+
+def test_pcm16_conversions_are_the_reference_casts():
+    from module import audio_io
+    pcm = torch.arange(-32768, 32768, 7, dtype=torch.int16)
+    f = audio_io.pcm16_to_float(pcm.to(DEV)).cpu()
+    assert torch.equal(f, pcm.float() / 32768)
+    w = torch.tensor([0.0, 0.5, -0.5, 0.99999, -1.0, 1.0, 1.2, -1.3, 3.0e-5, -3.0e-5, 0.123456], dtype=torch.float32)
+    got = audio_io.float_to_pcm16(w.to(DEV)).cpu().numpy()
+    with np.errstate(invalid="ignore"):
+        want = (w.numpy() * 32768).astype(np.int32).astype(np.int16)     # truncate toward zero, low 16 bits: numpy's astype on x86
+    assert np.array_equal(got, want), (got, want)
