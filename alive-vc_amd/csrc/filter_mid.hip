@@ -1,0 +1,284 @@
+// FilterBlock.forward for the 64-channel scale of the decoder's U-Net (/root/reference/module/decoder.py:105-150),
+// fused into ONE kernel like the 16- / 8-channel scales (filter_small.hip), on the split-bf16 MFMA.
+//
+// Conv by conv this scale (36 000 samples x 64 channels per window) is HBM-bound: every k5 conv reads and writes one or
+// two full fp32 tensors (4.7 GB per conv at 128 windows against 0.5 ms of MFMA work).  Here a block owns a tile of
+// 256 columns (200 outputs + the 56-column causal halo 4 x (1+1+2+2+4+4), recomputed instead of exchanged) and keeps
+// it on chip through the 1x1 input conv and the six GELU -> FiLM -> reflect-left causal k5 convs:
+//   * the modulated conv input z and the intermediate y live in two LDS buffers, ALREADY SPLIT into two bf16 planes
+//     (hi = bf16(v), lo = bf16(v - hi)) and stored [column][64 channels] so that an MFMA B fragment is one ds_read_b128;
+//     the 16-B chunk order of a 128-B row is XOR-swizzled with (row & 7): fragment reads are conflict-free at any tap
+//     shift;
+//   * a wave owns 16 output channels for all 256 columns (v_mfma_f32_16x16x32_bf16): its A fragments (10 k-steps x 2
+//     planes = 80 VGPRs) are loaded from L2 once per conv and stay in registers, the residual stream h (16 column tiles
+//     x 4) lives in registers in the MFMA C layout, so residual add, GELU, FiLM and the re-split of a tile are
+//     register-local and only the modulated planes go back to LDS;
+//   * a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, smallest terms first, fp32 accumulate (the "bf16x3" product of
+//     conv_split.hip, ~2^-16 per product).
+// HBM traffic drops to the input, the U-Net skip and the output (3 tensor passes instead of ~18).
+#include "conv_epilogue.h"
+
+namespace {
+
+constexpr int C = 64;
+constexpr int HALO = 56;
+constexpr int NCONV = 6;
+constexpr int BL = 256;                 // columns per tile incl. halo
+constexpr int TT = BL - HALO;           // 200 output columns per tile
+constexpr int NCT = BL / 16;            // 16 column tiles
+constexpr int NFP = 8;                  // FiLM frames staged per tile
+constexpr int ROWB = 128;               // bytes per LDS row (64 channels bf16)
+constexpr int PLANE = BL * ROWB;        // 32 KB
+constexpr int BUF = 2 * PLANE;          // hi + lo
+constexpr int W_IN = 2 * C * C;         // bf16 elements of the input conv [2][64][64]
+constexpr int W_K5 = 2 * C * 5 * C;     // bf16 elements of a k5 conv [2][64][320]
+constexpr int LDS_BYTES = 2 * BUF + NCONV * 2 * C * NFP * 4;
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t h = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+
+__global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __restrict__ U, int L,
+                                                                const unsigned short* __restrict__ W16,
+                                                                const float* __restrict__ biases,
+                                                                const float* __restrict__ film, int film_rows, int Lf,
+                                                                int film_off, float ratio, const float* __restrict__ skip,
+                                                                float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    unsigned char* bufZ = sm;
+    unsigned char* bufY = sm + BUF;
+    float* Fs = (float*)(sm + 2 * BUF);               // [NCONV][2][C][NFP]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, kq = lane >> 4;
+    const int n = blockIdx.y;
+    const int t0 = blockIdx.x * TT;
+    const int tbase = t0 - HALO;
+    const float* Un = U + (size_t)n * C * L;
+
+    // ---- FiLM rows of the tile ----
+    const int f_lo = lerp_coord(tbase < 0 ? 0 : tbase, ratio, Lf).i0;
+    for (int e = tid; e < NCONV * 2 * C * NFP; e += 256) {
+        const int f = e % NFP, c = (e / NFP) % C, sel = (e / (NFP * C)) & 1, q = e / (NFP * C * 2);
+        int fr = f_lo + f;
+        fr = fr < Lf ? fr : Lf - 1;
+        Fs[e] = film[((size_t)n * film_rows + film_off + q * 2 * C + sel * C + c) * Lf + fr];
+    }
+    // ---- stage the raw input tile, split into planes: thread = column, 8 channels (one 16-B chunk) at a time ----
+    {
+        const int t = tbase + tid;
+        const bool ok = t >= 0 && t < L;
+        const float* uc = Un + (ok ? t : 0);
+#pragma unroll
+        for (int ck = 0; ck < 8; ++ck) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = ok ? uc[(size_t)(ck * 8 + e) * L] : 0.0f;
+            u32x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned h = pack2(v[2 * e], v[2 * e + 1]);
+                hi[e] = h;
+                lo[e] = pack2(v[2 * e] - __uint_as_float(h << 16), v[2 * e + 1] - __uint_as_float(h & 0xffff0000u));
+            }
+            unsigned char* dst = bufZ + tid * ROWB + ((ck ^ (tid & 7)) << 4);
+            *(u32x4*)dst = hi;
+            *(u32x4*)(dst + PLANE) = lo;
+        }
+    }
+    __syncthreads();
+
+    // residual stream: h[ct][e] = channel 16 w + 4 kq + e of column 16 ct + c16 (MFMA C layout)
+    f32x4 h[NCT];
+
+    // gelu -> FiLM of conv q's input for the 4 channels of this lane at column `col`, re-split and stored as planes
+    auto modulate_store = [&](int q, unsigned char* dst, int col, const f32x4& v) {
+        int t = tbase + col;
+        t = t < 0 ? 0 : (t < L ? t : L - 1);
+        const Lerp lp = lerp_coord(t, ratio, Lf);
+        int i0 = lp.i0 - f_lo, i1 = lp.i1 - f_lo;
+        i0 = i0 < NFP - 1 ? i0 : NFP - 1;
+        i1 = i1 < NFP - 1 ? i1 : NFP - 1;
+        float z[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* f = Fs + ((q * 2) * C + 16 * w + 4 * kq + e) * NFP;
+            const float sc = fmaf(lp.w0, f[i0], lp.w1 * f[i1]);
+            const float sh = fmaf(lp.w0, f[C * NFP + i0], lp.w1 * f[C * NFP + i1]);
+            z[e] = gelu_fast(v[e]) * sc + sh;
+        }
+        const unsigned h01 = pack2(z[0], z[1]), h23 = pack2(z[2], z[3]);
+        const unsigned l01 = pack2(z[0] - __uint_as_float(h01 << 16), z[1] - __uint_as_float(h01 & 0xffff0000u));
+        const unsigned l23 = pack2(z[2] - __uint_as_float(h23 << 16), z[3] - __uint_as_float(h23 & 0xffff0000u));
+        // channels 16 w + 4 kq .. +3 -> chunk 2 w + (kq >> 1), byte 8 (kq & 1) inside it
+        unsigned char* p = dst + col * ROWB + (((2 * w + (kq >> 1)) ^ (col & 7)) << 4) + 8 * (kq & 1);
+        *(uint2*)p = make_uint2(h01, h23);
+        *(uint2*)(p + PLANE) = make_uint2(l01, l23);
+    };
+
+    // one conv over the whole tile: KS k-steps of 32 channels, A fragments (this wave's 16 rows) in registers
+    // B fragment of (row r, ci-block cb): 16 B at r * 128 + ((4 cb + kq) ^ (r & 7)) * 16, planes PLANE apart
+    // ---- input_conv (1x1, K = 64 = 2 k-steps): h = Win * U + b ; z0 = mod_0(h) written over the same columns ----
+    {
+        bf16x8 a[2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                a[s][pl] = *(const bf16x8*)(W16 + (size_t)pl * C * C + (size_t)(16 * w + c16) * C + s * 32 + 8 * kq);
+        f32x4 b4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b4[e] = biases[16 * w + 4 * kq + e];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int r = ct * 16 + c16;
+            f32x4 acc = b4;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const unsigned char* bp = bufZ + r * ROWB + (((4 * s + kq) ^ (r & 7)) << 4);
+                const bf16x8 bh = *(const bf16x8*)bp, bl = *(const bf16x8*)(bp + PLANE);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][1], bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][0], bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][0], bh, acc, 0, 0, 0);
+            }
+            h[ct] = acc;
+        }
+    }
+    __syncthreads();                       // every wave has read the raw columns
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) modulate_store(0, bufZ, ct * 16 + c16, h[ct]);
+    __syncthreads();
+
+    // ---- three FilterResBlocks: q = 2 j (c1), 2 j + 1 (c2), dilation 2^j    (decoder.py:128-134) ----
+#pragma unroll 1
+    for (int q = 0; q < NCONV; ++q) {
+        const unsigned short* Wq = W16 + W_IN + (size_t)q * W_K5;
+        bf16x8 a[10][2];                   // k-step s = 2 j + cb (tap j, channel block cb): k = j * 64 + cb * 32 + 8 kq
+#pragma unroll
+        for (int s = 0; s < 10; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                a[s][pl] = *(const bf16x8*)(Wq + (size_t)pl * C * 5 * C + (size_t)(16 * w + c16) * (5 * C) + s * 32 + 8 * kq);
+        f32x4 b4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b4[e] = biases[(1 + q) * C + 16 * w + 4 * kq + e];
+        const int d = 1 << (q >> 1);
+        const bool second = q & 1;
+        const unsigned char* in = second ? bufY : bufZ;
+        unsigned char* dst = second ? bufZ : bufY;
+
+        // LDS offsets of the five taps of column tile ct for this lane (reflect-left at the window start)
+        auto tap_offsets = [&](int ct, int (&off)[5]) {
+            const int col = ct * 16 + c16;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                int ta = tbase + col + (j - 4) * d;
+                ta = ta < 0 ? -ta : ta;                      // ReflectionPad1d on the left (common.py:88)
+                int r = ta - tbase;
+                r = r < 0 ? 0 : (r < BL ? r : BL - 1);       // only never-valid halo columns can be clamped
+                off[j] = r * ROWB + ((kq ^ (r & 7)) << 4);   // chunk 4 cb + kq: cb flips bit 6
+            }
+        };
+        bf16x8 bh[10], bl[10], nh[10], nl[10];
+        auto load_tile = [&](int ct, bf16x8 (&xh)[10], bf16x8 (&xl)[10]) {
+            int off[5];
+            tap_offsets(ct, off);
+#pragma unroll
+            for (int s = 0; s < 10; ++s) {
+                const unsigned char* bp = in + (off[s >> 1] ^ ((s & 1) << 6));
+                xh[s] = *(const bf16x8*)bp;
+                xl[s] = *(const bf16x8*)(bp + PLANE);
+            }
+        };
+        // one column tile: request the next tile's fragments, run the 30 MFMAs of this one, finish it in registers
+        auto body = [&](int ct, bf16x8 (&xh)[10], bf16x8 (&xl)[10], bf16x8 (&yh)[10], bf16x8 (&yl)[10], f32x4& hres) {
+            if (ct + 1 < NCT) load_tile(ct + 1, yh, yl);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc0 = b4, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int s = 0; s < 10; ++s) {
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][1], xh[s], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][0], xl[s], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < 10; ++s) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][0], xh[s], acc0, 0, 0, 0);
+            acc0 = acc0 + acc1;
+            if (second) {
+                acc0 = acc0 + hres;
+                hres = acc0;
+            }
+            if (q + 1 < NCONV) modulate_store(q + 1, dst, ct * 16 + c16, acc0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        load_tile(0, bh, bl);
+        // The column loop stays rolled (two tiles per trip, fragment buffers ping-pong): the residual registers are
+        // rotated by two per trip so that h[0], h[1] are always the current pair -- static register indices, no scratch.
+#pragma unroll 1
+        for (int cp = 0; cp < NCT / 2; ++cp) {
+            body(2 * cp, bh, bl, nh, nl, h[0]);
+            body(2 * cp + 1, nh, nl, bh, bl, h[1]);
+            if (second) {
+                const f32x4 f0 = h[0], f1 = h[1];
+#pragma unroll
+                for (int i = 0; i + 2 < NCT; ++i) h[i] = h[i + 2];
+                h[NCT - 2] = f0;
+                h[NCT - 1] = f1;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- store the tile (+ U-Net skip, decoder.py:191): through LDS so that global accesses are 16-B vectors along t ----
+    float* Ht = (float*)sm;                           // [64][BL + 4] fp32 = 66.5 KB over bufZ / bufY
+    constexpr int HP = BL + 4;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Ht[(16 * w + 4 * kq + e) * HP + ct * 16 + c16] = h[ct][e];
+    __syncthreads();
+    for (int g = tid; g < C * (TT / 4); g += 256) {
+        const int co = g / (TT / 4), c4 = (g - co * (TT / 4)) * 4;
+        const int t = t0 + c4;
+        if (t >= L) continue;
+        const size_t o = ((size_t)n * C + co) * L + t;
+        f32x4 v = *(const f32x4*)&Ht[co * HP + HALO + c4];
+        if (t + 3 < L) {
+            if (skip != nullptr) v = v + *(const f32x4*)(skip + o);
+            *(f32x4*)(out + o) = v;
+        } else {
+            for (int e = 0; e < 4 && t + e < L; ++e) out[o + e] = v[e] + (skip != nullptr ? skip[o + e] : 0.0f);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t alive_filter_block64_weights(void) { return (int64_t)W_IN + (int64_t)NCONV * W_K5; }
+
+extern "C" int alive_filter_block64(const float* U, int N, int L, const void* W16, const float* biases, const float* film,
+                                    int film_rows, int Lf, int film_off, const float* skip, float* out, void* stream) {
+    ALIVE_CHECK_ARG(U && W16 && biases && film && out, "alive_filter_block64: null pointer");
+    ALIVE_CHECK_ARG(N > 0 && L > 16 && Lf > 0, "alive_filter_block64: bad sizes (L must exceed the largest reflect pad, 16)");
+    ALIVE_CHECK_ARG(U != out, "alive_filter_block64: in-place not supported (tiles read a halo of their left neighbour)");
+    ALIVE_CHECK_ARG((L & 3) == 0 && ((((uintptr_t)out) | ((uintptr_t)skip)) & 15) == 0,
+                    "alive_filter_block64: L must be a multiple of 4 and out / skip 16-byte aligned");
+    ALIVE_CHECK_ARG((double)BL * Lf / L + 3.0 <= NFP, "alive_filter_block64: tile spans more than %d frames (L %d, Lf %d)", NFP, L, Lf);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)filter_block64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) {
+            alive_set_error("alive_filter_block64: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(e));
+            return ALIVE_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const float ratio = (float)Lf / (float)L;
+    dim3 g(cdiv(L, TT), N);
+    filter_block64_kernel<<<g, 256, LDS_BYTES, (hipStream_t)stream>>>(U, L, (const unsigned short*)W16, biases, film, film_rows,
+                                                                     Lf, film_off, ratio, skip, out);
+    ALIVE_CHECK_LAUNCH("alive_filter_block64");
+    return ALIVE_OK;
+}

@@ -26,8 +26,10 @@ constexpr float NORM_EPS = 1e-4f;
 constexpr int F_CH[4] = {256, 64, 16, 8};            // filter channels, coarse -> fine (decoder.py:157,171)
 constexpr int F_UP[4] = {10, 8, 2, 2};               // upsampling rates, coarse -> fine
 constexpr int FILM_ROWS = 6 * 2 * (256 + 64 + 16 + 8);   // 4128
-constexpr bool F_SPLIT[4] = {true, true, false, false};   // filter scales on the split-bf16 MFMA kernel (C = 256, 64);
-                                                          // the 16- / 8-channel scales run the fused VALU FilterBlock kernel
+// how a filter scale runs (module/_pack.py::FILTER_MODE): 0 conv by conv on the split-bf16 MFMA kernel (C = 256),
+// 1 fused FilterBlock on the split-bf16 MFMA (C = 64, filter_mid.hip), 2 fused on the f32 MFMA (C = 16, 8)
+constexpr int F_MODE[4] = {0, 1, 2, 2};
+constexpr bool F_SPLIT[4] = {true, true, false, false};   // ConvTranspose in front of the scale on the split kernel
 
 inline int pad16(int x) { return (x + 15) & ~15; }
 
@@ -65,7 +67,8 @@ const Names& names_of(int model) {
         for (int i = 0; i < 4; ++i) { dec.add("flt.up" + std::to_string(i) + ".W"); dec.add("flt.up" + std::to_string(i) + ".b"); }
         for (int s = 0; s < 4; ++s) {
             std::string b = "flt.blk" + std::to_string(s);
-            if (!F_SPLIT[s]) { dec.add(b + ".pack"); continue; }        // fused 16- / 8-channel FilterBlock
+            if (F_MODE[s] == 2) { dec.add(b + ".pack"); continue; }     // fused 16- / 8-channel FilterBlock
+            if (F_MODE[s] == 1) { dec.add(b + ".packW"); dec.add(b + ".packB"); continue; }   // fused 64-channel FilterBlock
             dec.add(b + ".in.W"); dec.add(b + ".in.b");
             for (int j = 0; j < 3; ++j)
                 for (int c = 1; c <= 2; ++c) {
@@ -400,9 +403,14 @@ extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, c
             RUN(alive_conv1d(&d, stream));
         }
         L *= r;
-        if (!F_SPLIT[s]) {      // whole FilterBlock (+ skip) in one kernel: U -> Hh
-            const float* wpack = t.next();
-            RUN(alive_filter_block_small(b.U, N, C, L, wpack, b.film, FILM_ROWS, Lf, film_off, skips[s], b.Hh, stream));
+        if (F_MODE[s] != 0) {   // whole FilterBlock (+ skip) in one kernel: U -> Hh
+            if (F_MODE[s] == 2) {
+                const float* wpack = t.next();
+                RUN(alive_filter_block_small(b.U, N, C, L, wpack, b.film, FILM_ROWS, Lf, film_off, skips[s], b.Hh, stream));
+            } else {
+                const float* w16 = t.next(); const float* bias = t.next();
+                RUN(alive_filter_block64(b.U, N, L, w16, bias, b.film, FILM_ROWS, Lf, film_off, skips[s], b.Hh, stream));
+            }
             film_off += 6 * 2 * C;
             cur = b.Hh;
             cin = C;

@@ -99,9 +99,23 @@ def pack_f0_estimator(sd):
 
 
 FILTER_CH = [256, 64, 16, 8]
-# filter scales whose convs run on the split-bf16 MFMA kernel (C = 256, 64); the 16- and 8-channel scales are
-# HBM-bound and stay on the fp32 kernel.  Must match F_SPLIT in csrc/networks.hip.
-SPLIT_SCALE = [True, True, False, False]
+# how each filter scale runs (must match F_MODE in csrc/networks.hip): "split" = conv by conv on the split-bf16 MFMA
+# kernel (C = 256), "mid" = whole FilterBlock fused on the split-bf16 MFMA (C = 64, csrc/filter_mid.hip),
+# "small" = whole FilterBlock fused on the f32 MFMA (C = 16, 8, csrc/filter_small.hip)
+FILTER_MODE = ["split", "mid", "small", "small"]
+SPLIT_SCALE = [m != "small" for m in FILTER_MODE]      # ConvTranspose in front of the scale on the split kernel
+
+
+def pack_filter_mid(sd, prefix):
+    """FilterBlock weights for the fused 64-channel kernel (csrc/filter_mid.hip):
+    -> (bf16 flat: input conv [2][64][64], then 6 x [2][64][k = j*64 + ci]; fp32 biases [7][64])"""
+    ws = [pack_conv_split(sd[prefix + ".input_conv.weight"]).reshape(-1)]
+    bs = [sd[prefix + ".input_conv.bias"].float()]
+    for j in range(3):
+        for cc in ("c1", "c2"):
+            ws.append(pack_conv_split(sd[f"{prefix}.blocks.{j}.{cc}.conv.conv.weight"]).reshape(-1))
+            bs.append(sd[f"{prefix}.blocks.{j}.{cc}.conv.conv.bias"].float())
+    return torch.cat(ws).contiguous(), torch.stack(bs, 0).contiguous()
 
 
 def pack_filter_small(sd, prefix):
@@ -168,8 +182,11 @@ def pack_decoder(sd):
         out[f"flt.up{i}.W"], out[f"flt.up{i}.b"] = pt(sd[f"{f}.ups.{i}.weight"], sd[f"{f}.ups.{i}.bias"])
     for s in range(4):
         b = f"{f}.blocks.{s}"
-        if not SPLIT_SCALE[s]:                       # 16- / 8-channel scales: one fused kernel per FilterBlock
+        if FILTER_MODE[s] == "small":                # 16- / 8-channel scales: one fused kernel per FilterBlock
             out[f"flt.blk{s}.pack"] = pack_filter_small(sd, b)
+            continue
+        if FILTER_MODE[s] == "mid":                  # 64-channel scale: fused, split-bf16
+            out[f"flt.blk{s}.packW"], out[f"flt.blk{s}.packB"] = pack_filter_mid(sd, b)
             continue
         out[f"flt.blk{s}.in.W"] = pack_conv_split(sd[b + ".input_conv.weight"])
         out[f"flt.blk{s}.in.b"] = _vec(sd[b + ".input_conv.bias"])

@@ -175,3 +175,17 @@ def filter_block_small(x, sd, prefix, film, film_off, skip=None):
     nat.check(nat.lib().alive_filter_block_small(nat.ptr(x), n, c, l, nat.ptr(w), nat.ptr(film), film.shape[1], film.shape[2],
                                                  film_off, nat.ptr(skip), nat.ptr(out), nat.stream()), "alive_filter_block_small")
     return out
+
+
+def filter_block64(x, sd, prefix, film, film_off, skip=None):
+    """fused FilterBlock for C = 64 (split-bf16 MFMA): x[N,64,L], reference-layout weights sd[prefix + ...]."""
+    from ._pack import pack_filter_mid
+    x, film, skip = _f(x), _f(film), _f(skip)
+    n, c, l = x.shape
+    w, b = pack_filter_mid(sd, prefix)
+    w, b = w.to(x.device), b.to(x.device)
+    assert w.numel() == nat.lib().alive_filter_block64_weights()
+    out = torch.empty_like(x)
+    nat.check(nat.lib().alive_filter_block64(nat.ptr(x), n, l, nat.ptr(w), nat.ptr(b), nat.ptr(film), film.shape[1], film.shape[2],
+                                             film_off, nat.ptr(skip), nat.ptr(out), nat.stream()), "alive_filter_block64")
+    return out

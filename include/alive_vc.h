@@ -154,6 +154,16 @@ int alive_filter_block_small_weights(int C);
 int alive_filter_block_small(const float* U, int N, int C, int L, const float* wpack, const float* film,
                              int film_rows, int Lf, int film_off, const float* skip, float* out, void* stream);
 
+/* FilterBlock.forward (decoder.py:137-150) for C = 64 fused into one kernel on the split-bf16 MFMA (filter_mid.hip):
+ * activations stay in LDS as two bf16 planes through the input conv and the six modulated k5 convs.
+ *   W16: bf16, alive_filter_block64_weights() elements = input conv [2 planes][64][64], then per conv q = 0..5
+ *        [2 planes][64][k = j*64 + ci]  (module/_pack.py::pack_filter_mid)
+ *   biases: fp32 [7][64], input conv first;  film / film_off / skip / out as alive_filter_block_small;
+ *   L a multiple of 4, out and skip 16-byte aligned, not in place. */
+int64_t alive_filter_block64_weights(void);
+int alive_filter_block64(const float* U, int N, int L, const void* W16, const float* biases, const float* film,
+                         int film_rows, int Lf, int film_off, const float* skip, float* out, void* stream);
+
 /* depthwise k7 conv + (Adaptive)ChannelNorm (common.py:20-26,35-41,55-56,75-76)
  *   affine_mode 0: gain[C], offset[C];  1: per-sample scale/shift rows in cond[N][cond_rows][T] */
 int alive_dwconv_norm(const float* X, int N, int C, int T, const float* dw_w, const float* dw_b,
