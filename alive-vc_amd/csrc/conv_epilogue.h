@@ -13,12 +13,12 @@ __device__ __attribute__((noinline)) static float apply_act(float v, int act) {
     return sinf(v);
 }
 
-// Branch-free GELU for the decoder's FiLM path: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7) on
-// v_rcp/v_exp; ~16 VALU, inlined.  Only used next to the split-bf16 GEMMs and the FiLM second output,
-// whose own error (~1e-5 relative) is two orders above it; the encoder / f0 paths keep erff.
+// Branch-free GELU for the split-bf16 paths: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7) on v_rcp_f32 / v_exp_f32
+// (the hardware reciprocal directly: __frcp_rn expands to the 12-instruction IEEE division sequence); ~17 VALU, inlined.
+// Only used next to the split-bf16 GEMMs and the FiLM second output, whose own error is at or above it.
 __device__ __forceinline__ float gelu_fast(float x) {
     const float ax = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
@@ -27,6 +27,26 @@ __device__ __forceinline__ float gelu_fast(float x) {
     const float e = __expf(-ax * ax);
     const float erf_abs = fmaf(-p, e, 1.0f);
     return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
+// the same on two values per lane: the polynomial runs on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_splat(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+    const f32x2 ax = __builtin_elementwise_abs(x) * 0.70710678118654752440f;
+    const f32x2 d = pk_fma(pk_splat(0.3275911f), ax, pk_splat(1.0f));
+    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2 p = pk_fma(pk_splat(1.061405429f), t, pk_splat(-1.453152027f));
+    p = pk_fma(p, t, pk_splat(1.421413741f));
+    p = pk_fma(p, t, pk_splat(-0.284496736f));
+    p = pk_fma(p, t, pk_splat(0.254829592f));
+    p = p * t;
+    const f32x2 m = -ax * ax;
+    const f32x2 e = {__expf(m[0]), __expf(m[1])};
+    const f32x2 erf_abs = pk_fma(-p, e, pk_splat(1.0f));
+    const f32x2 s = {copysignf(erf_abs[0], x[0]), copysignf(erf_abs[1], x[1])};
+    return (x * 0.5f) * (s + 1.0f);
 }
 
 // FiLM slab of one block in LDS: [row_local][2 (scale, shift)][FILM_NF frames]

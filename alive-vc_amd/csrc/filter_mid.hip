@@ -32,7 +32,7 @@ constexpr int PLANE = BL * ROWB;        // 32 KB
 constexpr int BUF = 2 * PLANE;          // hi + lo
 constexpr int W_IN = 2 * C * C;         // bf16 elements of the input conv [2][64][64]
 constexpr int W_K5 = 2 * C * 5 * C;     // bf16 elements of a k5 conv [2][64][320]
-constexpr int LDS_BYTES = 2 * BUF + NCONV * 2 * C * NFP * 4;
+constexpr int LDS_BYTES = 2 * BUF + NCONV * 2 * C * NFP * 4 + BL * 8;
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -45,11 +45,19 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
                                                                 const float* __restrict__ biases,
                                                                 const float* __restrict__ film, int film_rows, int Lf,
                                                                 int film_off, float ratio, const float* __restrict__ skip,
-                                                                float* __restrict__ out) {
+                                                                float* __restrict__ out, long long* stamps) {
+#ifdef ALIVE_STAMPS                 // diagnostic build only (make EXTRA=-DALIVE_STAMPS; tools/bench_filter_mid.py)
+#define STAMP(i) ts[i] = wall_clock64()
+    long long ts[4], tw = 0;
+#else
+#define STAMP(i)
+#endif
+    STAMP(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     unsigned char* bufZ = sm;
     unsigned char* bufY = sm + BUF;
     float* Fs = (float*)(sm + 2 * BUF);               // [NCONV][2][C][NFP]
+    uint2* Xc = (uint2*)(Fs + NCONV * 2 * C * NFP);   // [BL] interpolation coordinates of a column: (i0 | i1 << 16, w1)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,22 +75,32 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
         fr = fr < Lf ? fr : Lf - 1;
         Fs[e] = film[((size_t)n * film_rows + film_off + q * 2 * C + sel * C + c) * Lf + fr];
     }
-    // ---- stage the raw input tile, split into planes: thread = column, 8 channels (one 16-B chunk) at a time ----
+    {   // F.interpolate coordinates of this thread's column, relative to the staged FiLM frames
+        int t = tbase + tid;
+        t = t < 0 ? 0 : (t < L ? t : L - 1);
+        const Lerp lp = lerp_coord(t, ratio, Lf);
+        int i0 = lp.i0 - f_lo, i1 = lp.i1 - f_lo;
+        i0 = i0 < NFP - 1 ? i0 : NFP - 1;
+        i1 = i1 < NFP - 1 ? i1 : NFP - 1;
+        Xc[tid] = make_uint2((unsigned)i0 | ((unsigned)i1 << 16), __float_as_uint(lp.w1));
+    }
+    // ---- stage the raw input tile, split into planes: thread = column; all 64 channel loads are in flight together ----
     {
         const int t = tbase + tid;
         const bool ok = t >= 0 && t < L;
         const float* uc = Un + (ok ? t : 0);
+        float v[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = uc[(size_t)c * L];
 #pragma unroll
         for (int ck = 0; ck < 8; ++ck) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = ok ? uc[(size_t)(ck * 8 + e) * L] : 0.0f;
             u32x4 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const unsigned h = pack2(v[2 * e], v[2 * e + 1]);
+                const float x0 = ok ? v[ck * 8 + 2 * e] : 0.0f, x1 = ok ? v[ck * 8 + 2 * e + 1] : 0.0f;
+                const unsigned h = pack2(x0, x1);
                 hi[e] = h;
-                lo[e] = pack2(v[2 * e] - __uint_as_float(h << 16), v[2 * e + 1] - __uint_as_float(h & 0xffff0000u));
+                lo[e] = pack2(x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xffff0000u));
             }
             unsigned char* dst = bufZ + tid * ROWB + ((ck ^ (tid & 7)) << 4);
             *(u32x4*)dst = hi;
@@ -90,29 +108,47 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
         }
     }
     __syncthreads();
+    STAMP(1);
 
     // residual stream: h[ct][e] = channel 16 w + 4 kq + e of column 16 ct + c16 (MFMA C layout)
     f32x4 h[NCT];
 
-    // gelu -> FiLM of conv q's input for the 4 channels of this lane at column `col`, re-split and stored as planes
-    auto modulate_store = [&](int q, unsigned char* dst, int col, const f32x4& v) {
-        int t = tbase + col;
-        t = t < 0 ? 0 : (t < L ? t : L - 1);
-        const Lerp lp = lerp_coord(t, ratio, Lf);
-        int i0 = lp.i0 - f_lo, i1 = lp.i1 - f_lo;
-        i0 = i0 < NFP - 1 ? i0 : NFP - 1;
-        i1 = i1 < NFP - 1 ? i1 : NFP - 1;
-        float z[4];
+    // FiLM operands of one column tile for this lane: interpolation weight and, per channel pair, the scale / shift
+    // values at the two frames -- fetched one tile AHEAD of their use, so the epilogue has no LDS round trip in it
+    struct Film {
+        float w1;
+        f32x2 s0[2], s1[2], h0[2], h1[2];
+    };
+    auto film_fetch = [&](int q, int col, Film& F) {
+        const uint2 xc = Xc[col];
+        const int i0 = xc.x & 0xffff, i1 = xc.x >> 16;
+        F.w1 = __uint_as_float(xc.y);
+        const float* f = Fs + ((q * 2) * C + 16 * w + 4 * kq) * NFP;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float* f = Fs + ((q * 2) * C + 16 * w + 4 * kq + e) * NFP;
-            const float sc = fmaf(lp.w0, f[i0], lp.w1 * f[i1]);
-            const float sh = fmaf(lp.w0, f[C * NFP + i0], lp.w1 * f[C * NFP + i1]);
-            z[e] = gelu_fast(v[e]) * sc + sh;
+        for (int e = 0; e < 2; ++e) {
+            const float* fa = f + (2 * e) * NFP;
+            const float* fb = fa + NFP;
+            F.s0[e] = f32x2{fa[i0], fb[i0]};
+            F.s1[e] = f32x2{fa[i1], fb[i1]};
+            F.h0[e] = f32x2{fa[C * NFP + i0], fb[C * NFP + i0]};
+            F.h1[e] = f32x2{fa[C * NFP + i1], fb[C * NFP + i1]};
         }
-        const unsigned h01 = pack2(z[0], z[1]), h23 = pack2(z[2], z[3]);
-        const unsigned l01 = pack2(z[0] - __uint_as_float(h01 << 16), z[1] - __uint_as_float(h01 & 0xffff0000u));
-        const unsigned l23 = pack2(z[2] - __uint_as_float(h23 << 16), z[3] - __uint_as_float(h23 & 0xffff0000u));
+    };
+    // gelu -> FiLM of the next conv's input for the 4 channels of this lane at column `col`, re-split and stored as
+    // planes; two channels per instruction on the packed fp32 pipe
+    auto modulate_store = [&](const Film& F, unsigned char* dst, int col, const f32x4& v) {
+        const float w1 = F.w1, w0 = 1.0f - w1;
+        f32x2 z[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const f32x2 sc = pk_fma(pk_splat(w0), F.s0[e], pk_splat(w1) * F.s1[e]);    // fma(w0, a, round(w1 * b)): ATen's linear interp
+            const f32x2 sh = pk_fma(pk_splat(w0), F.h0[e], pk_splat(w1) * F.h1[e]);
+            z[e] = gelu_fast2(f32x2{v[2 * e], v[2 * e + 1]}) * sc + sh;
+        }
+        const unsigned h01 = pack2(z[0][0], z[0][1]), h23 = pack2(z[1][0], z[1][1]);
+        const f32x2 r0 = z[0] - f32x2{__uint_as_float(h01 << 16), __uint_as_float(h01 & 0xffff0000u)};
+        const f32x2 r1 = z[1] - f32x2{__uint_as_float(h23 << 16), __uint_as_float(h23 & 0xffff0000u)};
+        const unsigned l01 = pack2(r0[0], r0[1]), l23 = pack2(r1[0], r1[1]);
         // channels 16 w + 4 kq .. +3 -> chunk 2 w + (kq >> 1), byte 8 (kq & 1) inside it
         unsigned char* p = dst + col * ROWB + (((2 * w + (kq >> 1)) ^ (col & 7)) << 4) + 8 * (kq & 1);
         *(uint2*)p = make_uint2(h01, h23);
@@ -149,12 +185,21 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
     }
     __syncthreads();                       // every wave has read the raw columns
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) modulate_store(0, bufZ, ct * 16 + c16, h[ct]);
+    for (int ct = 0; ct < NCT; ++ct) {
+        Film F;
+        film_fetch(0, ct * 16 + c16, F);
+        modulate_store(F, bufZ, ct * 16 + c16, h[ct]);
+    }
     __syncthreads();
 
+    STAMP(2);
     // ---- three FilterResBlocks: q = 2 j (c1), 2 j + 1 (c2), dilation 2^j    (decoder.py:128-134) ----
+    const bool first_tile = tbase < 0;                       // block-uniform: ReflectionPad1d applies (common.py:88)
 #pragma unroll 1
     for (int q = 0; q < NCONV; ++q) {
+#ifdef ALIVE_STAMPS
+        const long long tq0 = wall_clock64();
+#endif
         const unsigned short* Wq = W16 + W_IN + (size_t)q * W_K5;
         bf16x8 a[10][2];                   // k-step s = 2 j + cb (tap j, channel block cb): k = j * 64 + cb * 32 + 8 kq
 #pragma unroll
@@ -170,67 +215,96 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
         const unsigned char* in = second ? bufY : bufZ;
         unsigned char* dst = second ? bufZ : bufY;
 
-        // LDS offsets of the five taps of column tile ct for this lane (reflect-left at the window start)
-        auto tap_offsets = [&](int ct, int (&off)[5]) {
-            const int col = ct * 16 + c16;
+        // B fragment of k-step s = 2 j + cb of column tile ct: row r = 16 ct + c16 + (j - 4) d, 16 B at
+        // r * 128 + ((4 cb + kq) ^ (r & 7)) * 16.  (r & 7) does not depend on ct, so the address is
+        // base[cb][j] + 2048 ct: one register per (tap, channel block) and an immediate per column tile.
+        int base[2][5];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                int ta = tbase + col + (j - 4) * d;
-                ta = ta < 0 ? -ta : ta;                      // ReflectionPad1d on the left (common.py:88)
-                int r = ta - tbase;
-                r = r < 0 ? 0 : (r < BL ? r : BL - 1);       // only never-valid halo columns can be clamped
-                off[j] = r * ROWB + ((kq ^ (r & 7)) << 4);   // chunk 4 cb + kq: cb flips bit 6
+        for (int j = 0; j < 5; ++j) {
+            const int r0 = c16 + (j - 4) * d;
+            base[0][j] = r0 * ROWB + ((kq ^ (r0 & 7)) << 4);
+            base[1][j] = base[0][j] ^ 64;
+        }
+        bf16x8 fh[10], fl[10];
+        auto load_frags = [&](int ct) {
+            // column tile 0 reaches left of the tile (rows that are never valid: clamp), and the first tile of a window
+            // reflects at t = 0 for the columns below 16 d + HALO: those take the per-lane form
+            if (ct == 0 || (first_tile && ct < 5)) {
+                const int col = ct * 16 + c16;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    int ta = tbase + col + (j - 4) * d;
+                    ta = ta < 0 ? -ta : ta;
+                    int r = ta - tbase;
+                    r = r < 0 ? 0 : (r < BL ? r : BL - 1);
+                    const int o = r * ROWB + ((kq ^ (r & 7)) << 4);
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        const unsigned char* bp = in + (o ^ (cb << 6));
+                        fh[2 * j + cb] = *(const bf16x8*)bp;
+                        fl[2 * j + cb] = *(const bf16x8*)(bp + PLANE);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        const unsigned char* bp = in + base[cb][j] + ct * (16 * ROWB);
+                        fh[2 * j + cb] = *(const bf16x8*)bp;
+                        fl[2 * j + cb] = *(const bf16x8*)(bp + PLANE);
+                    }
             }
         };
-        bf16x8 bh[10], bl[10], nh[10], nl[10];
-        auto load_tile = [&](int ct, bf16x8 (&xh)[10], bf16x8 (&xl)[10]) {
-            int off[5];
-            tap_offsets(ct, off);
+        load_frags(0);
+#ifdef ALIVE_STAMPS
+        __builtin_amdgcn_s_waitcnt(0);
+        tw += wall_clock64() - tq0;
+#endif
+        // The column loop is unrolled (residual registers and LDS immediates are static) and software-pipelined: the
+        // MFMAs of tile ct + 1 are issued BEFORE the epilogue of tile ct, so the epilogue's VALU / LDS work sits in the
+        // shadow of a dependent MFMA chain instead of behind it (one wave per SIMD: nothing else would fill it).
+        // One fragment buffer: the fragments of tile ct + 2 are requested right behind the MFMAs of tile ct + 1.
+        auto mma_tile = [&](f32x4& acc0, f32x4& acc1) {
+            acc0 = b4;
+            acc1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int s = 0; s < 10; ++s) {
-                const unsigned char* bp = in + (off[s >> 1] ^ ((s & 1) << 6));
-                xh[s] = *(const bf16x8*)bp;
-                xl[s] = *(const bf16x8*)(bp + PLANE);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][1], fh[s], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][0], fl[s], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][0], fh[s], acc0, 0, 0, 0);
             }
         };
-        // one column tile: request the next tile's fragments, run the 30 MFMAs of this one, finish it in registers
-        auto body = [&](int ct, bf16x8 (&xh)[10], bf16x8 (&xl)[10], bf16x8 (&yh)[10], bf16x8 (&yl)[10], f32x4& hres) {
-            if (ct + 1 < NCT) load_tile(ct + 1, yh, yl);
+        // the last conv has no consumer for the modulated output: it runs the same code with the FiLM rows of conv 5 and
+        // writes a tile nobody reads, which keeps the column body free of branches (one basic block per tile)
+        const int qn = q + 1 < NCONV ? q + 1 : NCONV - 1;
+        const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 p0, p1, n0, n1;
+        Film Fc, Fn;
+        film_fetch(qn, c16, Fc);
+        mma_tile(p0, p1);
+        load_frags(1);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            if (ct + 1 < NCT) {
+                film_fetch(qn, (ct + 1) * 16 + c16, Fn);
+                mma_tile(n0, n1);
+                if (ct + 2 < NCT) load_frags(ct + 2);
+            }
+            f32x4 v = (p0 + p1) + (second ? h[ct] : zero4);
+            h[ct] = second ? v : h[ct];
+            modulate_store(Fc, dst, ct * 16 + c16, v);
+            // The fence is load-bearing: with the 16 column bodies merged into one scheduling region hipcc (ROCm 7.2) produced a
+            // schedule whose results differed from run to run (1.5e-2 off); with one region per column tile they are exact.
             __builtin_amdgcn_sched_barrier(0);
-            f32x4 acc0 = b4, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int s = 0; s < 10; ++s) {
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][1], xh[s], acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][0], xl[s], acc1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int s = 0; s < 10; ++s) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][0], xh[s], acc0, 0, 0, 0);
-            acc0 = acc0 + acc1;
-            if (second) {
-                acc0 = acc0 + hres;
-                hres = acc0;
-            }
-            if (q + 1 < NCONV) modulate_store(q + 1, dst, ct * 16 + c16, acc0);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        load_tile(0, bh, bl);
-        // The column loop stays rolled (two tiles per trip, fragment buffers ping-pong): the residual registers are
-        // rotated by two per trip so that h[0], h[1] are always the current pair -- static register indices, no scratch.
-#pragma unroll 1
-        for (int cp = 0; cp < NCT / 2; ++cp) {
-            body(2 * cp, bh, bl, nh, nl, h[0]);
-            body(2 * cp + 1, nh, nl, bh, bl, h[1]);
-            if (second) {
-                const f32x4 f0 = h[0], f1 = h[1];
-#pragma unroll
-                for (int i = 0; i + 2 < NCT; ++i) h[i] = h[i + 2];
-                h[NCT - 2] = f0;
-                h[NCT - 1] = f1;
-            }
+            p0 = n0;
+            p1 = n1;
+            Fc = Fn;
         }
         __syncthreads();
     }
 
+    STAMP(3);
     // ---- store the tile (+ U-Net skip, decoder.py:191): through LDS so that global accesses are 16-B vectors along t ----
     float* Ht = (float*)sm;                           // [64][BL + 4] fp32 = 66.5 KB over bufZ / bufY
     constexpr int HP = BL + 4;
@@ -239,23 +313,42 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
 #pragma unroll
         for (int e = 0; e < 4; ++e) Ht[(16 * w + 4 * kq + e) * HP + ct * 16 + c16] = h[ct][e];
     __syncthreads();
-    for (int g = tid; g < C * (TT / 4); g += 256) {
+    constexpr int NV = (C * (TT / 4) + 255) / 256;          // 13 vectors of 4 columns per thread
+    f32x4 sk[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int g = tid + 256 * i;
         const int co = g / (TT / 4), c4 = (g - co * (TT / 4)) * 4;
         const int t = t0 + c4;
-        if (t >= L) continue;
+        sk[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (skip != nullptr && g < C * (TT / 4) && t + 3 < L) sk[i] = *(const f32x4*)(skip + ((size_t)n * C + co) * L + t);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int g = tid + 256 * i;
+        const int co = g / (TT / 4), c4 = (g - co * (TT / 4)) * 4;
+        const int t = t0 + c4;
+        if (g >= C * (TT / 4) || t >= L) continue;
         const size_t o = ((size_t)n * C + co) * L + t;
-        f32x4 v = *(const f32x4*)&Ht[co * HP + HALO + c4];
+        const f32x4 v = *(const f32x4*)&Ht[co * HP + HALO + c4];
         if (t + 3 < L) {
-            if (skip != nullptr) v = v + *(const f32x4*)(skip + o);
-            *(f32x4*)(out + o) = v;
+            *(f32x4*)(out + o) = v + sk[i];
         } else {
             for (int e = 0; e < 4 && t + e < L; ++e) out[o + e] = v[e] + (skip != nullptr ? skip[o + e] : 0.0f);
         }
     }
+#ifdef ALIVE_STAMPS
+    if (stamps != nullptr && tid == 0) {
+        long long* o = stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        o[0] = ts[1] - ts[0]; o[1] = ts[2] - ts[1]; o[2] = ts[3] - ts[2]; o[3] = wall_clock64() - ts[3]; o[4] = tw;
+    }
+#endif
 }
 
 }  // namespace
 
+static long long* g_stamps64 = nullptr;
+extern "C" void alive_debug_set_stamps64(long long* p) { g_stamps64 = p; }
 extern "C" int64_t alive_filter_block64_weights(void) { return (int64_t)W_IN + (int64_t)NCONV * W_K5; }
 
 extern "C" int alive_filter_block64(const float* U, int N, int L, const void* W16, const float* biases, const float* film,
@@ -278,7 +371,7 @@ extern "C" int alive_filter_block64(const float* U, int N, int L, const void* W1
     const float ratio = (float)Lf / (float)L;
     dim3 g(cdiv(L, TT), N);
     filter_block64_kernel<<<g, 256, LDS_BYTES, (hipStream_t)stream>>>(U, L, (const unsigned short*)W16, biases, film, film_rows,
-                                                                     Lf, film_off, ratio, skip, out);
+                                                                     Lf, film_off, ratio, skip, out, g_stamps64);
     ALIVE_CHECK_LAUNCH("alive_filter_block64");
     return ALIVE_OK;
 }

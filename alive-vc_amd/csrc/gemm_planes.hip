@@ -41,9 +41,11 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 
 template <int NP, int NS, int MINB, int ACT>
 __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int n_mt, int ntiles, int64_t cols,
-                                                             int64_t cols_pad, int co_pad, int co_pad32, int kpad, int dbg,
+                                                             int64_t cols_pad, int co_pad, int co_pad32, int kpad,
                                                              long long* stamps) {
+#ifdef ALIVE_STAMPS                 // diagnostic build only (make EXTRA=-DALIVE_STAMPS; tools/stamp_gemm.py)
     const long long ts0 = wall_clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SLOT = 2 * NP * PLANE_BYTES;
     constexpr int NI = 4 * NP;                    // DMA pieces per wave per step
@@ -60,10 +62,10 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
         const int L = blockIdx.x, xcd = L & 7, j = L >> 3, q = ntiles >> 3, r = ntiles & 7;
         v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
-    const int mt = v % n_mt, ct = (dbg & 1) ? 0 : v / n_mt;
+    const int mt = v % n_mt, ct = v / n_mt;
     const int m0 = mt * GM;
     const int64_t c0 = (int64_t)ct * GN;
-    const int nsteps = (dbg & 8) ? 1 : kpad / GK;
+    const int nsteps = kpad / GK;
 
     // ---- DMA geometry: piece q = w + 4 i  ->  (operand, plane, 16-row group) ----
     const int prow = lane >> 2;
@@ -87,7 +89,6 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
         ldst[i] = (op * NP + pl) * PLANE_BYTES + g * 1024;
     }
     auto issue = [&](int step, int i) {
-        if (((dbg & 2) && ldst[i] < NP * PLANE_BYTES) || ((dbg & 4) && ldst[i] >= NP * PLANE_BYTES)) return;
         __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + step * GK), (lptr_t)(smem + (step % NS) * SLOT + ldst[i]), 16, 0, 0);
     };
 
@@ -138,12 +139,16 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
             }
     };
 
+#ifdef ALIVE_STAMPS
     const long long ts1 = wall_clock64();
+#endif
     // stage 0 landed?  (NS - 1 younger stages may still be in flight)
     if (nsteps >= NS) wait_vmcnt<(NS - 1) * NI>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     load_frags(0, 0, fa[0], fb[0]);
+#ifdef ALIVE_STAMPS
     const long long ts2 = wall_clock64();
+#endif
 
     for (int s = 0; s < nsteps; ++s) {
         // the second half's fragments are requested behind the first MFMA group (a request in front of it would be
@@ -168,7 +173,9 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
         __builtin_amdgcn_sched_barrier(0);
     }
     wait_vmcnt<0>();
+#ifdef ALIVE_STAMPS
     const long long ts3 = wall_clock64();
+#endif
 
     // ---- epilogue, straight from the accumulators ----
     // A lane holds, per 32 x 32 tile, one column and 16 rows in 4 groups of 4 consecutive rows (8 g + 4 lh + e).
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
                 if (p.residual != nullptr) x += res[tj][r];
                 vv[r] = x;
             }
-            if (p.Y != nullptr && cok[tj] && !(dbg & 32)) {
+            if (p.Y != nullptr && cok[tj]) {
                 if (full_rows) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -263,11 +270,13 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
             }
         }
     }
+#ifdef ALIVE_STAMPS
     if (stamps != nullptr && tid == 0) {
         long long* o = stamps + (size_t)blockIdx.x * 8;
         o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3; o[4] = wall_clock64();
         o[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
     }
+#endif
 }
 
 // fp32 [N][C][T] -> planes [NP][cols_pad][C_pad] (zero padded in both directions)
@@ -338,7 +347,7 @@ int launch_gemm_act(const AliveGemm& d, hipStream_t s) {
     const int ntiles = n_mt * n_ct;
     gemm_planes_kernel<NP, NS, MINB, ACT><<<ntiles, 256, LDS, s>>>(
         d, n_mt, ntiles, cols, pad_cols(cols), (d.Co + 15) & ~15, pad32(d.Co), pad32(d.Ci),
-        getenv("ALIVE_GEMM_DEBUG") ? atoi(getenv("ALIVE_GEMM_DEBUG")) : 0, g_stamps);
+        g_stamps);
     ALIVE_CHECK_LAUNCH("alive_gemm_planes");
     return ALIVE_OK;
 }

@@ -1,4 +1,5 @@
-"""phase timing of gemm_planes blocks from in-kernel wall-clock stamps (100 MHz counter)"""
+"""phase timing of gemm_planes blocks from in-kernel wall-clock stamps (100 MHz counter).
+Needs the diagnostic build: make -C alive-vc_amd/csrc clean all EXTRA=-DALIVE_STAMPS (the production kernels carry no stamps)."""
 import ctypes as C, sys, os, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "alive-vc_amd"))
 from module import _native as nat
