@@ -297,7 +297,7 @@ extern "C" int alive_f0_estimate(const float* const* w, const float* spec, int N
 // ---- decoder ---------------------------------------------------------------------------------
 namespace {
 struct DecBuffers {
-    float *x, *y, *h, *sinb, *cond, *normfilm, *amps, *src, *film, *x0, *d0, *d1, *d2, *d3, *m, *U, *Hh, *Zz, *Z2;
+    float *x, *y, *h, *sinb, *cond, *normfilm, *amps, *src, *film, *d0, *d1, *d2, *d3, *m, *U, *Hh, *Zz, *Z2;
     void *Pa, *Ph;          // plane-packed scratch of the FeatureExtractor GEMMs (nullptr on the streaming path)
     void* osc_ws;
     size_t bytes;
@@ -322,7 +322,6 @@ DecBuffers dec_layout(void* ws, int N, int Lf) {
     b.amps = a.take<float>(f * NH);
     b.src = a.take<float>((size_t)N * Lw);
     b.film = a.take<float>(f * FILM_ROWS);
-    b.x0 = a.take<float>((size_t)N * 8 * Lw);
     b.d0 = a.take<float>((size_t)N * 16 * (Lw / 2));
     b.d1 = a.take<float>((size_t)N * 64 * (Lw / 4));
     b.d2 = a.take<float>((size_t)N * 256 * (Lw / 32));
@@ -372,12 +371,15 @@ extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, c
         AliveConv d = split(pw_desc(fW, fb, b.x, N, DEC_C, Lf, FILM_ROWS, b.film)); d.post_add = fpost; RUN(alive_conv1d(&d, stream));
     }
     const float* siW = t.next(); const float* sib = t.next();
-    { AliveConv d = conv_desc(siW, sib, b.src, N, 1, Lw, 8, 7, 1, 1, 3, 0, Lw, b.x0); RUN(alive_conv1d(&d, stream)); }
     const int dch[5] = {8, 16, 64, 256, 256};
     const int drate[4] = {2, 2, 8, 10};
-    float* dbuf[5] = {b.x0, b.d0, b.d1, b.d2, b.d3};
-    int len = Lw;
-    for (int i = 0; i < 4; ++i) {
+    float* dbuf[5] = {nullptr, b.d0, b.d1, b.d2, b.d3};
+    {   // source_in + downs[0] in one streaming kernel: the 8-channel tensor in between is not a skip
+        const float* W = t.next(); const float* bb = t.next();
+        RUN(alive_filter_source_in(b.src, N, Lw, siW, sib, W, bb, b.d0, stream));
+    }
+    int len = Lw / 2;
+    for (int i = 1; i < 4; ++i) {
         const float* W = t.next(); const float* bb = t.next();
         AliveConv d = conv_desc(W, bb, dbuf[i], N, dch[i], len, dch[i + 1], drate[i], drate[i], 1, 0, 0, len / drate[i], dbuf[i + 1]);
         RUN(alive_conv1d(&d, stream));
@@ -454,6 +456,5 @@ extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, c
         cin = C;
     }
     const float* oW = t.next(); const float* ob = t.next();
-    { AliveConv d = conv_desc(oW, ob, b.Hh, N, 8, Lw, 1, 7, 1, 1, 3, 0, Lw, wave); RUN(alive_conv1d(&d, stream)); }
-    return ALIVE_OK;
+    return alive_filter_source_out(b.Hh, N, Lw, oW, ob, wave, stream);
 }

@@ -56,6 +56,8 @@ PROTOTYPES = {
     "alive_filter_block_small": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
     "alive_filter_block64_weights": (_I64, []),
     "alive_filter_block64": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
+    "alive_filter_source_in": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "alive_filter_source_out": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP]),
     "alive_dwconv_norm": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP]),
     "alive_channel_norm": (_I, [_VP, _I, _I, _I, _VP, _VP, _F, _VP, _VP]),
     "alive_argmax_channels": (_I, [_VP, _I, _I, _I, _VP, _VP]),

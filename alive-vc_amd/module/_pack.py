@@ -170,10 +170,11 @@ def pack_decoder(sd):
     out["flt.film.W"] = pack_conv_split(torch.cat(ws, 0).float().unsqueeze(2))
     out["flt.film.b"] = _vec(torch.cat(bs, 0))
     out["flt.film.post"] = _vec(torch.cat(post, 0))
-    out["flt.in.W"] = pack_conv(sd[f + ".source_in.weight"])
+    out["flt.in.W"] = _vec(sd[f + ".source_in.weight"])          # [8][1][7] as is: streaming kernel (csrc/filter_edge.hip)
     out["flt.in.b"] = _vec(sd[f + ".source_in.bias"])
     for i in range(4):
-        out[f"flt.down{i}.W"] = pack_conv(sd[f"{f}.downs.{i}.weight"])
+        # downs[0] is fused with source_in (reference layout [16][8][2]); the others run on the fp32 MFMA kernel
+        out[f"flt.down{i}.W"] = _vec(sd[f"{f}.downs.{i}.weight"]) if i == 0 else pack_conv(sd[f"{f}.downs.{i}.weight"])
         out[f"flt.down{i}.b"] = _vec(sd[f"{f}.downs.{i}.bias"])
     out["flt.mid.W"] = pack_conv_split(sd[f + ".mid_conv.conv.weight"])
     out["flt.mid.b"] = _vec(sd[f + ".mid_conv.conv.bias"])
@@ -194,6 +195,6 @@ def pack_decoder(sd):
             for cc in ("c1", "c2"):
                 out[f"flt.blk{s}.{j}.{cc}.W"] = pack_conv_split(sd[f"{b}.blocks.{j}.{cc}.conv.conv.weight"])
                 out[f"flt.blk{s}.{j}.{cc}.b"] = _vec(sd[f"{b}.blocks.{j}.{cc}.conv.conv.bias"])
-    out["flt.out.W"] = pack_conv(sd[f + ".source_out.weight"])
+    out["flt.out.W"] = _vec(sd[f + ".source_out.weight"])        # [1][8][7] as is
     out["flt.out.b"] = _vec(sd[f + ".source_out.bias"])
     return out

@@ -189,3 +189,25 @@ def filter_block64(x, sd, prefix, film, film_off, skip=None):
     nat.check(nat.lib().alive_filter_block64(nat.ptr(x), n, l, nat.ptr(w), nat.ptr(b), nat.ptr(film), film.shape[1], film.shape[2],
                                              film_off, nat.ptr(skip), nat.ptr(out), nat.stream()), "alive_filter_block64")
     return out
+
+
+def filter_source_in(src, w_in, b_in, w_d, b_d):
+    """downs[0](source_in(src)) in one streaming kernel: src[N,1,Lw] -> [N,16,Lw/2] (reference-layout weights)"""
+    src = _f(src)
+    n, _, lw = src.shape
+    args = [_f(t).reshape(-1) for t in (w_in, b_in, w_d, b_d)]
+    out = torch.empty(n, 16, lw // 2, device=src.device)
+    nat.check(nat.lib().alive_filter_source_in(nat.ptr(src), n, lw, *[nat.ptr(a) for a in args], nat.ptr(out), nat.stream()),
+              "alive_filter_source_in")
+    return out
+
+
+def filter_source_out(h, w, b):
+    """source_out: h[N,8,Lw] -> [N,1,Lw]"""
+    h = _f(h)
+    n, _, lw = h.shape
+    w, b = _f(w).reshape(-1), _f(b).reshape(-1)
+    out = torch.empty(n, 1, lw, device=h.device)
+    nat.check(nat.lib().alive_filter_source_out(nat.ptr(h), n, lw, nat.ptr(w), nat.ptr(b), nat.ptr(out), nat.stream()),
+              "alive_filter_source_out")
+    return out

@@ -164,6 +164,15 @@ int64_t alive_filter_block64_weights(void);
 int alive_filter_block64(const float* U, int N, int L, const void* W16, const float* biases, const float* film,
                          int film_rows, int Lf, int film_off, const float* skip, float* out, void* stream);
 
+/* The waveform-rate edges of Filter.forward (decoder.py:164,182,186-188,194) as streaming kernels:
+ *   alive_filter_source_in : downs[0](source_in(src)):  src[N][Lw] -> d0[N][16][Lw/2]
+ *                            Win[8][7], bin[8] = source_in (pad 3); Wd[16][8][2], bd[16] = downs[0] (stride 2); fp32,
+ *                            reference layouts.  The 8-channel intermediate is not a skip and is never stored.
+ *   alive_filter_source_out: source_out(H):  H[N][8][Lw] -> wave[N][Lw];  W[8][7] (= weight[0]), b[1] */
+int alive_filter_source_in(const float* src, int N, int Lw, const float* Win, const float* bin, const float* Wd,
+                           const float* bd, float* d0, void* stream);
+int alive_filter_source_out(const float* H, int N, int Lw, const float* W, const float* b, float* wave, void* stream);
+
 /* depthwise k7 conv + (Adaptive)ChannelNorm (common.py:20-26,35-41,55-56,75-76)
  *   affine_mode 0: gain[C], offset[C];  1: per-sample scale/shift rows in cond[N][cond_rows][T] */
 int alive_dwconv_norm(const float* X, int N, int C, int T, const float* dw_w, const float* dw_b,

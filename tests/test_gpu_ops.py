@@ -482,3 +482,20 @@ def test_pcm16_conversions_are_the_reference_casts():
     with np.errstate(invalid="ignore"):
         want = (w.numpy() * 32768).astype(np.int32).astype(np.int16)     # truncate toward zero, low 16 bits: numpy's astype on x86
     assert np.array_equal(got, want), (got, want)
+
+
+@pytest.mark.parametrize("n,lw", [(2, 9600), (1, 1600), (3, 322)])
+def test_filter_edge_kernels(n, lw):
+    """source_in + downs[0] fused, and source_out (decoder.py:164,182,186-188,194), against torch conv1d"""
+    from module import ops
+    src = g(f"fes{lw}", (n, 1, lw))
+    w_in, b_in = g("fewi", (8, 1, 7), scale=0.3), g("febi", (8,), scale=0.1)
+    w_d, b_d = g("fewd", (16, 8, 2), scale=0.25), g("febd", (16,), scale=0.1)
+    ref = F.conv1d(F.conv1d(src.double(), w_in.double(), b_in.double(), padding=3), w_d.double(), b_d.double(), stride=2)
+    got = ops.filter_source_in(src.to(DEV), w_in.to(DEV), b_in.to(DEV), w_d.to(DEV), b_d.to(DEV))
+    assert got.shape == ref.shape and relerr(got, ref) < 5e-7
+    h = g(f"feh{lw}", (n, 8, lw))
+    w_o, b_o = g("fewo", (1, 8, 7), scale=0.2), g("febo", (1,), scale=0.1)
+    ref = F.conv1d(h.double(), w_o.double(), b_o.double(), padding=3)
+    got = ops.filter_source_out(h.to(DEV), w_o.to(DEV), b_o.to(DEV))
+    assert got.shape == ref.shape and relerr(got, ref) < 5e-7

@@ -64,12 +64,13 @@ def test_weight_tables_cover_the_schema():
         assert set(packed) == set(nat.weight_names(mid))
         for k, v in packed.items():
             assert v.dtype in (torch.float32, torch.bfloat16) and v.is_contiguous()
-            if k.endswith(".W") and v.dtype == torch.float32:          # exact-fp32 kernel: [Co_pad16][K_pad16]
+            if k.endswith(".W") and v.dtype == torch.float32 and v.dim() == 2:   # exact-fp32 MFMA kernel: [Co_pad16][K_pad16]
                 assert v.shape[0] % 16 == 0 and v.shape[1] % 16 == 0
             if k.endswith(".W") and v.dtype == torch.bfloat16:         # split kernel: [2][Co_pad16][KW * Ci_pad32]
                 assert v.shape[0] == (3 if mid < 2 else 2) and v.shape[1] % 16 == 0 and v.shape[2] % 32 == 0   # encoders: 3 planes
     sd = synthetic.make_state_dict(schema.decoder_schema(), 2)
     p = _pack.pack_decoder(sd)
+    assert p["flt.in.W"].shape == (56,) and p["flt.down0.W"].shape == (256,) and p["flt.out.W"].shape == (56,)   # streaming edge kernels
     assert p["flt.film.W"].shape == (2, 4128, 512) and p["flt.film.post"].sum().item() == 2064
     w = sd["filter.blocks.0.blocks.1.c2.conv.conv.weight"]                 # [256, 256, 5]
     hi, lo = p["flt.blk0.1.c2.W"][0].float(), p["flt.blk0.1.c2.W"][1].float()
