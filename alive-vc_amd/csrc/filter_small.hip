@@ -47,6 +47,7 @@ __global__ __launch_bounds__(NT, 2) void filter_block_small_kernel(const float* 
     float* bufZ = sm;                       // [C][P]
     float* bufY = bufZ + C * P;             // [C][P]
     float* Fs = bufY + C * P;               // [NCONV][2][C][NFP]
+    uint2* Xc = (uint2*)(Fs + NCONV * 2 * C * NFP);   // [BL] interpolation coordinates of a column: (i0 | i1 << 16, w1)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ln = lane & 15, lq = lane >> 4;
@@ -72,6 +73,15 @@ __global__ __launch_bounds__(NT, 2) void filter_block_small_kernel(const float* 
         fr = fr < Lf ? fr : Lf - 1;
         Fs[e] = film[((size_t)n * film_rows + film_off + q * 2 * C + sel * C + c) * Lf + fr];
     }
+    for (int i = tid; i < BL; i += NT) {
+        int t = tbase + i;
+        t = t < 0 ? 0 : (t < L ? t : L - 1);
+        const Lerp lp = lerp_coord(t, ratio, Lf);
+        int i0 = lp.i0 - f_lo, i1 = lp.i1 - f_lo;
+        i0 = i0 < NFP - 1 ? i0 : NFP - 1;
+        i1 = i1 < NFP - 1 ? i1 : NFP - 1;
+        Xc[i] = make_uint2((unsigned)i0 | ((unsigned)i1 << 16), __float_as_uint(lp.w1));
+    }
     // ---- stage the input tile (raw U) into bufZ ----
     for (int e = tid; e < C * BL; e += NT) {
         int c = e / BL, i = e - c * BL;
@@ -80,23 +90,25 @@ __global__ __launch_bounds__(NT, 2) void filter_block_small_kernel(const float* 
     }
     __syncthreads();
 
-    // gelu -> FiLM of conv q's input, for channel rows lq*4 + r of column `col`
+    // gelu -> FiLM of conv q's input, for channel rows lq*4 + r of column `col`; two channels per instruction on the
+    // packed fp32 pipe, interpolation coordinates from the per-column table
     auto modulate_store = [&](int q, float* dst, int col, const f32x4& v) {
-        int t = tbase + col;
-        t = t < 0 ? 0 : (t < L ? t : L - 1);
-        Lerp lp = lerp_coord(t, ratio, Lf);
-        int i0 = lp.i0 - f_lo, i1 = lp.i1 - f_lo;
-        i0 = i0 < NFP - 1 ? i0 : NFP - 1;
-        i1 = i1 < NFP - 1 ? i1 : NFP - 1;
+        const uint2 xc = Xc[col];
+        const int i0 = xc.x & 0xffff, i1 = xc.x >> 16;
+        const float w1 = __uint_as_float(xc.y), w0 = 1.0f - w1;
+        if (lq * 4 >= C) return;                         // C = 8: the upper half of the MFMA tile is padding
+        const float* f = Fs + ((q * 2) * C + lq * 4) * NFP;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = lq * 4 + r;
-            if (co < C) {
-                const float* f = Fs + ((q * 2) * C + co) * NFP;
-                float sc = fmaf(lp.w0, f[i0], lp.w1 * f[i1]);
-                float sh = fmaf(lp.w0, f[C * NFP + i0], lp.w1 * f[C * NFP + i1]);
-                dst[co * P + col] = gelu_fast(v[r]) * sc + sh;
-            }
+        for (int e = 0; e < 2; ++e) {
+            const float* fa = f + (2 * e) * NFP;
+            const float* fb = fa + NFP;
+            const f32x2 s0 = {fa[i0], fb[i0]}, s1 = {fa[i1], fb[i1]};
+            const f32x2 h0 = {fa[C * NFP + i0], fb[C * NFP + i0]}, h1 = {fa[C * NFP + i1], fb[C * NFP + i1]};
+            const f32x2 sc = pk_fma(pk_splat(w0), s0, pk_splat(w1) * s1);          // fma(w0, a, round(w1 * b))
+            const f32x2 sh = pk_fma(pk_splat(w0), h0, pk_splat(w1) * h1);
+            const f32x2 z = gelu_fast2(f32x2{v[2 * e], v[2 * e + 1]}) * sc + sh;
+            dst[(lq * 4 + 2 * e) * P + col] = z[0];
+            dst[(lq * 4 + 2 * e + 1) * P + col] = z[1];
         }
     };
 
@@ -201,7 +213,7 @@ template <int C>
 int launch_small(const float* U, int N, int L, const float* wpack, const float* film, int film_rows, int Lf, int film_off,
                  const float* skip, float* out, hipStream_t s) {
     using Cfg = SmallCfg<C>;
-    const int lds = (2 * C * Cfg::P + NCONV * 2 * C * NFP) * (int)sizeof(float);
+    const int lds = (2 * C * Cfg::P + NCONV * 2 * C * NFP) * (int)sizeof(float) + Cfg::BL * 8;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)filter_block_small_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -25,10 +25,43 @@ struct OscGeom {
     float sample_rate;
 };
 
+// x / 16000 correctly rounded, as one multiply and two fmas: q = x * rc, then one residual correction.  For this
+// divisor the result equals the IEEE quotient for EVERY fp32 x in [2^-24, 2^24) -- checked exhaustively on the GPU
+// (tests/test_gpu_ops.py::test_div16000_is_the_ieee_quotient); other sample rates take the IEEE sequence.
+__device__ __forceinline__ float div_rate(float x, float sample_rate) {
+    if (sample_rate == 16000.0f) {
+        const float rc = 6.25e-5f;
+        const float q = x * rc;
+        const float r = fmaf(-q, 16000.0f, x);
+        return fmaf(r, rc, q);
+    }
+    return __fdiv_rn(x, sample_rate);
+}
+
 __device__ __forceinline__ float formant_step(const float* f0n, float hmul, const Lerp& l, float sample_rate) {
     float a = f0n[l.i0] * hmul;
     float b = f0n[l.i1] * hmul;
-    return __fdiv_rn(lerp_apply(l, a, b), sample_rate);
+    return div_rate(lerp_apply(l, a, b), sample_rate);
+}
+
+// sin of an fp32 phase that reaches 1e6 rad: the argument is reduced in fp64 (k = rint(x * 2/pi), r = x - k * pi/2 with a
+// two-term pi/2: exact to 1e-10 rad at these magnitudes), then the Cephes single-precision sin / cos kernels on
+// |r| <= pi/4 (< 2 ulp).  ocml's sinf takes its Payne-Hanek path for such arguments: ~70 instructions against ~25.
+__device__ __forceinline__ float sin_phase(float theta) {
+    const double t = (double)theta;
+    const double k = rint(t * 0.63661977236758134308);
+    double r = fma(-k, 1.57079632679489655800, t);
+    r = fma(-k, 6.12323399573676603587e-17, r);
+    const int q = (int)k;
+    const float x = (float)r, x2 = x * x;
+    float sp = fmaf(-1.9515295891e-4f, x2, 8.3321608736e-3f);
+    sp = fmaf(sp, x2, -1.6666654611e-1f);
+    const float sn = fmaf(sp * x2, x, x);
+    float cp = fmaf(2.443315711809948e-5f, x2, -1.388731625493765e-3f);
+    cp = fmaf(cp, x2, 4.166664568298827e-2f);
+    const float cs = fmaf(cp * x2, x2, fmaf(-0.5f, x2, 1.0f));
+    const float v = (q & 1) ? cs : sn;
+    return (q & 2) ? -v : v;
 }
 
 __global__ __launch_bounds__(64) void osc_segsum_kernel(const float* __restrict__ f0, OscGeom g, double* __restrict__ S) {
@@ -72,11 +105,14 @@ __global__ __launch_bounds__(64) void osc_prefix_kernel(const float* __restrict_
     dt0[(size_t)n * g.H + h] = (float)acc;
 }
 
+constexpr int MAX_SEG = 512;
+
 __global__ __launch_bounds__(64) void osc_synth_kernel(const float* __restrict__ amps, const float* __restrict__ f0,
                                                        const float* __restrict__ phi_in, OscGeom g,
                                                        const double* __restrict__ P, const float* __restrict__ dt0,
                                                        int phi_col, float* __restrict__ wave, float* __restrict__ phi_out) {
     __shared__ float tile[64][65];
+    __shared__ uint2 coord[MAX_SEG];              // per sample of the frame: (i0 | i1 << 16, w1)
     const int f = blockIdx.x, n = blockIdx.y;
     const int lane = threadIdx.x;
     const int h = lane;
@@ -85,24 +121,35 @@ __global__ __launch_bounds__(64) void osc_synth_kernel(const float* __restrict__
     const float* an = amps + ((size_t)n * g.H + (hv ? h : 0)) * g.Lf;
     const float hmul = (float)(h + 1);
     const float TWO_PI_F = 6.283185307179586f;
+    const int u0 = f * g.seg;
+    for (int i = lane; i < g.seg; i += 64) {
+        const Lerp l = lerp_coord(u0 + i, g.ratio, g.Lf);
+        coord[i] = make_uint2((unsigned)l.i0 | ((unsigned)l.i1 << 16), __float_as_uint(l.w1));
+    }
+    // the interpolation of a frame's samples touches the frames f - 1, f, f + 1 only: keep their values in registers
+    const int fm = f > 0 ? f - 1 : 0, fp = f + 1 < g.Lf ? f + 1 : g.Lf - 1;
+    const float fo_m = f0n[fm] * hmul, fo_c = f0n[f] * hmul, fo_p = f0n[fp] * hmul;
+    const float am_m = an[fm], am_c = an[f], am_p = an[fp];
     double acc = hv ? P[((size_t)n * g.H + h) * g.Lf + f] : 0.0;
     const float d0 = hv ? dt0[(size_t)n * g.H + h] : 0.0f;
     const float ph = (hv && phi_in != nullptr) ? phi_in[(size_t)n * g.H + h] : 0.0f;
-    const int u0 = f * g.seg;
+    __syncthreads();
     for (int b0 = 0; b0 < g.seg; b0 += 64) {
         const int nb = (g.seg - b0) < 64 ? (g.seg - b0) : 64;
         for (int i = 0; i < nb; ++i) {
-            const int u = u0 + b0 + i;
-            Lerp l = lerp_coord(u, g.ratio, g.Lf);
+            const uint2 xc = coord[b0 + i];
+            const int i0 = xc.x & 0xffff, i1 = xc.x >> 16;
+            const float w1 = __uint_as_float(xc.y), w0 = 1.0f - w1;
+            const float fa = i0 == f ? fo_c : (i0 < f ? fo_m : fo_p), fb = i1 == f ? fo_c : (i1 < f ? fo_m : fo_p);
+            const float aa = i0 == f ? am_c : (i0 < f ? am_m : am_p), ab = i1 == f ? am_c : (i1 < f ? am_m : am_p);
             float c = 0.0f;
             if (hv) {
-                acc += (double)formant_step(f0n, hmul, l, g.sample_rate);
-                float dt = (float)acc - d0;
-                float theta = __fadd_rn(__fmul_rn(TWO_PI_F, dt), ph);
-                float sn = sinf(theta);
-                float a = lerp_apply(l, an[l.i0], an[l.i1]);
-                c = sn * a;
-                if (phi_out != nullptr && u == phi_col) phi_out[(size_t)n * g.H + h] = asinf(sn);
+                acc += (double)div_rate(fmaf(w0, fa, w1 * fb), g.sample_rate);
+                const float dt = (float)acc - d0;
+                const float theta = __fadd_rn(__fmul_rn(TWO_PI_F, dt), ph);
+                const float sn = sin_phase(theta);
+                c = sn * fmaf(w0, aa, w1 * ab);
+                if (phi_out != nullptr && u0 + b0 + i == phi_col) phi_out[(size_t)n * g.H + h] = asinf(sinf(theta));
             }
             tile[i][lane] = c;
         }
@@ -116,6 +163,13 @@ __global__ __launch_bounds__(64) void osc_synth_kernel(const float* __restrict__
     }
 }
 
+__global__ void div16000_check_kernel(unsigned first, unsigned count, unsigned* __restrict__ mismatches) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float x = __uint_as_float(first + i);
+    if (__float_as_uint(div_rate(x, 16000.0f)) != __float_as_uint(__fdiv_rn(x, 16000.0f))) atomicAdd(mismatches, 1u);
+}
+
 }  // namespace
 
 extern "C" size_t alive_oscillator_workspace_bytes(int N, int H, int Lf) {
@@ -126,7 +180,8 @@ extern "C" int alive_oscillator(const float* amps, const float* f0, const float*
                                 float sample_rate, int crop0, int phi_col, float* wave, float* phi_out, void* ws,
                                 void* stream) {
     ALIVE_CHECK_ARG(amps && f0 && wave && ws, "alive_oscillator: null pointer");
-    ALIVE_CHECK_ARG(N > 0 && H > 0 && H <= 64 && Lf > 0 && seg > 0, "alive_oscillator: bad sizes (H <= 64)");
+    ALIVE_CHECK_ARG(N > 0 && H > 0 && H <= 64 && Lf > 0 && Lf < 65536 && seg > 0 && seg <= MAX_SEG,
+                    "alive_oscillator: bad sizes (H <= 64, seg <= %d)", MAX_SEG);
     const int Lw = Lf * seg;
     ALIVE_CHECK_ARG(crop0 >= 0 && crop0 < Lw, "alive_oscillator: crop0 %d outside [0,%d)", crop0, Lw);
     ALIVE_CHECK_ARG(phi_out == nullptr || (phi_col >= 0 && phi_col < Lw), "alive_oscillator: phi_col outside wave");
@@ -139,5 +194,14 @@ extern "C" int alive_oscillator(const float* amps, const float* f0, const float*
     osc_prefix_kernel<<<dim3(N, cdiv(H, 64)), 64, 0, s>>>(f0, g, crop0, S, dt0);
     osc_synth_kernel<<<dim3(Lf, N), 64, 0, s>>>(amps, f0, phi_in, g, S, dt0, phi_col, wave, phi_out);
     ALIVE_CHECK_LAUNCH("alive_oscillator");
+    return ALIVE_OK;
+}
+
+// test hook: counts the fp32 bit patterns in [first, first + count) for which the fast division by 16000 differs from
+// the IEEE quotient (must be 0 over the whole range the oscillator can see)
+extern "C" int alive_debug_div16000_mismatches(unsigned first, unsigned count, unsigned* mismatches, void* stream) {
+    ALIVE_CHECK_ARG(mismatches && count > 0, "alive_debug_div16000_mismatches: bad args");
+    div16000_check_kernel<<<(count + 255) / 256, 256, 0, (hipStream_t)stream>>>(first, count, mismatches);
+    ALIVE_CHECK_LAUNCH("alive_debug_div16000_mismatches");
     return ALIVE_OK;
 }

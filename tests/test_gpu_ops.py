@@ -499,3 +499,16 @@ def test_filter_edge_kernels(n, lw):
     ref = F.conv1d(h.double(), w_o.double(), b_o.double(), padding=3)
     got = ops.filter_source_out(h.to(DEV), w_o.to(DEV), b_o.to(DEV))
     assert got.shape == ref.shape and relerr(got, ref) < 5e-7
+
+
+def test_div16000_is_the_ieee_quotient():
+    """the oscillator divides by the sample rate with one multiply and two fmas (csrc/oscillator.hip::div_rate); the
+    reference's `formants / 16000` is an IEEE division.  Exhaustive over every fp32 in [2^-24, 2^24)."""
+    import ctypes as C
+    from module import _native as nat
+    fn = nat.lib().alive_debug_div16000_mismatches
+    fn.restype, fn.argtypes = C.c_int, [C.c_uint, C.c_uint, C.c_void_p, C.c_void_p]
+    bad = torch.zeros(1, dtype=torch.int32, device=DEV)
+    first, last = 0x33800000, 0x4B800000          # 2^-24 .. 2^24
+    nat.check(fn(first, last - first, bad.data_ptr(), nat.stream()))
+    assert bad.item() == 0
