@@ -1,4 +1,4 @@
-// 1x1 convs over very few columns (N*T <= 32: the streaming path of realtime_inference.py, 5-24 frames per step).
+// Convs over very few GEMM columns (N*T <= 96: the streaming path of realtime_inference.py, 5-24 frames per step).
 //
 // At 8 frames a 512x1536 GEMM has 12 M MACs and 3 MB of weights: the tiled kernels run it as a handful of blocks that
 // walk K serially behind LDS round trips and barriers (70-95 us per launch, 33 launches per step).  Here the weight
@@ -10,23 +10,18 @@
 
 namespace {
 
-template <int NP>       // 0: fp32 weights; 2 / 3: bf16 planes
-__device__ __forceinline__ f32x4 load_w4(const AliveConv& p, int row, int k, int co_pad) {
-    if (NP == 0) {
-        return *(const f32x4*)(p.W + (size_t)row * p.K_pad + k);
-    } else {
-        const unsigned short* W16 = (const unsigned short*)p.W;
-        f32x4 w = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int pl = NP - 1; pl >= 0; --pl) {          // smallest plane first: the partial sums stay exact
-            const uint2 q = *(const uint2*)(W16 + ((size_t)pl * co_pad + row) * p.Ci_pad + k);
-            w[0] += __uint_as_float(q.x << 16);
-            w[1] += __uint_as_float(q.x & 0xffff0000u);
-            w[2] += __uint_as_float(q.y << 16);
-            w[3] += __uint_as_float(q.y & 0xffff0000u);
-        }
-        return w;
+// x value of GEMM column (n, t) at reduction index (ci, tap j): the implicit im2col of alive_conv1d
+__device__ __forceinline__ float skinny_x(const AliveConv& p, const float* xn, int ci, int t, int j) {
+    int tin = t * p.stride + j * p.dil - p.pad_left;
+    if (tin < 0) {
+        if (p.pad_mode == 0) return 0.0f;
+        tin = -tin;                                        // reflect (left: modes 1 and 2)
     }
+    if (tin >= p.Tin) {
+        if (p.pad_mode != 2) return 0.0f;
+        tin = 2 * (p.Tin - 1) - tin;                       // reflect right (STFT centre pad)
+    }
+    return (ci < p.Ci && tin >= 0 && tin < p.Tin) ? xn[(size_t)ci * p.Tin + tin] : 0.0f;
 }
 
 template <int NP>
@@ -35,21 +30,25 @@ __global__ __launch_bounds__(256) void conv_skinny_kernel(AliveConv p, int ncols
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ln = lane & 15, lq = lane >> 4;
     const int m0 = blockIdx.x * 16;
+    const int c0 = blockIdx.y * 32;                    // first GEMM column of this block
     const int co_pad = (p.Co + 15) & ~15;
-    const int Kp = NP == 0 ? p.K_pad : p.Ci_pad;       // padded K of the weight rows (zero padded)
+    const int Kp = NP == 0 ? p.K_pad : p.KW * p.Ci_pad;    // padded K of the weight rows (zero padded)
     int row = m0 + ln;
     row = row < co_pad ? row : co_pad - 1;
 
     // columns: c = n * Tout + t  (two 16-column MFMA tiles)
-    const float* xcol[2];
+    const float* xn[2];
+    int tcol[2];
     bool cok[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        int c = h * 16 + ln;
+        int c = c0 + h * 16 + ln;
         cok[h] = c < ncols;
-        int n = cok[h] ? c / p.Tout : 0, t = cok[h] ? c - n * p.Tout : 0;
-        xcol[h] = p.X + (size_t)n * p.Ci * p.Tin + t;
+        int n = cok[h] ? c / p.Tout : 0;
+        tcol[h] = cok[h] ? c - n * p.Tout : 0;
+        xn[h] = p.X + (size_t)n * p.Ci * p.Tin;
     }
+    const bool two = c0 + 16 < ncols;
     // wave 0 starts from the bias (a K == 1 conv is then the single fma(w, x, b) of the tiled kernel: F0Encoder.c1)
     f32x4 acc[2];
 #pragma unroll
@@ -59,33 +58,57 @@ __global__ __launch_bounds__(256) void conv_skinny_kernel(AliveConv p, int ncols
         acc[0][r] = b;
         acc[1][r] = b;
     }
-    // wave wv walks k = 16*(wv + 4*i) .. +15 ; lane (row ln, slot lq) holds k0 + 4*lq + s for MFMA step s
+    // wave wv walks k = 16*(wv + 4*i) .. +15 ; lane (row ln, slot lq) holds k0 + 4*lq + s for MFMA step s.
+    // fp32 weights: k = ci * KW + j;  bf16 planes: tap-major k = j * Ci_pad + ci (a 16-k group lies inside one tap)
     for (int k0 = wv * 16; k0 < Kp; k0 += 64) {
-        const f32x4 w = load_w4<NP>(p, row, k0 + 4 * lq, co_pad);
-        float x[2][4];
+        f32x4 w;
+        if (NP == 0) {
+            w = *(const f32x4*)(p.W + (size_t)row * p.K_pad + k0 + 4 * lq);
+        } else {
+            const unsigned short* W16 = (const unsigned short*)p.W;
+            w = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int k = k0 + 4 * lq + s;
-                x[h][s] = (cok[h] && k < p.Ci) ? xcol[h][(size_t)k * p.Tin] : 0.0f;
+            for (int pl = NP - 1; pl >= 0; --pl) {      // smallest plane first: the partial sums stay exact
+                const uint2 q = *(const uint2*)(W16 + ((size_t)pl * co_pad + row) * Kp + k0 + 4 * lq);
+                w[0] += __uint_as_float(q.x << 16);
+                w[1] += __uint_as_float(q.x & 0xffff0000u);
+                w[2] += __uint_as_float(q.y << 16);
+                w[3] += __uint_as_float(q.y & 0xffff0000u);
             }
+        }
+        float x[2][4];
+        const int jt = NP == 0 ? 0 : k0 / p.Ci_pad, cbase = NP == 0 ? 0 : k0 - jt * p.Ci_pad;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = k0 + 4 * lq + s;
+            int ci, j;
+            if (NP == 0) {
+                ci = p.KW == 1 ? k : k / p.KW;
+                j = k - ci * p.KW;
+            } else {
+                ci = cbase + 4 * lq + s;
+                j = jt;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) x[h][s] = cok[h] ? skinny_x(p, xn[h], ci, tcol[h], j) : 0.0f;
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], x[0][s], acc[0], 0, 0, 0);
-            if (ncols > 16) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], x[1][s], acc[1], 0, 0, 0);
+            if (two) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], x[1][s], acc[1], 0, 0, 0);
         }
     }
     red[0][wv][lane] = acc[0];
     red[1][wv][lane] = acc[1];
     __syncthreads();
     // wave h (0, 1) finishes column tile h: sum of the four K-quarters + bias, then the common epilogue
-    if (wv < 2 && wv * 16 < ncols) {
+    if (wv < 2 && c0 + wv * 16 < ncols) {
         f32x4 v = red[wv][0][lane] + red[wv][1][lane] + red[wv][2][lane] + red[wv][3][lane];
-        const int c = wv * 16 + ln;
+        const int c = c0 + wv * 16 + ln;
         if (c < ncols) {
             const int n = c / p.Tout, t = c - n * p.Tout;
             Lerp lp;
+            if (p.Z != nullptr) lp = lerp_coord(t, (float)p.Lf / (float)p.Tout, p.Lf);
             FilmTile ft{nullptr, 0};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -100,11 +123,15 @@ __global__ __launch_bounds__(256) void conv_skinny_kernel(AliveConv p, int ncols
 
 }  // namespace
 
-// true if the descriptor qualifies; launches the skinny kernel
+// true if the descriptor qualifies; launches the skinny kernel.  Any conv of alive_conv1d over at most SKINNY_COLS GEMM
+// columns: the 1x1 convs, the DFT, the strided down-convs, the k5 filter convs and the transposed convs of a
+// streaming step (8 frames: 8 .. 80 columns below the 16-channel scale).
+constexpr int SKINNY_COLS = 96;
 bool alive_conv_skinny_try(const AliveConv* d, hipStream_t s, int* rc) {
     const int ncols = d->N * d->Tout;
-    if (d->KW != 1 || d->stride != 1 || ncols > 32 || d->Z != nullptr || d->Tout != d->Tin) return false;
-    dim3 g(cdiv(d->Co, 16));
+    if (ncols > SKINNY_COLS) return false;
+    if (d->precision == 0 && (d->K_pad & 15)) return false;
+    dim3 g(cdiv(d->Co, 16), cdiv(ncols, 32));
     if (d->precision == 0) conv_skinny_kernel<0><<<g, 256, 0, s>>>(*d, ncols);
     else if (d->precision == 1) conv_skinny_kernel<2><<<g, 256, 0, s>>>(*d, ncols);
     else conv_skinny_kernel<3><<<g, 256, 0, s>>>(*d, ncols);

@@ -512,3 +512,31 @@ def test_div16000_is_the_ieee_quotient():
     first, last = 0x33800000, 0x4B800000          # 2^-24 .. 2^24
     nat.check(fn(first, last - first, bad.data_ptr(), nat.stream()))
     assert bad.item() == 0
+
+
+@pytest.mark.parametrize("co,ci,kw,stride,dil,pad,mode,tin,tout,prec", [
+    (1282, 1, 1280, 320, 1, 640, 2, 2560, 8, "fp32"),        # the DFT of an 8-frame ring (reflect both)
+    (256, 64, 8, 8, 1, 0, 0, 640, 80, "fp32"),               # downs[2]
+    (256, 256, 10, 10, 1, 0, 0, 80, 8, "fp32"),              # downs[3]
+    (256, 256, 5, 1, 4, 16, 1, 80, 80, "bf16x3"),            # dilated causal k5, reflect left
+    (256, 256, 5, 1, 1, 4, 1, 8, 8, "bf16x3"),               # mid conv on 8 frames
+    (24, 40, 3, 1, 2, 4, 0, 31, 31, "fp32"),                 # odd sizes, zero pad
+])
+def test_conv1d_few_columns_any_geometry(co, ci, kw, stride, dil, pad, mode, tin, tout, prec):
+    """<= 96 GEMM columns (a streaming step): the K-split skinny kernel serves every conv geometry of alive_conv1d"""
+    from module import ops
+    x = g(f"fcx{co}{ci}{kw}", (1, ci, tin))
+    w = g(f"fcw{co}{ci}{kw}", (co, ci, kw), scale=1.0 / np.sqrt(ci * kw))
+    b = g(f"fcb{co}{ci}{kw}", (co,), scale=0.1)
+    if mode == 2:
+        xp = F.pad(x, (pad, pad), mode="reflect")
+    elif mode == 1:
+        xp = F.pad(x, (pad, 0), mode="reflect")
+    else:
+        xp = F.pad(x, (pad, 0))
+    ref = F.conv1d(xp.double(), w.double(), b.double(), stride=stride, dilation=dil)[:, :, :tout]
+    y, _ = ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), stride=stride, dilation=dil, pad_left=pad, pad_mode=mode, out_len=tout,
+                      precision=prec)
+    assert y.shape == ref.shape
+    e = relerr(y, ref)
+    assert e < (2e-5 if prec == "bf16x3" else 5e-7), e
