@@ -106,6 +106,44 @@ __global__ __launch_bounds__(256) void src_prep_kernel(const float* __restrict__
     }
 }
 
+// the same for a handful of frames (streaming): one block per frame, threads along d -- the kernel above walks d
+// serially with one frame per lane, which for 8 frames is 2 x 192 dependent strided loads per wave
+__global__ __launch_bounds__(256) void src_prep_small_kernel(const float* __restrict__ src, int T, int64_t Tt,
+                                                             float* __restrict__ s_f32, unsigned short* __restrict__ s_bf16) {
+    __shared__ float red[4];
+    const int64_t ft = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (ft >= Tt) {                                  // padding frames of the last 256-frame block: zero rows
+        for (int d = tid; d < D; d += 256) s_bf16[(size_t)ft * D + d] = 0;
+        return;
+    }
+    const int64_t n = ft / T;
+    const int t = (int)(ft - n * T);
+    const float* col = src + (size_t)n * D * T + t;
+    float v[D / 256];
+    // the norm sums d in the order of the kernel above: four interleaved partial sums (d mod 4), then their sum
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < D / 256; ++i) v[i] = col[(size_t)(tid + 256 * i) * T];
+    // partial sum of residue class (tid & 3), accumulated in ascending d like the serial loop: gather through LDS
+    __shared__ float xs[D];
+#pragma unroll
+    for (int i = 0; i < D / 256; ++i) xs[tid + 256 * i] = v[i];
+    __syncthreads();
+    if (tid < 4) {
+        for (int d = tid; d < D; d += 4) ss = fmaf(xs[d], xs[d], ss);
+        red[tid] = ss;
+    }
+    __syncthreads();
+    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+#pragma unroll
+    for (int i = 0; i < D / 256; ++i) {
+        const float q = v[i] / nrm;
+        s_f32[(size_t)ft * D + tid + 256 * i] = q;
+        s_bf16[(size_t)ft * D + tid + 256 * i] = f32_to_bf16_rn(q);
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // scoring: frames stationary in registers, library streamed through LDS by LDS-DMA
 // ----------------------------------------------------------------------------------------------
@@ -355,21 +393,41 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
     const f32x4* sp = (const f32x4*)(s_f32 + (size_t)ft * D);
     f32x4 s0 = sp[lane], s1 = sp[lane + 64], s2 = sp[lane + 128];
     float my_score = -INFINITY;
-    for (int c = 0; c < 64; ++c) {
-        int idx = __shfl(my_idx, c);
-        if (idx < 0) continue;                           // wave-uniform
-        const f32x4* rp = (const f32x4*)(rows + (size_t)idx * D);
-        float nn = norms[idx];
-        f32x4 r0 = rp[lane], r1 = rp[lane + 64], r2 = rp[lane + 128];
-        float p = 0.0f;
+    // four candidates per trip: their 3-KB rows are requested together (one wave per frame: a serial walk pays one
+    // gather latency per candidate)
+    for (int c0 = 0; c0 < 64; c0 += 4) {
+        int idx[4];
+        bool any = false;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) p = fmaf(s0[j], r0[j] / nn, p);
+        for (int u = 0; u < 4; ++u) {
+            idx[u] = __shfl(my_idx, c0 + u);
+            any |= idx[u] >= 0;
+        }
+        if (!any) continue;                              // wave-uniform
+        f32x4 r0[4], r1[4], r2[4];
+        float nn[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) p = fmaf(s1[j], r1[j] / nn, p);
+        for (int u = 0; u < 4; ++u) {
+            const int ii = idx[u] >= 0 ? idx[u] : 0;
+            const f32x4* rp = (const f32x4*)(rows + (size_t)ii * D);
+            r0[u] = rp[lane];
+            r1[u] = rp[lane + 64];
+            r2[u] = rp[lane + 128];
+            nn[u] = norms[ii];
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) p = fmaf(s2[j], r2[j] / nn, p);
-        p = wave_sum(p);
-        if (lane == c) my_score = p;
+        for (int u = 0; u < 4; ++u) {
+            if (idx[u] < 0) continue;                    // wave-uniform
+            float p = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p = fmaf(s0[j], r0[u][j] / nn[u], p);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p = fmaf(s1[j], r1[u][j] / nn[u], p);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p = fmaf(s2[j], r2[u][j] / nn[u], p);
+            p = wave_sum(p);
+            if (lane == c0 + u) my_score = p;
+        }
     }
 
     // ---- exact top-k, descending, ties to the lower library index ----
@@ -537,7 +595,8 @@ extern "C" int alive_knn_search(const float* src, int N, int T, const void* lib_
         }
         attr_set = true;
     }
-    src_prep_kernel<<<(unsigned)(p.Tt_pad / 64), 256, 0, s>>>(src, T, p.Tt, p.Tt_pad, s_f32, s_bf16);
+    if (p.Tt <= 512) src_prep_small_kernel<<<(unsigned)p.Tt_pad, 256, 0, s>>>(src, T, p.Tt, s_f32, s_bf16);
+    else src_prep_kernel<<<(unsigned)(p.Tt_pad / 64), 256, 0, s>>>(src, T, p.Tt, p.Tt_pad, s_f32, s_bf16);
     if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
     knn_score_kernel<<<dim3((unsigned)(p.Tt_pad / FT), p.split), 256, SCORE_LDS, s>>>(
         s_bf16, (const unsigned short*)lib_bf16, M, p.tiles_total, p.tiles_per_split, p.P, cv, ci);
