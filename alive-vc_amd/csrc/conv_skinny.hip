@@ -2,31 +2,33 @@
 //
 // At 8 frames a 512x1536 GEMM has 12 M MACs and 3 MB of weights: the tiled kernels run it as a handful of blocks that
 // walk K serially behind LDS round trips and barriers (70-95 us per launch, 33 launches per step).  Here the weight
-// matrix is cut into 16-row slabs, one block each (32..258 blocks), the block's four waves split K between them and
-// stream their weights straight from L2 into f32-MFMA A fragments (v_mfma_f32_16x16x4_f32), the four partial tiles are
+// matrix is cut into 16-row slabs, one block each (32..258 blocks), the block's eight waves split K between them and
+// stream their weights straight from L2 into f32-MFMA A fragments (v_mfma_f32_16x16x4_f32), the partial tiles are
 // summed through LDS and go through the common epilogue.  Weights are read in whatever format the layer was packed
 // for the tiled kernels: fp32 [Co_pad][K_pad], or 2 / 3 bf16 planes whose sum is the (16- / 24-bit mantissa) weight.
 #include "conv_epilogue.h"
 
 namespace {
 
-// x value of GEMM column (n, t) at reduction index (ci, tap j): the implicit im2col of alive_conv1d
+// x value of GEMM column (n, t) at reduction index (ci, tap j): the implicit im2col of alive_conv1d.  Branch-free (one
+// unconditional load from a clamped address) so that the loads of several k-steps can be in flight together.
 __device__ __forceinline__ float skinny_x(const AliveConv& p, const float* xn, int ci, int t, int j) {
     int tin = t * p.stride + j * p.dil - p.pad_left;
-    if (tin < 0) {
-        if (p.pad_mode == 0) return 0.0f;
-        tin = -tin;                                        // reflect (left: modes 1 and 2)
-    }
-    if (tin >= p.Tin) {
-        if (p.pad_mode != 2) return 0.0f;
-        tin = 2 * (p.Tin - 1) - tin;                       // reflect right (STFT centre pad)
-    }
-    return (ci < p.Ci && tin >= 0 && tin < p.Tin) ? xn[(size_t)ci * p.Tin + tin] : 0.0f;
+    bool ok = ci < p.Ci;
+    ok = ok && !(tin < 0 && p.pad_mode == 0);
+    tin = tin < 0 ? -tin : tin;                            // reflect (left: modes 1 and 2)
+    ok = ok && !(tin >= p.Tin && p.pad_mode != 2);
+    tin = tin >= p.Tin ? 2 * (p.Tin - 1) - tin : tin;      // reflect right (STFT centre pad)
+    ok = ok && tin >= 0 && tin < p.Tin;
+    const float v = xn[ok ? (size_t)ci * p.Tin + tin : 0];
+    return ok ? v : 0.0f;
 }
 
+constexpr int SKW = 8;                  // waves per block = K-split
+
 template <int NP>
-__global__ __launch_bounds__(256) void conv_skinny_kernel(AliveConv p, int ncols) {
-    __shared__ f32x4 red[2][4][64];
+__global__ __launch_bounds__(64 * SKW) void conv_skinny_kernel(AliveConv p, int ncols) {
+    __shared__ f32x4 red[2][SKW][64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ln = lane & 15, lq = lane >> 4;
     const int m0 = blockIdx.x * 16;
@@ -58,9 +60,9 @@ __global__ __launch_bounds__(256) void conv_skinny_kernel(AliveConv p, int ncols
         acc[0][r] = b;
         acc[1][r] = b;
     }
-    // wave wv walks k = 16*(wv + 4*i) .. +15 ; lane (row ln, slot lq) holds k0 + 4*lq + s for MFMA step s.
+    // wave wv walks k = 16*(wv + SKW*i) .. +15 ; lane (row ln, slot lq) holds k0 + 4*lq + s for MFMA step s.
     // fp32 weights: k = ci * KW + j;  bf16 planes: tap-major k = j * Ci_pad + ci (a 16-k group lies inside one tap)
-    for (int k0 = wv * 16; k0 < Kp; k0 += 64) {
+    for (int k0 = wv * 16; k0 < Kp; k0 += 16 * SKW) {
         f32x4 w;
         if (NP == 0) {
             w = *(const f32x4*)(p.W + (size_t)row * p.K_pad + k0 + 4 * lq);
@@ -101,9 +103,11 @@ __global__ __launch_bounds__(256) void conv_skinny_kernel(AliveConv p, int ncols
     red[0][wv][lane] = acc[0];
     red[1][wv][lane] = acc[1];
     __syncthreads();
-    // wave h (0, 1) finishes column tile h: sum of the four K-quarters + bias, then the common epilogue
+    // wave h (0, 1) finishes column tile h: sum of the K-parts + bias, then the common epilogue
     if (wv < 2 && c0 + wv * 16 < ncols) {
-        f32x4 v = red[wv][0][lane] + red[wv][1][lane] + red[wv][2][lane] + red[wv][3][lane];
+        f32x4 v = red[wv][0][lane];
+#pragma unroll
+        for (int i = 1; i < SKW; ++i) v = v + red[wv][i][lane];
         const int c = c0 + wv * 16 + ln;
         if (c < ncols) {
             const int n = c / p.Tout, t = c - n * p.Tout;
@@ -132,9 +136,9 @@ bool alive_conv_skinny_try(const AliveConv* d, hipStream_t s, int* rc) {
     if (ncols > SKINNY_COLS) return false;
     if (d->precision == 0 && (d->K_pad & 15)) return false;
     dim3 g(cdiv(d->Co, 16), cdiv(ncols, 32));
-    if (d->precision == 0) conv_skinny_kernel<0><<<g, 256, 0, s>>>(*d, ncols);
-    else if (d->precision == 1) conv_skinny_kernel<2><<<g, 256, 0, s>>>(*d, ncols);
-    else conv_skinny_kernel<3><<<g, 256, 0, s>>>(*d, ncols);
+    if (d->precision == 0) conv_skinny_kernel<0><<<g, 64 * SKW, 0, s>>>(*d, ncols);
+    else if (d->precision == 1) conv_skinny_kernel<2><<<g, 64 * SKW, 0, s>>>(*d, ncols);
+    else conv_skinny_kernel<3><<<g, 64 * SKW, 0, s>>>(*d, ncols);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         alive_set_error("alive_conv1d(skinny): %s", hipGetErrorString(e));
