@@ -122,3 +122,44 @@ def test_voice_library_format_and_match(golden_dir, tmp_path):
     big = VoiceLibrary().to(DEV)
     big.load_state_dict({"tokens": synthetic.make_library(1000, 3)})     # M != 512 loads too
     assert big.tokens.shape == (1, 768, 1000)
+
+
+def test_knn_full_size_properties():
+    """BASELINE size (1 M vectors, one batch of 128 windows x 450 frames) through properties that do not need the oracle:
+    planted copies are retrieved, values are the exact fp32 cosines of the returned rows and sorted, and on a sample of
+    frames the index set equals a brute-force fp32 scan of the whole library (outside near-ties)."""
+    from module.common import PackedLibrary
+    M, N, T, k = 1_000_000, 128, 450, 4
+    g = torch.Generator(device=DEV).manual_seed(21)
+    lib = torch.randn(768, M, device=DEV, generator=g)
+    src = torch.randn(N, 768, T, device=DEV, generator=g)
+    # every 7th frame of window 3 is a scaled copy of a library row, every 5th of window 90 a slightly noisy copy
+    rows_a = torch.arange(0, T, 7, device=DEV)
+    planted_a = (rows_a * 2003 + 17) % M
+    src[3][:, rows_a] = 2.5 * lib[:, planted_a]
+    rows_b = torch.arange(0, T, 5, device=DEV)
+    planted_b = (rows_b * 1009 + 5) % M
+    src[90][:, rows_b] = lib[:, planted_b] + 0.05 * torch.randn(768, rows_b.numel(), device=DEV, generator=g)
+    pl = PackedLibrary(lib)
+    val, idx = pl.search(src, k)
+    val, idx = val.view(N, T, k), idx.view(N, T, k)
+    assert (idx >= 0).all() and (idx < M).all()
+    assert (val[:, :, :-1] >= val[:, :, 1:]).all()
+    assert torch.equal(idx[3][rows_a, 0].long(), planted_a) and (val[3][rows_a, 0] > 0.99999).all()
+    assert torch.equal(idx[90][rows_b, 0].long(), planted_b)
+    # exact cosines of the returned rows, recomputed in fp64 for 512 random frames
+    sel = torch.randint(0, N * T, (512,), device=DEV, generator=g)
+    s = src.permute(0, 2, 1).reshape(N * T, 768)[sel].double()
+    r = lib.t()[idx.view(N * T, k)[sel].long()].double()                        # [512, k, 768]
+    cos = torch.einsum("fd,fkd->fk", s / s.norm(dim=1, keepdim=True), r / r.norm(dim=2, keepdim=True))
+    assert (cos.float() - val.view(N * T, k)[sel]).abs().max().item() < 2e-6
+    # brute force on 96 frames: same top-k set wherever the (k, k+1) gap is not a near-tie
+    sel = sel[:96]
+    sn = (src.permute(0, 2, 1).reshape(N * T, 768)[sel])
+    sn = sn / sn.norm(dim=1, keepdim=True)
+    full = sn @ (lib / lib.norm(dim=0, keepdim=True))                           # [96, M] fp32
+    top = torch.topk(full, k + 1, dim=1)
+    safe = (top.values[:, k - 1] - top.values[:, k]) > 1e-5
+    got = torch.sort(idx.view(N * T, k)[sel].long(), dim=1).values[safe]
+    want = torch.sort(top.indices[:, :k], dim=1).values[safe]
+    assert safe.sum().item() > 80 and torch.equal(got, want)

@@ -138,3 +138,18 @@ def test_default_window_end_to_end(nets):
     full, mid = rms(out, ref), rms(out[:, 48000:96000], ref[:, 48000:96000])
     print(f"450-frame window: rms error full {full:.3e}, kept centre third {mid:.3e}, signal rms {ref.pow(2).mean().sqrt():.3f}")
     assert mid < RMS_BAR, (full, mid)
+
+
+def test_batch_invariance_of_the_networks(nets):
+    """throughput mode runs 128 windows per launch: a window's result must not depend on its batch (bitwise)"""
+    ce, pe, dec, _ = nets
+    spec = torch.from_numpy(np.abs(synthetic.gaussian("bi.spec", 31, (3, 641, 450)).numpy())).to(DEV)
+    feats, f0 = ce(spec), pe.estimate(spec)
+    for i in range(3):
+        assert torch.equal(ce(spec[i:i + 1].contiguous()), feats[i:i + 1])
+        assert torch.equal(pe.estimate(spec[i:i + 1].contiguous()), f0[i:i + 1])
+    f0 = 100.0 + 20.0 * f0 / 4096.0
+    wave, _ = dec(feats, f0=f0)
+    for i in (0, 2):
+        w1, _ = dec(feats[i:i + 1].contiguous(), f0=f0[i:i + 1].contiguous())
+        assert torch.equal(w1, wave[i:i + 1])
