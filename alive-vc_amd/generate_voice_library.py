@@ -4,7 +4,9 @@ generate_voice_library.py:13-43 (torch.save({'tokens': float32[1, 768, M]})).
 The reference fills 512 fixed slots with one random content frame from each of up to 513 random
 7680-sample clips (unseeded).  This build batches the content encoder over all clips on the
 MI355X, takes --frames-per-clip frames per clip, is seedable, and writes any M (--num-tokens,
-default 512 so the file stays loadable by the reference's VoiceLibrary()).
+default 512 so the file stays loadable by the reference's VoiceLibrary()).  --dedup COS drops frames whose cosine
+to an earlier kept frame exceeds COS (silence and sustained vowels fill real corpora with near-duplicates that only
+dilute a k = 4 match); the scan is the library's own kNN kernel run against itself.
 """
 import argparse
 import glob
@@ -44,6 +46,22 @@ def collect_clips(root, max_clips, rng):
     return clips[order[:max_clips]]
 
 
+def dedup_mask(tokens_DxM, threshold, k=8):
+    """keep[m] = False when some kept frame m' < m has cos(m, m') > threshold.  Greedy in index order; neighbours come
+    from the HIP kNN search of the library against itself (k nearest, the frame itself included)."""
+    from module.common import PackedLibrary
+    m = tokens_DxM.shape[1]
+    k = min(k, m)
+    val, idx = PackedLibrary(tokens_DxM.contiguous()).search(tokens_DxM.unsqueeze(0).contiguous(), k)
+    val, idx = val.cpu(), idx.cpu().long()
+    keep = torch.ones(m, dtype=torch.bool)
+    for i in range(m):
+        near = idx[i][(val[i] > threshold) & (idx[i] < i) & (idx[i] >= 0)]
+        if near.numel() and keep[near].any():
+            keep[i] = False
+    return keep
+
+
 def main(argv=None):
     parser = argparse.ArgumentParser(description="Generate voice library from wave files")
     parser.add_argument("dataset")
@@ -52,6 +70,8 @@ def main(argv=None):
     parser.add_argument('--num-tokens', default=512, type=int)
     parser.add_argument('--frames-per-clip', default=1, type=int)
     parser.add_argument('--seed', default=None, type=int)
+    parser.add_argument('--dedup', default=None, type=float, metavar="COS",
+                        help="drop a frame when an earlier frame of the library has cosine similarity above COS")
     parser.add_argument('-d', '--device', default='cuda')
     args = parser.parse_args(argv)
     rng = random.Random(args.seed)
@@ -74,7 +94,13 @@ def main(argv=None):
                 if filled < args.num_tokens:
                     VL.tokens[0, :, filled] = feats[b, :, fr]
                     filled += 1
-    print(f"Writing file... ({filled} of {args.num_tokens} slots from data)")
+    if args.dedup is not None and filled > 1:
+        keep = dedup_mask(VL.tokens[0, :, :filled].to(device), args.dedup)
+        kept = VL.tokens[0, :, :filled][:, keep.cpu()]
+        print(f"dedup: {filled - kept.shape[1]} of {filled} frames have an earlier neighbour above cos {args.dedup}")
+        VL.tokens = torch.cat([kept, VL.tokens[0, :, filled:]], 1).unsqueeze(0).contiguous()
+        filled = kept.shape[1]
+    print(f"Writing file... ({filled} of {VL.tokens.shape[2]} slots from data)")
     torch.save(VL.state_dict(), args.voice_library_path)
     print("Complete!")
 

@@ -110,6 +110,15 @@ def test_generate_voice_library_writes_reference_format(workdir):
     VoiceLibrary().load_state_dict(sd)
 
 
+def test_voice_library_dedup_drops_later_near_duplicates():
+    import generate_voice_library as gvl
+    base = synthetic.gaussian("dd.base", 5, (768, 40))
+    toks = torch.cat([base, base[:, :10] * 1.7 + 1e-4 * synthetic.gaussian("dd.n", 6, (768, 10)), base[:, 20:25]], 1)   # 55 frames
+    keep = gvl.dedup_mask(toks.to("cuda"), 0.999)
+    assert keep[:40].all() and not keep[40:].any()
+    assert gvl.dedup_mask(toks.to("cuda"), 1.5).all()                 # nothing is above an impossible threshold
+
+
 def test_realtime_graph_capture_equals_eager(workdir):
     """the whole per-step device pipeline captured into one hipGraph replays to the same samples as eager execution"""
     from module.content_encoder import ContentEncoder
