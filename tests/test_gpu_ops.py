@@ -333,6 +333,9 @@ def test_fused_filter_block_small(c, l, lf):
     out = fused(x.to(DEV), {k: v.to(DEV) for k, v in sd.items()}, "n", film, pad_rows, skip=skip.to(DEV))
     e = relerr(out, ref)
     assert e < (4e-5 if c == 64 else 5e-6), e
+    for _ in range(3):                                # run-to-run determinism (see DESIGN.md 3.2b': the scheduling fence)
+        again = fused(x.to(DEV), {k: v.to(DEV) for k, v in sd.items()}, "n", film, pad_rows, skip=skip.to(DEV))
+        assert torch.equal(again, out)
 
 
 @pytest.mark.parametrize("co,ci,t", [(512, 641, 450), (1536, 512, 37), (4096, 256, 130), (768, 512, 450)])
