@@ -79,6 +79,111 @@ __global__ __launch_bounds__(256) void dwconv_norm_kernel(
     }
 }
 
+// ---- the same, single pass, plane-packed output for the GEMM that follows (gemm_planes.hip) ----
+// The kernel above writes dw(x) to memory and re-reads it twice for the statistics and the affine (three passes at
+// ~1.1 TB/s), and alive_to_planes then re-reads the result to split it.  Here a block keeps its [C][64 columns] tile of
+// dw(x) in LDS (133 KB at C = 512), takes mean / sigma from it, applies the affine in place (lanes along time, so the
+// per-sample scale / shift rows of the adaptive form are read coalesced) and leaves through an LDS transpose as bf16
+// planes [col][C]: HBM sees x once and the planes once.
+constexpr int NPT = 512;                 // 8 waves: channels are split over the waves
+// TW = columns per tile: 64 (a wave row is one channel) or 32 (a wave row is two channels; halves the LDS tile so that two
+// blocks share a CU at C = 512 -- with one block of 8 waves per CU the passes are latency-bound)
+template <int NP, int TW>
+__global__ __launch_bounds__(NPT) void dwconv_norm_planes_kernel(
+    const float* __restrict__ X, int C, int T, const float* __restrict__ dw_w, const float* __restrict__ dw_b, int dw,
+    int affine_mode, const float* __restrict__ gain, const float* __restrict__ offset, const float* __restrict__ cond,
+    int cond_rows, int scale_row, int shift_row, float eps, unsigned short* __restrict__ P, int64_t cols_pad) {
+    extern __shared__ float tile[];                      // [C][TW + 1]
+    constexpr int CPW = 64 / TW;                         // channels per wave row
+    constexpr int NR = NPT / 64 * CPW;                   // channel rows in flight per block
+    __shared__ float red[NR][TW];
+    constexpr int PT = TW + 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tl = lane % TW, crow = wv * CPW + lane / TW;
+    const int n = blockIdx.y, t0 = blockIdx.x * TW;
+    const int t = t0 + tl;
+    const bool ok = t < T;
+    const float* Xn = X + (size_t)n * C * T;
+    // pass 1: depthwise conv (zero pad 3) -> LDS, running sum
+    float s = 0.0f;
+    for (int c = crow; c < C; c += NR) {
+        float y = 0.0f;
+        if (ok) {
+            const float* xc = Xn + (size_t)c * T;
+            if (dw) {
+                y = dw_b[c];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const int ti = t + j - 3;
+                    const float xv = (ti >= 0 && ti < T) ? xc[ti] : 0.0f;
+                    y = fmaf(dw_w[c * 7 + j], xv, y);
+                }
+            } else {
+                y = xc[t];
+            }
+        }
+        tile[c * PT + tl] = y;
+        s += y;
+    }
+    red[crow][tl] = s;
+    __syncthreads();
+    float mean = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) mean += red[i][tl];
+    mean = mean / (float)C;
+    __syncthreads();
+    // pass 2: centred sum of squares
+    float ss = 0.0f;
+    for (int c = crow; c < C; c += NR) {
+        const float d = tile[c * PT + tl] - mean;
+        ss = fmaf(d, d, ss);
+    }
+    red[crow][tl] = ok ? ss : 0.0f;
+    __syncthreads();
+    float var = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) var += red[i][tl];
+    const float sigma = sqrtf(var / (float)(C - 1)) + eps;
+    // pass 3: normalise + affine, in place
+    for (int c = crow; c < C; c += NR) {
+        const float v = (tile[c * PT + tl] - mean) / sigma;
+        float g = 1.0f, o = 0.0f;
+        if (affine_mode == 0) {
+            g = gain[c];
+            o = offset[c];
+        } else if (ok) {
+            g = cond[((size_t)n * cond_rows + scale_row + c) * T + t];
+            o = cond[((size_t)n * cond_rows + shift_row + c) * T + t];
+        }
+        tile[c * PT + tl] = ok ? v * g + o : 0.0f;
+    }
+    __syncthreads();
+    // pass 4: [C][col] -> planes [col][C]: thread = (column, 8-channel chunk)
+    const int chunks = C / 8;
+    for (int item = threadIdx.x; item < TW * chunks; item += NPT) {
+        const int ck = item % chunks, cl = item / chunks;
+        if (t0 + cl >= T) continue;
+        float vv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vv[e] = tile[(ck * 8 + e) * PT + cl];
+        const int64_t col = (int64_t)n * T + t0 + cl;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            u32x4 o4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                const bf16x2_t hp = {(__bf16)vv[2 * e], (__bf16)vv[2 * e + 1]};
+                const unsigned h = __builtin_bit_cast(unsigned, hp);
+                o4[e] = h;
+                vv[2 * e] -= __uint_as_float(h << 16);
+                vv[2 * e + 1] -= __uint_as_float(h & 0xffff0000u);
+            }
+            *(u32x4*)(P + ((size_t)pl * cols_pad + col) * C + ck * 8) = o4;
+        }
+    }
+}
+
 // ---- small-T variants (streaming: a handful of frames): one block per (frame, window), threads along the channels ----
 __device__ __forceinline__ float block_sum(float v, float* sh) {
 #pragma unroll
@@ -263,6 +368,45 @@ extern "C" int alive_dwconv_norm(const float* X, int N, int C, int T, const floa
     dwconv_norm_kernel<true><<<g, 256, 0, (hipStream_t)stream>>>(X, C, T, dw_w, dw_b, affine_mode, gain, offset, cond,
                                                                 cond_rows, scale_row, shift_row, eps, Y);
     ALIVE_CHECK_LAUNCH("alive_dwconv_norm");
+    return ALIVE_OK;
+}
+
+// dw conv (or none: dw_w == NULL) + (Adaptive)ChannelNorm with plane-packed output; C a multiple of 32
+extern "C" int alive_dwconv_norm_planes(const float* X, int N, int C, int T, const float* dw_w, const float* dw_b,
+                                        int affine_mode, const float* gain, const float* offset, const float* cond,
+                                        int cond_rows, int scale_row, int shift_row, float eps, int planes, void* P,
+                                        void* stream) {
+    ALIVE_CHECK_ARG(X && P && N > 0 && C > 1 && T > 0, "alive_dwconv_norm_planes: bad args");
+    ALIVE_CHECK_ARG((dw_w == nullptr) == (dw_b == nullptr), "alive_dwconv_norm_planes: dw_w and dw_b go together");
+    ALIVE_CHECK_ARG(affine_mode == 0 ? (gain && offset) : (cond != nullptr), "alive_dwconv_norm_planes: affine params");
+    ALIVE_CHECK_ARG((C & 31) == 0 && (planes == 2 || planes == 3), "alive_dwconv_norm_planes: C %d must be a multiple of 32, planes 2 or 3", C);
+    const int tw = C > 256 ? 32 : 64;                    // <= 68 KB of LDS per block: two blocks per CU
+    const size_t lds = (size_t)C * (tw + 1) * sizeof(float);
+    ALIVE_CHECK_ARG(lds <= 150 * 1024, "alive_dwconv_norm_planes: C %d does not fit the LDS tile", C);
+    const int64_t cols = (int64_t)N * T, cols_pad = (cols + 127) / 128 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipSuccess;
+        const void* fns[4] = {(const void*)dwconv_norm_planes_kernel<2, 32>, (const void*)dwconv_norm_planes_kernel<3, 32>,
+                              (const void*)dwconv_norm_planes_kernel<2, 64>, (const void*)dwconv_norm_planes_kernel<3, 64>};
+        for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) {
+            alive_set_error("alive_dwconv_norm_planes: cannot reserve LDS: %s", hipGetErrorString(e));
+            return ALIVE_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    dim3 g(cdiv(T, tw), N);
+#define LAUNCH_DNP(NP_, TW_)                                                                                                   \
+    dwconv_norm_planes_kernel<NP_, TW_><<<g, NPT, lds, (hipStream_t)stream>>>(X, C, T, dw_w, dw_b, dw_w != nullptr, affine_mode, gain, \
+                                                                             offset, cond, cond_rows, scale_row, shift_row, eps,  \
+                                                                             (unsigned short*)P, cols_pad)
+    if (planes == 2 && tw == 32) LAUNCH_DNP(2, 32);
+    else if (planes == 3 && tw == 32) LAUNCH_DNP(3, 32);
+    else if (planes == 2) LAUNCH_DNP(2, 64);
+    else LAUNCH_DNP(3, 64);
+#undef LAUNCH_DNP
+    ALIVE_CHECK_LAUNCH("alive_dwconv_norm_planes");
     return ALIVE_OK;
 }
 

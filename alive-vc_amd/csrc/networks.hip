@@ -153,13 +153,14 @@ int pw_gemm(const float* W, const float* b, const void* P, int N, int T, int Ci,
 // Pa / Ph: plane-packed scratch for the normalised input and the hidden layer (nullptr: fp32-activation path via hbuf)
 int convnext_layer(const ConvNeXtW& w, float* x, float* ybuf, float* hbuf, void* Pa, void* Ph, int N, int C, int H, int T,
                    const float* cond, int cond_rows, int scale_row, int shift_row, int planes, void* s) {
-    RUN(alive_dwconv_norm(x, N, C, T, w.dw_w, w.dw_b, cond ? 1 : 0, w.gain, w.offset, cond, cond_rows, scale_row,
-                          shift_row, NORM_EPS, ybuf, s));
     if (Pa != nullptr) {
-        RUN(alive_to_planes(ybuf, N, C, T, planes, Pa, s));
+        RUN(alive_dwconv_norm_planes(x, N, C, T, w.dw_w, w.dw_b, cond ? 1 : 0, w.gain, w.offset, cond, cond_rows, scale_row,
+                                     shift_row, NORM_EPS, planes, Pa, s));
         RUN(pw_gemm(w.pw1W, w.pw1b, Pa, N, T, C, H, planes, 1, nullptr, nullptr, nullptr, nullptr, Ph, s));
         return pw_gemm(w.pw2W, w.pw2b, Ph, N, T, H, C, planes, 0, nullptr, w.scale, x, x, nullptr, s);
     }
+    RUN(alive_dwconv_norm(x, N, C, T, w.dw_w, w.dw_b, cond ? 1 : 0, w.gain, w.offset, cond, cond_rows, scale_row,
+                          shift_row, NORM_EPS, ybuf, s));
     AliveConv d1 = pw_desc(w.pw1W, w.pw1b, ybuf, N, C, T, H, hbuf);
     d1.act = 1;
     d1 = planes == 3 ? split3(d1) : split(d1);
@@ -288,9 +289,14 @@ extern "C" int alive_f0_estimate(const float* const* w, const float* spec, int N
         RUN(convnext_layer(cw, b.x, b.y, b.h, b.Pa, b.Ph, N, PE_C, PE_H, T, nullptr, 0, 0, 0, 3, stream));
     }
     const float* g = t.next(); const float* of = t.next();
-    RUN(alive_channel_norm(b.x, N, PE_C, T, g, of, NORM_EPS, b.y, stream));
     const float* oW = t.next(); const float* ob = t.next();
-    RUN(pw_conv(oW, ob, b.y, b.Pa, N, T, PE_C, PE_OUT, 3, 0, nullptr, b.lg, stream));
+    if (b.Pa != nullptr) {
+        RUN(alive_dwconv_norm_planes(b.x, N, PE_C, T, nullptr, nullptr, 0, g, of, nullptr, 0, 0, 0, NORM_EPS, 3, b.Pa, stream));
+        RUN(pw_gemm(oW, ob, b.Pa, N, T, PE_C, PE_OUT, 3, 0, nullptr, nullptr, nullptr, b.lg, nullptr, stream));
+    } else {
+        RUN(alive_channel_norm(b.x, N, PE_C, T, g, of, NORM_EPS, b.y, stream));
+        RUN(pw_conv(oW, ob, b.y, b.Pa, N, T, PE_C, PE_OUT, 3, 0, nullptr, b.lg, stream));
+    }
     return alive_argmax_channels(b.lg, N, PE_OUT, T, f0, stream);
 }
 

@@ -59,6 +59,7 @@ PROTOTYPES = {
     "alive_filter_source_in": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "alive_filter_source_out": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP]),
     "alive_dwconv_norm": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP]),
+    "alive_dwconv_norm_planes": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _VP, _I, _I, _I, _F, _I, _VP, _VP]),
     "alive_channel_norm": (_I, [_VP, _I, _I, _I, _VP, _VP, _F, _VP, _VP]),
     "alive_argmax_channels": (_I, [_VP, _I, _I, _I, _VP, _VP]),
     "alive_oscillator_workspace_bytes": (_SZ, [_I, _I, _I]),

@@ -211,3 +211,15 @@ def filter_source_out(h, w, b):
     nat.check(nat.lib().alive_filter_source_out(nat.ptr(h), n, lw, nat.ptr(w), nat.ptr(b), nat.ptr(out), nat.stream()),
               "alive_filter_source_out")
     return out
+
+
+def dwconv_norm_planes(x, dw_w, dw_b, gain=None, offset=None, cond=None, scale_row=0, shift_row=0, eps=1e-4, planes=2):
+    """dw conv k7 (or none: dw_w=None) + (Adaptive)ChannelNorm, one pass, plane-packed output for gemm_planes"""
+    x = _f(x)
+    n, c, t = x.shape
+    dw_w, dw_b, gain, offset, cond = map(_f, (dw_w, dw_b, gain, offset, cond))
+    P = torch.empty(nat.lib().alive_planes_bytes(n * t, c, planes), dtype=torch.uint8, device=x.device)
+    nat.check(nat.lib().alive_dwconv_norm_planes(nat.ptr(x), n, c, t, nat.ptr(dw_w), nat.ptr(dw_b), 0 if cond is None else 1,
+                                                 nat.ptr(gain), nat.ptr(offset), nat.ptr(cond), 0 if cond is None else cond.shape[1],
+                                                 scale_row, shift_row, eps, planes, nat.ptr(P), nat.stream()), "alive_dwconv_norm_planes")
+    return P

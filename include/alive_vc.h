@@ -179,6 +179,12 @@ int alive_dwconv_norm(const float* X, int N, int C, int T, const float* dw_w, co
                       int affine_mode, const float* gain, const float* offset,
                       const float* cond, int cond_rows, int scale_row, int shift_row,
                       float eps, float* Y, void* stream);
+/* the same with plane-packed output for alive_gemm_planes (dw_w == dw_b == NULL: the norm alone); one pass over memory:
+ * the [C][64 columns] tile stays in LDS between the conv, the statistics, the affine and the split.  C a multiple of 32. */
+int alive_dwconv_norm_planes(const float* X, int N, int C, int T, const float* dw_w, const float* dw_b,
+                             int affine_mode, const float* gain, const float* offset,
+                             const float* cond, int cond_rows, int scale_row, int shift_row,
+                             float eps, int planes, void* P, void* stream);
 /* ChannelNorm alone (f0_estimator.py:25) */
 int alive_channel_norm(const float* X, int N, int C, int T, const float* gain, const float* offset,
                        float eps, float* Y, void* stream);

@@ -543,3 +543,24 @@ def test_conv1d_few_columns_any_geometry(co, ci, kw, stride, dil, pad, mode, tin
     assert y.shape == ref.shape
     e = relerr(y, ref)
     assert e < (2e-5 if prec == "bf16x3" else 5e-7), e
+
+
+@pytest.mark.parametrize("planes", [2, 3])
+@pytest.mark.parametrize("n,c,t,adaptive,dw", [(2, 512, 450, False, True), (3, 256, 130, False, True), (2, 512, 70, True, True),
+                                              (2, 256, 450, False, False)])
+def test_dwconv_norm_planes_single_pass(planes, n, c, t, adaptive, dw):
+    """dw conv + (Adaptive)ChannelNorm straight to planes == the fp32 kernel followed by alive_to_planes (common.py:20-41,55-56)"""
+    from module import ops
+    x = g(f"dnp{c}{t}", (n, c, t))
+    w, b = (g("dnpw", (c, 1, 7), scale=0.3), g("dnpb", (c,), scale=0.1)) if dw else (None, None)
+    gain, off = g("dnpg", (c,), scale=0.5) + 1.0, g("dnpo", (c,), scale=0.2)
+    cond = g("dnpc", (n, 2 * c + 5, t)) if adaptive else None
+    y = F.conv1d(x.double(), w.double(), b.double(), padding=3, groups=c) if dw else x.double()
+    mu, sd = y.mean(dim=1, keepdim=True), y.std(dim=1, keepdim=True) + 1e-4
+    ref = (y - mu) / sd
+    ref = ref * cond[:, 5:5 + c].double() + cond[:, 5 + c:5 + 2 * c].double() if adaptive else ref * gain.double().view(1, -1, 1) + off.double().view(1, -1, 1)
+    P = ops.dwconv_norm_planes(x.to(DEV), None if w is None else w.to(DEV), None if b is None else b.to(DEV),
+                               None if adaptive else gain.to(DEV), None if adaptive else off.to(DEV),
+                               cond.to(DEV) if adaptive else None, 5, 5 + c, planes=planes)
+    got = ops.planes_to_float(P, n, c, t, planes)
+    assert relerr(got, ref) < (1e-5 if planes == 2 else 2e-6)
