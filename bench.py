@@ -205,6 +205,24 @@ def main():
     roofline["achieved_uncorrelated_frames"] = round(2.0 * 768 * M * tt_frames / (a.elapsed_time(b) * 1e-3) / 1e12, 1)
     del rnd
 
+    # PCIe-inclusive rate (never `value`): the same step with the windows arriving from pinned host memory and the
+    # waveforms returned to it, as the CLI edge does (inference.py:88-94,134)
+    pcie = None
+    if rank == 0 and world == 1:
+        library.search = orig_search
+        host_in = windows.cpu().pin_memory()
+        host_out = torch.empty_like(host_in).pin_memory()
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(2):
+            wdev = host_in.to(dev, non_blocking=True)
+            host_out.copy_(conv.convert_windows(wdev, k=args.k, window_batch=args.window_batch), non_blocking=True)
+        torch.cuda.synchronize()
+        tp = (time.perf_counter() - tp) / 2
+        pcie = {"value": round(frames_per_step / tp, 1), "unit": "frames/s", "ms_per_step": round(tp * 1e3, 2),
+                "bytes_per_step": int(2 * host_in.numel() * 4)}
+        del host_in, host_out, wdev
+
     sharded = None
     if args.shard_library and world > 1:
         from module.sharded import bench_sharded_knn
@@ -236,6 +254,7 @@ def main():
             "rtf": round((dt / args.steps) / audio_s, 6),
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "pcie_inclusive": pcie,
         }
         if sharded is not None:
             line["sharded_knn"] = sharded
