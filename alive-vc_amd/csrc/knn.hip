@@ -444,6 +444,110 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
 }
 
 // ----------------------------------------------------------------------------------------------
+// a handful of frames (streaming): exact fp32 scan, no candidate stage
+// ----------------------------------------------------------------------------------------------
+// With Tt * k <= 64 (a ring of 8 .. 16 frames at k = 4) the bf16 scoring kernel would run one 256-frame block that is
+// 97 % padding, followed by a rescoring pass that walks 64 candidates per frame one after the other.  Here every wave
+// streams its share of the fp32 rows once, scores each row against ALL frames with the arithmetic of
+// knn_rescore_kernel (so the values are bitwise those of the batch path: divide by the norm, fmaf over d in the same
+// lane partition, xor-tree wave sum) and keeps the exact top-k of every frame in ONE register pair per lane:
+// lane = frame * k + slot, sorted descending, ties to the lower row.  A second kernel merges the per-wave lists.
+// HBM-bound: M * 3 KB once (154 MB at 50 k vectors).
+constexpr int64_t SCAN_ROWS_MAX = 262144; // beyond this the 3-KB fp32 rows cost more than the bf16 pass (1.5 KB) saves
+constexpr int SCAN_WAVES = 4;           // waves per block
+constexpr int SCAN_MAX_LISTS = 4096;    // total waves
+
+__global__ __launch_bounds__(64 * SCAN_WAVES) void knn_scan_kernel(const float* __restrict__ s_f32, const float* __restrict__ rows,
+                                                                   const float* __restrict__ norms, int64_t M, int Tt, int k,
+                                                                   float* __restrict__ part_val, int* __restrict__ part_idx) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gw = blockIdx.x * SCAN_WAVES + wv, nw = gridDim.x * SCAN_WAVES;
+    const int my_t = lane / k;                       // lane = frame * k + slot (lanes >= Tt * k idle)
+    const bool live = lane < Tt * k;
+    float lv = -INFINITY;
+    int li = 0x7fffffff;
+    for (int64_t r = gw; r < M; r += nw) {
+        const f32x4* rp = (const f32x4*)(rows + (size_t)r * D);
+        const float nn = norms[r];
+        f32x4 q0 = rp[lane], q1 = rp[lane + 64], q2 = rp[lane + 128];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { q0[j] = q0[j] / nn; q1[j] = q1[j] / nn; q2[j] = q2[j] / nn; }
+        float p = -INFINITY;                             // the score of this lane's frame (the wave sum is lane-uniform)
+        for (int t = 0; t < Tt; ++t) {
+            const f32x4* sp = (const f32x4*)(s_f32 + (size_t)t * D);
+            const f32x4 s0 = sp[lane], s1 = sp[lane + 64], s2 = sp[lane + 128];
+            float d = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d = fmaf(s0[j], q0[j], d);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d = fmaf(s1[j], q1[j], d);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d = fmaf(s2[j], q2[j], d);
+            d = wave_sum(d);
+            if (live && t == my_t) p = d;
+        }
+        // sorted insert inside the k lanes of this frame: entries that rank before (p, r) stay, the others move down one
+        const bool before = lv > p || (lv == p && li < (int)r);
+        const float up_v = __shfl_up(lv, 1);
+        const int up_i = __shfl_up(li, 1);
+        const bool up_before = (lane % k == 0) ? true : (up_v > p || (up_v == p && up_i < (int)r));
+        if (live && !before) {
+            lv = up_before ? p : up_v;
+            li = up_before ? (int)r : up_i;
+        }
+    }
+    part_val[(size_t)gw * 64 + lane] = lv;
+    part_idx[(size_t)gw * 64 + lane] = li;
+}
+
+// one block per frame: merge nw partial lists of k entries -> exact top-k (descending, ties to the lower row)
+__global__ __launch_bounds__(256) void knn_scan_merge_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx,
+                                                             int nw, int k, int64_t idx_base, float* __restrict__ out_val,
+                                                             int* __restrict__ out_idx) {
+    __shared__ float sv[256];
+    __shared__ int si[256], sw[256];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    // every thread owns the lists of waves tid, tid + 256, ...: a cursor per list is not needed because each list is
+    // sorted -- the thread's best remaining candidate is found by scanning its few (<= 16) lists' heads
+    int head[SCAN_MAX_LISTS / 256];
+#pragma unroll
+    for (int i = 0; i < SCAN_MAX_LISTS / 256; ++i) head[i] = 0;
+    for (int j = 0; j < k; ++j) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff, bl = -1;
+#pragma unroll
+        for (int i = 0; i < SCAN_MAX_LISTS / 256; ++i) {
+            const int w = tid + 256 * i;
+            if (w < nw && head[i] < k) {
+                const float v = part_val[(size_t)w * 64 + t * k + head[i]];
+                const int id = part_idx[(size_t)w * 64 + t * k + head[i]];
+                if (v > bv || (v == bv && id < bi)) { bv = v; bi = id; bl = i; }
+            }
+        }
+        sv[tid] = bv; si[tid] = bi; sw[tid] = tid;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) {
+                const float ov = sv[tid + o];
+                const int oi = si[tid + o];
+                if (ov > sv[tid] || (ov == sv[tid] && oi < si[tid])) { sv[tid] = ov; si[tid] = oi; sw[tid] = sw[tid + o]; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            out_val[(size_t)t * k + j] = sv[0];
+            out_idx[(size_t)t * k + j] = (si[0] == 0x7fffffff || !(sv[0] > -INFINITY)) ? -1 : (int)(idx_base + si[0]);
+        }
+        if (sw[0] == tid && bl >= 0) {
+#pragma unroll
+            for (int i = 0; i < SCAN_MAX_LISTS / 256; ++i)
+                if (i == bl) head[i]++;
+        }
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // merge shards + gather + mean + blend.  Block = 32 consecutive frames of one window.
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void knn_merge_gather_kernel(const float* __restrict__ cand_val,
@@ -481,7 +585,7 @@ __global__ __launch_bounds__(256) void knn_merge_gather_kernel(const float* __re
             int wi = __shfl(bi, win);
             if (lane == 0) {
                 sel[f][j] = wi;
-                if (final_idx != nullptr) final_idx[(size_t)ft * k + j] = wi;
+                if (final_idx != nullptr && blockIdx.z == 0) final_idx[(size_t)ft * k + j] = wi;
             }
             if (lane == win) {
                 if (second) v[1] = -INFINITY; else v[0] = -INFINITY;
@@ -490,8 +594,10 @@ __global__ __launch_bounds__(256) void knn_merge_gather_kernel(const float* __re
     }
     __syncthreads();
 
-    // phase 2: 64-feature slabs; gather (lane = feature), transpose through LDS, store (lane = frame)
-    for (int d0 = 0; d0 < D; d0 += 64) {
+    // phase 2: 64-feature slabs; gather (lane = feature), transpose through LDS, store (lane = frame).
+    // gridDim.z == 1: this block walks all 12 slabs; gridDim.z == 12 (few frames: streaming): one slab per block
+    const int d_begin = gridDim.z == 1 ? 0 : blockIdx.z * 64, d_end = gridDim.z == 1 ? D : d_begin + 64;
+    for (int d0 = d_begin; d0 < d_end; d0 += 64) {
         for (int f = wv; f < nf; f += 4) {
             float acc = 0.0f;
             for (int j = 0; j < k; ++j) {
@@ -569,6 +675,7 @@ extern "C" size_t alive_knn_workspace_bytes(int64_t Tt, int64_t M) {
     b += align_up((size_t)Tt * D * 4, 256);                        // s_f32
     b += align_up((size_t)p.Tt_pad * D * 2, 256);                  // s_bf16
     b += 2 * align_up((size_t)p.Tt_pad * p.P * KP * 4, 256);       // candidate lists
+    b += 2 * align_up((size_t)SCAN_MAX_LISTS * 64 * 4, 256);       // partial lists of the small-T scan
     return b + 1024;
 }
 
@@ -585,7 +692,21 @@ extern "C" int alive_knn_search(const float* src, int N, int T, const void* lib_
     unsigned short* s_bf16 = a.take<unsigned short>((size_t)p.Tt_pad * D);
     float* cv = a.take<float>((size_t)p.Tt_pad * p.P * KP);
     int* ci = a.take<int>((size_t)p.Tt_pad * p.P * KP);
+    float* pv = a.take<float>((size_t)SCAN_MAX_LISTS * 64);
+    int* pi = a.take<int>((size_t)SCAN_MAX_LISTS * 64);
     hipStream_t s = (hipStream_t)stream;
+    if (p.Tt * k <= 64 && M <= SCAN_ROWS_MAX) {        // a handful of frames: exact fp32 scan of the rows, no candidate stage
+        src_prep_small_kernel<<<(unsigned)p.Tt, 256, 0, s>>>(src, T, p.Tt, s_f32, s_bf16);
+        int blocks = (int)((M + 4 * SCAN_WAVES - 1) / (4 * SCAN_WAVES));          // >= 4 rows per wave
+        if (blocks > SCAN_MAX_LISTS / SCAN_WAVES) blocks = SCAN_MAX_LISTS / SCAN_WAVES;
+        if (blocks < 1) blocks = 1;
+        if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
+        knn_scan_kernel<<<blocks, 64 * SCAN_WAVES, 0, s>>>(s_f32, rows_f32, norms, M, (int)p.Tt, k, pv, pi);
+        if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
+        knn_scan_merge_kernel<<<(unsigned)p.Tt, 256, 0, s>>>(pv, pi, blocks * SCAN_WAVES, k, idx_base, out_val, out_idx);
+        ALIVE_CHECK_LAUNCH("alive_knn_search(scan)");
+        return ALIVE_OK;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)knn_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_LDS);
@@ -620,7 +741,9 @@ extern "C" int alive_knn_merge_gather(const float* cand_val, const int32_t* cand
     ALIVE_CHECK_ARG(k >= 1 && k <= ALIVE_MAX_K && n_shards >= 1 && n_shards * k <= 128,
                     "alive_knn_merge_gather: n_shards*k = %d exceeds 128", n_shards * k);
     ALIVE_CHECK_ARG(N > 0 && T > 0, "alive_knn_merge_gather: empty source");
-    knn_merge_gather_kernel<<<dim3(cdiv(T, 32), N), 256, 0, (hipStream_t)stream>>>(
+    // with only a few blocks of frames the 12 feature slabs go to separate blocks (streaming: 1 block -> 12)
+    const int zs = (int64_t)cdiv(T, 32) * N < 64 ? D / 64 : 1;
+    knn_merge_gather_kernel<<<dim3(cdiv(T, 32), N, zs), 256, 0, (hipStream_t)stream>>>(
         cand_val, cand_idx, n_shards, k, (float)alpha, (float)(1.0 - alpha), rows_f32_full, src, T, (int64_t)N * T, out,
         final_idx);
     ALIVE_CHECK_LAUNCH("alive_knn_merge_gather");
