@@ -39,6 +39,104 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(unsigned, h);
 }
 
+// ---- epilogue, straight from the accumulators (shared by the one-tile and the persistent kernel) ----
+template <int NP, int ACT>
+__device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[2][2], int m0, int64_t c0, int wr, int wc, int lr,
+                                              int lh, int64_t cols, int64_t cols_pad, int co_pad32) {
+    // A lane holds, per 32 x 32 tile, one column and 16 rows in 4 groups of 4 consecutive rows (8 g + 4 lh + e).
+    // Offsets are 32-bit (checked on the host) against uniform bases; per-row vectors (bias, post_add, ch_scale) come
+    // as clamped loads, and all residual values of a 32-row half are requested before its first store (Y may alias the
+    // residual, so the compiler may not hoist them).  Tiles that lie completely inside Co take the store path without
+    // per-row tests.
+    unsigned obase[2];
+    bool cok[2];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        const int64_t col = c0 + wc * 64 + tj * 32 + lr;
+        cok[tj] = col < cols;
+        const int64_t n = cok[tj] ? col / p.T : 0;
+        obase[tj] = (unsigned)(n * p.Co * p.T + (cok[tj] ? col - n * p.T : 0));
+    }
+    const bool full_rows = m0 + GM <= p.Co;            // block-uniform
+    const float* __restrict__ bias = p.bias;
+    const float* __restrict__ post_add = p.post_add;
+    const float* __restrict__ ch_scale = p.ch_scale;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int rbase = m0 + wr * 64 + ti * 32 + 4 * lh;
+        float bia[4][4], pad[4][4], scl[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int row = rbase + 8 * g + e;
+                row = row < p.Co ? row : p.Co - 1;
+                bia[g][e] = bias != nullptr ? bias[row] : 0.0f;
+                pad[g][e] = post_add != nullptr ? post_add[row] : 0.0f;
+                scl[g][e] = ch_scale != nullptr ? ch_scale[row] : 1.0f;
+            }
+        float res[2][16];
+        if (p.residual != nullptr) {
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = rbase + (r & 3) + 8 * (r >> 2);
+                    row = row < p.Co ? row : p.Co - 1;
+                    res[tj][r] = p.residual[obase[tj] + (unsigned)(row * p.T)];
+                }
+        }
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            float vv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = acc[ti][tj][r] + bia[r >> 2][r & 3];
+                if (ACT == 1) x = gelu_fast(x);
+                else if (ACT == 2) x = expf(x);
+                x = (x + pad[r >> 2][r & 3]) * scl[r >> 2][r & 3];
+                if (p.residual != nullptr) x += res[tj][r];
+                vv[r] = x;
+            }
+            if (p.Y != nullptr && cok[tj]) {
+                if (full_rows) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        p.Y[obase[tj] + (unsigned)((rbase + (r & 3) + 8 * (r >> 2)) * p.T)] = vv[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + (r & 3) + 8 * (r >> 2);
+                        if (row < p.Co) p.Y[obase[tj] + (unsigned)(row * p.T)] = vv[r];
+                    }
+                }
+            }
+            if (p.Pout != nullptr && cok[tj]) {
+                // plane-packed output for the next GEMM: 4 consecutive channels of one column -> 8 B per plane
+                unsigned short* Po = (unsigned short*)p.Pout;
+                const int64_t col = c0 + wc * 64 + tj * 32 + lr;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = rbase + 8 * g;
+                    if (row >= co_pad32) continue;
+                    float q[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) q[e] = (full_rows || row + e < p.Co) ? vv[4 * g + e] : 0.0f;
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) {
+                        const unsigned h01 = pack_bf16x2(q[0], q[1]), h23 = pack_bf16x2(q[2], q[3]);
+                        *(uint2*)(Po + ((size_t)pl * cols_pad + col) * co_pad32 + row) = make_uint2(h01, h23);
+                        q[0] -= __uint_as_float(h01 << 16);
+                        q[1] -= __uint_as_float(h01 & 0xffff0000u);
+                        q[2] -= __uint_as_float(h23 << 16);
+                        q[3] -= __uint_as_float(h23 & 0xffff0000u);
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int NP, int NS, int MINB, int ACT>
 __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int n_mt, int ntiles, int64_t cols,
                                                              int64_t cols_pad, int co_pad, int co_pad32, int kpad,
@@ -177,99 +275,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
     const long long ts3 = wall_clock64();
 #endif
 
-    // ---- epilogue, straight from the accumulators ----
-    // A lane holds, per 32 x 32 tile, one column and 16 rows in 4 groups of 4 consecutive rows (8 g + 4 lh + e).
-    // Offsets are 32-bit (checked on the host) against uniform bases; per-row vectors (bias, post_add, ch_scale) come
-    // as clamped loads, and all residual values of a 32-row half are requested before its first store (Y may alias the
-    // residual, so the compiler may not hoist them).  Tiles that lie completely inside Co take the store path without
-    // per-row tests.
-    unsigned obase[2];
-    bool cok[2];
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
-        const int64_t col = c0 + wc * 64 + tj * 32 + lr;
-        cok[tj] = col < cols;
-        const int64_t n = cok[tj] ? col / p.T : 0;
-        obase[tj] = (unsigned)(n * p.Co * p.T + (cok[tj] ? col - n * p.T : 0));
-    }
-    const bool full_rows = m0 + GM <= p.Co;            // block-uniform
-    const float* __restrict__ bias = p.bias;
-    const float* __restrict__ post_add = p.post_add;
-    const float* __restrict__ ch_scale = p.ch_scale;
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-        const int rbase = m0 + wr * 64 + ti * 32 + 4 * lh;
-        float bia[4][4], pad[4][4], scl[4][4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                int row = rbase + 8 * g + e;
-                row = row < p.Co ? row : p.Co - 1;
-                bia[g][e] = bias != nullptr ? bias[row] : 0.0f;
-                pad[g][e] = post_add != nullptr ? post_add[row] : 0.0f;
-                scl[g][e] = ch_scale != nullptr ? ch_scale[row] : 1.0f;
-            }
-        float res[2][16];
-        if (p.residual != nullptr) {
-#pragma unroll
-            for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int row = rbase + (r & 3) + 8 * (r >> 2);
-                    row = row < p.Co ? row : p.Co - 1;
-                    res[tj][r] = p.residual[obase[tj] + (unsigned)(row * p.T)];
-                }
-        }
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj) {
-            float vv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float x = acc[ti][tj][r] + bia[r >> 2][r & 3];
-                if (ACT == 1) x = gelu_fast(x);
-                else if (ACT == 2) x = expf(x);
-                x = (x + pad[r >> 2][r & 3]) * scl[r >> 2][r & 3];
-                if (p.residual != nullptr) x += res[tj][r];
-                vv[r] = x;
-            }
-            if (p.Y != nullptr && cok[tj]) {
-                if (full_rows) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        p.Y[obase[tj] + (unsigned)((rbase + (r & 3) + 8 * (r >> 2)) * p.T)] = vv[r];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = rbase + (r & 3) + 8 * (r >> 2);
-                        if (row < p.Co) p.Y[obase[tj] + (unsigned)(row * p.T)] = vv[r];
-                    }
-                }
-            }
-            if (p.Pout != nullptr && cok[tj]) {
-                // plane-packed output for the next GEMM: 4 consecutive channels of one column -> 8 B per plane
-                unsigned short* Po = (unsigned short*)p.Pout;
-                const int64_t col = c0 + wc * 64 + tj * 32 + lr;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int row = rbase + 8 * g;
-                    if (row >= co_pad32) continue;
-                    float q[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) q[e] = (full_rows || row + e < p.Co) ? vv[4 * g + e] : 0.0f;
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) {
-                        const unsigned h01 = pack_bf16x2(q[0], q[1]), h23 = pack_bf16x2(q[2], q[3]);
-                        *(uint2*)(Po + ((size_t)pl * cols_pad + col) * co_pad32 + row) = make_uint2(h01, h23);
-                        q[0] -= __uint_as_float(h01 << 16);
-                        q[1] -= __uint_as_float(h01 & 0xffff0000u);
-                        q[2] -= __uint_as_float(h23 << 16);
-                        q[3] -= __uint_as_float(h23 & 0xffff0000u);
-                    }
-                }
-            }
-        }
-    }
+    gemm_epilogue<NP, ACT>(p, acc, m0, c0, wr, wc, lr, lh, cols, cols_pad, co_pad32);
 #ifdef ALIVE_STAMPS
     if (stamps != nullptr && tid == 0) {
         long long* o = stamps + (size_t)blockIdx.x * 8;
@@ -277,6 +283,162 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
         o[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
     }
 #endif
+}
+
+// ---- persistent form: one block per CU walks its tiles with the DMA ring running ACROSS the tile seams ----
+// In the one-tile kernel a block spends 3 us issuing its first stages and 7 us in its epilogue next to 12 - 22 us of
+// k-steps (in-kernel stamps), with nothing else resident on the CU at NP = 3.  Here the refill of step s
+// targets step s + NS of the SAME stream: once a tile's last steps are reached, the pieces come from the next tile, so
+// that tile's first NS stages land under this tile's epilogue and the next main loop starts on landed data.
+// Waits stay counted: before the epilogue the wave waits for stage 0 of the next tile (its loads / stores are not issued
+// yet), afterwards a wait is only ever conservative (older stores still in flight make it wait for more DMA stages,
+// never fewer).  Needs nsteps >= NS.
+template <int NP, int NS, int ACT>
+__global__ __launch_bounds__(256, 1) void gemm_planes_persistent_kernel(AliveGemm p, int n_mt, int ntiles, int64_t cols,
+                                                                        int64_t cols_pad, int co_pad, int co_pad32, int kpad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int SLOT = 2 * NP * PLANE_BYTES;
+    constexpr int NI = 4 * NP;
+    constexpr int NPROD = NP * (NP + 1) / 2;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int nsteps = kpad / GK;
+
+    // tiles of this block: the XCD's contiguous chunk of the (column tile, row tile) order, strided by the XCD's blocks
+    int v, v_end;
+    const int v_stride = gridDim.x >> 3;
+    {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, q = ntiles >> 3, r = ntiles & 7;
+        const int beg = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        v_end = beg + q + (xcd < r ? 1 : 0);
+        v = beg + j;
+    }
+    if (v >= v_end) return;
+
+    // ---- DMA geometry: piece q = w + 4 i  ->  (operand, plane, 16-row group); byte offsets from W / P ----
+    const int prow = lane >> 2;
+    const int pchunk = (lane & 3) ^ ((prow >> 2) & 3);
+    int ldst[NI];
+    bool isB[NI];
+    unsigned off[2][NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int q = w + 4 * i;
+        isB[i] = q / (8 * NP) != 0;
+        ldst[i] = ((isB[i] ? NP : 0) + (q % (8 * NP)) / 8) * PLANE_BYTES + (q % 8) * 1024;
+    }
+    auto tile_offsets = [&](int tv, unsigned (&o)[NI]) {
+        const int mt = tv % n_mt;
+        const int64_t c0 = (int64_t)(tv / n_mt) * GN;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int q = w + 4 * i;
+            const int pl = (q % (8 * NP)) / 8, r = (q % 8) * 16 + prow;
+            if (!isB[i]) {
+                int row = mt * GM + r;
+                row = row < co_pad ? row : co_pad - 1;
+                o[i] = (unsigned)((((size_t)pl * co_pad + row) * kpad + pchunk * 8) * 2);
+            } else {
+                int64_t col = c0 + r;
+                col = col < cols_pad ? col : cols_pad - 1;
+                o[i] = (unsigned)((((size_t)pl * cols_pad + col) * kpad + pchunk * 8) * 2);
+            }
+        }
+    };
+    // stream element = (tile parity `which`, step); slot = running step count mod NS
+    auto issue = [&](int which, int step, int slot, int i) {
+        const unsigned char* base = isB[i] ? (const unsigned char*)p.P : (const unsigned char*)p.W;
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + off[which][i] + step * (GK * 2)), (lptr_t)(smem + slot * SLOT + ldst[i]), 16, 0, 0);
+    };
+
+    const int sw = (lr >> 2) & 3;
+    const int a_off = (wr * 64 + lr) * 64 + ((lh ^ sw) << 4);
+    const int b_off = NP * PLANE_BYTES + (wc * 64 + lr) * 64 + ((lh ^ sw) << 4);
+    bf16x8 fa[2][2][NP], fb[2][2][NP];
+    auto load_frags = [&](int slot, int ks, bf16x8 (&a)[2][NP], bf16x8 (&b)[2][NP]) {
+        const unsigned char* S = smem + slot * SLOT;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                a[t][pl] = *(const bf16x8*)(S + ((a_off + t * 2048) ^ (ks << 5)) + pl * PLANE_BYTES);
+                b[t][pl] = *(const bf16x8*)(S + ((b_off + t * 2048) ^ (ks << 5)) + pl * PLANE_BYTES);
+            }
+    };
+    f32x16 acc[2][2];
+    auto mma = [&](bf16x8 (&a)[2][NP], bf16x8 (&b)[2][NP], auto&& hook) {
+        int n = 0;
+#pragma unroll
+        for (int sum = NP - 1; sum >= 0; --sum)
+#pragma unroll
+            for (int i = 0; i <= sum; ++i) {
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj)
+                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][i], b[tj][sum - i], acc[ti][tj], 0, 0, 0);
+                hook(n++);
+            }
+    };
+
+    int cur = 0, qb = 0;                     // tile parity of off[], slot of the current tile's step 0
+    tile_offsets(v, off[0]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) issue(0, s, s, i);
+    wait_vmcnt<(NS - 1) * NI>();             // stage 0 of the first tile (this wave's pieces)
+
+    while (true) {
+        const int vn = v + v_stride;
+        const bool has_next = vn < v_end;
+        if (has_next) tile_offsets(vn, off[cur ^ 1]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0.0f; acc[i][1][r] = 0.0f; }
+        __builtin_amdgcn_s_barrier();        // every wave's stage-0 pieces have landed (and its epilogue is done)
+        load_frags(qb, 0, fa[0], fb[0]);
+
+        for (int s = 0; s < nsteps; ++s) {
+            const int slot = (qb + s) % NS;
+            const int slot1 = slot + 1 == NS ? 0 : slot + 1;
+            mma(fa[0], fb[0], [&](int n) {
+                if (n == 0) load_frags(slot, 1, fa[1], fb[1]);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            wait_lgkmcnt0();
+            // stage s + 1 must have landed; NS - 2 younger stages stay in flight while the stream goes on
+            if (s + NS - 1 < nsteps || has_next) wait_vmcnt<(NS - 2) * NI>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (s + 1 < nsteps) load_frags(slot1, 0, fa[0], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            // the slot of step s is free: refill it with stream element s + NS (this tile's, or the next tile's first steps)
+            const int ts = s + NS;
+            const bool in_tile = ts < nsteps;
+            const bool refill = in_tile || has_next;
+            const int rwhich = in_tile ? cur : (cur ^ 1), rstep = in_tile ? ts : ts - nsteps;
+            mma(fa[1], fb[1], [&](int n) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    if (i * NPROD / NI == n && refill) issue(rwhich, rstep, slot, i);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // stage 0 of the next tile before this tile's loads / stores enter the counter
+        if (has_next) wait_vmcnt<(NS - 1) * NI>(); else wait_vmcnt<0>();
+        {
+            const int mt = v % n_mt;
+            gemm_epilogue<NP, ACT>(p, acc, mt * GM, (int64_t)(v / n_mt) * GN, wr, wc, lr, lh, cols, cols_pad, co_pad32);
+        }
+        if (!has_next) break;
+        v = vn;
+        cur ^= 1;
+        qb = (qb + nsteps) % NS;
+    }
 }
 
 // fp32 [N][C][T] -> planes [NP][cols_pad][C_pad] (zero padded in both directions)
@@ -352,6 +514,34 @@ int launch_gemm_act(const AliveGemm& d, hipStream_t s) {
     return ALIVE_OK;
 }
 
+template <int NP, int NS, int ACT>
+int launch_gemm_persistent_act(const AliveGemm& d, hipStream_t s) {
+    constexpr int LDS = NS * 2 * NP * PLANE_BYTES;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_planes_persistent_kernel<NP, NS, ACT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            alive_set_error("alive_gemm_planes: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return ALIVE_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    const int64_t cols = (int64_t)d.N * d.T;
+    const int n_mt = cdiv(d.Co, GM), n_ct = cdiv(cols, GN);
+    gemm_planes_persistent_kernel<NP, NS, ACT><<<256, 256, LDS, s>>>(d, n_mt, n_mt * n_ct, cols, pad_cols(cols), (d.Co + 15) & ~15,
+                                                                   pad32(d.Co), pad32(d.Ci));
+    ALIVE_CHECK_LAUNCH("alive_gemm_planes(persistent)");
+    return ALIVE_OK;
+}
+
+template <int NP, int NS>
+int launch_gemm_persistent(const AliveGemm& d, hipStream_t s) {
+    if (d.act == 1) return launch_gemm_persistent_act<NP, NS, 1>(d, s);
+    if (d.act == 2) return launch_gemm_persistent_act<NP, NS, 2>(d, s);
+    return launch_gemm_persistent_act<NP, NS, 0>(d, s);
+}
+
 template <int NP, int NS, int MINB>
 int launch_gemm(const AliveGemm& d, hipStream_t s) {
     if (d.act == 1) return launch_gemm_act<NP, NS, MINB, 1>(d, s);
@@ -390,7 +580,16 @@ extern "C" int alive_gemm_planes(const AliveGemm* d, void* stream) {
     ALIVE_CHECK_ARG((d->Y == nullptr) != (d->Pout == nullptr), "alive_gemm_planes: exactly one of Y / Pout");
     ALIVE_CHECK_ARG((int64_t)d->N * d->Co * d->T < (1ll << 30), "alive_gemm_planes: fp32 tensor of %lld elements exceeds the 32-bit offsets",
                     (long long)d->N * d->Co * d->T);
+    // variants (A/B switch for tools/bench_gemm_planes.py): 0 = default, 1 = one-tile kernels only, 2 = persistent for both
     static const int variant = getenv("ALIVE_GEMM_VARIANT") ? atoi(getenv("ALIVE_GEMM_VARIANT")) : 0;
-    if (d->planes == 2) return variant == 1 ? launch_gemm<2, 4, 1>(*d, (hipStream_t)stream) : launch_gemm<2, 2, 2>(*d, (hipStream_t)stream);
+    const int64_t ntiles = (int64_t)cdiv(d->Co, GM) * cdiv((int64_t)d->N * d->T, GN);
+    const int nsteps = pad32(d->Ci) / GK;
+    const bool can_persist = ntiles >= 1024 && variant != 1 &&      // >= 4 tiles per CU, else the seams buy nothing
+                             (int64_t)d->planes * pad_cols((int64_t)d->N * d->T) * pad32(d->Ci) * 2 < (1ll << 32);   // 32-bit DMA offsets
+    if (d->planes == 2) {
+        if (can_persist && variant == 2 && nsteps >= 4) return launch_gemm_persistent<2, 4>(*d, (hipStream_t)stream);
+        return launch_gemm<2, 2, 2>(*d, (hipStream_t)stream);
+    }
+    if (can_persist && nsteps >= 3) return launch_gemm_persistent<3, 3>(*d, (hipStream_t)stream);
     return launch_gemm<3, 3, 1>(*d, (hipStream_t)stream);
 }

@@ -411,6 +411,8 @@ def test_to_planes_roundtrip(planes, n, c, t):
     (4096, 256, 2, 200),      # f0 logits, K = 256 (8 steps)
     (40, 24, 3, 50),          # K = 32: a single step, fewer than the ring depth
     (256, 64, 1, 129),        # two steps
+    (4096, 256, 10, 450),     # 1152 tiles: the persistent kernel (DMA ring running across the tile seams), ragged last column tile
+    (1536, 512, 24, 450),     # 1020 / 1032 tiles around the persistence threshold
 ])
 def test_gemm_planes_vs_float64(planes, tol, co, ci, n, t):
     from module import ops
