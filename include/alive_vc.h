@@ -33,7 +33,9 @@ extern "C" {
 
 #define ALIVE_DIM 768          /* content feature width (voice_library.py:7) */
 #define ALIVE_KPRIME 16        /* bf16 candidates kept per partial list       */
-#define ALIVE_MAX_K 16         /* largest k accepted by the kNN entry points  */
+#define ALIVE_MAX_K 8          /* largest k accepted by the kNN entry points: the scoring kernel keeps two
+                                * lane-private half-lists of 8 bf16 candidates per frame and library split, and all
+                                * k true neighbours may fall into one of them                                  */
 
 const char* alive_last_error(void);
 int alive_version(void);
