@@ -30,6 +30,14 @@ def stitch(window_out, total, chunk=48000):
     return window_out[:, chunk:2 * chunk].reshape(1, -1)[:, :total]
 
 
+# Frames of the matched features that can reach an output frame t through the decoder (module/decoder.py of the
+# reference): the FeatureExtractor is four k7 depthwise convs (+-12 frames); the Filter is causal -- mid conv 4 frames,
+# the 256 / 64 / 16 / 8-channel blocks 56 columns each at 32 / 4 / 2 / 1 samples (6.7 frames together) -- and reads FiLM
+# / amplitudes interpolated from the neighbouring frames (+-1); source_in / source_out add 3 samples either side.
+# => features [t - 24, t + 13].  The margins below leave slack and are checked bitwise by the tests.
+TRIM_LEFT, TRIM_RIGHT = 32, 16
+
+
 class Converter:
     def __init__(self, content_encoder: ContentEncoder, f0_estimator: F0Estimator, decoder: Decoder, device="cuda"):
         self.device = torch.device(device)
@@ -52,10 +60,14 @@ class Converter:
         val, idx = self.library.search(feat, k)
         return merge_gather(val, idx, 1, k, alpha, self.library.rows, feat)
 
-    def convert_windows(self, windows, k=4, alpha=0.0, pitch_shift=0.0, intonation=1.0, f0_rate=1.0, window_batch=64):
+    def convert_windows(self, windows, k=4, alpha=0.0, pitch_shift=0.0, intonation=1.0, f0_rate=1.0, window_batch=64,
+                        keep_frames=None):
         """windows [n, L] on the device -> waveforms [n, L]; L a multiple of 320.
         Networks run in batches of `window_batch` windows (bounded scratch); the kNN match runs ONCE over the frames
-        of all windows, so every library tile streamed from L2 is used by as many frames as possible."""
+        of all windows, so every library tile streamed from L2 is used by as many frames as possible.
+        keep_frames = (a, b): the caller keeps only the output of frames [a, b) of every window (inference.py keeps the
+        centre third).  The match is then restricted to the frames that can reach them through the decoder; the kept
+        samples are bitwise the same as without it (the other frames of the window decode from unmatched features)."""
         n, L = windows.shape
         lf = L // 320
         feat = torch.empty(n, 768, lf, device=windows.device)
@@ -63,13 +75,19 @@ class Converter:
         for i in range(0, n, window_batch):
             feat[i:i + window_batch], f0[i:i + window_batch] = self.features(windows[i:i + window_batch], pitch_shift,
                                                                            intonation, f0_rate)
-        feat = self.match(feat, k, alpha)
+        if keep_frames is None:
+            feat = self.match(feat, k, alpha)
+        else:
+            lo, hi = max(0, keep_frames[0] - TRIM_LEFT), min(lf, keep_frames[1] + TRIM_RIGHT)
+            feat[:, :, lo:hi] = self.match(feat[:, :, lo:hi].contiguous(), k, alpha)
         out = torch.empty_like(windows)
         for i in range(0, n, window_batch):
             out[i:i + window_batch], _ = self.dec(feat[i:i + window_batch], f0[i:i + window_batch])
         return out
 
-    def convert(self, wf, chunk=48000, **kw):
-        """one utterance: wf [1, L] at 16 kHz (already normalised / mono) -> [1, L]"""
+    def convert(self, wf, chunk=48000, trim_context=False, **kw):
+        """one utterance: wf [1, L] at 16 kHz (already normalised / mono) -> [1, L].
+        trim_context: match only the frames that can reach the kept centre third (same samples, ~44 % of the kNN work)"""
         windows, total = make_windows(wf.to(self.device), chunk)
-        return stitch(self.convert_windows(windows, **kw), total, chunk)
+        keep = (chunk // 320, 2 * chunk // 320) if trim_context else None
+        return stitch(self.convert_windows(windows, keep_frames=keep, **kw), total, chunk)

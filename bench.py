@@ -205,6 +205,26 @@ def main():
     roofline["achieved_uncorrelated_frames"] = round(2.0 * 768 * M * tt_frames / (a.elapsed_time(b) * 1e-3) / 1e12, 1)
     del rnd
 
+    # Optional mode of the build, reported beside the headline and never as `value`: inference.py keeps the centre third of
+    # every window, so only the frames that can reach it through the decoder need the kNN match (Converter(keep_frames=...),
+    # `--trim-context`).  The kept samples are bitwise those of the full computation (asserted here on the whole batch).
+    trim = None
+    if rank == 0 and world == 1:
+        library.search = orig_search
+        cf = (L // FRAME) // 3
+        ref_out = out[:, cf * FRAME:2 * cf * FRAME].clone()
+        torch.cuda.synchronize()
+        tt0 = time.perf_counter()
+        for _ in range(2):
+            out_t = conv.convert_windows(windows, k=args.k, window_batch=args.window_batch, keep_frames=(cf, 2 * cf))
+        torch.cuda.synchronize()
+        tt0 = (time.perf_counter() - tt0) / 2
+        assert torch.equal(out_t[:, cf * FRAME:2 * cf * FRAME], ref_out), "context trim changed kept samples"
+        trim = {"ms_per_step": round(tt0 * 1e3, 2), "windows_per_s": round(n_win / tt0, 1),
+                "useful_frames_per_s": round(useful_frames / tt0, 1), "kept_samples_bitwise_equal": True,
+                "note": "kNN match restricted to frames [cf-32, 2cf+16) of each window; every other stage unchanged"}
+        del out_t, ref_out
+
     # PCIe-inclusive rate (never `value`): the same step with the windows arriving from pinned host memory and the
     # waveforms returned to it, as the CLI edge does (inference.py:88-94,134)
     pcie = None
@@ -255,6 +275,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "pcie_inclusive": pcie,
+            "context_trim": trim,
         }
         if sharded is not None:
             line["sharded_knn"] = sharded

@@ -153,3 +153,19 @@ def test_batch_invariance_of_the_networks(nets):
     for i in (0, 2):
         w1, _ = dec(feats[i:i + 1].contiguous(), f0=f0[i:i + 1].contiguous())
         assert torch.equal(w1, wave[i:i + 1])
+
+
+def test_context_trim_keeps_the_centre_third_bitwise(nets):
+    """inference.py keeps the centre third of every window: matching only the frames that can reach it through the
+    decoder must not change a single kept sample"""
+    from module.pipeline import Converter, make_windows, stitch
+    ce, pe, dec, _ = nets
+    conv = Converter(ce, pe, dec, DEV).set_library(synthetic.make_library(3000, 9).to(DEV))
+    wf = (0.3 * synthetic.make_waveform(16000 * 7, 41)).to(DEV)
+    full = conv.convert(wf, chunk=48000, k=4, alpha=0.1)
+    trimmed = conv.convert(wf, chunk=48000, k=4, alpha=0.1, trim_context=True)
+    assert torch.equal(full, trimmed)
+    windows, _ = make_windows(wf, 48000)
+    a = conv.convert_windows(windows, k=4)
+    b = conv.convert_windows(windows, k=4, keep_frames=(150, 300))
+    assert torch.equal(a[:, 48000:96000], b[:, 48000:96000]) and not torch.equal(a, b)     # the context thirds do differ
