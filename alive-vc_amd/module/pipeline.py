@@ -36,6 +36,7 @@ def stitch(window_out, total, chunk=48000):
 # / amplitudes interpolated from the neighbouring frames (+-1); source_in / source_out add 3 samples either side.
 # => features [t - 24, t + 13].  The margins below leave slack and are checked bitwise by the tests.
 TRIM_LEFT, TRIM_RIGHT = 32, 16
+CE_MARGIN = 16          # ContentEncoder: four k7 depthwise convs (+-12 frames) between the spectrogram and its output
 
 
 class Converter:
@@ -49,12 +50,21 @@ class Converter:
         self.library = tokens if isinstance(tokens, PackedLibrary) else PackedLibrary(tokens[0].to(self.device))
         return self
 
-    def features(self, windows, pitch_shift=0.0, intonation=1.0, f0_rate=1.0):
-        """spectrogram -> f0 (+ per-window pitch transform) and content features   (inference.py:112-128)"""
+    def features(self, windows, pitch_shift=0.0, intonation=1.0, f0_rate=1.0, frames=None):
+        """spectrogram -> f0 (+ per-window pitch transform) and content features   (inference.py:112-128).
+        frames = (lo, hi): content features are only needed on [lo, hi) (context trimming): the encoder runs on that range
+        plus its own receptive field; the other frames come back as zeros.  f0 always covers the whole window (the pitch
+        transform uses the window's mean pitch, the oscillator accumulates phase from the first frame)."""
         spec = spectrogram(windows)
         f0 = self.pe.estimate(spec)
         f0 = ops.pitch_transform_(f0, 0, f0_rate=f0_rate, pitch_shift=pitch_shift, intonation=intonation)
-        return self.ce(spec), f0
+        if frames is None:
+            return self.ce(spec), f0
+        lf = spec.shape[2]
+        a, b = max(0, frames[0] - CE_MARGIN), min(lf, frames[1] + CE_MARGIN)
+        feat = torch.zeros(spec.shape[0], 768, lf, device=spec.device)
+        feat[:, :, a:b] = self.ce(spec[:, :, a:b].contiguous())
+        return feat, f0
 
     def match(self, feat, k=4, alpha=0.0):
         val, idx = self.library.search(feat, k)
@@ -72,14 +82,14 @@ class Converter:
         lf = L // 320
         feat = torch.empty(n, 768, lf, device=windows.device)
         f0 = torch.empty(n, 1, lf, device=windows.device)
+        rng = None if keep_frames is None else (max(0, keep_frames[0] - TRIM_LEFT), min(lf, keep_frames[1] + TRIM_RIGHT))
         for i in range(0, n, window_batch):
             feat[i:i + window_batch], f0[i:i + window_batch] = self.features(windows[i:i + window_batch], pitch_shift,
-                                                                           intonation, f0_rate)
-        if keep_frames is None:
+                                                                           intonation, f0_rate, frames=rng)
+        if rng is None:
             feat = self.match(feat, k, alpha)
         else:
-            lo, hi = max(0, keep_frames[0] - TRIM_LEFT), min(lf, keep_frames[1] + TRIM_RIGHT)
-            feat[:, :, lo:hi] = self.match(feat[:, :, lo:hi].contiguous(), k, alpha)
+            feat[:, :, rng[0]:rng[1]] = self.match(feat[:, :, rng[0]:rng[1]].contiguous(), k, alpha)
         out = torch.empty_like(windows)
         for i in range(0, n, window_batch):
             out[i:i + window_batch], _ = self.dec(feat[i:i + window_batch], f0[i:i + window_batch])

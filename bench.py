@@ -222,7 +222,7 @@ def main():
         assert torch.equal(out_t[:, cf * FRAME:2 * cf * FRAME], ref_out), "context trim changed kept samples"
         trim = {"ms_per_step": round(tt0 * 1e3, 2), "windows_per_s": round(n_win / tt0, 1),
                 "useful_frames_per_s": round(useful_frames / tt0, 1), "kept_samples_bitwise_equal": True,
-                "note": "kNN match restricted to frames [cf-32, 2cf+16) of each window; every other stage unchanged"}
+                "note": "kNN match on frames [cf-32, 2cf+16) of each window, content encoder on that range +-16; f0 estimator, spectrogram and decoder on the whole window"}
         del out_t, ref_out
 
     # PCIe-inclusive rate (never `value`): the same step with the windows arriving from pinned host memory and the
