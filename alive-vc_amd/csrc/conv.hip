@@ -189,9 +189,11 @@ extern "C" int alive_conv1d(const AliveConv* d, void* stream) {
     if (d->Z) ALIVE_CHECK_ARG(d->film && d->Lf > 0, "alive_conv1d: Z needs film");
     {
         int rc;
-        if (alive_conv_skinny_try(d, (hipStream_t)stream, &rc)) return rc;      // <= 32 columns (streaming)
+        if (d->film_ld == 0 && alive_conv_skinny_try(d, (hipStream_t)stream, &rc)) return rc;      // few columns (streaming)
     }
-    if (d->precision >= 1) return alive_conv_split_launch(d, d->Z ? (float)d->Lf / (float)d->Tout : 0.0f, (hipStream_t)stream);
+    if (d->precision >= 1)
+        return alive_conv_split_launch(d, d->Z ? (float)(d->film_ld ? d->film_ld : d->Lf) / (float)d->Tout : 0.0f, (hipStream_t)stream);
+    ALIVE_CHECK_ARG(d->film_ld == 0, "alive_conv1d: a film frame range needs the split kernel (precision 1 / 2)");
     const unsigned magic = d->Ci == 1 ? 0u : (unsigned)(((1u << 20) + d->KW - 1) / d->KW);
     const float ratio = d->Z ? (float)d->Lf / (float)d->Tout : 0.0f;
     hipStream_t s = (hipStream_t)stream;

@@ -61,7 +61,7 @@ struct FilmTile {
 __device__ __forceinline__ bool film_tile_range(const AliveConv& p, float ratio, int t0, int ncols, int& f_lo, int& nf) {
     int t1 = t0 + ncols - 1;
     if (t1 > p.Tout - 1) t1 = p.Tout - 1;
-    Lerp a = lerp_coord(t0, ratio, p.Lf), b = lerp_coord(t1, ratio, p.Lf);
+    Lerp a = lerp_coord(t0 + p.film_t0, ratio, p.Lf), b = lerp_coord(t1 + p.film_t0, ratio, p.Lf);
     f_lo = a.i0;
     nf = b.i1 - a.i0 + 1;
     return nf <= FILM_NF;

@@ -214,8 +214,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
                 int f = e % FILM_NF, sel = (e / FILM_NF) & 1, pr = e / (2 * FILM_NF);
                 int row = m0 + ps * 64 + pr;
                 float v = 0.0f;
-                if (row < p.Co && f < nf)
-                    v = p.film[((size_t)n * p.film_rows + (sel == 0 ? p.film_scale_row : p.film_shift_row) + row) * p.Lf + f_lo + f];
+                if (row < p.Co && f < nf) {
+                    const int ld = p.film_ld ? p.film_ld : p.Lf;
+                    int c = f_lo + f - p.film_f0;                    // frame f_lo + f of the window -> column of the film tensor
+                    c = c < 0 ? 0 : (c < ld ? c : ld - 1);
+                    v = p.film[((size_t)n * p.film_rows + (sel == 0 ? p.film_scale_row : p.film_shift_row) + row) * ld + c];
+                }
                 Ft[e] = v;
             }
         }
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
                     f32x4 z;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        Lerp lp = lerp_coord(t + q, film_ratio, p.Lf);
+                        Lerp lp = lerp_coord(t + q + p.film_t0, film_ratio, p.Lf);
                         float sc = lerp_apply(lp, fs[lp.i0], fs[lp.i1]);
                         float sh = lerp_apply(lp, fs[FILM_NF + lp.i0], fs[FILM_NF + lp.i1]);
                         z[q] = gelu_fast(v[q]) * sc + sh;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
                     if (p.Y != nullptr) p.Y[o] = v;
                     if (p.Z != nullptr) {
                         const float* fs = Ft + pr * 2 * FILM_NF - f_lo;
-                        Lerp lp = lerp_coord(t, film_ratio, p.Lf);
+                        Lerp lp = lerp_coord(t + p.film_t0, film_ratio, p.Lf);
                         float sc = lerp_apply(lp, fs[lp.i0], fs[lp.i1]);
                         float sh = lerp_apply(lp, fs[FILM_NF + lp.i0], fs[FILM_NF + lp.i1]);
                         p.Z[o] = gelu_fast(v) * sc + sh;
@@ -296,7 +300,7 @@ int alive_conv_split_launch(const AliveConv* d, float ratio, hipStream_t s) {
     ALIVE_CHECK_ARG(((((uintptr_t)d->Y) | ((uintptr_t)d->Z) | ((uintptr_t)d->residual) | ((uintptr_t)d->skip)) & 15) == 0,
                     "alive_conv1d(split): Y / Z / residual / skip must be 16-byte aligned");
     if (d->Z) {
-        const double span = (double)d->Lf / (double)d->Tout * BN + 3.0;
+        const double span = (double)(d->film_ld ? d->film_ld : d->Lf) / (double)d->Tout * BN + 3.0;
         ALIVE_CHECK_ARG(span <= FILM_NF, "alive_conv1d(split): FiLM second output needs Tout >= ~8 Lf (got Lf %d, Tout %d)", d->Lf, d->Tout);
     }
     ALIVE_CHECK_ARG(d->act >= 0 && d->act <= 2, "alive_conv1d(split): activation %d not available on the split kernel", d->act);

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
                                                                 const unsigned short* __restrict__ W16,
                                                                 const float* __restrict__ biases,
                                                                 const float* __restrict__ film, int film_rows, int Lf,
-                                                                int film_off, float ratio, const float* __restrict__ skip,
+                                                                int film_off, float ratio, int t_off, int f_off, int film_ld, const float* __restrict__ skip,
                                                                 float* __restrict__ out, long long* stamps) {
 #ifdef ALIVE_STAMPS                 // diagnostic build only (make EXTRA=-DALIVE_STAMPS; tools/bench_filter_mid.py)
 #define STAMP(i) ts[i] = wall_clock64()
@@ -68,17 +68,19 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
     const float* Un = U + (size_t)n * C * L;
 
     // ---- FiLM rows of the tile ----
-    const int f_lo = lerp_coord(tbase < 0 ? 0 : tbase, ratio, Lf).i0;
+    const int f_lo = lerp_coord((tbase < 0 ? 0 : tbase) + t_off, ratio, Lf).i0;     // frames of the WINDOW (t_off: range mode)
     for (int e = tid; e < NCONV * 2 * C * NFP; e += 256) {
         const int f = e % NFP, c = (e / NFP) % C, sel = (e / (NFP * C)) & 1, q = e / (NFP * C * 2);
         int fr = f_lo + f;
         fr = fr < Lf ? fr : Lf - 1;
-        Fs[e] = film[((size_t)n * film_rows + film_off + q * 2 * C + sel * C + c) * Lf + fr];
+        int fc = fr - f_off;                             // frame of the window -> column of the film tensor
+        fc = fc < 0 ? 0 : (fc < film_ld ? fc : film_ld - 1);
+        Fs[e] = film[((size_t)n * film_rows + film_off + q * 2 * C + sel * C + c) * film_ld + fc];
     }
     {   // F.interpolate coordinates of this thread's column, relative to the staged FiLM frames
         int t = tbase + tid;
         t = t < 0 ? 0 : (t < L ? t : L - 1);
-        const Lerp lp = lerp_coord(t, ratio, Lf);
+        const Lerp lp = lerp_coord(t + t_off, ratio, Lf);
         int i0 = lp.i0 - f_lo, i1 = lp.i1 - f_lo;
         i0 = i0 < NFP - 1 ? i0 : NFP - 1;
         i1 = i1 < NFP - 1 ? i1 : NFP - 1;
@@ -353,12 +355,19 @@ extern "C" int64_t alive_filter_block64_weights(void) { return (int64_t)W_IN + (
 
 extern "C" int alive_filter_block64(const float* U, int N, int L, const void* W16, const float* biases, const float* film,
                                     int film_rows, int Lf, int film_off, const float* skip, float* out, void* stream) {
+    return alive_filter_block64_range(U, N, L, W16, biases, film, film_rows, Lf, film_off, 0, 0, Lf, skip, out, stream);
+}
+
+extern "C" int alive_filter_block64_range(const float* U, int N, int L, const void* W16, const float* biases, const float* film,
+                                          int film_rows, int Lf, int film_off, int t0, int f0, int film_ld, const float* skip,
+                                          float* out, void* stream) {
     ALIVE_CHECK_ARG(U && W16 && biases && film && out, "alive_filter_block64: null pointer");
     ALIVE_CHECK_ARG(N > 0 && L > 16 && Lf > 0, "alive_filter_block64: bad sizes (L must exceed the largest reflect pad, 16)");
     ALIVE_CHECK_ARG(U != out, "alive_filter_block64: in-place not supported (tiles read a halo of their left neighbour)");
     ALIVE_CHECK_ARG((L & 3) == 0 && ((((uintptr_t)out) | ((uintptr_t)skip)) & 15) == 0,
                     "alive_filter_block64: L must be a multiple of 4 and out / skip 16-byte aligned");
-    ALIVE_CHECK_ARG((double)BL * Lf / L + 3.0 <= NFP, "alive_filter_block64: tile spans more than %d frames (L %d, Lf %d)", NFP, L, Lf);
+    ALIVE_CHECK_ARG(film_ld > 0 && t0 >= 0 && f0 >= 0, "alive_filter_block64: bad frame range");
+    ALIVE_CHECK_ARG((double)BL * film_ld / L + 3.0 <= NFP, "alive_filter_block64: tile spans more than %d frames (L %d, frames %d)", NFP, L, film_ld);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)filter_block64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -368,10 +377,10 @@ extern "C" int alive_filter_block64(const float* U, int N, int L, const void* W1
         }
         attr_set = true;
     }
-    const float ratio = (float)Lf / (float)L;
+    const float ratio = (float)film_ld / (float)L;       // == window frames / window samples at this rate
     dim3 g(cdiv(L, TT), N);
     filter_block64_kernel<<<g, 256, LDS_BYTES, (hipStream_t)stream>>>(U, L, (const unsigned short*)W16, biases, film, film_rows,
-                                                                     Lf, film_off, ratio, skip, out, g_stamps64);
+                                                                     Lf, film_off, ratio, t0, f0, film_ld, skip, out, g_stamps64);
     ALIVE_CHECK_LAUNCH("alive_filter_block64");
     return ALIVE_OK;
 }

@@ -39,7 +39,7 @@ template <int C>
 __global__ __launch_bounds__(NT, 2) void filter_block_small_kernel(const float* __restrict__ U, int L,
                                                                    const float* __restrict__ wpack,
                                                                    const float* __restrict__ film, int film_rows, int Lf,
-                                                                   int film_off, float ratio, const float* __restrict__ skip,
+                                                                   int film_off, float ratio, int t_off, int f_off, int film_ld, const float* __restrict__ skip,
                                                                    float* __restrict__ out) {
     using Cfg = SmallCfg<C>;
     constexpr int BL = Cfg::BL, TT = Cfg::TT, P = Cfg::P, G = Cfg::G, KS = Cfg::KS, KS_IN = Cfg::KS_IN;
@@ -66,17 +66,19 @@ __global__ __launch_bounds__(NT, 2) void filter_block_small_kernel(const float* 
     for (int r = 0; r < 4; ++r) bias_in[r] = wpack[(C + NCONV * 5 * C) * 16 + lq * 4 + r];
 
     // ---- FiLM rows of the tile ----
-    const int f_lo = lerp_coord(tbase < 0 ? 0 : tbase, ratio, Lf).i0;
+    const int f_lo = lerp_coord((tbase < 0 ? 0 : tbase) + t_off, ratio, Lf).i0;     // frames of the WINDOW (t_off: range mode)
     for (int e = tid; e < NCONV * 2 * C * NFP; e += NT) {
         int f = e % NFP, c = (e / NFP) % C, sel = (e / (NFP * C)) & 1, q = e / (NFP * C * 2);
         int fr = f_lo + f;
         fr = fr < Lf ? fr : Lf - 1;
-        Fs[e] = film[((size_t)n * film_rows + film_off + q * 2 * C + sel * C + c) * Lf + fr];
+        int fc = fr - f_off;                             // frame of the window -> column of the film tensor
+        fc = fc < 0 ? 0 : (fc < film_ld ? fc : film_ld - 1);
+        Fs[e] = film[((size_t)n * film_rows + film_off + q * 2 * C + sel * C + c) * film_ld + fc];
     }
     for (int i = tid; i < BL; i += NT) {
         int t = tbase + i;
         t = t < 0 ? 0 : (t < L ? t : L - 1);
-        const Lerp lp = lerp_coord(t, ratio, Lf);
+        const Lerp lp = lerp_coord(t + t_off, ratio, Lf);
         int i0 = lp.i0 - f_lo, i1 = lp.i1 - f_lo;
         i0 = i0 < NFP - 1 ? i0 : NFP - 1;
         i1 = i1 < NFP - 1 ? i1 : NFP - 1;
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(NT, 2) void filter_block_small_kernel(const float* 
 
 template <int C>
 int launch_small(const float* U, int N, int L, const float* wpack, const float* film, int film_rows, int Lf, int film_off,
-                 const float* skip, float* out, hipStream_t s) {
+                 int t0, int f0, int film_ld, const float* skip, float* out, hipStream_t s) {
     using Cfg = SmallCfg<C>;
     const int lds = (2 * C * Cfg::P + NCONV * 2 * C * NFP) * (int)sizeof(float) + Cfg::BL * 8;
     static bool attr_set = false;
@@ -223,10 +225,10 @@ int launch_small(const float* U, int N, int L, const float* wpack, const float* 
         }
         attr_set = true;
     }
-    const float ratio = (float)Lf / (float)L;
-    ALIVE_CHECK_ARG((double)Cfg::BL * Lf / L + 3.0 <= NFP, "alive_filter_block_small: tile spans more than %d frames (L %d, Lf %d)", NFP, L, Lf);
+    const float ratio = (float)film_ld / (float)L;       // == window frames / window samples at this rate
+    ALIVE_CHECK_ARG((double)Cfg::BL * film_ld / L + 3.0 <= NFP, "alive_filter_block_small: tile spans more than %d frames (L %d, frames %d)", NFP, L, film_ld);
     dim3 g(cdiv(L, Cfg::TT), N);
-    filter_block_small_kernel<C><<<g, NT, lds, s>>>(U, L, wpack, film, film_rows, Lf, film_off, ratio, skip, out);
+    filter_block_small_kernel<C><<<g, NT, lds, s>>>(U, L, wpack, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld, skip, out);
     ALIVE_CHECK_LAUNCH("alive_filter_block_small");
     return ALIVE_OK;
 }
@@ -239,10 +241,17 @@ extern "C" int alive_filter_block_small_weights(int C) {
 
 extern "C" int alive_filter_block_small(const float* U, int N, int C, int L, const float* wpack, const float* film,
                                         int film_rows, int Lf, int film_off, const float* skip, float* out, void* stream) {
+    return alive_filter_block_small_range(U, N, C, L, wpack, film, film_rows, Lf, film_off, 0, 0, Lf, skip, out, stream);
+}
+
+extern "C" int alive_filter_block_small_range(const float* U, int N, int C, int L, const float* wpack, const float* film,
+                                              int film_rows, int Lf, int film_off, int t0, int f0, int film_ld,
+                                              const float* skip, float* out, void* stream) {
     ALIVE_CHECK_ARG(U && wpack && film && out, "alive_filter_block_small: null pointer");
     ALIVE_CHECK_ARG(N > 0 && L > 16 && Lf > 0, "alive_filter_block_small: bad sizes (L must exceed the largest reflect pad, 16)");
     ALIVE_CHECK_ARG(C == 8 || C == 16, "alive_filter_block_small: C must be 8 or 16, got %d", C);
     ALIVE_CHECK_ARG(U != out, "alive_filter_block_small: in-place not supported (tiles read a halo of their left neighbour)");
-    if (C == 8) return launch_small<8>(U, N, L, wpack, film, film_rows, Lf, film_off, skip, out, (hipStream_t)stream);
-    return launch_small<16>(U, N, L, wpack, film, film_rows, Lf, film_off, skip, out, (hipStream_t)stream);
+    ALIVE_CHECK_ARG(film_ld > 0 && t0 >= 0 && f0 >= 0, "alive_filter_block_small: bad frame range");
+    if (C == 8) return launch_small<8>(U, N, L, wpack, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, (hipStream_t)stream);
+    return launch_small<16>(U, N, L, wpack, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, (hipStream_t)stream);
 }

@@ -346,12 +346,18 @@ DecBuffers dec_layout(void* ws, int N, int Lf) {
 
 extern "C" size_t alive_decoder_workspace_bytes(int N, int Lf) { return dec_layout(nullptr, N, Lf).bytes; }
 
-extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, const float* f0, const float* phi_in, int crop0,
-                                     int phi_col, int N, int Lf, float* wave, float* phi_out, void* ws, void* stream) {
-    ALIVE_CHECK_ARG(w && x_in && f0 && wave && ws && N > 0, "alive_decoder_forward: bad args");
-    ALIVE_CHECK_ARG(Lf >= 5, "alive_decoder_forward: needs at least 5 frames (reflect pad 4 on the bottleneck), got %d", Lf);
+namespace {
+__global__ void slice_frames_kernel(const float* __restrict__ f0, int Lf, int f_begin, int n_frames, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_frames) out[(size_t)blockIdx.y * n_frames + i] = f0[(size_t)blockIdx.y * Lf + f_begin + i];
+}
+
+// Decoder.forward on the frames [fb, fb + Lf) of windows of Lw_frames frames (fb = 0, Lf = Lw_frames: the whole window).
+// f0_win: f0 of the whole window (oscillator phase); f0: the range's own frames, contiguous [N][Lf].
+int decoder_run(const float* const* w, const float* x_in, const float* f0, const float* f0_win, const float* phi_in, int crop0,
+                int phi_col, int N, int Lf, int Lw_frames, int f_begin, float* wave, float* phi_out, DecBuffers& b, void* stream) {
+    const bool ranged = Lf != Lw_frames;
     Table t(w);
-    DecBuffers b = dec_layout(ws, N, Lf);
     const int Lw = Lf * SEG;
     // -- FeatureExtractor (decoder.py:43-48)
     const float* inW = t.next(); const float* inb = t.next();
@@ -368,7 +374,7 @@ extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, c
     // -- HarmonicOscillator (decoder.py:66-102)
     const float* aW = t.next(); const float* ab = t.next();
     RUN(pw_conv(aW, ab, b.x, b.Pa, N, Lf, DEC_C, NH, 2, 2, nullptr, b.amps, stream));
-    RUN(alive_oscillator(b.amps, f0, phi_in, N, NH, Lf, SEG, SR, crop0, phi_col, b.src, phi_out, b.osc_ws, stream));
+    RUN(alive_oscillator_range(b.amps, f0_win, phi_in, N, NH, Lw_frames, SEG, SR, crop0, phi_col, f_begin, Lf, b.src, phi_out, b.osc_ws, stream));
     // -- Filter (decoder.py:184-195); FiLM scale(+1)/shift of all 24 modulated convs in one GEMM
     const float* fW = t.next(); const float* fb = t.next(); const float* fpost = t.next();
     if (b.Pa != nullptr) {      // b.Pa still holds the planes of b.x (to_amps above)
@@ -414,10 +420,12 @@ extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, c
         if (F_MODE[s] != 0) {   // whole FilterBlock (+ skip) in one kernel: U -> Hh
             if (F_MODE[s] == 2) {
                 const float* wpack = t.next();
-                RUN(alive_filter_block_small(b.U, N, C, L, wpack, b.film, FILM_ROWS, Lf, film_off, skips[s], b.Hh, stream));
+                RUN(alive_filter_block_small_range(b.U, N, C, L, wpack, b.film, FILM_ROWS, Lw_frames, film_off, f_begin * (L / Lf), f_begin, Lf,
+                                                   skips[s], b.Hh, stream));
             } else {
                 const float* w16 = t.next(); const float* bias = t.next();
-                RUN(alive_filter_block64(b.U, N, L, w16, bias, b.film, FILM_ROWS, Lf, film_off, skips[s], b.Hh, stream));
+                RUN(alive_filter_block64_range(b.U, N, L, w16, bias, b.film, FILM_ROWS, Lw_frames, film_off, f_begin * (L / Lf), f_begin, Lf,
+                                               skips[s], b.Hh, stream));
             }
             film_off += 6 * 2 * C;
             cur = b.Hh;
@@ -427,7 +435,8 @@ extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, c
         const float* iW = t.next(); const float* ib = t.next();
         {   // FilterBlock.input_conv; second output feeds blocks[0].c1 (gelu + FiLM)
             AliveConv d = pw_desc(iW, ib, b.U, N, C, L, C, b.Hh);
-            d.Z = b.Zz; d.film = b.film; d.film_rows = FILM_ROWS; d.Lf = Lf;
+            d.Z = b.Zz; d.film = b.film; d.film_rows = FILM_ROWS; d.Lf = Lw_frames;
+            if (ranged) { d.film_t0 = f_begin * (L / Lf); d.film_f0 = f_begin; d.film_ld = Lf; }
             d.film_scale_row = film_off; d.film_shift_row = film_off + C;
             if (F_SPLIT[s]) d = split(d);
             RUN(alive_conv1d(&d, stream));
@@ -439,7 +448,8 @@ extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, c
             (void)f1;
             {   // c1: conv(Zz) -> only the modulated input of c2 is kept
                 AliveConv d = conv_desc(W1, b1, b.Zz, N, C, L, C, 5, 1, dil, 4 * dil, 1, L, nullptr);
-                d.Z = b.Z2; d.film = b.film; d.film_rows = FILM_ROWS; d.Lf = Lf;
+                d.Z = b.Z2; d.film = b.film; d.film_rows = FILM_ROWS; d.Lf = Lw_frames;
+            if (ranged) { d.film_t0 = f_begin * (L / Lf); d.film_f0 = f_begin; d.film_ld = Lf; }
                 d.film_scale_row = f2; d.film_shift_row = f2 + C;
                 if (F_SPLIT[s]) d = split(d);
                 RUN(alive_conv1d(&d, stream));
@@ -450,7 +460,8 @@ extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, c
                 if (j == 2) d.skip = skips[s];
                 if (j < 2) {
                     const int fn = film_off + ((j + 1) * 2) * 2 * C;
-                    d.Z = b.Zz; d.film = b.film; d.film_rows = FILM_ROWS; d.Lf = Lf;
+                    d.Z = b.Zz; d.film = b.film; d.film_rows = FILM_ROWS; d.Lf = Lw_frames;
+            if (ranged) { d.film_t0 = f_begin * (L / Lf); d.film_f0 = f_begin; d.film_ld = Lf; }
                     d.film_scale_row = fn; d.film_shift_row = fn + C;
                 }
                 if (F_SPLIT[s]) d = split(d);
@@ -463,4 +474,27 @@ extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, c
     }
     const float* oW = t.next(); const float* ob = t.next();
     return alive_filter_source_out(b.Hh, N, Lw, oW, ob, wave, stream);
+}
+}  // namespace
+
+extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, const float* f0, const float* phi_in, int crop0,
+                                     int phi_col, int N, int Lf, float* wave, float* phi_out, void* ws, void* stream) {
+    ALIVE_CHECK_ARG(w && x_in && f0 && wave && ws && N > 0, "alive_decoder_forward: bad args");
+    ALIVE_CHECK_ARG(Lf >= 5, "alive_decoder_forward: needs at least 5 frames (reflect pad 4 on the bottleneck), got %d", Lf);
+    DecBuffers b = dec_layout(ws, N, Lf);
+    return decoder_run(w, x_in, f0, f0, phi_in, crop0, phi_col, N, Lf, Lf, 0, wave, phi_out, b, stream);
+}
+
+extern "C" int alive_decoder_forward_range(const float* const* w, const float* x_in, const float* f0, int N, int Lf, int f_begin,
+                                           int n_frames, float* wave, void* ws, void* stream) {
+    ALIVE_CHECK_ARG(w && x_in && f0 && wave && ws && N > 0, "alive_decoder_forward_range: bad args");
+    ALIVE_CHECK_ARG(n_frames >= 5 && f_begin >= 0 && f_begin + n_frames <= Lf, "alive_decoder_forward_range: frames [%d, %d) of %d",
+                    f_begin, f_begin + n_frames, Lf);
+    // scratch: the range's own buffers, then an oscillator workspace for the whole window and the f0 slice
+    DecBuffers b = dec_layout(ws, N, n_frames);
+    Arena a((char*)ws + b.bytes);
+    b.osc_ws = a.take<char>(alive_oscillator_workspace_bytes(N, NH, Lf));
+    float* f0s = a.take<float>((size_t)N * n_frames);
+    slice_frames_kernel<<<dim3(cdiv(n_frames, 256), N), 256, 0, (hipStream_t)stream>>>(f0, Lf, f_begin, n_frames, f0s);
+    return decoder_run(w, x_in, f0s, f0, nullptr, 0, 0, N, n_frames, Lf, f_begin, wave, nullptr, b, stream);
 }

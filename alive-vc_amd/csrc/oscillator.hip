@@ -110,15 +110,17 @@ constexpr int MAX_SEG = 512;
 __global__ __launch_bounds__(64) void osc_synth_kernel(const float* __restrict__ amps, const float* __restrict__ f0,
                                                        const float* __restrict__ phi_in, OscGeom g,
                                                        const double* __restrict__ P, const float* __restrict__ dt0,
-                                                       int phi_col, float* __restrict__ wave, float* __restrict__ phi_out) {
+                                                       int phi_col, int f_off, int amp_ld, float* __restrict__ wave,
+                                                       float* __restrict__ phi_out) {
     __shared__ float tile[64][65];
     __shared__ uint2 coord[MAX_SEG];              // per sample of the frame: (i0 | i1 << 16, w1)
-    const int f = blockIdx.x, n = blockIdx.y;
+    // frame f of the WINDOW; amps / wave hold the frames [f_off, f_off + amp_ld) only (range mode; else f_off = 0, amp_ld = Lf)
+    const int f = blockIdx.x + f_off, n = blockIdx.y;
     const int lane = threadIdx.x;
     const int h = lane;
     const bool hv = h < g.H;
     const float* f0n = f0 + (size_t)n * g.Lf;
-    const float* an = amps + ((size_t)n * g.H + (hv ? h : 0)) * g.Lf;
+    const float* an = amps + ((size_t)n * g.H + (hv ? h : 0)) * amp_ld;
     const float hmul = (float)(h + 1);
     const float TWO_PI_F = 6.283185307179586f;
     const int u0 = f * g.seg;
@@ -129,7 +131,8 @@ __global__ __launch_bounds__(64) void osc_synth_kernel(const float* __restrict__
     // the interpolation of a frame's samples touches the frames f - 1, f, f + 1 only: keep their values in registers
     const int fm = f > 0 ? f - 1 : 0, fp = f + 1 < g.Lf ? f + 1 : g.Lf - 1;
     const float fo_m = f0n[fm] * hmul, fo_c = f0n[f] * hmul, fo_p = f0n[fp] * hmul;
-    const float am_m = an[fm], am_c = an[f], am_p = an[fp];
+    auto acol = [&](int fr) { int c = fr - f_off; return c < 0 ? 0 : (c < amp_ld ? c : amp_ld - 1); };
+    const float am_m = an[acol(fm)], am_c = an[acol(f)], am_p = an[acol(fp)];
     double acc = hv ? P[((size_t)n * g.H + h) * g.Lf + f] : 0.0;
     const float d0 = hv ? dt0[(size_t)n * g.H + h] : 0.0f;
     const float ph = (hv && phi_in != nullptr) ? phi_in[(size_t)n * g.H + h] : 0.0f;
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(64) void osc_synth_kernel(const float* __restrict__
         if (lane < nb) {
             float s = 0.0f;
             for (int hh = 0; hh < g.H; ++hh) s += tile[lane][hh];
-            wave[(size_t)n * g.Lw + u0 + b0 + lane] = s / (float)g.H;
+            wave[(size_t)n * amp_ld * g.seg + (u0 - f_off * g.seg) + b0 + lane] = s / (float)g.H;
         }
         __syncthreads();
     }
@@ -179,7 +182,15 @@ extern "C" size_t alive_oscillator_workspace_bytes(int N, int H, int Lf) {
 extern "C" int alive_oscillator(const float* amps, const float* f0, const float* phi_in, int N, int H, int Lf, int seg,
                                 float sample_rate, int crop0, int phi_col, float* wave, float* phi_out, void* ws,
                                 void* stream) {
+    return alive_oscillator_range(amps, f0, phi_in, N, H, Lf, seg, sample_rate, crop0, phi_col, 0, Lf, wave, phi_out, ws, stream);
+}
+
+extern "C" int alive_oscillator_range(const float* amps, const float* f0, const float* phi_in, int N, int H, int Lf, int seg,
+                                      float sample_rate, int crop0, int phi_col, int f_begin, int n_frames, float* wave,
+                                      float* phi_out, void* ws, void* stream) {
     ALIVE_CHECK_ARG(amps && f0 && wave && ws, "alive_oscillator: null pointer");
+    ALIVE_CHECK_ARG(f_begin >= 0 && n_frames > 0 && f_begin + n_frames <= Lf, "alive_oscillator: frame range [%d, %d) outside [0, %d)",
+                    f_begin, f_begin + n_frames, Lf);
     ALIVE_CHECK_ARG(N > 0 && H > 0 && H <= 64 && Lf > 0 && Lf < 65536 && seg > 0 && seg <= MAX_SEG,
                     "alive_oscillator: bad sizes (H <= 64, seg <= %d)", MAX_SEG);
     const int Lw = Lf * seg;
@@ -192,7 +203,7 @@ extern "C" int alive_oscillator(const float* amps, const float* f0, const float*
     hipStream_t s = (hipStream_t)stream;
     osc_segsum_kernel<<<dim3(Lf, N, cdiv(H, 64)), 64, 0, s>>>(f0, g, S);
     osc_prefix_kernel<<<dim3(N, cdiv(H, 64)), 64, 0, s>>>(f0, g, crop0, S, dt0);
-    osc_synth_kernel<<<dim3(Lf, N), 64, 0, s>>>(amps, f0, phi_in, g, S, dt0, phi_col, wave, phi_out);
+    osc_synth_kernel<<<dim3(n_frames, N), 64, 0, s>>>(amps, f0, phi_in, g, S, dt0, phi_col, f_begin, n_frames, wave, phi_out);
     ALIVE_CHECK_LAUNCH("alive_oscillator");
     return ALIVE_OK;
 }

@@ -24,6 +24,7 @@ class AliveConv(C.Structure):
         ("Y", C.c_void_p), ("Z", C.c_void_p), ("film", C.c_void_p),
         ("film_rows", C.c_int), ("Lf", C.c_int), ("film_scale_row", C.c_int), ("film_shift_row", C.c_int),
         ("precision", C.c_int), ("Ci_pad", C.c_int),
+        ("film_t0", C.c_int), ("film_f0", C.c_int), ("film_ld", C.c_int),
     ]
 
 
@@ -54,8 +55,10 @@ PROTOTYPES = {
     "alive_gemm_planes": (_I, [C.POINTER(AliveGemm), _VP]),
     "alive_filter_block_small_weights": (_I, [_I]),
     "alive_filter_block_small": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
+    "alive_filter_block_small_range": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "alive_filter_block64_weights": (_I64, []),
     "alive_filter_block64": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
+    "alive_filter_block64_range": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "alive_filter_source_in": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "alive_filter_source_out": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP]),
     "alive_dwconv_norm": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP]),
@@ -64,6 +67,7 @@ PROTOTYPES = {
     "alive_argmax_channels": (_I, [_VP, _I, _I, _I, _VP, _VP]),
     "alive_oscillator_workspace_bytes": (_SZ, [_I, _I, _I]),
     "alive_oscillator": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _F, _I, _I, _VP, _VP, _VP, _VP]),
+    "alive_oscillator_range": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _F, _I, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "alive_dft_basis_bytes": (_SZ, []),
     "alive_dft_basis": (_I, [_VP, _VP]),
     "alive_spectrogram_workspace_bytes": (_SZ, [_I, _I]),
@@ -82,6 +86,7 @@ PROTOTYPES = {
     "alive_f0_estimate": (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP]),
     "alive_decoder_workspace_bytes": (_SZ, [_I, _I]),
     "alive_decoder_forward": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP]),
+    "alive_decoder_forward_range": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP]),
     "alive_pitch_transform": (_I, [_VP, _I, _I, _I, _F, _F, _F, _VP]),
 }
 

@@ -68,4 +68,23 @@ class Decoder(PackedNet):
                   "alive_decoder_forward")
         return wave, PhaseColumn(phi_col, phi_out, lw)
 
+    def forward_range(self, x, f0, f_begin):
+        """Decoder.forward restricted to the frames [f_begin, f_begin + x.shape[2]) of windows whose f0 [N,1,Lf] is given
+        in full (context trimming).  Frames further than the decoder's receptive field from the range edges come out
+        bitwise as in forward() on the whole window; -> wave [N, 320 * frames]."""
+        x = x.contiguous().float()
+        f0 = f0.contiguous().float()
+        n, c, nf = x.shape
+        lf = f0.shape[2]
+        if c != schema.CONTENT_DIM or f0.shape[:2] != (n, 1) or f_begin < 0 or f_begin + nf > lf:
+            raise ValueError(f"Decoder.forward_range: x {tuple(x.shape)}, f0 {tuple(f0.shape)}, f_begin {f_begin}")
+        if nf < 5:
+            raise ValueError(f"Decoder needs at least 5 frames, got {nf}")
+        L = nat.lib()
+        wave = torch.empty(n, nf * schema.SEGMENT, device=x.device)
+        ws = self._ws.get(L.alive_decoder_workspace_bytes(n, nf) + L.alive_decoder_workspace_bytes(n, lf), x.device)
+        nat.check(L.alive_decoder_forward_range(self.table().array, nat.ptr(x), nat.ptr(f0), n, lf, int(f_begin), nf,
+                                                nat.ptr(wave), nat.ptr(ws), nat.stream()), "alive_decoder_forward_range")
+        return wave
+
     __call__ = forward

@@ -90,9 +90,17 @@ class Converter:
             feat = self.match(feat, k, alpha)
         else:
             feat[:, :, rng[0]:rng[1]] = self.match(feat[:, :, rng[0]:rng[1]].contiguous(), k, alpha)
-        out = torch.empty_like(windows)
+        if rng is None:
+            out = torch.empty_like(windows)
+            for i in range(0, n, window_batch):
+                out[i:i + window_batch], _ = self.dec(feat[i:i + window_batch], f0[i:i + window_batch])
+            return out
+        # decode the matched range only (the oscillator still accumulates phase over the whole window); samples outside it
+        # are not kept by the caller and stay zero
+        out = torch.zeros_like(windows)
         for i in range(0, n, window_batch):
-            out[i:i + window_batch], _ = self.dec(feat[i:i + window_batch], f0[i:i + window_batch])
+            out[i:i + window_batch, rng[0] * 320:rng[1] * 320] = self.dec.forward_range(
+                feat[i:i + window_batch, :, rng[0]:rng[1]].contiguous(), f0[i:i + window_batch], rng[0])
         return out
 
     def convert(self, wf, chunk=48000, trim_context=False, **kw):

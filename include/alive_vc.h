@@ -116,6 +116,11 @@ typedef struct AliveConv {
      *                 W = bf16 [2][Co_pad][KW*Ci_pad] (plane 0 hi, plane 1 lo), tap-major k = j*Ci_pad + ci,
      *                 Ci_pad a multiple of 32; stride must be 1. */
     int precision, Ci_pad;
+    /* FiLM of a frame RANGE of a longer window (alive_decoder_forward_range): this conv's columns start at sample
+     * film_t0 of the window (at its own rate) and `film` holds the frames [film_f0, film_f0 + film_ld) only, row pitch
+     * film_ld; Lf stays the window's frame count, so the interpolation coordinates are those of the whole window.
+     * film_ld == 0: film covers the whole window (film_t0 = film_f0 = 0, pitch Lf).  Split kernel only. */
+    int film_t0, film_f0, film_ld;
 } AliveConv;
 int alive_conv1d(const AliveConv* desc, void* stream);
 
@@ -155,6 +160,11 @@ int alive_gemm_planes(const AliveGemm* desc, void* stream);
 int alive_filter_block_small_weights(int C);
 int alive_filter_block_small(const float* U, int N, int C, int L, const float* wpack, const float* film,
                              int film_rows, int Lf, int film_off, const float* skip, float* out, void* stream);
+/* the same on a frame range of a longer window (see AliveConv.film_t0): L samples starting at sample t0 of the window's
+ * tensor at this rate, film[N][film_rows][film_ld] holding the frames from f0 on, Lf = frames of the whole window */
+int alive_filter_block_small_range(const float* U, int N, int C, int L, const float* wpack, const float* film,
+                                   int film_rows, int Lf, int film_off, int t0, int f0, int film_ld, const float* skip,
+                                   float* out, void* stream);
 
 /* FilterBlock.forward (decoder.py:137-150) for C = 64 fused into one kernel on the split-bf16 MFMA (filter_mid.hip):
  * activations stay in LDS as two bf16 planes through the input conv and the six modulated k5 convs.
@@ -165,6 +175,9 @@ int alive_filter_block_small(const float* U, int N, int C, int L, const float* w
 int64_t alive_filter_block64_weights(void);
 int alive_filter_block64(const float* U, int N, int L, const void* W16, const float* biases, const float* film,
                          int film_rows, int Lf, int film_off, const float* skip, float* out, void* stream);
+int alive_filter_block64_range(const float* U, int N, int L, const void* W16, const float* biases, const float* film,
+                               int film_rows, int Lf, int film_off, int t0, int f0, int film_ld, const float* skip,
+                               float* out, void* stream);
 
 /* The waveform-rate edges of Filter.forward (decoder.py:164,182,186-188,194) as streaming kernels:
  *   alive_filter_source_in : downs[0](source_in(src)):  src[N][Lw] -> d0[N][16][Lw/2]
@@ -201,6 +214,11 @@ size_t alive_oscillator_workspace_bytes(int N, int H, int Lf);
 int alive_oscillator(const float* amps, const float* f0, const float* phi_in, int N, int H, int Lf,
                      int seg, float sample_rate, int crop0, int phi_col,
                      float* wave, float* phi_out, void* ws, void* stream);
+/* the frames [f_begin, f_begin + n_frames) of the window only: amps[N][H][n_frames], wave[N][n_frames*seg]; f0 and the
+ * phase accumulation cover the whole window, so the samples are bitwise those of alive_oscillator */
+int alive_oscillator_range(const float* amps, const float* f0, const float* phi_in, int N, int H, int Lf,
+                           int seg, float sample_rate, int crop0, int phi_col, int f_begin, int n_frames,
+                           float* wave, float* phi_out, void* ws, void* stream);
 
 /* magnitude STFT 1280/320, rect window, reflect centre pad, last frame dropped
  * (module/spectrogram.py:5-10): wav[N][L] -> spec[N][641][L/320], as a DFT GEMM on the
@@ -210,6 +228,14 @@ size_t alive_dft_basis_bytes(void);
 int alive_dft_basis(float* basis, void* stream);
 size_t alive_spectrogram_workspace_bytes(int N, int L);
 int alive_spectrogram(const float* basis, const float* wav, int N, int L, float* spec, void* ws, void* stream);
+
+/* Decoder.forward on the frames [f_begin, f_begin + n_frames) of windows of Lf frames (context trimming: inference.py
+ * keeps the centre third of a window).  x[N][768][n_frames] are the matched features of that range, f0[N][Lf] covers the
+ * whole window (phase accumulation), wave[N][320*n_frames].  Frames further than the decoder's receptive field from the
+ * range edges (12 + 12 to the left, 13 to the right) are bitwise those of alive_decoder_forward on the whole window.
+ * ws: alive_decoder_workspace_bytes(N, n_frames) + alive_decoder_workspace_bytes(N, Lf) is enough. */
+int alive_decoder_forward_range(const float* const* w, const float* x, const float* f0, int N, int Lf, int f_begin,
+                                int n_frames, float* wave, void* ws, void* stream);
 
 /* ------------------------------------------------------- audio edges (f2) ----
  * torchaudio.functional.resample (sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99) as a polyphase filter bank,
