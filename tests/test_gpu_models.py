@@ -169,3 +169,21 @@ def test_context_trim_keeps_the_centre_third_bitwise(nets):
     a = conv.convert_windows(windows, k=4)
     b = conv.convert_windows(windows, k=4, keep_frames=(150, 300))
     assert torch.equal(a[:, 48000:96000], b[:, 48000:96000]) and not torch.equal(a, b)     # the context thirds do differ
+
+
+def test_decoder_forward_range_is_bitwise_inside_its_margins(nets):
+    """alive_decoder_forward_range: the decoder on frames [118, 316) of 450-frame windows reproduces frames [150, 300) of the
+    whole-window decode bit for bit (interpolation coordinates and oscillator phase are those of the whole window)"""
+    _, _, dec, _ = nets
+    x = synthetic.gaussian("dr.x", 51, (2, 768, 450)).to(DEV)
+    f0 = (90.0 + 60.0 * torch.from_numpy(synthetic.uniform01("dr.f0", 52, 2 * 450)).float()).view(2, 1, 450).to(DEV)
+    full, _ = dec(x, f0=f0)
+    a, b = 118, 316
+    part = dec.forward_range(x[:, :, a:b].contiguous(), f0, a)
+    assert part.shape == (2, (b - a) * 320)
+    assert torch.equal(part[:, (150 - a) * 320:(300 - a) * 320], full[:, 150 * 320:300 * 320])
+    # a range that starts at the window's first frame keeps the left edge exact as well
+    head = dec.forward_range(x[:, :, :200].contiguous(), f0, 0)
+    assert torch.equal(head[:, :180 * 320], full[:, :180 * 320])
+    with pytest.raises(ValueError):
+        dec.forward_range(x[:, :, :10].contiguous(), f0, 445)
