@@ -101,7 +101,8 @@ def main():
     ap.add_argument("-k", type=int, default=4)
     ap.add_argument("--window-batch", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-oracle leg (0 = skip)")
-    ap.add_argument("--shard-library", action="store_true", help="also time the library-sharded kNN + all-gather")
+    ap.add_argument("--shard-library", action="store_true", help="(default when --gpus > 1) also time the library-sharded kNN + all-gather")
+    ap.add_argument("--no-shard-library", action="store_true", help="skip the library-sharded kNN leg of a multi-GPU run")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real thing); gloo + --same-device only exercise the multi-rank code path on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true", help="test only: every rank uses cuda:0")
@@ -245,9 +246,15 @@ def main():
         del host_in, host_out, wdev
 
     sharded = None
-    if args.shard_library and world > 1:
+    if world > 1 and not args.no_shard_library:
+        # BASELINE config 4 (never part of `value`): the library cut into `world` row slabs, every rank scores one window
+        # batch against its slab, exact per-shard top-k merged after one all-gather over RCCL
         from module.sharded import bench_sharded_knn
-        sharded = bench_sharded_knn(conv, windows[: args.window_batch], M, args.k, world, rank, dev)
+        library.search = orig_search
+        try:
+            sharded = bench_sharded_knn(conv, windows[: args.window_batch], M, args.k, world, rank, dev)
+        except Exception as e:                                # keep the headline line even if this leg fails
+            sharded = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
