@@ -48,6 +48,18 @@ def test_inference_cli_matches_oracle(workdir):
     assert err < 1e-3, err
 
 
+def test_inference_cli_trim_context_writes_the_same_file(workdir):
+    import inference
+    d, _, _ = workdir
+    base = ["-i", str(d / "inputs"), "-dep", str(d / "decoder.pt"), "-cep", str(d / "content_encoder.pt"), "-f0ep", str(d / "f0_estimator.pt"),
+            "-lib", str(d / "voice_library.pt"), "-d", "cuda", "-c", "6400", "-p", "-1", "-a", "0.05"]      # 20 frames per chunk
+    inference.main(base + ["-o", str(d / "out_full")])
+    inference.main(base + ["-o", str(d / "out_trim"), "--trim-context"])
+    a, _ = audio_io.load(str(d / "out_full" / "0_utt.wav"))
+    b, _ = audio_io.load(str(d / "out_trim" / "0_utt.wav"))
+    assert torch.equal(a, b)
+
+
 def test_realtime_converter_matches_oracle(workdir):
     from module.content_encoder import ContentEncoder
     from module.decoder import Decoder
