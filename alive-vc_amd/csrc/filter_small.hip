@@ -18,6 +18,10 @@
 
 namespace {
 
+#ifdef ALIVE_STAMPS
+__device__ long long* g_small_stamps = nullptr;
+#endif
+
 constexpr int HALO = 56;
 constexpr int NCONV = 6;
 constexpr int NFP = 10;         // FiLM frames staged per tile (tile span / 160 or / 320 + 2 taps + slack)
@@ -43,6 +47,13 @@ __global__ __launch_bounds__(NT, 2) void filter_block_small_kernel(const float* 
                                                                    float* __restrict__ out) {
     using Cfg = SmallCfg<C>;
     constexpr int BL = Cfg::BL, TT = Cfg::TT, P = Cfg::P, G = Cfg::G, KS = Cfg::KS, KS_IN = Cfg::KS_IN;
+#ifdef ALIVE_STAMPS                 // diagnostic build only (make EXTRA=-DALIVE_STAMPS; tools/bench_filter_small.py)
+#define FS_STAMP(i) ts[i] = wall_clock64()
+    long long ts[5];
+#else
+#define FS_STAMP(i)
+#endif
+    FS_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* bufZ = sm;                       // [C][P]
     float* bufY = bufZ + C * P;             // [C][P]
@@ -84,11 +95,26 @@ __global__ __launch_bounds__(NT, 2) void filter_block_small_kernel(const float* 
         i1 = i1 < NFP - 1 ? i1 : NFP - 1;
         Xc[i] = make_uint2((unsigned)i0 | ((unsigned)i1 << 16), __float_as_uint(lp.w1));
     }
-    // ---- stage the input tile (raw U) into bufZ ----
-    for (int e = tid; e < C * BL; e += NT) {
-        int c = e / BL, i = e - c * BL;
-        int t = tbase + i;
-        bufZ[c * P + i] = (t >= 0 && t < L) ? Un[(size_t)c * L + t] : 0.0f;
+    // ---- stage the input tile (raw U) into bufZ: 16-B vectors, all of a thread's loads in flight together ----
+    // (tbase, L and the row pitch are multiples of 4, so a vector lies entirely inside or outside [0, L))
+    {
+        constexpr int NVEC = C * (BL / 4) / NT;          // 8 (C = 16) or 4 (C = 8) vectors per thread
+        f32x4 v[NVEC];
+#pragma unroll
+        for (int k = 0; k < NVEC; ++k) {
+            const int e = tid + NT * k;
+            const int c = e / (BL / 4), i4 = (e - c * (BL / 4)) * 4;
+            const int t = tbase + i4;
+            v[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (t >= 0 && t + 3 < L) v[k] = *(const f32x4*)(Un + (size_t)c * L + t);
+            else if (t >= 0 && t < L) { for (int q = 0; q < 4 && t + q < L; ++q) v[k][q] = Un[(size_t)c * L + t + q]; }
+        }
+#pragma unroll
+        for (int k = 0; k < NVEC; ++k) {
+            const int e = tid + NT * k;
+            const int c = e / (BL / 4), i4 = (e - c * (BL / 4)) * 4;
+            *(f32x4*)&bufZ[c * P + i4] = v[k];
+        }
     }
     __syncthreads();
 
@@ -119,6 +145,7 @@ __global__ __launch_bounds__(NT, 2) void filter_block_small_kernel(const float* 
 #pragma unroll
     for (int u = 0; u < C / 4; ++u) rowoff[u] = (4 * u + lq) * P;
 
+    FS_STAMP(1);
     // residual stream of this wave's column groups (group g = wv + 8*i, column = 16 g + ln), MFMA C layout
     f32x4 h[G];
 
@@ -138,6 +165,7 @@ __global__ __launch_bounds__(NT, 2) void filter_block_small_kernel(const float* 
     for (int i = 0; i < G; ++i) modulate_store(0, bufZ, (wv + 8 * i) * 16 + ln, h[i]);
     __syncthreads();
 
+    FS_STAMP(2);
     // ---- three FilterResBlocks: q = 2j (c1), 2j+1 (c2), dilation 2^j    (decoder.py:128-134) ----
 #pragma unroll 1
     for (int q = 0; q < NCONV; ++q) {
@@ -192,23 +220,48 @@ __global__ __launch_bounds__(NT, 2) void filter_block_small_kernel(const float* 
         __syncthreads();
     }
 
-    // ---- store the tile (+ U-Net skip, decoder.py:191) ----
+    FS_STAMP(3);
+    // ---- store the tile (+ U-Net skip, decoder.py:191): through LDS, so that global accesses are 16-B vectors along t and
+    // all skip vectors of a thread are in flight together ----
+    float* Ht = bufZ;                                    // [C][P] fp32: both conv buffers are free now
 #pragma unroll
     for (int i = 0; i < G; ++i) {
-        const int col = (wv + 8 * i) * 16 + ln, t = tbase + col;
-        if (col >= HALO && t < L) {
+        const int col = (wv + 8 * i) * 16 + ln;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = lq * 4 + r;
-                if (co < C) {
-                    const size_t o = ((size_t)n * C + co) * L + t;
-                    float v = h[i][r];
-                    if (skip != nullptr) v = v + skip[o];
-                    out[o] = v;
-                }
+        for (int r = 0; r < 4; ++r)
+            if (lq * 4 + r < C) Ht[(lq * 4 + r) * P + col] = h[i][r];
+    }
+    __syncthreads();
+    {
+        constexpr int NV = (C * (TT / 4) + NT - 1) / NT;     // 242 vectors per channel row
+        f32x4 sk[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int e = tid + NT * k;
+            const int c = e / (TT / 4), t = t0 + (e - c * (TT / 4)) * 4;
+            sk[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (skip != nullptr && e < C * (TT / 4) && t + 3 < L) sk[k] = *(const f32x4*)(skip + ((size_t)n * C + c) * L + t);
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int e = tid + NT * k;
+            const int c = e / (TT / 4), c4 = (e - c * (TT / 4)) * 4, t = t0 + c4;
+            if (e >= C * (TT / 4) || t >= L) continue;
+            const size_t o = ((size_t)n * C + c) * L + t;
+            const f32x4 v = *(const f32x4*)&Ht[c * P + HALO + c4];
+            if (t + 3 < L) {
+                *(f32x4*)(out + o) = v + sk[k];
+            } else {
+                for (int q = 0; q < 4 && t + q < L; ++q) out[o + q] = v[q] + (skip != nullptr ? skip[o + q] : 0.0f);
             }
         }
     }
+#ifdef ALIVE_STAMPS
+    if (g_small_stamps != nullptr && tid == 0) {
+        long long* o = g_small_stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+        o[0] = ts[1] - ts[0]; o[1] = ts[2] - ts[1]; o[2] = ts[3] - ts[2]; o[3] = wall_clock64() - ts[3];
+    }
+#endif
 }
 
 template <int C>
@@ -251,7 +304,13 @@ extern "C" int alive_filter_block_small_range(const float* U, int N, int C, int 
     ALIVE_CHECK_ARG(N > 0 && L > 16 && Lf > 0, "alive_filter_block_small: bad sizes (L must exceed the largest reflect pad, 16)");
     ALIVE_CHECK_ARG(C == 8 || C == 16, "alive_filter_block_small: C must be 8 or 16, got %d", C);
     ALIVE_CHECK_ARG(U != out, "alive_filter_block_small: in-place not supported (tiles read a halo of their left neighbour)");
+    ALIVE_CHECK_ARG((L & 3) == 0 && ((((uintptr_t)U) | ((uintptr_t)out) | ((uintptr_t)skip)) & 15) == 0,
+                    "alive_filter_block_small: L must be a multiple of 4 and U / out / skip 16-byte aligned");
     ALIVE_CHECK_ARG(film_ld > 0 && t0 >= 0 && f0 >= 0, "alive_filter_block_small: bad frame range");
     if (C == 8) return launch_small<8>(U, N, L, wpack, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, (hipStream_t)stream);
     return launch_small<16>(U, N, L, wpack, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, (hipStream_t)stream);
 }
+
+#ifdef ALIVE_STAMPS
+extern "C" void alive_debug_set_stamps_small(long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_small_stamps), &p, sizeof(p)); }
+#endif

@@ -18,3 +18,12 @@ a.record()
 for _ in range(5): run()
 b.record(); torch.cuda.synchronize()
 print(f"C {C}: {a.elapsed_time(b)/5:.3f} ms per call")
+if hasattr(nat.lib(), "alive_debug_set_stamps_small"):          # diagnostic build: make -C alive-vc_amd/csrc clean all EXTRA=-DALIVE_STAMPS
+    import ctypes as Ct
+    TT = 968
+    nb = N * ((L + TT - 1) // TT)
+    stamps = torch.zeros(nb, 4, dtype=torch.int64, device=dev)
+    f = nat.lib().alive_debug_set_stamps_small; f.argtypes = [Ct.c_void_p]; f.restype = None
+    f(stamps.data_ptr()); run(); torch.cuda.synchronize(); f(None)
+    s = stamps.cpu().double() / 100.0
+    print("per tile mean us: FiLM/coords/staging %.1f  input conv %.1f  six convs %.1f  store %.1f" % tuple(s[:, i].mean().item() for i in range(4)))
