@@ -179,10 +179,15 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
             int row = m0 + r;
             row = row < co_pad ? row : co_pad - 1;
             src[i] = (const unsigned short*)p.W + ((size_t)pl * co_pad + row) * kpad + pchunk * 8;
-        } else {
+        } else if (p.b_row == 0) {
             int64_t col = c0 + r;
             col = col < cols_pad ? col : cols_pad - 1;
             src[i] = (const unsigned short*)p.P + ((size_t)pl * cols_pad + col) * kpad + pchunk * 8;
+        } else {                                         // custom row placement (overlapping rows: the STFT)
+            int64_t col = c0 + r;
+            col = col < cols ? col : cols - 1;
+            const int64_t nn = col / p.T;
+            src[i] = (const unsigned short*)p.P + (size_t)pl * p.b_plane + (size_t)nn * p.b_win + (size_t)(col - nn * p.T) * p.b_row + pchunk * 8;
         }
         ldst[i] = (op * NP + pl) * PLANE_BYTES + g * 1024;
     }
@@ -341,10 +346,15 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_persistent_kernel(AliveGem
                 int row = mt * GM + r;
                 row = row < co_pad ? row : co_pad - 1;
                 o[i] = (unsigned)((((size_t)pl * co_pad + row) * kpad + pchunk * 8) * 2);
-            } else {
+            } else if (p.b_row == 0) {
                 int64_t col = c0 + r;
                 col = col < cols_pad ? col : cols_pad - 1;
                 o[i] = (unsigned)((((size_t)pl * cols_pad + col) * kpad + pchunk * 8) * 2);
+            } else {                                     // custom row placement (overlapping rows: the STFT)
+                int64_t col = c0 + r;
+                col = col < cols ? col : cols - 1;
+                const int64_t nn = col / p.T;
+                o[i] = (unsigned)(((size_t)pl * p.b_plane + (size_t)nn * p.b_win + (size_t)(col - nn * p.T) * p.b_row + pchunk * 8) * 2);
             }
         }
     };
@@ -574,6 +584,8 @@ extern "C" int alive_gemm_planes(const AliveGemm* d, void* stream) {
     ALIVE_CHECK_ARG(d && d->W && d->P && (d->Y || d->Pout), "alive_gemm_planes: null pointer");
     ALIVE_CHECK_ARG(d->N > 0 && d->T > 0 && d->Ci > 0 && d->Co > 0, "alive_gemm_planes: bad shape");
     ALIVE_CHECK_ARG(d->planes == 2 || d->planes == 3, "alive_gemm_planes: planes must be 2 or 3, got %d", d->planes);
+    ALIVE_CHECK_ARG(d->b_row == 0 || ((d->b_row | d->b_win | d->b_plane) & 7) == 0, "alive_gemm_planes: custom row placement must be in multiples of 8 elements");
+    ALIVE_CHECK_ARG(d->b_row == 0 || (d->Ci & 31) == 0, "alive_gemm_planes: custom row placement needs Ci %% 32 == 0");
     ALIVE_CHECK_ARG(d->act >= 0 && d->act <= 2, "alive_gemm_planes: activation %d", d->act);
     ALIVE_CHECK_ARG(((((uintptr_t)d->W) | ((uintptr_t)d->P) | ((uintptr_t)d->Pout)) & 15) == 0,
                     "alive_gemm_planes: W / P / Pout must be 16-byte aligned");
@@ -585,7 +597,8 @@ extern "C" int alive_gemm_planes(const AliveGemm* d, void* stream) {
     const int64_t ntiles = (int64_t)cdiv(d->Co, GM) * cdiv((int64_t)d->N * d->T, GN);
     const int nsteps = pad32(d->Ci) / GK;
     const bool can_persist = ntiles >= 1024 && variant != 1 &&      // >= 4 tiles per CU, else the seams buy nothing
-                             (int64_t)d->planes * pad_cols((int64_t)d->N * d->T) * pad32(d->Ci) * 2 < (1ll << 32);   // 32-bit DMA offsets
+                             (d->b_row == 0 ? (int64_t)d->planes * pad_cols((int64_t)d->N * d->T) * pad32(d->Ci)
+                                            : (int64_t)d->planes * d->b_plane) * 2 < (1ll << 32);          // 32-bit DMA offsets
     if (d->planes == 2) {
         if (can_persist && variant == 2 && nsteps >= 4) return launch_gemm_persistent<2, 4>(*d, (hipStream_t)stream);
         return launch_gemm<2, 2, 2>(*d, (hipStream_t)stream);

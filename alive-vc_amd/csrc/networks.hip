@@ -212,15 +212,58 @@ extern "C" const char* alive_weight_name(int model, int index) {
 }
 
 // ---- spectrogram -------------------------------------------------------------------------------
-extern "C" size_t alive_dft_basis_bytes(void) { return (size_t)DFT_ROWS * NFFT * sizeof(float); }
+// basis buffer: fp32 [1296][1280] (streaming path: exact f32-MFMA conv), then bf16 [3 planes][1296][1280] (batch path)
+namespace {
+constexpr size_t BASIS_F32 = (size_t)DFT_ROWS * NFFT;
+
+__global__ void dft_basis_planes_kernel(unsigned short* planes) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= DFT_ROWS * NFFT) return;
+    int row = i / NFFT, j = i % NFFT;
+    float v = 0.0f;
+    if (row < 2 * BINS) {
+        int f = row < BINS ? row : row - BINS;
+        int ph = (int)(((long long)f * j) % NFFT);
+        double sn, cs;
+        sincospi(2.0 * (double)ph / (double)NFFT, &sn, &cs);
+        v = row < BINS ? (float)cs : (float)(-sn);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        const unsigned short h = f32_to_bf16_rn(v);
+        planes[(size_t)pl * DFT_ROWS * NFFT + i] = h;
+        v -= __uint_as_float((unsigned)h << 16);
+    }
+}
+
+// wav[N][L] -> planes [3][N][L + 1280] of the centre-padded signal (reflect, torch.stft center=True)
+__global__ void wav_to_planes_kernel(const float* __restrict__ wav, int L, int Lpad, size_t plane_stride, unsigned short* __restrict__ P) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Lpad) return;
+    const int n = blockIdx.y;
+    int sidx = i - NFFT / 2;
+    sidx = sidx < 0 ? -sidx : sidx;
+    sidx = sidx >= L ? 2 * (L - 1) - sidx : sidx;
+    float v = wav[(size_t)n * L + sidx];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        const unsigned short h = f32_to_bf16_rn(v);
+        P[(size_t)pl * plane_stride + (size_t)n * Lpad + i] = h;
+        v -= __uint_as_float((unsigned)h << 16);
+    }
+}
+}  // namespace
+
+extern "C" size_t alive_dft_basis_bytes(void) { return BASIS_F32 * sizeof(float) + 3 * BASIS_F32 * sizeof(unsigned short); }
 extern "C" int alive_dft_basis(float* basis, void* stream) {
     ALIVE_CHECK_ARG(basis, "alive_dft_basis: null");
     dft_basis_kernel<<<cdiv((int64_t)DFT_ROWS * NFFT, 256), 256, 0, (hipStream_t)stream>>>(basis);
+    dft_basis_planes_kernel<<<cdiv((int64_t)DFT_ROWS * NFFT, 256), 256, 0, (hipStream_t)stream>>>((unsigned short*)(basis + BASIS_F32));
     ALIVE_CHECK_LAUNCH("alive_dft_basis");
     return ALIVE_OK;
 }
 extern "C" size_t alive_spectrogram_workspace_bytes(int N, int L) {
-    return align_up((size_t)N * 2 * BINS * (L / HOP) * sizeof(float), 256) + 256;
+    return align_up((size_t)N * 2 * BINS * (L / HOP) * sizeof(float), 256) + align_up((size_t)3 * N * (L + NFFT) * 2, 256) + 512;
 }
 extern "C" int alive_spectrogram(const float* basis, const float* wav, int N, int L, float* spec, void* ws, void* stream) {
     ALIVE_CHECK_ARG(basis && wav && spec && ws, "alive_spectrogram: null pointer");
@@ -228,6 +271,19 @@ extern "C" int alive_spectrogram(const float* basis, const float* wav, int N, in
     const int T = L / HOP;
     Arena a(ws);
     float* ri = a.take<float>((size_t)N * 2 * BINS * T);
+    if (use_planes(N, T) && L % 8 == 0) {
+        // batch path: the padded signal is split into three bf16 planes ONCE; the frames are overlapping rows of it
+        // (row stride = hop), so the DFT is a plane-packed GEMM ("bf16x6", fp32-grade) without an im2col
+        const int Lpad = L + NFFT;
+        unsigned short* wp = a.take<unsigned short>((size_t)3 * N * Lpad);
+        wav_to_planes_kernel<<<dim3(cdiv(Lpad, 256), N), 256, 0, (hipStream_t)stream>>>(wav, L, Lpad, (size_t)N * Lpad, wp);
+        AliveGemm g;
+        memset(&g, 0, sizeof(g));
+        g.W = basis + BASIS_F32; g.P = wp; g.N = N; g.T = T; g.Ci = NFFT; g.Co = 2 * BINS; g.planes = 3; g.Y = ri;
+        g.b_plane = (int64_t)N * Lpad; g.b_win = Lpad; g.b_row = HOP;
+        RUN(alive_gemm_planes(&g, stream));
+        return alive_magnitude(ri, N, BINS, T, spec, (hipStream_t)stream);
+    }
     AliveConv d = conv_desc(basis, nullptr, wav, N, 1, L, 2 * BINS, NFFT, HOP, 1, NFFT / 2, 2, T, ri);
     RUN(alive_conv1d(&d, stream));
     return alive_magnitude(ri, N, BINS, T, spec, (hipStream_t)stream);

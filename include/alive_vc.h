@@ -148,6 +148,11 @@ typedef struct AliveGemm {
     const float* residual; /* [N][Co][T] or NULL */
     float* Y;              /* fp32 output [N][Co][T] or NULL */
     void* Pout;            /* plane-packed output [planes][cols_pad][Co_pad32] or NULL (Co_pad32 = Co rounded up to 32) */
+    /* custom placement of the input rows (all 0: the packed form above).  Row (n, t) of plane pl starts at element
+     * pl*b_plane + n*b_win + t*b_row: overlapping rows (b_row < Ci) make the GEMM a strided convolution over a signal
+     * stored once -- the STFT runs this way (b_row = hop 320, Ci = 1280).  Multiples of 8 elements. */
+    int64_t b_plane, b_win;
+    int b_row;
 } AliveGemm;
 int alive_gemm_planes(const AliveGemm* desc, void* stream);
 
