@@ -27,12 +27,14 @@ constexpr int BL = 256;                 // columns per tile incl. halo
 constexpr int TT = BL - HALO;           // 200 output columns per tile
 constexpr int NCT = BL / 16;            // 16 column tiles
 constexpr int NFP = 8;                  // FiLM frames staged per tile
+constexpr int NFS = NFP + 1;            // row pitch of the staged FiLM table: the four channel groups of a column (lanes kq = 0..3,
+                                        // 4 rows apart) land on different banks (pitch 8 put them 128 B apart: 4-way conflicts)
 constexpr int ROWB = 128;               // bytes per LDS row (64 channels bf16)
 constexpr int PLANE = BL * ROWB;        // 32 KB
 constexpr int BUF = 2 * PLANE;          // hi + lo
 constexpr int W_IN = 2 * C * C;         // bf16 elements of the input conv [2][64][64]
 constexpr int W_K5 = 2 * C * 5 * C;     // bf16 elements of a k5 conv [2][64][320]
-constexpr int LDS_BYTES = 2 * BUF + NCONV * 2 * C * NFP * 4 + BL * 8;
+constexpr int LDS_BYTES = 2 * BUF + NCONV * 2 * C * NFS * 4 + BL * 8;
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -56,8 +58,8 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     unsigned char* bufZ = sm;
     unsigned char* bufY = sm + BUF;
-    float* Fs = (float*)(sm + 2 * BUF);               // [NCONV][2][C][NFP]
-    uint2* Xc = (uint2*)(Fs + NCONV * 2 * C * NFP);   // [BL] interpolation coordinates of a column: (i0 | i1 << 16, w1)
+    float* Fs = (float*)(sm + 2 * BUF);               // [NCONV][2][C][NFS]
+    uint2* Xc = (uint2*)(Fs + NCONV * 2 * C * NFS);   // [BL] interpolation coordinates of a column: (i0 | i1 << 16, w1)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
         fr = fr < Lf ? fr : Lf - 1;
         int fc = fr - f_off;                             // frame of the window -> column of the film tensor
         fc = fc < 0 ? 0 : (fc < film_ld ? fc : film_ld - 1);
-        Fs[e] = film[((size_t)n * film_rows + film_off + q * 2 * C + sel * C + c) * film_ld + fc];
+        Fs[((q * 2 + sel) * C + c) * NFS + f] = film[((size_t)n * film_rows + film_off + q * 2 * C + sel * C + c) * film_ld + fc];
     }
     {   // F.interpolate coordinates of this thread's column, relative to the staged FiLM frames
         int t = tbase + tid;
@@ -125,15 +127,15 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
         const uint2 xc = Xc[col];
         const int i0 = xc.x & 0xffff, i1 = xc.x >> 16;
         F.w1 = __uint_as_float(xc.y);
-        const float* f = Fs + ((q * 2) * C + 16 * w + 4 * kq) * NFP;
+        const float* f = Fs + ((q * 2) * C + 16 * w + 4 * kq) * NFS;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const float* fa = f + (2 * e) * NFP;
-            const float* fb = fa + NFP;
+            const float* fa = f + (2 * e) * NFS;
+            const float* fb = fa + NFS;
             F.s0[e] = f32x2{fa[i0], fb[i0]};
             F.s1[e] = f32x2{fa[i1], fb[i1]};
-            F.h0[e] = f32x2{fa[C * NFP + i0], fb[C * NFP + i0]};
-            F.h1[e] = f32x2{fa[C * NFP + i1], fb[C * NFP + i1]};
+            F.h0[e] = f32x2{fa[C * NFS + i0], fb[C * NFS + i0]};
+            F.h1[e] = f32x2{fa[C * NFS + i1], fb[C * NFS + i1]};
         }
     };
     // gelu -> FiLM of the next conv's input for the 4 channels of this lane at column `col`, re-split and stored as
