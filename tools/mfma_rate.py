@@ -1,0 +1,21 @@
+"""what bf16 MFMA rate the chip sustains on random data at the scoring kernel's occupancy (csrc/diag.hip)"""
+import ctypes as C, os, sys, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "alive-vc_amd"))
+from module import _native as nat
+L_ = nat.lib()
+fn = L_.alive_debug_mfma_rate
+fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+dev = "cuda"
+st = torch.cuda.current_stream().cuda_stream
+sink = torch.zeros(4, device=dev)
+iters = 200000
+for name, rnd in (("random", torch.randn(32768, device=dev).to(torch.bfloat16)), ("zeros", torch.zeros(32768, device=dev, dtype=torch.bfloat16))):
+    for mode in (0, 1):
+        nat.check(fn(rnd.data_ptr(), 256, 2000, mode, sink.data_ptr(), st))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        nat.check(fn(rnd.data_ptr(), 256, iters, mode, sink.data_ptr(), st))
+        b.record(); torch.cuda.synchronize()
+        ms = a.elapsed_time(b)
+        flops = 256 * 4 * 8.0 * iters * 2 * 32 * 32 * 16
+        print(f"{name:7s} mode {mode} ({'registers only' if mode == 0 else 'one ds_read_b128 per two MFMAs'}): {ms:8.1f} ms  {flops / ms / 1e9:7.1f} TFLOP/s")
