@@ -23,7 +23,7 @@ namespace {
 constexpr int BK = 16;
 constexpr int A_LD = BK + 4;   // 20 floats = 80 B rows: keeps b128 reads 16-B aligned, spreads banks
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool UPV = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(AliveConv p, unsigned kw_magic, float film_ratio) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MR = TM / 16, NR = TN / 16;
@@ -150,6 +150,34 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(AliveConv p, unsigned kw
             ft.f_lo = f_lo;
         }
     }
+    if constexpr (UPV) {      // host: up == 2 or 4, no activation / post_add / ch_scale.  Its own instantiation: as a run-time branch
+                              // of the general kernel it slowed the strided convs that never take it by 15-25 % (A/B, same box)
+        // ConvTranspose1d(k == stride == up): the 4 consecutive rows (co, j) a lane holds for its column t are up consecutive
+        // samples of 4 / up channels -- one 8- or 16-B store per channel, 16 lanes = one contiguous run, instead of 4-B
+        // stores scattered at a stride of up floats
+        const size_t Lout = (size_t)p.Tout * p.up;
+        const int Cq = p.Co / p.up;
+#pragma unroll
+        for (int nn = 0; nn < NR; ++nn) {
+            const int t = t0 + wn * TN + nn * 16 + lr;
+            if (t >= p.Tout) continue;
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                const int row = m0 + wm * TM + m * 16 + lq * 4;          // multiple of 4, Co is a multiple of up
+                if (p.up == 4) {
+                    if (row < p.Co) *(f32x4*)(p.Y + ((size_t)n * Cq + (row >> 2)) * Lout + (size_t)t * 4) = acc[m][nn];
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        if (row + 2 * h < p.Co) {
+                            f32x2 v = {acc[m][nn][2 * h], acc[m][nn][2 * h + 1]};
+                            *(f32x2*)(p.Y + ((size_t)n * Cq + (row >> 1) + h) * Lout + (size_t)t * 2) = v;
+                        }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int nn = 0; nn < NR; ++nn) {
         const int t = t0 + wn * TN + nn * 16 + lr;
@@ -205,7 +233,10 @@ extern "C" int alive_conv1d(const AliveConv* d, void* stream) {
         conv_gemm_kernel<64, 128, 1, 4><<<g, 256, 0, s>>>(*d, magic, ratio);
     } else {
         dim3 g(cdiv(d->Tout, 256), 1, d->N);
-        conv_gemm_kernel<16, 256, 1, 4><<<g, 256, 0, s>>>(*d, magic, ratio);
+        if ((d->up == 2 || d->up == 4) && d->act == 0 && !d->post_add && !d->ch_scale)
+            conv_gemm_kernel<16, 256, 1, 4, true><<<g, 256, 0, s>>>(*d, magic, ratio);      // vector stores of the transposed conv
+        else
+            conv_gemm_kernel<16, 256, 1, 4><<<g, 256, 0, s>>>(*d, magic, ratio);
     }
     ALIVE_CHECK_LAUNCH("alive_conv1d");
     return ALIVE_OK;

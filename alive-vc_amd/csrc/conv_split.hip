@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
     int f_lo = 0, nf = 0;
     if (p.Z != nullptr) film_tile_range(p, film_ratio, t0, BN, f_lo, nf);       // fit is checked on the host
     const bool vec = (p.up == 1) && ((p.Tout & 3) == 0);
+    const bool upvec = p.up >= 4 && (p.up & (p.up - 1)) == 0 && p.up <= PR && (p.Co & (p.up - 1)) == 0;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
         if ((wrow >> 1) == ps) {                     // wave-uniform: the two 32-row waves of this pass deposit their tiles
@@ -255,6 +256,63 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
                     *(f32x4*)(p.Z + o) = z;
                 }
             }
+        } else if (upvec) {
+            // ConvTranspose1d(k == stride == up), up a multiple of 4 dividing PR: the rows (co, j) of one output channel hold
+            // the up * BN CONSECUTIVE samples Y[co][t0 * up ...] in [t][j] order -- gather them from the staged tile and store
+            // 16-B vectors (the scalar path below scatters 4-B stores at a stride of up floats)
+            const int sh = __builtin_ctz((unsigned)p.up);
+            const size_t Lout = (size_t)p.Tout * p.up;
+#pragma unroll
+            for (int g = tid; g < PR * (BN / 4); g += 256) {
+                const int e = g * 4;                                   // element of the pass: [co_l][t_l][j]
+                const int co_l = e >> (7 + sh), rem = e & ((BN << sh) - 1);
+                const int t_l = rem >> sh, j0 = rem & (p.up - 1);
+                const int pr = (co_l << sh) + j0;
+                const int row = m0 + ps * 64 + pr;
+                const int t = t0 + t_l;
+                if (row >= p.Co || t >= p.Tout) continue;
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float x = Ct[(pr + q) * CP + t_l];
+                    if (p.act == 1) x = gelu_fast(x);
+                    else if (p.act == 2) x = expf(x);
+                    if (p.post_add != nullptr) x += p.post_add[row + q];
+                    if (p.ch_scale != nullptr) x *= p.ch_scale[row + q];
+                    v[q] = x;
+                }
+                *(f32x4*)(p.Y + ((size_t)n * (p.Co >> sh) + (row >> sh)) * Lout + ((size_t)t << sh) + j0) = v;
+            }
+        } else if (p.up > 1) {
+            // any other ConvTranspose1d rate (10 on the coarsest filter scale): walk the OUTPUT order [co][t][j] of the
+            // channels this pass touches, so that consecutive lanes store consecutive samples; rows of the first / last
+            // channel that belong to the neighbouring pass are skipped
+            const unsigned inv_up = (unsigned)((0x100000000ull + (unsigned)p.up - 1) / (unsigned)p.up);   // exact floor(x / up), x < 2^25
+            const int R0 = m0 + ps * 64;
+            const int c_first = (int)__umulhi((unsigned)R0, inv_up);
+            int R1 = R0 + PR - 1;
+            R1 = R1 < p.Co ? R1 : p.Co - 1;
+            const int nch = (int)__umulhi((unsigned)R1, inv_up) - c_first + 1;
+            const int per_ch = BN * p.up;
+            const size_t Lout = (size_t)p.Tout * p.up;
+            const int Cq = (int)__umulhi((unsigned)p.Co, inv_up);
+#pragma unroll 1
+            for (int ch = 0; ch < nch; ++ch) {
+                const int co = c_first + ch;
+                float* yrow = p.Y + ((size_t)n * Cq + co) * Lout + (size_t)t0 * p.up;
+#pragma unroll 2
+                for (int e = tid; e < per_ch; e += 256) {
+                    const int t_l = (int)__umulhi((unsigned)e, inv_up), jj = e - t_l * p.up;
+                    const int row = co * p.up + jj;
+                    if (row < R0 || row > R1 || t0 + t_l >= p.Tout) continue;
+                    float v = Ct[(row - R0) * CP + t_l];
+                    if (p.act == 1) v = gelu_fast(v);
+                    else if (p.act == 2) v = expf(v);
+                    if (p.post_add != nullptr) v = v + p.post_add[row];
+                    if (p.ch_scale != nullptr) v = v * p.ch_scale[row];
+                    yrow[e] = v;
+                }
+            }
         } else {
 #pragma unroll 1
             for (int g = tid; g < PR * BN; g += 256) {
@@ -267,21 +325,16 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
                 else if (p.act == 2) v = expf(v);
                 if (p.post_add != nullptr) v = v + p.post_add[row];
                 if (p.ch_scale != nullptr) v = v * p.ch_scale[row];
-                if (p.up == 1) {
-                    const size_t o = ((size_t)n * p.Co + row) * p.Tout + t;
-                    if (p.residual != nullptr) v = v + p.residual[o];
-                    if (p.skip != nullptr) v = v + p.skip[o];
-                    if (p.Y != nullptr) p.Y[o] = v;
-                    if (p.Z != nullptr) {
-                        const float* fs = Ft + pr * 2 * FILM_NF - f_lo;
-                        Lerp lp = lerp_coord(t + p.film_t0, film_ratio, p.Lf);
-                        float sc = lerp_apply(lp, fs[lp.i0], fs[lp.i1]);
-                        float sh = lerp_apply(lp, fs[FILM_NF + lp.i0], fs[FILM_NF + lp.i1]);
-                        p.Z[o] = gelu_fast(v) * sc + sh;
-                    }
-                } else {
-                    const int co = row / p.up, jj = row - co * p.up;
-                    p.Y[((size_t)n * (p.Co / p.up) + co) * ((size_t)p.Tout * p.up) + (size_t)t * p.up + jj] = v;
+                const size_t o = ((size_t)n * p.Co + row) * p.Tout + t;
+                if (p.residual != nullptr) v = v + p.residual[o];
+                if (p.skip != nullptr) v = v + p.skip[o];
+                if (p.Y != nullptr) p.Y[o] = v;
+                if (p.Z != nullptr) {
+                    const float* fs = Ft + pr * 2 * FILM_NF - f_lo;
+                    Lerp lp = lerp_coord(t + p.film_t0, film_ratio, p.Lf);
+                    float sc = lerp_apply(lp, fs[lp.i0], fs[lp.i1]);
+                    float sh = lerp_apply(lp, fs[FILM_NF + lp.i0], fs[FILM_NF + lp.i1]);
+                    p.Z[o] = gelu_fast(v) * sc + sh;
                 }
             }
         }

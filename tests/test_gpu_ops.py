@@ -92,7 +92,7 @@ def test_conv1d_epilogue_scale_residual_skip():
     torch.testing.assert_close(y.cpu(), ref, rtol=1e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("ci,co,r,t", [(256, 256, 10, 45), (256, 64, 8, 450), (64, 16, 2, 999), (16, 8, 2, 2000)])
+@pytest.mark.parametrize("ci,co,r,t", [(256, 256, 10, 45), (256, 64, 8, 450), (64, 16, 2, 999), (16, 8, 2, 2000), (32, 12, 4, 333), (32, 4, 4, 333)])
 def test_conv_transpose(ci, co, r, t):
     from module import ops
     x = g(f"tx{ci}{r}", (2, ci, t))
@@ -258,7 +258,7 @@ def test_conv1d_split_bf16(co, ci, kw, dil, pad, mode, t):
     assert e < 2e-5, e          # 2-term split: ~2^-16 per product; fp32 kernel is ~1e-7, plain bf16 would be ~3e-3
 
 
-@pytest.mark.parametrize("ci,co,r,t", [(256, 256, 10, 45), (256, 64, 8, 450)])
+@pytest.mark.parametrize("ci,co,r,t", [(256, 256, 10, 45), (256, 64, 8, 450), (64, 40, 4, 1001), (96, 24, 16, 300)])
 def test_conv_transpose_split_bf16(ci, co, r, t):
     from module import ops
     x = g(f"tsx{ci}{r}", (2, ci, t))
