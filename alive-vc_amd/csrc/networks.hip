@@ -62,7 +62,10 @@ const Names& names_of(int model) {
         dec.add("osc.amps.W"); dec.add("osc.amps.b");
         dec.add("flt.film.W"); dec.add("flt.film.b"); dec.add("flt.film.post");
         dec.add("flt.in.W"); dec.add("flt.in.b");
-        for (int i = 0; i < 4; ++i) { dec.add("flt.down" + std::to_string(i) + ".W"); dec.add("flt.down" + std::to_string(i) + ".b"); }
+        for (int i = 0; i < 4; ++i) {
+            dec.add("flt.down" + std::to_string(i) + ".W"); dec.add("flt.down" + std::to_string(i) + ".b");
+            if (i >= 2) dec.add("flt.down" + std::to_string(i) + ".Wp");      // the same weights as bf16 planes, tap-major (batch path)
+        }
         dec.add("flt.mid.W"); dec.add("flt.mid.b");
         for (int i = 0; i < 4; ++i) { dec.add("flt.up" + std::to_string(i) + ".W"); dec.add("flt.up" + std::to_string(i) + ".b"); }
         for (int s = 0; s < 4; ++s) {
@@ -390,9 +393,9 @@ DecBuffers dec_layout(void* ws, int N, int Lf) {
     b.d3 = a.take<float>(f * 256);
     b.m = a.take<float>(f * 256);
     const size_t big = (size_t)N * 64 * (Lw / 4);      // largest filter-scale tensor (64 x 36000 per window)
-    b.U = a.take<float>(big);
+    b.U = a.take<float>(big + 32768);                  // + the column padding of the planes of d1 it doubles as scratch for
     b.Hh = a.take<float>(big);
-    b.Zz = a.take<float>(big);
+    b.Zz = a.take<float>(big + 32768);                 // (planes of d2)
     b.Z2 = a.take<float>(big);
     b.osc_ws = a.take<char>(alive_oscillator_workspace_bytes(N, NH, Lf));
     b.bytes = a.used() + 1024;
@@ -449,9 +452,28 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
     int len = Lw / 2;
     for (int i = 1; i < 4; ++i) {
         const float* W = t.next(); const float* bb = t.next();
-        AliveConv d = conv_desc(W, bb, dbuf[i], N, dch[i], len, dch[i + 1], drate[i], drate[i], 1, 0, 0, len / drate[i], dbuf[i + 1]);
-        RUN(alive_conv1d(&d, stream));
-        len /= drate[i];
+        const float* Wp = i >= 2 ? t.next() : nullptr;
+        const int r = drate[i];
+        if (Wp != nullptr && b.Pa != nullptr) {
+            // Conv1d(k == stride == r, no padding) on the batch path: with the input as time-major bf16 planes, the K vector of
+            // output column t is the r consecutive plane rows r t .. r t + r - 1 -- a plane GEMM whose B rows overlap nothing
+            // and start every r rows (the same custom row placement the STFT uses), 16/3 the rate of the exact-fp32 kernel
+            void* Pd = i == 2 ? (void*)b.U : (void*)b.Zz;             // both idle until the up path starts
+            const int cpad = (dch[i] + 31) & ~31;
+            RUN(alive_to_planes(dbuf[i], N, dch[i], len, 2, Pd, stream));
+            AliveGemm g;
+            memset(&g, 0, sizeof(g));
+            g.W = Wp; g.bias = bb; g.P = Pd; g.N = N; g.T = len / r; g.Ci = r * cpad; g.Co = dch[i + 1]; g.planes = 2;
+            g.Y = dbuf[i + 1];
+            g.b_plane = (int64_t)(alive_planes_bytes((int64_t)N * len, dch[i], 2) / 4);      // elements per plane
+            g.b_win = (int64_t)len * cpad;
+            g.b_row = (int64_t)r * cpad;
+            RUN(alive_gemm_planes(&g, stream));
+        } else {
+            AliveConv d = conv_desc(W, bb, dbuf[i], N, dch[i], len, dch[i + 1], r, r, 1, 0, 0, len / r, dbuf[i + 1]);
+            RUN(alive_conv1d(&d, stream));
+        }
+        len /= r;
     }
     const float* mW = t.next(); const float* mb = t.next();
     {   // mid CausalConv1d(256,256,5) + skips[3]   (decoder.py:190-191)

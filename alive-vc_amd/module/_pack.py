@@ -176,6 +176,8 @@ def pack_decoder(sd):
         # downs[0] is fused with source_in (reference layout [16][8][2]); the others run on the fp32 MFMA kernel
         out[f"flt.down{i}.W"] = _vec(sd[f"{f}.downs.{i}.weight"]) if i == 0 else pack_conv(sd[f"{f}.downs.{i}.weight"])
         out[f"flt.down{i}.b"] = _vec(sd[f"{f}.downs.{i}.bias"])
+        if i >= 2:      # batch path: the strided conv as a plane GEMM (networks.hip::decoder_run)
+            out[f"flt.down{i}.Wp"] = pack_conv_split(sd[f"{f}.downs.{i}.weight"])
     out["flt.mid.W"] = pack_conv_split(sd[f + ".mid_conv.conv.weight"])
     out["flt.mid.b"] = _vec(sd[f + ".mid_conv.conv.bias"])
     for i in range(4):
