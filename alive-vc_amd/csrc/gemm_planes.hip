@@ -48,6 +48,41 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
     // as clamped loads, and all residual values of a 32-row half are requested before its first store (Y may alias the
     // residual, so the compiler may not hoist them).  Tiles that lie completely inside Co take the store path without
     // per-row tests.
+    if constexpr (ACT == 3) {
+        // argmax over the rows: the wave's 64 x 64 sub-tile leaves one (value, row) candidate per column.  A lane walks
+        // its 32 rows in ascending order, the two half-waves of a column (rows 8 g + 4 lh + e) meet through one
+        // cross-lane exchange; value = accumulator + bias, bitwise what the Y path would have stored.
+        float bv[2] = {-INFINITY, -INFINITY};
+        int bi[2] = {0x7fffffff, 0x7fffffff};
+        auto take = [](float v, int vi, float b, int i) { return (v > b) || (v == b && vi < i) || (v != v && b == b); };
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const int rbase = m0 + wr * 64 + ti * 32 + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                const float b = p.bias != nullptr ? p.bias[row < p.Co ? row : p.Co - 1] : 0.0f;
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) {
+                    const float x = acc[ti][tj][r] + b;
+                    if (row < p.Co && take(x, row, bv[tj], bi[tj])) { bv[tj] = x; bi[tj] = row; }
+                }
+            }
+        }
+        const int blk = (m0 + wr * 64) >> 6;
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const float ov = __shfl_xor(bv[tj], 32);
+            const int oi = __shfl_xor(bi[tj], 32);
+            if (take(ov, oi, bv[tj], bi[tj])) { bv[tj] = ov; bi[tj] = oi; }
+            const int64_t col = c0 + wc * 64 + tj * 32 + lr;
+            if (lh == 0 && col < cols && m0 + wr * 64 < p.Co) {
+                p.arg_val[(size_t)blk * cols + col] = bv[tj];
+                p.arg_idx[(size_t)blk * cols + col] = bi[tj];
+            }
+        }
+        return;
+    }
     unsigned obase[2];
     bool cok[2];
 #pragma unroll
@@ -547,6 +582,7 @@ int launch_gemm_persistent_act(const AliveGemm& d, hipStream_t s) {
 
 template <int NP, int NS>
 int launch_gemm_persistent(const AliveGemm& d, hipStream_t s) {
+    if constexpr (NP == 3) { if (d.act == 3) return launch_gemm_persistent_act<NP, NS, 3>(d, s); }
     if (d.act == 1) return launch_gemm_persistent_act<NP, NS, 1>(d, s);
     if (d.act == 2) return launch_gemm_persistent_act<NP, NS, 2>(d, s);
     return launch_gemm_persistent_act<NP, NS, 0>(d, s);
@@ -554,12 +590,36 @@ int launch_gemm_persistent(const AliveGemm& d, hipStream_t s) {
 
 template <int NP, int NS, int MINB>
 int launch_gemm(const AliveGemm& d, hipStream_t s) {
+    if constexpr (NP == 3) { if (d.act == 3) return launch_gemm_act<NP, NS, MINB, 3>(d, s); }
     if (d.act == 1) return launch_gemm_act<NP, NS, MINB, 1>(d, s);
     if (d.act == 2) return launch_gemm_act<NP, NS, MINB, 2>(d, s);
     return launch_gemm_act<NP, NS, MINB, 0>(d, s);
 }
 
 }  // namespace
+
+namespace {
+__global__ __launch_bounds__(256) void argmax_merge_kernel(const float* __restrict__ val, const int* __restrict__ idx, int nblk,
+                                                           int64_t cols, float* __restrict__ out) {
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= cols) return;
+    float b = val[col];
+    int i = idx[col];
+    for (int k = 1; k < nblk; ++k) {
+        const float v = val[(size_t)k * cols + col];
+        const int vi = idx[(size_t)k * cols + col];
+        if ((v > b) || (v == b && vi < i) || (v != v && b == b)) { b = v; i = vi; }
+    }
+    out[col] = (float)i;
+}
+}  // namespace
+
+extern "C" int alive_argmax_merge(const float* arg_val, const int32_t* arg_idx, int nblk, int64_t cols, float* out, void* stream) {
+    ALIVE_CHECK_ARG(arg_val && arg_idx && out && nblk > 0 && cols > 0, "alive_argmax_merge: bad args");
+    argmax_merge_kernel<<<(unsigned)((cols + 255) / 256), 256, 0, (hipStream_t)stream>>>(arg_val, arg_idx, nblk, cols, out);
+    ALIVE_CHECK_LAUNCH("alive_argmax_merge");
+    return ALIVE_OK;
+}
 
 extern "C" void alive_debug_set_stamps(long long* p) { g_stamps = p; }
 
@@ -581,17 +641,22 @@ extern "C" int alive_to_planes(const float* X, int N, int C, int T, int planes, 
 }
 
 extern "C" int alive_gemm_planes(const AliveGemm* d, void* stream) {
-    ALIVE_CHECK_ARG(d && d->W && d->P && (d->Y || d->Pout), "alive_gemm_planes: null pointer");
+    ALIVE_CHECK_ARG(d && d->W && d->P, "alive_gemm_planes: null pointer");
+    if (d->act == 3) {
+        ALIVE_CHECK_ARG(d->planes == 3 && d->arg_val && d->arg_idx && !d->Y && !d->Pout && !d->residual && !d->post_add && !d->ch_scale,
+                        "alive_gemm_planes: act 3 (argmax) takes 3 planes, arg_val / arg_idx and no other output or epilogue term");
+    } else {
+        ALIVE_CHECK_ARG(d->Y || d->Pout, "alive_gemm_planes: no output");
+    }
     ALIVE_CHECK_ARG(d->N > 0 && d->T > 0 && d->Ci > 0 && d->Co > 0, "alive_gemm_planes: bad shape");
     ALIVE_CHECK_ARG(d->planes == 2 || d->planes == 3, "alive_gemm_planes: planes must be 2 or 3, got %d", d->planes);
     ALIVE_CHECK_ARG(d->b_row == 0 || ((d->b_row | d->b_win | d->b_plane) & 7) == 0, "alive_gemm_planes: custom row placement must be in multiples of 8 elements");
     ALIVE_CHECK_ARG(d->b_row == 0 || (d->Ci & 31) == 0, "alive_gemm_planes: custom row placement needs Ci %% 32 == 0");
-    ALIVE_CHECK_ARG(d->act >= 0 && d->act <= 2, "alive_gemm_planes: activation %d", d->act);
+    ALIVE_CHECK_ARG(d->act >= 0 && d->act <= 3, "alive_gemm_planes: activation %d", d->act);
     ALIVE_CHECK_ARG(((((uintptr_t)d->W) | ((uintptr_t)d->P) | ((uintptr_t)d->Pout)) & 15) == 0,
                     "alive_gemm_planes: W / P / Pout must be 16-byte aligned");
-    ALIVE_CHECK_ARG((d->Y == nullptr) != (d->Pout == nullptr), "alive_gemm_planes: exactly one of Y / Pout");
-    ALIVE_CHECK_ARG((int64_t)d->N * d->Co * d->T < (1ll << 30), "alive_gemm_planes: fp32 tensor of %lld elements exceeds the 32-bit offsets",
-                    (long long)d->N * d->Co * d->T);
+    ALIVE_CHECK_ARG(!(d->Y || d->residual) || (int64_t)d->N * d->Co * d->T < (1ll << 30),
+                    "alive_gemm_planes: fp32 tensor of %lld elements exceeds the 32-bit offsets", (long long)d->N * d->Co * d->T);
     // variants (A/B switch for tools/bench_gemm_planes.py): 0 = default, 1 = one-tile kernels only, 2 = persistent for both
     static const int variant = getenv("ALIVE_GEMM_VARIANT") ? atoi(getenv("ALIVE_GEMM_VARIANT")) : 0;
     const int64_t ntiles = (int64_t)cdiv(d->Co, GM) * cdiv((int64_t)d->N * d->T, GN);

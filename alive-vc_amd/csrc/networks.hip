@@ -351,7 +351,17 @@ extern "C" int alive_f0_estimate(const float* const* w, const float* spec, int N
     const float* oW = t.next(); const float* ob = t.next();
     if (b.Pa != nullptr) {
         RUN(alive_dwconv_norm_planes(b.x, N, PE_C, T, nullptr, nullptr, 0, g, of, nullptr, 0, 0, 0, NORM_EPS, 3, b.Pa, stream));
-        RUN(pw_gemm(oW, ob, b.Pa, N, T, PE_C, PE_OUT, 3, 0, nullptr, nullptr, nullptr, b.lg, nullptr, stream));
+        // 256 -> 4096 classes with the argmax in the GEMM's epilogue: the logits (16 KB per frame) are never stored;
+        // b.lg holds the per-64-row-block candidates instead (512 B per frame)
+        const int nblk = (PE_OUT + 63) / 64;
+        const int64_t cols = (int64_t)N * T;
+        AliveGemm g;
+        memset(&g, 0, sizeof(g));
+        g.W = oW; g.bias = ob; g.P = b.Pa; g.N = N; g.T = T; g.Ci = PE_C; g.Co = PE_OUT; g.planes = 3; g.act = 3;
+        g.arg_val = b.lg;
+        g.arg_idx = (int32_t*)(b.lg + (size_t)nblk * cols);
+        RUN(alive_gemm_planes(&g, stream));
+        return alive_argmax_merge(g.arg_val, g.arg_idx, nblk, cols, f0, stream);
     } else {
         RUN(alive_channel_norm(b.x, N, PE_C, T, g, of, NORM_EPS, b.y, stream));
         RUN(pw_conv(oW, ob, b.y, b.Pa, N, T, PE_C, PE_OUT, 3, 0, nullptr, b.lg, stream));
@@ -460,11 +470,12 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
             // and start every r rows (the same custom row placement the STFT uses), 16/3 the rate of the exact-fp32 kernel
             void* Pd = i == 2 ? (void*)b.U : (void*)b.Zz;             // both idle until the up path starts
             const int cpad = (dch[i] + 31) & ~31;
-            RUN(alive_to_planes(dbuf[i], N, dch[i], len, 2, Pd, stream));
+            if (i == 2) RUN(alive_to_planes(dbuf[i], N, dch[i], len, 2, Pd, stream));      // i == 3: left there by downs[2]'s epilogue
             AliveGemm g;
             memset(&g, 0, sizeof(g));
             g.W = Wp; g.bias = bb; g.P = Pd; g.N = N; g.T = len / r; g.Ci = r * cpad; g.Co = dch[i + 1]; g.planes = 2;
             g.Y = dbuf[i + 1];
+            if (i == 2) g.Pout = b.Zz;                                 // d2 as planes too: the input of downs[3]
             g.b_plane = (int64_t)(alive_planes_bytes((int64_t)N * len, dch[i], 2) / 4);      // elements per plane
             g.b_win = (int64_t)len * cpad;
             g.b_row = (int64_t)r * cpad;

@@ -35,6 +35,7 @@ class AliveGemm(C.Structure):
         ("post_add", C.c_void_p), ("ch_scale", C.c_void_p), ("residual", C.c_void_p),
         ("Y", C.c_void_p), ("Pout", C.c_void_p),
         ("b_plane", C.c_int64), ("b_win", C.c_int64), ("b_row", C.c_int),
+        ("arg_val", C.c_void_p), ("arg_idx", C.c_void_p),
     ]
 
 
@@ -54,6 +55,7 @@ PROTOTYPES = {
     "alive_planes_bytes": (_SZ, [_I64, _I, _I]),
     "alive_to_planes": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "alive_gemm_planes": (_I, [C.POINTER(AliveGemm), _VP]),
+    "alive_argmax_merge": (_I, [_VP, _VP, _I, _I64, _VP, _VP]),
     "alive_filter_block_small_weights": (_I, [_I]),
     "alive_filter_block_small": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
     "alive_filter_block_small_range": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),

@@ -109,6 +109,25 @@ def gemm_planes(P, n, t, weight, bias=None, planes=2, act=None, post_add=None, c
     return Y, Po
 
 
+def gemm_planes_argmax(P, n, t, weight, bias=None, planes=3):
+    """argmax over the output channels of a 1x1 conv without storing its output (AliveGemm.act = 3 + alive_argmax_merge):
+    float indices [n, 1, t] like F0Estimator.estimate."""
+    co, ci = weight.shape[0], weight.shape[1]
+    W = pack_conv_split(weight, planes)
+    b = _f(bias)
+    nblk = (co + 63) // 64
+    val = torch.empty(nblk, n * t, device=P.device)
+    idx = torch.empty(nblk, n * t, dtype=torch.int32, device=P.device)
+    d = nat.AliveGemm()
+    d.W, d.bias, d.P = nat.ptr(W), nat.ptr(b), nat.ptr(P)
+    d.N, d.T, d.Ci, d.Co, d.planes, d.act = n, t, ci, co, planes, 3
+    d.arg_val, d.arg_idx = nat.ptr(val), nat.ptr(idx)
+    nat.check(nat.lib().alive_gemm_planes(C.byref(d), nat.stream()), "alive_gemm_planes")
+    out = torch.empty(n, 1, t, device=P.device)
+    nat.check(nat.lib().alive_argmax_merge(nat.ptr(val), nat.ptr(idx), nblk, n * t, nat.ptr(out), nat.stream()), "alive_argmax_merge")
+    return out
+
+
 def dwconv_norm(x, dw_w, dw_b, gain=None, offset=None, cond=None, scale_row=0, shift_row=0, eps=1e-4):
     x = _f(x)
     n, c, t = x.shape

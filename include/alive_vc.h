@@ -142,7 +142,7 @@ typedef struct AliveGemm {
     int N, T;              /* cols = N*T; fp32 outputs are [N][Co][T] */
     int Ci, Co;
     int planes;            /* 2: bf16x3, 3: bf16x6 (both operands) */
-    int act;               /* 0 none, 1 gelu, 2 exp */
+    int act;               /* 0 none, 1 gelu, 2 exp, 3 argmax over Co (3 planes only): no Y / Pout, see arg_val */
     const float* post_add; /* [Co] or NULL */
     const float* ch_scale; /* [Co] or NULL */
     const float* residual; /* [N][Co][T] or NULL */
@@ -153,8 +153,16 @@ typedef struct AliveGemm {
      * stored once -- the STFT runs this way (b_row = hop 320, Ci = 1280).  Multiples of 8 elements. */
     int64_t b_plane, b_win;
     int b_row;
+    /* act == 3: the [Co][cols] product is never stored.  Each 64-row block of the GEMM leaves, per column, its largest
+     * value (bias included) and the row it sits in -- arg_val / arg_idx [ceil(Co/64)][N*T], first row on ties, NaN wins
+     * like ATen -- and alive_argmax_merge reduces the blocks: F0Estimator.estimate (f0_estimator.py:30-34) without the
+     * 4096-class logits tensor. */
+    float* arg_val;
+    int32_t* arg_idx;
 } AliveGemm;
 int alive_gemm_planes(const AliveGemm* desc, void* stream);
+/* out[col] = (float) row of the largest value over the nblk per-block candidates of column col (smallest row on ties) */
+int alive_argmax_merge(const float* arg_val, const int32_t* arg_idx, int nblk, int64_t cols, float* out, void* stream);
 
 /* FilterBlock.forward (decoder.py:137-150) for C = 8 or 16 fused into one kernel: input_conv 1x1 + three
  * FilterResBlocks (six GELU -> FiLM -> reflect-left causal k5 convs, dilations 1,1,2,2,4,4), optional U-Net skip

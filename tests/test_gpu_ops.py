@@ -458,7 +458,41 @@ def test_gemm_planes_argument_errors():
     with pytest.raises(ValueError):
         ops.gemm_planes(P, 1, 8, torch.zeros(8, 32, 1, device=DEV), want_fp32=False, want_planes=False)
     with pytest.raises(ValueError):
-        ops.gemm_planes(P, 1, 8, torch.zeros(8, 32, 1, device=DEV), want_fp32=True, want_planes=True)
+        ops.gemm_planes_argmax(P, 1, 8, torch.zeros(8, 32, 1, device=DEV), planes=2)      # argmax mode: 3 planes only
+
+
+def test_gemm_planes_both_outputs_agree():
+    """fp32 and plane-packed output of one launch (a decoder down conv feeds a skip and the next GEMM)"""
+    from module import ops
+    n, ci, co, t = 2, 96, 200, 333
+    x, w, b = g("gbx", (n, ci, t)), g("gbw", (co, ci, 1), scale=0.1), g("gbb", (co,), scale=0.1)
+    P = ops.to_planes(x.to(DEV), 2)
+    y, Po = ops.gemm_planes(P, n, t, w.to(DEV), b.to(DEV), want_fp32=True, want_planes=True)
+    y1, _ = ops.gemm_planes(P, n, t, w.to(DEV), b.to(DEV))
+    assert torch.equal(y, y1)
+    back = ops.planes_to_float(Po, n, co, t, 2)
+    assert (back - y).abs().max().item() <= 2.0 ** -15 * y.abs().max().item()
+
+
+@pytest.mark.parametrize("n,ci,co,t", [(2, 256, 4096, 450), (1, 64, 100, 130), (3, 32, 64, 7), (128, 256, 4096, 45)])
+def test_gemm_planes_argmax_equals_argmax_of_the_stored_product(n, ci, co, t):
+    """act = 3 keeps one candidate per 64-row block and column; merged, it is the argmax of the very values the Y path stores
+    (same accumulators, same bias add) -- first index on ties, planted below"""
+    from module import ops
+    x = g(f"gax{co}", (n, ci, t))
+    w = g(f"gaw{co}", (co, ci, 1), scale=1.0 / np.sqrt(ci))
+    w[co // 2 + 1] = w[3]                      # duplicate rows: exact ties, the lower row must win
+    w[co - 1] = w[3]
+    b = g(f"gab{co}", (co,), scale=0.01)
+    b[co // 2 + 1] = b[3]
+    b[co - 1] = b[3]
+    P = ops.to_planes(x.to(DEV), 3)
+    y, _ = ops.gemm_planes(P, n, t, w.to(DEV), b.to(DEV), planes=3)
+    want = torch.argmax(y, dim=1, keepdim=True).float()
+    first = (y == y.max(dim=1, keepdim=True).values).float().argmax(dim=1, keepdim=True).float()     # first index of the max
+    got = ops.gemm_planes_argmax(P, n, t, w.to(DEV), b.to(DEV))
+    assert torch.equal(got, first)
+    assert (got != want).float().mean().item() < 0.01          # torch.argmax may pick another of the tied rows
 
 
 # ---- audio edges (SURVEY 8 f2): resampler, gain, int16 conversions on the device -----------------------------------
