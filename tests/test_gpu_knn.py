@@ -85,6 +85,27 @@ def test_knn_edge_cases():
         torch.testing.assert_close(got.cpu()[:, :, safe], ref[:, :, safe], rtol=1e-5, atol=1e-6)
 
 
+def test_knn_library_with_duplicate_rows():
+    """collisions: a library that holds 300 of its rows twice (generate_voice_library without --dedup on repeated audio).
+    Tied neighbours are interchangeable -- whichever copy is returned, the regressed features equal the oracle's."""
+    from module.common import match_features
+    base = synthetic.make_library(600, 17)
+    lib = torch.cat([base, base[:, :, :300]], dim=2).contiguous()             # rows 600..899 repeat rows 0..299
+    src = synthetic.gaussian("dup.src", 18, (2, 768, 130))
+    got, gi = match_features(src.to(DEV), lib.to(DEV), k=4, return_indices=True)
+    ref, ri, cos = O.match_features(src, lib.expand(2, -1, -1), 4, 0.0, return_indices=True)
+    top = torch.topk(cos, 5, dim=2)
+    for n in range(2):
+        v, i = top.values[n], top.indices[n]
+        twin = (i[:, 3] - i[:, 4]).abs() == 600                               # 4th and 5th are the two copies of one row
+        safe = ((v[:, 3] - v[:, 4]) > 1e-5) | twin
+        assert safe.float().mean().item() > 0.9
+        torch.testing.assert_close(got[n].cpu()[:, safe], ref[n][:, safe], rtol=1e-5, atol=1e-6)
+        rows = gi.view(2, 130, 4)[n].cpu() % 600                              # fold copies onto their originals
+        want = ri[n] % 600
+        assert np.array_equal(np.sort(rows.numpy(), 1)[safe.numpy()], np.sort(want.numpy(), 1)[safe.numpy()])
+
+
 def test_knn_sharded_merge_equals_single_shard():
     """library split into 4 contiguous shards, per-shard exact top-k, merged: same as unsharded."""
     from module.common import PackedLibrary, merge_gather
