@@ -69,6 +69,46 @@ __global__ __launch_bounds__(256) void lib_pack_kernel(const float* __restrict__
     }
 }
 
+// ---- fp8 (OCP e4m3) form of the scoring operands: value * 2^8, so that the elements of unit vectors (|x| ~ 0.04)
+// sit in e4m3's normal range (2^-6 .. 448); scores come out scaled by 2^16, which a ranking does not see
+constexpr float F8_SCALE = 256.0f;
+__device__ __forceinline__ unsigned char to_fp8(float v) {
+    return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v * F8_SCALE, 0.0f, 0, false) & 0xff);
+}
+__device__ __forceinline__ unsigned to_fp8x4(float a, float b, float c, float d) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a * F8_SCALE, b * F8_SCALE, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c * F8_SCALE, d * F8_SCALE, w, true);
+    return (unsigned)w;
+}
+
+// lib_bf16[M_pad][D] (normalised rows) -> lib_f8[M_pad][D]; 8 elements per thread
+__global__ __launch_bounds__(256) void lib_to_fp8_kernel(const unsigned short* __restrict__ lib, int64_t n8, uint2* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const u32x4 v = ((const u32x4*)lib)[i];
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[2 * j] = __uint_as_float(v[j] << 16);
+        f[2 * j + 1] = __uint_as_float(v[j] & 0xffff0000u);
+    }
+    out[i] = make_uint2(to_fp8x4(f[0], f[1], f[2], f[3]), to_fp8x4(f[4], f[5], f[6], f[7]));
+}
+
+// s_bf16[Tt_pad][D] -> s_f8[Tt_pad][D]
+__global__ __launch_bounds__(256) void src_to_fp8_kernel(const unsigned short* __restrict__ s_bf16, int64_t n8, uint2* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const u32x4 v = ((const u32x4*)s_bf16)[i];
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[2 * j] = __uint_as_float(v[j] << 16);
+        f[2 * j + 1] = __uint_as_float(v[j] & 0xffff0000u);
+    }
+    out[i] = make_uint2(to_fp8x4(f[0], f[1], f[2], f[3]), to_fp8x4(f[4], f[5], f[6], f[7]));
+}
+
 // src[N][D][T] -> s_f32[Tt][D] (normalised, fp32), s_bf16[Tt_pad][D]
 __global__ __launch_bounds__(256) void src_prep_kernel(const float* __restrict__ src, int T, int64_t Tt, int64_t Tt_pad,
                                                        float* __restrict__ s_f32, unsigned short* __restrict__ s_bf16) {
@@ -314,6 +354,171 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
 }
 
 // ----------------------------------------------------------------------------------------------
+// scoring on the block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3 operands, scales 2^0)
+// ----------------------------------------------------------------------------------------------
+// The same kernel shape at twice the MFMA rate and half the operand bytes: a k-step is 64 features (one 32-byte fragment
+// per lane = two ds_read_b128), a library tile is 32 rows x 768 B = 24 KB, a wave's stationary frame fragments take 192
+// registers instead of 384.  fp8 scores carry ~20x the error of bf16 scores (sigma ~ 1.5e-3 .. 2.5e-3 in cosine against
+// ~1e-4), so the candidate lists are twice as deep -- 16 per half-wave list, 32 per frame and library split -- and the exact
+// fp32 rescoring behind it is unchanged: the fp8 pass only has to put the true neighbours among the candidates.
+constexpr int KH8 = 16;                    // entries per half-list
+constexpr int KP8 = 2 * KH8;               // candidates per frame and split
+constexpr int NK64 = D / 64;               // 12 MFMA k-steps
+constexpr int NPIECE8 = 4 * (D / 128);     // 4 row groups x 6 segments of 128 B
+constexpr int ABUF8 = NPIECE8 * PIECE;     // 27648 B per tile buffer
+constexpr int SCORE8_LDS = 2 * ABUF8 + FT * KP8 * 8;   // 120832 B
+typedef int v8i __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256, 1) void knn_score8_kernel(const unsigned char* __restrict__ s_f8,
+                                                            const unsigned char* __restrict__ lib, int64_t M, int tiles_total,
+                                                            int tiles_per_split, int P, float* __restrict__ cand_val,
+                                                            int* __restrict__ cand_idx, int abl) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* Lv = (float*)(smem + 2 * ABUF8);
+    int* Li = (int*)(Lv + FT * KP8);           // both entry-major: [KH8][512 lane-columns]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int64_t frame0 = (int64_t)blockIdx.x * FT;
+    const int split = blockIdx.y;
+    const int tile_begin = split * tiles_per_split;
+    int tile_end = tile_begin + tiles_per_split;
+    if (tile_end > tiles_total) tile_end = tiles_total;
+
+    for (int e = tid; e < FT * KP8; e += 256) { Lv[e] = -INFINITY; Li[e] = -1; }
+
+    // DMA: wave w copies rows 8 w .. 8 w + 7 of the tile, 6 pieces of 8 rows x 128 B; chunk order swizzled on the source
+    const int dma_row = 8 * w + (lane >> 3);
+    const int dma_chunk = (lane & 7) ^ (lane >> 3);
+    auto issue_tile = [&](int tile, int buf) {
+        const unsigned char* g = lib + ((size_t)tile * LT + dma_row) * D + dma_chunk * 16;
+        unsigned char* l = smem + buf * ABUF8 + w * PIECE;
+#pragma unroll
+        for (int sg = 0; sg < D / 128; ++sg)
+            __builtin_amdgcn_global_load_lds((gptr_t)(g + sg * 128), (lptr_t)(l + sg * 4 * PIECE), 16, 0, 0);
+    };
+    if (tile_begin < tile_end) issue_tile(tile_begin, 0);
+
+    // stationary B fragments: frame = frame0 + 64 w + 32 ni + lr, features 64 ks + 32 lh .. + 31 (32 bytes)
+    v8i bq[2][NK64];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const unsigned char* fp = s_f8 + (size_t)(frame0 + 64 * w + 32 * ni + lr) * D + 32 * lh;
+#pragma unroll
+        for (int ks = 0; ks < NK64; ++ks) {
+            const u32x4 lo = *(const u32x4*)(fp + 64 * ks), hi = *(const u32x4*)(fp + 64 * ks + 16);
+            bq[ni][ks] = v8i{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        }
+    }
+
+    // A fragment of k-step ks: row lr, bytes 64 ks + 32 lh .. +31 = chunks c0 = 4 (ks & 1) + 2 lh and c0 + 1 of segment ks >> 1;
+    // chunk c of line rr sits at position c ^ rr
+    const int rr = lr & 7;
+    int a_off[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) a_off[j][c] = (lr >> 3) * PIECE + rr * 128 + (((4 * j + 2 * lh + c) ^ rr) << 4);
+
+    float thr[2] = {-INFINITY, -INFINITY};
+    const int lc0 = w * 128 + lane;
+    __syncthreads();
+
+    auto load_a = [&](const unsigned char* Ab, int ks) {
+        const unsigned char* q = Ab + (ks >> 1) * 4 * PIECE;
+        const u32x4 lo = *(const u32x4*)(q + a_off[ks & 1][0]);
+        const u32x4 hi = *(const u32x4*)(q + a_off[ks & 1][1]);
+        return v8i{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+    };
+
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const int buf = (tile - tile_begin) & 1;
+        const int next_tile = tile + 1 < tile_end ? tile + 1 : tile;
+        const unsigned char* gnext = lib + ((size_t)next_tile * LT + dma_row) * D + dma_chunk * 16;
+        unsigned char* lnext = smem + (buf ^ 1) * ABUF8 + w * PIECE;
+        const unsigned char* Ab = smem + buf * ABUF8;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+        constexpr int PD = 2;
+        v8i a[PD + 1];
+#pragma unroll
+        for (int i = 0; i < PD; ++i) a[i] = load_a(Ab, i);
+#pragma unroll
+        for (int ks = 0; ks < NK64; ++ks) {
+            if (ks + PD < NK64) a[(ks + PD) % (PD + 1)] = load_a(Ab, ks + PD);
+            if ((ks & 1) == 1)
+                __builtin_amdgcn_global_load_lds((gptr_t)(gnext + (ks >> 1) * 128), (lptr_t)(lnext + (ks >> 1) * 4 * PIECE), 16, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[ks % (PD + 1)], bq[0][ks], acc0, 0, 0, 0, 127, 0, 127);
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[ks % (PD + 1)], bq[1][ks], acc1, 0, 0, 0, 127, 0, 127);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- fold the 32 x 64 wave tile into the per-frame candidate lists (see knn_score_kernel) ----
+        const int64_t row0 = (int64_t)tile * LT;
+        const bool ragged = row0 + LT > M;
+        if (abl == 1) { thr[0] += acc0[0] + acc1[3]; __syncthreads(); continue; }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            f32x16& acc = ni == 0 ? acc0 : acc1;
+            if (ragged) {
+                asm volatile("" ::: "memory");
+                const int left = (int)(M - row0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (4 * lh >= left - ((r & 3) + 8 * (r >> 2))) acc[r] = -INFINITY;
+            }
+            float mx = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+            if (abl == 2) { thr[ni] = fmaxf(thr[ni], mx * 0.5f); continue; }
+            while (__builtin_amdgcn_ballot_w64(mx > thr[ni]) != 0) {
+                const bool has = mx > thr[ni];
+                int rsel = 0;
+#pragma unroll
+                for (int r = 1; r < 16; ++r) rsel = (acc[r] == mx) ? r : rsel;
+                float* lv = Lv + lc0 + ni * 64;
+                int* li = Li + lc0 + ni * 64;
+                float m1 = lv[0], m2 = INFINITY;
+                int pos = 0;
+#pragma unroll
+                for (int e = 1; e < KH8; ++e) {
+                    float x = lv[e * 512];
+                    bool lt = x < m1;
+                    m2 = lt ? m1 : fminf(m2, x);
+                    pos = lt ? e : pos;
+                    m1 = lt ? x : m1;
+                }
+                if (has) {
+                    lv[pos * 512] = mx;
+                    li[pos * 512] = (int)(row0 + (rsel & 3) + 8 * (rsel >> 2) + 4 * lh);
+                    thr[ni] = fminf(m2, mx);
+                }
+                float nmx = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (has && r == rsel) acc[r] = -INFINITY;
+                    nmx = fmaxf(nmx, acc[r]);
+                }
+                mx = nmx;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- cand[frame][P][KP8]: entries 0 .. 15 from the lower half-wave, 16 .. 31 from the upper ----
+    for (int e = tid; e < FT * KP8; e += 256) {
+        const int k = e % KP8, col = e / KP8;
+        const int lc = (col >> 6) * 128 + ((col >> 5) & 1) * 64 + (k / KH8) * 32 + (col & 31);
+        const size_t o = (((size_t)(frame0 + col)) * P + split) * KP8 + k;
+        cand_val[o] = Lv[(k % KH8) * 512 + lc];
+        cand_idx[o] = Li[(k % KH8) * 512 + lc];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // exact fp32 rescoring + top-k  (one wave per frame)
 // ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
@@ -339,14 +544,14 @@ __device__ __forceinline__ int wave_argbest(float v, int idx) {
 }
 
 __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
-                                                          int P, const float* __restrict__ s_f32,
+                                                          int P, int kp, const float* __restrict__ s_f32,
                                                           const float* __restrict__ rows, const float* __restrict__ norms,
                                                           int64_t Tt, int64_t idx_base, int k, float* __restrict__ out_val,
                                                           int* __restrict__ out_idx) {
     const int lane = threadIdx.x & 63;
     const int64_t ft = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ft >= Tt) return;
-    const int R = P * KP;
+    const int R = P * kp;                  // kp candidates per frame and split: KP (bf16 scoring) or KP8 (fp8 scoring)
     const float* cv = cand_val + (size_t)ft * R;
     const int* ci = cand_idx + (size_t)ft * R;
 
@@ -630,14 +835,14 @@ struct SearchPlan {
 
 // Grid = (Tt_pad / 256 frame blocks) x (split library ranges), one block per CU at a time (1 wave / SIMD).
 // The split is chosen so that the last round of blocks over the 256 CUs is as full as possible.
-static SearchPlan make_plan(int64_t Tt, int64_t M) {
+static SearchPlan make_plan(int64_t Tt, int64_t M, int split_cap = MAX_SPLIT) {
     SearchPlan p;
     p.Tt = Tt;
     p.Tt_pad = (Tt + FT - 1) / FT * FT;
     p.tiles_total = (int)(((M + TILE - 1) / TILE * TILE) / LT);
     const int64_t fb = p.Tt_pad / FT;
     int max_split = p.tiles_total / 8;                 // at least 8 tiles (256 rows) per block
-    if (max_split > MAX_SPLIT) max_split = MAX_SPLIT;
+    if (max_split > split_cap) max_split = split_cap;
     if (max_split < 1) max_split = 1;
     int best = 1;
     double best_eff = -1.0;
@@ -669,12 +874,27 @@ extern "C" int alive_library_pack(const float* tokens, int64_t M, int Dd, void* 
     return ALIVE_OK;
 }
 
+constexpr int MAX_SPLIT8 = 1024 / KP8;     // the rescoring kernel takes up to 1024 candidates per frame
+
+extern "C" size_t alive_library_fp8_bytes(int64_t M) { return (size_t)alive_library_padded_rows(M) * D; }
+
+extern "C" int alive_library_pack_fp8(const void* lib_bf16, int64_t M, void* lib_f8, void* stream) {
+    ALIVE_CHECK_ARG(lib_bf16 && lib_f8 && M >= 1, "alive_library_pack_fp8: bad args");
+    const int64_t n8 = alive_library_padded_rows(M) * D / 8;
+    lib_to_fp8_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, (hipStream_t)stream>>>((const unsigned short*)lib_bf16, n8, (uint2*)lib_f8);
+    ALIVE_CHECK_LAUNCH("alive_library_pack_fp8");
+    return ALIVE_OK;
+}
+
 extern "C" size_t alive_knn_workspace_bytes(int64_t Tt, int64_t M) {
     SearchPlan p = make_plan(Tt, M);
+    const SearchPlan p8 = make_plan(Tt, M, MAX_SPLIT8);
     size_t b = 0;
     b += align_up((size_t)Tt * D * 4, 256);                        // s_f32
     b += align_up((size_t)p.Tt_pad * D * 2, 256);                  // s_bf16
-    b += 2 * align_up((size_t)p.Tt_pad * p.P * KP * 4, 256);       // candidate lists
+    b += align_up((size_t)p.Tt_pad * D, 256);                      // s_f8
+    const size_t c16 = (size_t)p.Tt_pad * p.P * KP * 4, c8 = (size_t)p8.Tt_pad * p8.P * KP8 * 4;
+    b += 2 * align_up(c16 > c8 ? c16 : c8, 256);                   // candidate lists
     b += 2 * align_up((size_t)SCAN_MAX_LISTS * 64 * 4, 256);       // partial lists of the small-T scan
     return b + 1024;
 }
@@ -690,8 +910,12 @@ extern "C" int alive_knn_search(const float* src, int N, int T, const void* lib_
     Arena a(ws);
     float* s_f32 = a.take<float>((size_t)p.Tt * D);
     unsigned short* s_bf16 = a.take<unsigned short>((size_t)p.Tt_pad * D);
-    float* cv = a.take<float>((size_t)p.Tt_pad * p.P * KP);
-    int* ci = a.take<int>((size_t)p.Tt_pad * p.P * KP);
+    unsigned char* s_f8 = a.take<unsigned char>((size_t)p.Tt_pad * D);
+    (void)s_f8;
+    const SearchPlan p8w = make_plan((int64_t)N * T, M, MAX_SPLIT8);
+    const size_t c16 = (size_t)p.Tt_pad * p.P * KP, c8 = (size_t)p8w.Tt_pad * p8w.P * KP8;
+    float* cv = a.take<float>(c16 > c8 ? c16 : c8);
+    int* ci = a.take<int>(c16 > c8 ? c16 : c8);
     float* pv = a.take<float>((size_t)SCAN_MAX_LISTS * 64);
     int* pi = a.take<int>((size_t)SCAN_MAX_LISTS * 64);
     hipStream_t s = (hipStream_t)stream;
@@ -722,9 +946,51 @@ extern "C" int alive_knn_search(const float* src, int N, int T, const void* lib_
     knn_score_kernel<<<dim3((unsigned)(p.Tt_pad / FT), p.split), 256, SCORE_LDS, s>>>(
         s_bf16, (const unsigned short*)lib_bf16, M, p.tiles_total, p.tiles_per_split, p.P, cv, ci);
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
-    knn_rescore_kernel<<<(unsigned)((p.Tt + 3) / 4), 256, 0, s>>>(cv, ci, p.P, s_f32, rows_f32, norms, p.Tt, idx_base, k,
+    knn_rescore_kernel<<<(unsigned)((p.Tt + 3) / 4), 256, 0, s>>>(cv, ci, p.P, KP, s_f32, rows_f32, norms, p.Tt, idx_base, k,
                                                                  out_val, out_idx);
     ALIVE_CHECK_LAUNCH("alive_knn_search");
+    return ALIVE_OK;
+}
+
+// The same search with the candidate stage on the fp8 MFMA (knn_score8_kernel); lib_f8 from alive_library_pack_fp8.
+extern "C" int alive_knn_search_fp8(const float* src, int N, int T, const void* lib_f8, const float* rows_f32,
+                                    const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
+                                    void* ws, void* stream) {
+    ALIVE_CHECK_ARG(src && lib_f8 && rows_f32 && norms && out_val && out_idx && ws, "alive_knn_search_fp8: null pointer");
+    ALIVE_CHECK_ARG(N > 0 && T > 0, "alive_knn_search_fp8: empty source");
+    ALIVE_CHECK_ARG(k >= 1 && k <= ALIVE_MAX_K, "alive_knn_search_fp8: k=%d outside [1,%d]", k, ALIVE_MAX_K);
+    ALIVE_CHECK_ARG(M >= k, "alive_knn_search_fp8: library shard has %lld vectors, fewer than k=%d", (long long)M, k);
+    const SearchPlan p16 = make_plan((int64_t)N * T, M);
+    const SearchPlan p = make_plan((int64_t)N * T, M, MAX_SPLIT8);
+    Arena a(ws);                                       // the layout of alive_knn_search
+    float* s_f32 = a.take<float>((size_t)p.Tt * D);
+    unsigned short* s_bf16 = a.take<unsigned short>((size_t)p.Tt_pad * D);
+    unsigned char* s_f8 = a.take<unsigned char>((size_t)p.Tt_pad * D);
+    const size_t c16 = (size_t)p16.Tt_pad * p16.P * KP, c8 = (size_t)p.Tt_pad * p.P * KP8;
+    float* cv = a.take<float>(c16 > c8 ? c16 : c8);
+    int* ci = a.take<int>(c16 > c8 ? c16 : c8);
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)knn_score8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SCORE8_LDS);
+        if (e != hipSuccess) {
+            alive_set_error("alive_knn_search_fp8: cannot reserve %d B of LDS: %s", SCORE8_LDS, hipGetErrorString(e));
+            return ALIVE_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    if (p.Tt <= 512) src_prep_small_kernel<<<(unsigned)p.Tt_pad, 256, 0, s>>>(src, T, p.Tt, s_f32, s_bf16);
+    else src_prep_kernel<<<(unsigned)(p.Tt_pad / 64), 256, 0, s>>>(src, T, p.Tt, p.Tt_pad, s_f32, s_bf16);
+    const int64_t n8 = p.Tt_pad * D / 8;
+    src_to_fp8_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>(s_bf16, n8, (uint2*)s_f8);
+    if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
+    knn_score8_kernel<<<dim3((unsigned)(p.Tt_pad / FT), p.split), 256, SCORE8_LDS, s>>>(
+        s_f8, (const unsigned char*)lib_f8, M, p.tiles_total, p.tiles_per_split, p.P, cv, ci,
+        getenv("ALIVE_KNN8_ABL") ? atoi(getenv("ALIVE_KNN8_ABL")) : 0);
+    if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
+    knn_rescore_kernel<<<(unsigned)((p.Tt + 3) / 4), 256, 0, s>>>(cv, ci, p.P, KP8, s_f32, rows_f32, norms, p.Tt, idx_base, k,
+                                                                 out_val, out_idx);
+    ALIVE_CHECK_LAUNCH("alive_knn_search_fp8");
     return ALIVE_OK;
 }
 

@@ -7,11 +7,14 @@ LDS-staged top-k' lists, exact fp32 rescoring, gather-mean-blend.  The library
 is packed (normalised bf16 rows + fp32 rows + norms) once per reference tensor
 and cached, so the per-window calls of inference.py:129 only pay for the search.
 """
+import os
+
 import torch
 
 from . import _native as nat
 
 DIM = 768
+DEFAULT_PREFILTER = "bf16"       # candidate stage of the search: "bf16" or "fp8" MFMA (env ALIVE_KNN_PREFILTER overrides)
 
 
 class PackedLibrary:
@@ -20,7 +23,10 @@ class PackedLibrary:
     lib_bf16[M_pad,768] normalised rows (MFMA operand), rows[M,768] fp32 raw rows,
     norms[M].  `idx_base` is the global index of row 0 when the library is sharded."""
 
-    def __init__(self, tokens_DxM: torch.Tensor, idx_base: int = 0):
+    def __init__(self, tokens_DxM: torch.Tensor, idx_base: int = 0, prefilter: str = None):
+        self.prefilter = prefilter or os.environ.get("ALIVE_KNN_PREFILTER", DEFAULT_PREFILTER)
+        if self.prefilter not in ("bf16", "fp8"):
+            raise ValueError(f"prefilter must be 'bf16' or 'fp8', got {self.prefilter!r}")
         if tokens_DxM.dim() != 2 or tokens_DxM.shape[0] != DIM:
             raise ValueError(f"library must be [768, M], got {tuple(tokens_DxM.shape)}")
         t = tokens_DxM.contiguous().float()
@@ -34,6 +40,11 @@ class PackedLibrary:
         self.norms = torch.empty(self.M, dtype=torch.float32, device=dev)
         nat.check(L.alive_library_pack(nat.ptr(t), self.M, DIM, nat.ptr(self.lib_bf16), nat.ptr(self.rows),
                                        nat.ptr(self.norms), nat.stream()), "alive_library_pack")
+        self.lib_f8 = None
+        if self.prefilter == "fp8":
+            self.lib_f8 = torch.empty(L.alive_library_fp8_bytes(self.M), dtype=torch.uint8, device=dev)
+            nat.check(L.alive_library_pack_fp8(nat.ptr(self.lib_bf16), self.M, nat.ptr(self.lib_f8), nat.stream()),
+                      "alive_library_pack_fp8")
         self._ws = nat.Workspace()
 
     def search(self, source, k):
@@ -43,6 +54,11 @@ class PackedLibrary:
         val = torch.empty(n * t, k, dtype=torch.float32, device=source.device)
         idx = torch.empty(n * t, k, dtype=torch.int32, device=source.device)
         ws = self._ws.get(L.alive_knn_workspace_bytes(n * t, self.M), source.device)
+        if self.lib_f8 is not None:
+            nat.check(L.alive_knn_search_fp8(nat.ptr(source), n, t, nat.ptr(self.lib_f8), nat.ptr(self.rows),
+                                             nat.ptr(self.norms), self.M, self.idx_base, k, nat.ptr(val), nat.ptr(idx),
+                                             nat.ptr(ws), nat.stream()), "alive_knn_search_fp8")
+            return val, idx
         nat.check(L.alive_knn_search(nat.ptr(source), n, t, nat.ptr(self.lib_bf16), nat.ptr(self.rows),
                                      nat.ptr(self.norms), self.M, self.idx_base, k, nat.ptr(val), nat.ptr(idx),
                                      nat.ptr(ws), nat.stream()), "alive_knn_search")

@@ -68,6 +68,18 @@ int alive_knn_search(const float* src, int N, int T,
                      int64_t M, int64_t idx_base, int k,
                      float* out_val, int32_t* out_idx, void* ws, void* stream);
 
+/* The same search with the candidate stage on the block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, OCP e4m3
+ * operands = normalised rows x 2^8, scales 2^0): about twice the scoring rate at ~20x the score error of bf16, so the
+ * lists hold twice as many candidates (32 per frame and library split) in front of the same exact fp32 rescoring.
+ *   lib_f8[M_pad][D]: alive_library_fp8_bytes(M) bytes, made from lib_bf16 by alive_library_pack_fp8.
+ *   Same workspace, same outputs and the same contract as alive_knn_search. */
+size_t alive_library_fp8_bytes(int64_t M);
+int alive_library_pack_fp8(const void* lib_bf16, int64_t M, void* lib_f8, void* stream);
+int alive_knn_search_fp8(const float* src, int N, int T,
+                         const void* lib_f8, const float* rows_f32, const float* norms,
+                         int64_t M, int64_t idx_base, int k,
+                         float* out_val, int32_t* out_idx, void* ws, void* stream);
+
 /* Measurement hook (bench.py): when both are non-NULL hipEvent_t handles, every following
  * alive_knn_search on this host thread records them on its stream immediately before / after the
  * bf16 scoring kernel (the dominant kernel).  Pass NULLs to switch off. */
