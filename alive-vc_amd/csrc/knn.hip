@@ -205,13 +205,41 @@ constexpr int NPIECE = 4 * (D / 64);     // 4 row groups x 12 k-segments = 48
 constexpr int ABUF = NPIECE * PIECE;     // 55296 B per tile buffer
 constexpr int SCORE_LDS = 2 * ABUF + FT * KP * 8;   // 143360 B
 
+// Fallback kernels of the fp8 search are launched unconditionally (no host sync) and decide on the device whether they
+// have work: active iff lo < *cnt <= hi (cnt = number of frames whose fp8 candidate set could not be certified).
+__device__ __forceinline__ bool gate_open(const int* cnt, int lo, int hi, int& c) {
+    c = 0x7fffffff;
+    if (cnt == nullptr) return true;
+    c = *cnt;
+    return c > lo && c <= hi;
+}
+
+// compacts the bf16 operand rows of the flagged frames: out[slot] = s_bf16[list[slot]], zero rows up to the next 256
+__global__ __launch_bounds__(128) void gather_frames_kernel(const unsigned short* __restrict__ s_bf16, const int* __restrict__ list,
+                                                            const int* __restrict__ cnt, int cap, unsigned short* __restrict__ out) {
+    int c;
+    if (!gate_open(cnt, 0, cap, c)) return;
+    const int slot = blockIdx.x;
+    if (slot >= (c + 255) / 256 * 256) return;
+    if (threadIdx.x >= 96) return;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (slot < c) v = ((const u32x4*)(s_bf16 + (size_t)list[slot] * D))[threadIdx.x];
+    ((u32x4*)(out + (size_t)slot * D))[threadIdx.x] = v;
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short* __restrict__ s_bf16,
                                                            const unsigned short* __restrict__ lib, int64_t M, int tiles_total,
                                                            int tiles_per_split, int P, float* __restrict__ cand_val,
-                                                           int* __restrict__ cand_idx) {
+                                                           int* __restrict__ cand_idx, const int* __restrict__ gate_cnt,
+                                                           int gate_lo, int gate_hi, int by_count) {
+    {
+        int c;
+        if (!gate_open(gate_cnt, gate_lo, gate_hi, c)) return;                       // block-uniform
+        if (by_count && (int64_t)blockIdx.x * 256 >= c) return;                      // compacted frames: only c of them
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Lv = (float*)(smem + 2 * ABUF);
     int* Li = (int*)(Lv + FT * KP);            // both entry-major: [KH][512 lane-columns] -> wave-wide conflict-free access
@@ -547,18 +575,36 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
                                                           int P, int kp, const float* __restrict__ s_f32,
                                                           const float* __restrict__ rows, const float* __restrict__ norms,
                                                           int64_t Tt, int64_t idx_base, int k, float* __restrict__ out_val,
-                                                          int* __restrict__ out_idx) {
+                                                          int* __restrict__ out_idx, const int* __restrict__ frame_list,
+                                                          const int* __restrict__ gate_cnt, int gate_lo, int gate_hi,
+                                                          int* __restrict__ flag_list, int* __restrict__ flag_cnt, float zsig) {
     const int lane = threadIdx.x & 63;
-    const int64_t ft = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ft >= Tt) return;
+    const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // candidate lists are indexed by slot
+    int gc;
+    if (!gate_open(gate_cnt, gate_lo, gate_hi, gc)) return;
+    if (slot >= Tt || (frame_list != nullptr && slot >= gc)) return;
+    const int64_t ft = frame_list != nullptr ? frame_list[slot] : slot;     // frame: source row and output row
     const int R = P * kp;                  // kp candidates per frame and split: KP (bf16 scoring) or KP8 (fp8 scoring)
-    const float* cv = cand_val + (size_t)ft * R;
-    const int* ci = cand_idx + (size_t)ft * R;
+    const float* cv = cand_val + (size_t)slot * R;
+    const int* ci = cand_idx + (size_t)slot * R;
+    const bool certify = flag_list != nullptr;
+    float c_cut = -INFINITY;               // certificate: the best prefilter score a row OUTSIDE the rescored set can have
+    float my_pre = 0.0f;                   // prefilter score of this lane's candidate
 
     // ---- candidate selection: this lane ends up with (at most) one candidate ----
     int my_idx = -1;
+    // smallest entry of each FULL partial list (16 consecutive entries; an empty slot holds -inf): rows that never entered
+    auto list_floor = [&](float v) {
+        v = fminf(v, __shfl_xor(v, 1)); v = fminf(v, __shfl_xor(v, 2));
+        v = fminf(v, __shfl_xor(v, 4)); v = fminf(v, __shfl_xor(v, 8));
+        return v;
+    };
     if (R <= 64) {
         if (lane < R) my_idx = ci[lane];
+        if (certify) {
+            my_pre = lane < R ? cv[lane] : -INFINITY;
+            c_cut = list_floor((lane < R && my_idx >= 0) ? my_pre : -INFINITY);
+        }
     } else {
         // keep the 64 best bf16 scores: R/64 candidates per lane in registers (R <= 1024)
         float v[16];
@@ -571,6 +617,7 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
             v[j] = in ? cv[e] : -INFINITY;
             id[j] = in ? ci[e] : -1;
             if (id[j] < 0) v[j] = -INFINITY;
+            if (certify) c_cut = fmaxf(c_cut, list_floor(v[j]));
         }
         for (int sel = 0; sel < 64; ++sel) {
             float bv = v[0];
@@ -585,12 +632,16 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
             int win = wave_argbest(bv, bid);
             int widx = __shfl(bid, win);
             float wval = __shfl(bv, win);
-            if (lane == sel) my_idx = (wval > -INFINITY) ? widx : -1;
+            if (lane == sel) { my_idx = (wval > -INFINITY) ? widx : -1; my_pre = wval; }
             if (lane == win) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
                     if (j == bj) v[j] = -INFINITY;
             }
+        }
+        if (certify) {                     // candidates the selection of 64 left behind
+#pragma unroll
+            for (int j = 0; j < 16; ++j) c_cut = fmaxf(c_cut, v[j]);
         }
     }
 
@@ -635,7 +686,23 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
         }
     }
 
+    // ---- certificate statistics: error of the prefilter score on the rescored candidates of THIS frame ----
+    float err_mu = 0.0f, err_sd = 0.0f;
+    if (certify) {
+        const bool okc = my_idx >= 0 && my_score > -INFINITY;
+        const float e = okc ? my_pre * (1.0f / (F8_SCALE * F8_SCALE)) - my_score : 0.0f;
+        const float n = wave_sum(okc ? 1.0f : 0.0f);
+        err_mu = wave_sum(e) / fmaxf(n, 1.0f);
+        const float d = okc ? e - err_mu : 0.0f;
+        err_sd = sqrtf(wave_sum(d * d) / fmaxf(n, 1.0f));
+        c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 16));
+        c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 32));
+        c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 1)); c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 2));
+        c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 4)); c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 8));
+    }
+
     // ---- exact top-k, descending, ties to the lower library index ----
+    float vk = -INFINITY;
     for (int j = 0; j < k; ++j) {
         int win = wave_argbest(my_score, my_idx < 0 ? 0x7fffffff : my_idx);
         float wv = __shfl(my_score, win);
@@ -645,6 +712,14 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
             out_idx[(size_t)ft * k + j] = (wi < 0 || !(wv > -INFINITY)) ? -1 : (int)(idx_base + wi);
         }
         if (lane == win) my_score = -INFINITY;
+        vk = wv;
+    }
+    // A row outside the rescored set has prefilter score <= c_cut, hence (prefilter = exact + error, error ~ (mu, sd) as
+    // measured on this frame's own candidates) an exact score below c_cut - mu + z sd except in the z-sigma tail.  If the
+    // k-th exact score does not clear that, the frame goes to the bf16 candidate stage (alive_knn_search_fp8).
+    if (certify && lane == 0 && c_cut > -INFINITY) {
+        const float bound = c_cut * (1.0f / (F8_SCALE * F8_SCALE)) - err_mu + zsig * err_sd;
+        if (!(vk > bound)) flag_list[atomicAdd(flag_cnt, 1)] = (int)ft;
     }
 }
 
@@ -874,7 +949,24 @@ extern "C" int alive_library_pack(const float* tokens, int64_t M, int Dd, void* 
     return ALIVE_OK;
 }
 
-constexpr int MAX_SPLIT8 = 1024 / KP8;     // the rescoring kernel takes up to 1024 candidates per frame
+static int knn_scan_launch(const float* src, int T, int64_t Tt, const float* rows_f32, const float* norms, int64_t M,
+                           int64_t idx_base, int k, float* s_f32, unsigned short* s_bf16, float* pv, int* pi, float* out_val,
+                           int32_t* out_idx, hipStream_t s) {
+    src_prep_small_kernel<<<(unsigned)Tt, 256, 0, s>>>(src, T, Tt, s_f32, s_bf16);
+    int blocks = (int)((M + 4 * SCAN_WAVES - 1) / (4 * SCAN_WAVES));          // >= 4 rows per wave
+    if (blocks > SCAN_MAX_LISTS / SCAN_WAVES) blocks = SCAN_MAX_LISTS / SCAN_WAVES;
+    if (blocks < 1) blocks = 1;
+    if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
+    knn_scan_kernel<<<blocks, 64 * SCAN_WAVES, 0, s>>>(s_f32, rows_f32, norms, M, (int)Tt, k, pv, pi);
+    if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
+    knn_scan_merge_kernel<<<(unsigned)Tt, 256, 0, s>>>(pv, pi, blocks * SCAN_WAVES, k, idx_base, out_val, out_idx);
+    ALIVE_CHECK_LAUNCH("alive_knn_search(scan)");
+    return ALIVE_OK;
+}
+
+constexpr int MAX_SPLIT8 = 1024 / KP8;
+constexpr int FCAP = 4096;                // frames the compacted (tier 1) fallback of the fp8 search takes
+constexpr float CERT_Z = 7.0f;            // sigmas of fp8 score error the certificate allows for     // the rescoring kernel takes up to 1024 candidates per frame
 
 extern "C" size_t alive_library_fp8_bytes(int64_t M) { return (size_t)alive_library_padded_rows(M) * D; }
 
@@ -896,6 +988,11 @@ extern "C" size_t alive_knn_workspace_bytes(int64_t Tt, int64_t M) {
     const size_t c16 = (size_t)p.Tt_pad * p.P * KP * 4, c8 = (size_t)p8.Tt_pad * p8.P * KP8 * 4;
     b += 2 * align_up(c16 > c8 ? c16 : c8, 256);                   // candidate lists
     b += 2 * align_up((size_t)SCAN_MAX_LISTS * 64 * 4, 256);       // partial lists of the small-T scan
+    const int fcap = p.Tt_pad < FCAP ? (int)p.Tt_pad : FCAP;       // fallback of the fp8 search (alive_knn_search_fp8)
+    const SearchPlan pt = make_plan(fcap, M);
+    b += align_up((size_t)p.Tt_pad * 4, 256) + 256;                // flagged frames + their count
+    b += align_up((size_t)pt.Tt_pad * D * 2, 256);                 // their compacted bf16 rows
+    b += 2 * align_up((size_t)pt.Tt_pad * pt.P * KP * 4, 256);     // their candidate lists
     return b + 1024;
 }
 
@@ -919,18 +1016,8 @@ extern "C" int alive_knn_search(const float* src, int N, int T, const void* lib_
     float* pv = a.take<float>((size_t)SCAN_MAX_LISTS * 64);
     int* pi = a.take<int>((size_t)SCAN_MAX_LISTS * 64);
     hipStream_t s = (hipStream_t)stream;
-    if (p.Tt * k <= 64 && M <= SCAN_ROWS_MAX) {        // a handful of frames: exact fp32 scan of the rows, no candidate stage
-        src_prep_small_kernel<<<(unsigned)p.Tt, 256, 0, s>>>(src, T, p.Tt, s_f32, s_bf16);
-        int blocks = (int)((M + 4 * SCAN_WAVES - 1) / (4 * SCAN_WAVES));          // >= 4 rows per wave
-        if (blocks > SCAN_MAX_LISTS / SCAN_WAVES) blocks = SCAN_MAX_LISTS / SCAN_WAVES;
-        if (blocks < 1) blocks = 1;
-        if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
-        knn_scan_kernel<<<blocks, 64 * SCAN_WAVES, 0, s>>>(s_f32, rows_f32, norms, M, (int)p.Tt, k, pv, pi);
-        if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
-        knn_scan_merge_kernel<<<(unsigned)p.Tt, 256, 0, s>>>(pv, pi, blocks * SCAN_WAVES, k, idx_base, out_val, out_idx);
-        ALIVE_CHECK_LAUNCH("alive_knn_search(scan)");
-        return ALIVE_OK;
-    }
+    if (p.Tt * k <= 64 && M <= SCAN_ROWS_MAX)          // a handful of frames: exact fp32 scan of the rows, no candidate stage
+        return knn_scan_launch(src, T, p.Tt, rows_f32, norms, M, idx_base, k, s_f32, s_bf16, pv, pi, out_val, out_idx, s);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)knn_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_LDS);
@@ -944,41 +1031,59 @@ extern "C" int alive_knn_search(const float* src, int N, int T, const void* lib_
     else src_prep_kernel<<<(unsigned)(p.Tt_pad / 64), 256, 0, s>>>(src, T, p.Tt, p.Tt_pad, s_f32, s_bf16);
     if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
     knn_score_kernel<<<dim3((unsigned)(p.Tt_pad / FT), p.split), 256, SCORE_LDS, s>>>(
-        s_bf16, (const unsigned short*)lib_bf16, M, p.tiles_total, p.tiles_per_split, p.P, cv, ci);
+        s_bf16, (const unsigned short*)lib_bf16, M, p.tiles_total, p.tiles_per_split, p.P, cv, ci, nullptr, 0, 0, 0);
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
     knn_rescore_kernel<<<(unsigned)((p.Tt + 3) / 4), 256, 0, s>>>(cv, ci, p.P, KP, s_f32, rows_f32, norms, p.Tt, idx_base, k,
-                                                                 out_val, out_idx);
+                                                                 out_val, out_idx, nullptr, nullptr, 0, 0, nullptr, nullptr, 0.0f);
     ALIVE_CHECK_LAUNCH("alive_knn_search");
     return ALIVE_OK;
 }
 
 // The same search with the candidate stage on the fp8 MFMA (knn_score8_kernel); lib_f8 from alive_library_pack_fp8.
-extern "C" int alive_knn_search_fp8(const float* src, int N, int T, const void* lib_f8, const float* rows_f32,
+// Frames whose candidate set cannot be certified (knn_rescore_kernel) are searched again through the bf16 stage:
+//   tier 1 (1 .. FCAP frames, the usual handful): their operand rows are compacted and run as a small bf16 search;
+//   tier 2 (more: a library whose best cosines lie closer together than the fp8 error): the whole call is repeated on bf16.
+// All of it is launched up front -- the kernels read the count on the device and return at once when it is not theirs.
+
+extern "C" int alive_knn_search_fp8(const float* src, int N, int T, const void* lib_f8, const void* lib_bf16, const float* rows_f32,
                                     const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
                                     void* ws, void* stream) {
-    ALIVE_CHECK_ARG(src && lib_f8 && rows_f32 && norms && out_val && out_idx && ws, "alive_knn_search_fp8: null pointer");
+    ALIVE_CHECK_ARG(src && lib_f8 && lib_bf16 && rows_f32 && norms && out_val && out_idx && ws, "alive_knn_search_fp8: null pointer");
     ALIVE_CHECK_ARG(N > 0 && T > 0, "alive_knn_search_fp8: empty source");
     ALIVE_CHECK_ARG(k >= 1 && k <= ALIVE_MAX_K, "alive_knn_search_fp8: k=%d outside [1,%d]", k, ALIVE_MAX_K);
     ALIVE_CHECK_ARG(M >= k, "alive_knn_search_fp8: library shard has %lld vectors, fewer than k=%d", (long long)M, k);
     const SearchPlan p16 = make_plan((int64_t)N * T, M);
     const SearchPlan p = make_plan((int64_t)N * T, M, MAX_SPLIT8);
-    Arena a(ws);                                       // the layout of alive_knn_search
+    const int fcap = p.Tt_pad < FCAP ? (int)p.Tt_pad : FCAP;
+    const SearchPlan pt = make_plan(fcap, M);
+    Arena a(ws);                                       // the layout of alive_knn_search, then the fallback's own buffers
     float* s_f32 = a.take<float>((size_t)p.Tt * D);
     unsigned short* s_bf16 = a.take<unsigned short>((size_t)p.Tt_pad * D);
     unsigned char* s_f8 = a.take<unsigned char>((size_t)p.Tt_pad * D);
     const size_t c16 = (size_t)p16.Tt_pad * p16.P * KP, c8 = (size_t)p.Tt_pad * p.P * KP8;
     float* cv = a.take<float>(c16 > c8 ? c16 : c8);
     int* ci = a.take<int>(c16 > c8 ? c16 : c8);
+    float* pv = a.take<float>((size_t)SCAN_MAX_LISTS * 64);
+    int* pi = a.take<int>((size_t)SCAN_MAX_LISTS * 64);
+    int* flag_list = a.take<int>((size_t)p.Tt_pad);
+    int* flag_cnt = a.take<int>(64);
+    unsigned short* s_c = a.take<unsigned short>((size_t)pt.Tt_pad * D);
+    float* cv1 = a.take<float>((size_t)pt.Tt_pad * pt.P * KP);
+    int* ci1 = a.take<int>((size_t)pt.Tt_pad * pt.P * KP);
     hipStream_t s = (hipStream_t)stream;
+    if (p.Tt * k <= 64 && M <= SCAN_ROWS_MAX)          // streaming ring: the exact scan, no candidate stage at all
+        return knn_scan_launch(src, T, p.Tt, rows_f32, norms, M, idx_base, k, s_f32, s_bf16, pv, pi, out_val, out_idx, s);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)knn_score8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SCORE8_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)knn_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_LDS);
         if (e != hipSuccess) {
             alive_set_error("alive_knn_search_fp8: cannot reserve %d B of LDS: %s", SCORE8_LDS, hipGetErrorString(e));
             return ALIVE_ERR_LAUNCH;
         }
         attr_set = true;
     }
+    (void)hipMemsetAsync(flag_cnt, 0, sizeof(int), s);
     if (p.Tt <= 512) src_prep_small_kernel<<<(unsigned)p.Tt_pad, 256, 0, s>>>(src, T, p.Tt, s_f32, s_bf16);
     else src_prep_kernel<<<(unsigned)(p.Tt_pad / 64), 256, 0, s>>>(src, T, p.Tt, p.Tt_pad, s_f32, s_bf16);
     const int64_t n8 = p.Tt_pad * D / 8;
@@ -989,9 +1094,41 @@ extern "C" int alive_knn_search_fp8(const float* src, int N, int T, const void* 
         getenv("ALIVE_KNN8_ABL") ? atoi(getenv("ALIVE_KNN8_ABL")) : 0);
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
     knn_rescore_kernel<<<(unsigned)((p.Tt + 3) / 4), 256, 0, s>>>(cv, ci, p.P, KP8, s_f32, rows_f32, norms, p.Tt, idx_base, k,
-                                                                 out_val, out_idx);
+                                                                 out_val, out_idx, nullptr, nullptr, 0, 0, flag_list, flag_cnt, CERT_Z);
+    // ---- tier 1: 0 < flagged <= fcap ----
+    gather_frames_kernel<<<(unsigned)pt.Tt_pad, 128, 0, s>>>(s_bf16, flag_list, flag_cnt, fcap, s_c);
+    knn_score_kernel<<<dim3((unsigned)(pt.Tt_pad / FT), pt.split), 256, SCORE_LDS, s>>>(
+        s_c, (const unsigned short*)lib_bf16, M, pt.tiles_total, pt.tiles_per_split, pt.P, cv1, ci1, flag_cnt, 0, fcap, 1);
+    knn_rescore_kernel<<<(unsigned)((fcap + 3) / 4), 256, 0, s>>>(cv1, ci1, pt.P, KP, s_f32, rows_f32, norms, fcap, idx_base, k,
+                                                                 out_val, out_idx, flag_list, flag_cnt, 0, fcap, nullptr, nullptr, 0.0f);
+    // ---- tier 2: flagged > fcap ----
+    if (p.Tt_pad > fcap) {
+        knn_score_kernel<<<dim3((unsigned)(p16.Tt_pad / FT), p16.split), 256, SCORE_LDS, s>>>(
+            s_bf16, (const unsigned short*)lib_bf16, M, p16.tiles_total, p16.tiles_per_split, p16.P, cv, ci, flag_cnt, fcap,
+            0x7fffffff, 0);
+        knn_rescore_kernel<<<(unsigned)((p.Tt + 3) / 4), 256, 0, s>>>(cv, ci, p16.P, KP, s_f32, rows_f32, norms, p.Tt, idx_base, k,
+                                                                     out_val, out_idx, nullptr, flag_cnt, fcap, 0x7fffffff, nullptr,
+                                                                     nullptr, 0.0f);
+    }
     ALIVE_CHECK_LAUNCH("alive_knn_search_fp8");
     return ALIVE_OK;
+}
+
+// number of frames the last alive_knn_search_fp8 on this workspace sent to the bf16 stage (device int, for tests / bench)
+extern "C" const int* alive_knn_fp8_fallback_count(int N, int T, int64_t M, void* ws) {
+    const SearchPlan p16 = make_plan((int64_t)N * T, M);
+    const SearchPlan p = make_plan((int64_t)N * T, M, MAX_SPLIT8);
+    Arena a(ws);
+    a.take<float>((size_t)p.Tt * D);
+    a.take<unsigned short>((size_t)p.Tt_pad * D);
+    a.take<unsigned char>((size_t)p.Tt_pad * D);
+    const size_t c16 = (size_t)p16.Tt_pad * p16.P * KP, c8 = (size_t)p.Tt_pad * p.P * KP8;
+    a.take<float>(c16 > c8 ? c16 : c8);
+    a.take<int>(c16 > c8 ? c16 : c8);
+    a.take<float>((size_t)SCAN_MAX_LISTS * 64);
+    a.take<int>((size_t)SCAN_MAX_LISTS * 64);
+    a.take<int>((size_t)p.Tt_pad);
+    return a.take<int>(64);
 }
 
 extern "C" int alive_knn_set_timing_events(void* ev_start, void* ev_stop) {

@@ -2,9 +2,9 @@
 
   match_features(source, reference, k=4, alpha=0.0)   <- /root/reference/module/common.py:96-109
 
-runs on the MI355X through libalive_vc.so: bf16-MFMA candidate scoring with
+runs on the MI355X through libalive_vc.so: fp8- (or bf16-) MFMA candidate scoring with
 LDS-staged top-k' lists, exact fp32 rescoring, gather-mean-blend.  The library
-is packed (normalised bf16 rows + fp32 rows + norms) once per reference tensor
+is packed (normalised fp8 / bf16 rows + fp32 rows + norms) once per reference tensor
 and cached, so the per-window calls of inference.py:129 only pay for the search.
 """
 import os
@@ -14,7 +14,13 @@ import torch
 from . import _native as nat
 
 DIM = 768
-DEFAULT_PREFILTER = "bf16"       # candidate stage of the search: "bf16" or "fp8" MFMA (env ALIVE_KNN_PREFILTER overrides)
+# Candidate stage of the search: "fp8" (block-scaled e4m3 MFMA, 32 candidates per frame and library split) or "bf16"
+# (16 candidates); both feed the same exact fp32 rescoring.  env ALIVE_KNN_PREFILTER overrides.
+DEFAULT_PREFILTER = "fp8"
+
+
+def _prefilter():
+    return os.environ.get("ALIVE_KNN_PREFILTER", DEFAULT_PREFILTER)
 
 
 class PackedLibrary:
@@ -24,7 +30,7 @@ class PackedLibrary:
     norms[M].  `idx_base` is the global index of row 0 when the library is sharded."""
 
     def __init__(self, tokens_DxM: torch.Tensor, idx_base: int = 0, prefilter: str = None):
-        self.prefilter = prefilter or os.environ.get("ALIVE_KNN_PREFILTER", DEFAULT_PREFILTER)
+        self.prefilter = prefilter or _prefilter()
         if self.prefilter not in ("bf16", "fp8"):
             raise ValueError(f"prefilter must be 'bf16' or 'fp8', got {self.prefilter!r}")
         if tokens_DxM.dim() != 2 or tokens_DxM.shape[0] != DIM:
@@ -55,14 +61,28 @@ class PackedLibrary:
         idx = torch.empty(n * t, k, dtype=torch.int32, device=source.device)
         ws = self._ws.get(L.alive_knn_workspace_bytes(n * t, self.M), source.device)
         if self.lib_f8 is not None:
-            nat.check(L.alive_knn_search_fp8(nat.ptr(source), n, t, nat.ptr(self.lib_f8), nat.ptr(self.rows),
-                                             nat.ptr(self.norms), self.M, self.idx_base, k, nat.ptr(val), nat.ptr(idx),
-                                             nat.ptr(ws), nat.stream()), "alive_knn_search_fp8")
+            nat.check(L.alive_knn_search_fp8(nat.ptr(source), n, t, nat.ptr(self.lib_f8), nat.ptr(self.lib_bf16),
+                                             nat.ptr(self.rows), nat.ptr(self.norms), self.M, self.idx_base, k,
+                                             nat.ptr(val), nat.ptr(idx), nat.ptr(ws), nat.stream()), "alive_knn_search_fp8")
+            self._last = (n, t, k, ws)
             return val, idx
         nat.check(L.alive_knn_search(nat.ptr(source), n, t, nat.ptr(self.lib_bf16), nat.ptr(self.rows),
                                      nat.ptr(self.norms), self.M, self.idx_base, k, nat.ptr(val), nat.ptr(idx),
                                      nat.ptr(ws), nat.stream()), "alive_knn_search")
         return val, idx
+
+
+    def fallback_frames(self):
+        """frames the last fp8 search could not certify and searched again through the bf16 stage (syncs; tests / bench)"""
+        if self.lib_f8 is None or getattr(self, "_last", None) is None:
+            return 0
+        n, t, k, ws = self._last
+        p = nat.lib().alive_knn_fp8_fallback_count(n, t, self.M, nat.ptr(ws))
+        if n * t * k <= 64 and self.M <= 262144:     # the streaming scan has no candidate stage
+            return 0
+        torch.cuda.synchronize()
+        off = (p - ws.data_ptr())
+        return int(ws[off:off + 4].view(torch.int32).item())
 
 
 def merge_gather(cand_val, cand_idx, n_shards, k, alpha, rows_full, source, return_indices=False):
@@ -80,7 +100,7 @@ _cache = {}
 
 
 def _packed_for(reference_DxM):
-    key = (reference_DxM.data_ptr(), tuple(reference_DxM.shape), reference_DxM._version, str(reference_DxM.device))
+    key = (reference_DxM.data_ptr(), tuple(reference_DxM.shape), reference_DxM._version, str(reference_DxM.device), _prefilter())
     hit = _cache.get(key)
     if hit is None:
         if len(_cache) >= 4:

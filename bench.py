@@ -28,6 +28,7 @@ import torch.distributed as dist                           # noqa: E402
 
 FRAME = 320
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_FP8_TFLOPS = 5000.0           # dense fp8 MFMA peak (block-scaled 32x32x64 e4m3), same table
 
 
 def synth_windows(n_utt, seconds, chunk, device, seed):
@@ -141,7 +142,7 @@ def main():
     frames_per_step = n_win * (L // FRAME)
     useful_frames = args.utterances * int(args.seconds * 16000) // FRAME
 
-    # ---- per-launch timing of the dominant kernel (bf16 MFMA scoring) with events on its stream ----
+    # ---- per-launch timing of the dominant kernel (the MFMA candidate scoring) with events on its stream ----
     ev_pairs = []
     orig_search = library.search
 
@@ -179,6 +180,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     assert torch.isfinite(out).all(), "non-finite waveform"
+    researched = library.fallback_frames() if library.prefilter == "fp8" else None     # of the last timed step's search
 
     # ---- roofline of the scoring kernel ----
     flops, ms = 0.0, 0.0
@@ -187,11 +189,14 @@ def main():
         flops += 2.0 * 768 * M * tt_frames
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "knn_score_pmc.json")
+    fp8 = library.prefilter == "fp8"
+    peak = PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS
+    pmc = os.path.join(ROOT, "profiles", "knn_score8_pmc.json" if fp8 else "knn_score_pmc.json")
     if os.path.exists(pmc):
         traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-    roofline = {"kernel": "knn_score_kernel", "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+    roofline = {"kernel": "knn_score8_kernel" if fp8 else "knn_score_kernel", "bound": "mfma", "achieved": round(achieved, 1),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                "mfma_dtype": "fp8 e4m3, block-scaled 32x32x64" if fp8 else "bf16 32x32x16",
                 "launches": len(ev_pairs), "avg_launch_ms": round(ms / max(1, len(ev_pairs)), 3),
                 "kernel_share_of_step": round(ms * 1e-3 / dt, 3)}
 
@@ -205,6 +210,9 @@ def main():
     a, b, tt_frames = ev_pairs[-1]
     roofline["achieved_uncorrelated_frames"] = round(2.0 * 768 * M * tt_frames / (a.elapsed_time(b) * 1e-3) / 1e12, 1)
     del rnd
+    if fp8:            # frames of the last timed batch whose fp8 candidate set was not certified and went through the bf16 stage
+        roofline["frames_researched_on_bf16"] = {"timed_batch": researched, "uncorrelated_batch": library.fallback_frames(),
+                                                 "of": frames_per_step}
 
     # Optional mode of the build, reported beside the headline and never as `value`: inference.py keeps the centre third of
     # every window, so only the frames that can reach it through the decoder need the kNN match (Converter(keep_frames=...),
@@ -277,7 +285,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 MFMA scoring + exact f32 rescoring; 3-plane split-bf16 (fp32-grade) encoder GEMMs; 2-plane split-bf16 decoder GEMMs; f32 MFMA DFT / strided / small-channel convs; f64 phase scan",
+            "dtype": ("fp8 (e4m3) MFMA candidate scoring, certified, + exact f32 rescoring" if library.prefilter == "fp8" else
+                      "bf16 MFMA scoring + exact f32 rescoring") + "; 3-plane split-bf16 (fp32-grade) encoder GEMMs; 2-plane split-bf16 decoder GEMMs; f32 MFMA DFT / strided / small-channel convs; f64 phase scan",
             "data": "synthetic",
             "config": {"workload": f"{args.utterances} utterances x {args.seconds:g} s per GPU -> {n_win} windows x "
                                    f"{L // FRAME} frames per step, {M}-vector library (BASELINE config 3/4 shape)",

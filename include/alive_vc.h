@@ -72,13 +72,21 @@ int alive_knn_search(const float* src, int N, int T,
  * operands = normalised rows x 2^8, scales 2^0): about twice the scoring rate at ~20x the score error of bf16, so the
  * lists hold twice as many candidates (32 per frame and library split) in front of the same exact fp32 rescoring.
  *   lib_f8[M_pad][D]: alive_library_fp8_bytes(M) bytes, made from lib_bf16 by alive_library_pack_fp8.
- *   Same workspace, same outputs and the same contract as alive_knn_search. */
+ *   Same workspace, same outputs and the same contract as alive_knn_search.
+ * Exactness does not rest on the fp8 scores: after the exact rescoring every frame is CERTIFIED -- a row outside its
+ * rescored set has an fp8 score <= c (the floor of the partial list it failed to enter, or the best candidate the
+ * selection of 64 dropped), so an exact cosine <= c - mu + 7 sigma with (mu, sigma) the fp8 error measured on that
+ * frame's own rescored candidates; the frame passes if its k-th exact cosine clears that.  Frames that do not pass are
+ * searched again through the bf16 stage inside the same call (compacted when they are few; the whole batch when the
+ * library's best cosines lie closer together than the fp8 error) -- launched up front, decided on the device, no sync.
+ * alive_knn_fp8_fallback_count: device pointer (inside ws) to the number of frames the last call re-searched. */
 size_t alive_library_fp8_bytes(int64_t M);
 int alive_library_pack_fp8(const void* lib_bf16, int64_t M, void* lib_f8, void* stream);
 int alive_knn_search_fp8(const float* src, int N, int T,
-                         const void* lib_f8, const float* rows_f32, const float* norms,
+                         const void* lib_f8, const void* lib_bf16, const float* rows_f32, const float* norms,
                          int64_t M, int64_t idx_base, int k,
                          float* out_val, int32_t* out_idx, void* ws, void* stream);
+const int* alive_knn_fp8_fallback_count(int N, int T, int64_t M, void* ws);
 
 /* Measurement hook (bench.py): when both are non-NULL hipEvent_t handles, every following
  * alive_knn_search on this host thread records them on its stream immediately before / after the

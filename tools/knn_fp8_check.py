@@ -31,7 +31,9 @@ for name, lib in (("bf16", lib16), ("fp8", lib8)):
     nat.lib().alive_knn_set_timing_events(None, None)
     ms = a.elapsed_time(b)
     res[name] = (v, i)
-    print(f"{name}: scoring kernel {ms:.3f} ms  {2*768*M*N*T/ms/1e9:.1f} TFLOP/s")
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record(); lib.search(src, 4); t1.record(); torch.cuda.synchronize()
+    print(f"{name}: scoring kernel {ms:.3f} ms  {2*768*M*N*T/ms/1e9:.1f} TFLOP/s; whole search {t0.elapsed_time(t1):.2f} ms; re-searched frames {lib.fallback_frames()}")
 (v0, i0), (v1, i1) = res["bf16"], res["fp8"]
 same = (i0 == i1).all(dim=1)
 print(f"frames {N*T}: identical ordered top-4 in {int(same.sum())}  differing {int((~same).sum())}")
