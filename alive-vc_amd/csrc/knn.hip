@@ -449,6 +449,15 @@ __global__ __launch_bounds__(256, 1) void knn_score8_kernel(const unsigned char*
 #pragma unroll
         for (int c = 0; c < 2; ++c) a_off[j][c] = (lr >> 3) * PIECE + rr * 128 + (((4 * j + 2 * lh + c) ^ rr) << 4);
 
+    // Candidate lists: 16 entries per lane and column group in LDS, cached in registers as four quarters of four -- the
+    // smallest value of each quarter (qv) and where it sits (qp).  The list minimum (the admission threshold) is min(qv); an
+    // insertion overwrites that entry and rescans ONE quarter (4 LDS reads) instead of the list.
+    float qv[2][4];
+    int qp[2][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { qv[ni][q] = -INFINITY; qp[ni][q] = 4 * q; }
     float thr[2] = {-INFINITY, -INFINITY};
     const int lc0 = w * 128 + lane;
     __syncthreads();
@@ -469,18 +478,23 @@ __global__ __launch_bounds__(256, 1) void knn_score8_kernel(const unsigned char*
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-        constexpr int PD = 2;
-        v8i a[PD + 1];
-#pragma unroll
-        for (int i = 0; i < PD; ++i) a[i] = load_a(Ab, i);
+        // hipcc waits lgkmcnt(0) in front of every MFMA that takes an LDS fragment, i.e. for EVERYTHING in flight -- a
+        // prefetch issued before the MFMAs of a step is waited for at once (measured: 46 % of the loop idle).  So the
+        // fragment of step ks + 1 is requested between the two MFMAs of step ks: the wait then falls in front of the next
+        // step's first MFMA, ~120 cycles later, behind this step's second MFMA in the matrix pipe.
+        v8i a[2];
+        a[0] = load_a(Ab, 0);
 #pragma unroll
         for (int ks = 0; ks < NK64; ++ks) {
-            if (ks + PD < NK64) a[(ks + PD) % (PD + 1)] = load_a(Ab, ks + PD);
-            if ((ks & 1) == 1)
-                __builtin_amdgcn_global_load_lds((gptr_t)(gnext + (ks >> 1) * 128), (lptr_t)(lnext + (ks >> 1) * 4 * PIECE), 16, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[ks % (PD + 1)], bq[0][ks], acc0, 0, 0, 0, 127, 0, 127);
-            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[ks % (PD + 1)], bq[1][ks], acc1, 0, 0, 0, 127, 0, 127);
+            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[ks & 1], bq[0][ks], acc0, 0, 0, 0, 127, 0, 127);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < NK64) a[(ks + 1) & 1] = load_a(Ab, ks + 1);
+            if (ks < D / 128)              // the 6 DMA pieces of the next tile go out in the FIRST half of this one: the barrier
+                                           // at its end waits vmcnt(0), and a piece issued in the last step exposes a whole L2 / HBM round trip
+                __builtin_amdgcn_global_load_lds((gptr_t)(gnext + ks * 128), (lptr_t)(lnext + ks * 4 * PIECE), 16, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[ks & 1], bq[1][ks], acc1, 0, 0, 0, 127, 0, 127);
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -502,35 +516,59 @@ __global__ __launch_bounds__(256, 1) void knn_score8_kernel(const unsigned char*
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
             if (abl == 2) { thr[ni] = fmaxf(thr[ni], mx * 0.5f); continue; }
+            if (__builtin_amdgcn_ballot_w64(mx > thr[ni]) == 0) continue;
+            // Rare path (wave-uniform).  The register index r is packed into the 4 low mantissa bits of every score (2^-19
+            // relative, far below the fp8 error), so the 16 values of a lane are distinct, the row of a maximum is mx & 15 and
+            // "the next candidate" is the largest value below the current one: no search for the index, no retiring.
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = __uint_as_float((__float_as_uint(acc[r]) & ~15u) | (unsigned)r);
+            if (ragged) {                               // -inf with index bits is a NaN: put the rows beyond M back to -inf
+                asm volatile("" ::: "memory");
+                const int left = (int)(M - row0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (4 * lh >= left - ((r & 3) + 8 * (r >> 2))) acc[r] = -INFINITY;
+            }
+            mx = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+            float* lv = Lv + lc0 + ni * 64;
+            int* li = Li + lc0 + ni * 64;
             while (__builtin_amdgcn_ballot_w64(mx > thr[ni]) != 0) {
                 const bool has = mx > thr[ni];
-                int rsel = 0;
-#pragma unroll
-                for (int r = 1; r < 16; ++r) rsel = (acc[r] == mx) ? r : rsel;
-                float* lv = Lv + lc0 + ni * 64;
-                int* li = Li + lc0 + ni * 64;
-                float m1 = lv[0], m2 = INFINITY;
-                int pos = 0;
-#pragma unroll
-                for (int e = 1; e < KH8; ++e) {
-                    float x = lv[e * 512];
-                    bool lt = x < m1;
-                    m2 = lt ? m1 : fminf(m2, x);
-                    pos = lt ? e : pos;
-                    m1 = lt ? x : m1;
-                }
+                // quarter that holds the list minimum
+                const bool b01 = qv[ni][1] < qv[ni][0], b23 = qv[ni][3] < qv[ni][2];
+                const float m01 = b01 ? qv[ni][1] : qv[ni][0], m23 = b23 ? qv[ni][3] : qv[ni][2];
+                const int p01 = b01 ? qp[ni][1] : qp[ni][0], p23 = b23 ? qp[ni][3] : qp[ni][2];
+                const bool bq = m23 < m01;
+                const int tpos = bq ? p23 : p01;                     // entry to overwrite
+                const int tq = tpos >> 2;                            // its quarter
                 if (has) {
-                    lv[pos * 512] = mx;
-                    li[pos * 512] = (int)(row0 + (rsel & 3) + 8 * (rsel >> 2) + 4 * lh);
-                    thr[ni] = fminf(m2, mx);
+                    lv[tpos * 512] = mx;
+                    li[tpos * 512] = (int)(row0 + ((__float_as_uint(mx) & 3u) + 8u * ((__float_as_uint(mx) >> 2) & 3u)) + 4 * lh);
                 }
+                // rescan that quarter (after the write: LDS operations of a wave complete in order)
+                const float* qb = lv + (tq * 4) * 512;
+                const float x0 = qb[0], x1 = qb[512], x2 = qb[1024], x3 = qb[1536];
+                const bool c1 = x1 < x0, c3 = x3 < x2;
+                const float n01 = c1 ? x1 : x0, n23 = c3 ? x3 : x2;
+                const int e01 = c1 ? 1 : 0, e23 = c3 ? 3 : 2;
+                const bool c = n23 < n01;
+                const float nq = c ? n23 : n01;
+                const int np = tq * 4 + (c ? e23 : e01);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool hit = has && tq == q;
+                    qv[ni][q] = hit ? nq : qv[ni][q];
+                    qp[ni][q] = hit ? np : qp[ni][q];
+                }
+                thr[ni] = fminf(fminf(qv[ni][0], qv[ni][1]), fminf(qv[ni][2], qv[ni][3]));
+                // next candidate of this lane: the largest score below the one just taken (a lane that took none keeps its mx,
+                // which may already be its 2nd or 3rd value -- it must not fall back to the top one)
                 float nmx = -INFINITY;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (has && r == rsel) acc[r] = -INFINITY;
-                    nmx = fmaxf(nmx, acc[r]);
-                }
-                mx = nmx;
+                for (int r = 0; r < 16; ++r) nmx = fmaxf(nmx, acc[r] < mx ? acc[r] : -INFINITY);
+                mx = has ? nmx : mx;
             }
         }
         __syncthreads();
