@@ -400,7 +400,7 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256, 1) void knn_score8_kernel(const unsigned char* __restrict__ s_f8,
                                                             const unsigned char* __restrict__ lib, int64_t M, int tiles_total,
                                                             int tiles_per_split, int P, float* __restrict__ cand_val,
-                                                            int* __restrict__ cand_idx, int abl) {
+                                                            int* __restrict__ cand_idx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Lv = (float*)(smem + 2 * ABUF8);
     int* Li = (int*)(Lv + FT * KP8);           // both entry-major: [KH8][512 lane-columns]
@@ -469,110 +469,149 @@ __global__ __launch_bounds__(256, 1) void knn_score8_kernel(const unsigned char*
         return v8i{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
     };
 
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
+    // ---- folding a 32 x 32 accumulator tile (column group ni) into the per-frame candidate lists, in pieces ----
+    // rows beyond M (only in the library's last tiles: a real, wave-uniform branch)
+    auto mask_ragged = [&](f32x16& acc, int tile) {
+        const int64_t row0 = (int64_t)tile * LT;
+        if (row0 + LT > M) {
+            asm volatile("" ::: "memory");
+            const int left = (int)(M - row0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (4 * lh >= left - ((r & 3) + 8 * (r >> 2))) acc[r] = -INFINITY;
+        }
+    };
+    // running maximum over 8 of the 16 registers: small enough to sit between two MFMAs of the next tile
+    auto max8 = [&](const f32x16& acc, int lo, float m) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) m = fmaxf(m, acc[lo + r]);
+        return m;
+    };
+    auto fold_rare = [&](f32x16& acc, int ni, int tile, float mx) {
+        if (__builtin_amdgcn_ballot_w64(mx > thr[ni]) == 0) return;
+        const int64_t row0 = (int64_t)tile * LT;
+        const bool ragged = row0 + LT > M;
+        // Rare path (wave-uniform).  The register index r is packed into the 4 low mantissa bits of every score (2^-19
+        // relative, far below the fp8 error), so the 16 values of a lane are distinct, the row of a maximum is mx & 15 and
+        // "the next candidate" is the largest value below the current one: no search for the index, no retiring.
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = __uint_as_float((__float_as_uint(acc[r]) & ~15u) | (unsigned)r);
+        if (ragged) {                                   // -inf with index bits is a NaN: put the rows beyond M back to -inf
+            asm volatile("" ::: "memory");
+            const int left = (int)(M - row0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (4 * lh >= left - ((r & 3) + 8 * (r >> 2))) acc[r] = -INFINITY;
+        }
+        mx = acc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+        float* lv = Lv + lc0 + ni * 64;
+        int* li = Li + lc0 + ni * 64;
+        while (__builtin_amdgcn_ballot_w64(mx > thr[ni]) != 0) {
+            const bool has = mx > thr[ni];
+            // quarter that holds the list minimum
+            const bool b01 = qv[ni][1] < qv[ni][0], b23 = qv[ni][3] < qv[ni][2];
+            const float m01 = b01 ? qv[ni][1] : qv[ni][0], m23 = b23 ? qv[ni][3] : qv[ni][2];
+            const int p01 = b01 ? qp[ni][1] : qp[ni][0], p23 = b23 ? qp[ni][3] : qp[ni][2];
+            const bool bq = m23 < m01;
+            const int tpos = bq ? p23 : p01;                     // entry to overwrite
+            const int tq = tpos >> 2;                            // its quarter
+            if (has) {
+                lv[tpos * 512] = mx;
+                li[tpos * 512] = (int)(row0 + ((__float_as_uint(mx) & 3u) + 8u * ((__float_as_uint(mx) >> 2) & 3u)) + 4 * lh);
+            }
+            // rescan that quarter (after the write: LDS operations of a wave complete in order)
+            const float* qb = lv + (tq * 4) * 512;
+            const float x0 = qb[0], x1 = qb[512], x2 = qb[1024], x3 = qb[1536];
+            const bool c1 = x1 < x0, c3 = x3 < x2;
+            const float n01 = c1 ? x1 : x0, n23 = c3 ? x3 : x2;
+            const int e01 = c1 ? 1 : 0, e23 = c3 ? 3 : 2;
+            const bool c = n23 < n01;
+            const float nq = c ? n23 : n01;
+            const int np = tq * 4 + (c ? e23 : e01);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool hit = has && tq == q;
+                qv[ni][q] = hit ? nq : qv[ni][q];
+                qp[ni][q] = hit ? np : qp[ni][q];
+            }
+            thr[ni] = fminf(fminf(qv[ni][0], qv[ni][1]), fminf(qv[ni][2], qv[ni][3]));
+            // next candidate of this lane: the largest score below the one just taken (a lane that took none keeps its mx,
+            // which may already be its 2nd or 3rd value -- it must not fall back to the top one)
+            float nmx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nmx = fmaxf(nmx, acc[r] < mx ? acc[r] : -INFINITY);
+            mx = has ? nmx : mx;
+        }
+    };
+
+    // One tile: 24 MFMAs into (c0, c1).  The accumulators of the PREVIOUS tile (p0, p1) are folded in the shadow of this tile's
+    // first MFMAs, a few VALU instructions after each (one wave per SIMD: nothing else would fill the matrix pipe between the
+    // last MFMA of a tile and the end of its fold -- measured 23 ms of 107 with the fold behind the tile).  Before the first
+    // tile p0 / p1 hold -inf: its fold finds nothing.
+    auto do_tile = [&](int tile, f32x16& c0, f32x16& c1, f32x16& p0, f32x16& p1) {
         const int buf = (tile - tile_begin) & 1;
         const int next_tile = tile + 1 < tile_end ? tile + 1 : tile;
         const unsigned char* gnext = lib + ((size_t)next_tile * LT + dma_row) * D + dma_chunk * 16;
         unsigned char* lnext = smem + (buf ^ 1) * ABUF8 + w * PIECE;
         const unsigned char* Ab = smem + buf * ABUF8;
-        f32x16 acc0, acc1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+        for (int r = 0; r < 16; ++r) { c0[r] = 0.0f; c1[r] = 0.0f; }
         // hipcc waits lgkmcnt(0) in front of every MFMA that takes an LDS fragment, i.e. for EVERYTHING in flight -- a
         // prefetch issued before the MFMAs of a step is waited for at once (measured: 46 % of the loop idle).  So the
         // fragment of step ks + 1 is requested between the two MFMAs of step ks: the wait then falls in front of the next
         // step's first MFMA, ~120 cycles later, behind this step's second MFMA in the matrix pipe.
         v8i a[2];
         a[0] = load_a(Ab, 0);
-#pragma unroll
-        for (int ks = 0; ks < NK64; ++ks) {
-            __builtin_amdgcn_sched_barrier(0);
-            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[ks & 1], bq[0][ks], acc0, 0, 0, 0, 127, 0, 127);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks + 1 < NK64) a[(ks + 1) & 1] = load_a(Ab, ks + 1);
-            if (ks < D / 128)              // the 6 DMA pieces of the next tile go out in the FIRST half of this one: the barrier
-                                           // at its end waits vmcnt(0), and a piece issued in the last step exposes a whole L2 / HBM round trip
-                __builtin_amdgcn_global_load_lds((gptr_t)(gnext + ks * 128), (lptr_t)(lnext + ks * 4 * PIECE), 16, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[ks & 1], bq[1][ks], acc1, 0, 0, 0, 127, 0, 127);
-            __builtin_amdgcn_sched_barrier(0);
+        float pm0 = -INFINITY, pm1 = -INFINITY;
+        // written out step by step: with the folds inside a `for` hipcc gives up unrolling it and indexes bq dynamically (scratch)
+#define K8_STEP(ks, AFTER0, AFTER1)                                                                                              \
+        {                                                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                                   \
+            c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(ks) & 1], bq[0][ks], c0, 0, 0, 0, 127, 0, 127);              \
+            __builtin_amdgcn_sched_barrier(0);                                                                                   \
+            if ((ks) + 1 < NK64) a[((ks) + 1) & 1] = load_a(Ab, (ks) + 1);                                                       \
+            if ((ks) < D / 128) /* the 6 DMA pieces of the next tile go out in the FIRST half of this one: the barrier at its */  \
+                                /* end waits vmcnt(0), and a piece issued in the last step exposes a whole L2 / HBM round trip */ \
+                __builtin_amdgcn_global_load_lds((gptr_t)(gnext + (ks) * 128), (lptr_t)(lnext + (ks) * 4 * PIECE), 16, 0, 0);    \
+            AFTER0;                                                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                                   \
+            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(ks) & 1], bq[1][ks], c1, 0, 0, 0, 127, 0, 127);              \
+            __builtin_amdgcn_sched_barrier(0);                                                                                   \
+            AFTER1;                                                                                                              \
         }
+        K8_STEP(0, (mask_ragged(p0, tile - 1), pm0 = max8(p0, 0, pm0)), pm0 = max8(p0, 8, pm0))
+        K8_STEP(1, (mask_ragged(p1, tile - 1), pm1 = max8(p1, 0, pm1)), pm1 = max8(p1, 8, pm1))
+        K8_STEP(2, (void)0, fold_rare(p0, 0, tile - 1, pm0))
+        K8_STEP(3, (void)0, fold_rare(p1, 1, tile - 1, pm1))
+        K8_STEP(4, (void)0, (void)0) K8_STEP(5, (void)0, (void)0) K8_STEP(6, (void)0, (void)0) K8_STEP(7, (void)0, (void)0)
+        K8_STEP(8, (void)0, (void)0) K8_STEP(9, (void)0, (void)0) K8_STEP(10, (void)0, (void)0) K8_STEP(11, (void)0, (void)0)
+#undef K8_STEP
+        __syncthreads();                   // next tile landed (vmcnt(0)), this buffer free for tile + 2
+    };
+    auto fold_now = [&](f32x16& p0, f32x16& p1, int tile) {          // the last tile of the split has no successor to hide behind
+        mask_ragged(p0, tile);
+        mask_ragged(p1, tile);
+        fold_rare(p0, 0, tile, max8(p0, 8, max8(p0, 0, -INFINITY)));
+        fold_rare(p1, 1, tile, max8(p1, 8, max8(p1, 0, -INFINITY)));
+    };
 
-        // ---- fold the 32 x 64 wave tile into the per-frame candidate lists (see knn_score_kernel) ----
-        const int64_t row0 = (int64_t)tile * LT;
-        const bool ragged = row0 + LT > M;
-        if (abl == 1) { thr[0] += acc0[0] + acc1[3]; __syncthreads(); continue; }
+    f32x16 A0, A1, B0, B1;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            f32x16& acc = ni == 0 ? acc0 : acc1;
-            if (ragged) {
-                asm volatile("" ::: "memory");
-                const int left = (int)(M - row0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (4 * lh >= left - ((r & 3) + 8 * (r >> 2))) acc[r] = -INFINITY;
-            }
-            float mx = acc[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
-            if (abl == 2) { thr[ni] = fmaxf(thr[ni], mx * 0.5f); continue; }
-            if (__builtin_amdgcn_ballot_w64(mx > thr[ni]) == 0) continue;
-            // Rare path (wave-uniform).  The register index r is packed into the 4 low mantissa bits of every score (2^-19
-            // relative, far below the fp8 error), so the 16 values of a lane are distinct, the row of a maximum is mx & 15 and
-            // "the next candidate" is the largest value below the current one: no search for the index, no retiring.
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = __uint_as_float((__float_as_uint(acc[r]) & ~15u) | (unsigned)r);
-            if (ragged) {                               // -inf with index bits is a NaN: put the rows beyond M back to -inf
-                asm volatile("" ::: "memory");
-                const int left = (int)(M - row0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (4 * lh >= left - ((r & 3) + 8 * (r >> 2))) acc[r] = -INFINITY;
-            }
-            mx = acc[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
-            float* lv = Lv + lc0 + ni * 64;
-            int* li = Li + lc0 + ni * 64;
-            while (__builtin_amdgcn_ballot_w64(mx > thr[ni]) != 0) {
-                const bool has = mx > thr[ni];
-                // quarter that holds the list minimum
-                const bool b01 = qv[ni][1] < qv[ni][0], b23 = qv[ni][3] < qv[ni][2];
-                const float m01 = b01 ? qv[ni][1] : qv[ni][0], m23 = b23 ? qv[ni][3] : qv[ni][2];
-                const int p01 = b01 ? qp[ni][1] : qp[ni][0], p23 = b23 ? qp[ni][3] : qp[ni][2];
-                const bool bq = m23 < m01;
-                const int tpos = bq ? p23 : p01;                     // entry to overwrite
-                const int tq = tpos >> 2;                            // its quarter
-                if (has) {
-                    lv[tpos * 512] = mx;
-                    li[tpos * 512] = (int)(row0 + ((__float_as_uint(mx) & 3u) + 8u * ((__float_as_uint(mx) >> 2) & 3u)) + 4 * lh);
-                }
-                // rescan that quarter (after the write: LDS operations of a wave complete in order)
-                const float* qb = lv + (tq * 4) * 512;
-                const float x0 = qb[0], x1 = qb[512], x2 = qb[1024], x3 = qb[1536];
-                const bool c1 = x1 < x0, c3 = x3 < x2;
-                const float n01 = c1 ? x1 : x0, n23 = c3 ? x3 : x2;
-                const int e01 = c1 ? 1 : 0, e23 = c3 ? 3 : 2;
-                const bool c = n23 < n01;
-                const float nq = c ? n23 : n01;
-                const int np = tq * 4 + (c ? e23 : e01);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool hit = has && tq == q;
-                    qv[ni][q] = hit ? nq : qv[ni][q];
-                    qp[ni][q] = hit ? np : qp[ni][q];
-                }
-                thr[ni] = fminf(fminf(qv[ni][0], qv[ni][1]), fminf(qv[ni][2], qv[ni][3]));
-                // next candidate of this lane: the largest score below the one just taken (a lane that took none keeps its mx,
-                // which may already be its 2nd or 3rd value -- it must not fall back to the top one)
-                float nmx = -INFINITY;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) nmx = fmaxf(nmx, acc[r] < mx ? acc[r] : -INFINITY);
-                mx = has ? nmx : mx;
-            }
-        }
-        __syncthreads();
+    for (int r = 0; r < 16; ++r) { B0[r] = -INFINITY; B1[r] = -INFINITY; }
+    int tile = tile_begin;
+    for (; tile + 1 < tile_end; tile += 2) {
+        do_tile(tile, A0, A1, B0, B1);
+        do_tile(tile + 1, B0, B1, A0, A1);
     }
+    if (tile < tile_end) {                 // odd count: one more tile into A, then its own fold
+        do_tile(tile, A0, A1, B0, B1);
+        fold_now(A0, A1, tile);
+    } else if (tile_begin < tile_end) {    // even count: the last tile's accumulators are in B
+        fold_now(B0, B1, tile_end - 1);
+    }
+    __syncthreads();
 
     // ---- cand[frame][P][KP8]: entries 0 .. 15 from the lower half-wave, 16 .. 31 from the upper ----
     for (int e = tid; e < FT * KP8; e += 256) {
@@ -1128,8 +1167,7 @@ extern "C" int alive_knn_search_fp8(const float* src, int N, int T, const void* 
     src_to_fp8_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>(s_bf16, n8, (uint2*)s_f8);
     if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
     knn_score8_kernel<<<dim3((unsigned)(p.Tt_pad / FT), p.split), 256, SCORE8_LDS, s>>>(
-        s_f8, (const unsigned char*)lib_f8, M, p.tiles_total, p.tiles_per_split, p.P, cv, ci,
-        getenv("ALIVE_KNN8_ABL") ? atoi(getenv("ALIVE_KNN8_ABL")) : 0);
+        s_f8, (const unsigned char*)lib_f8, M, p.tiles_total, p.tiles_per_split, p.P, cv, ci);
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
     knn_rescore_kernel<<<(unsigned)((p.Tt + 3) / 4), 256, 0, s>>>(cv, ci, p.P, KP8, s_f32, rows_f32, norms, p.Tt, idx_base, k,
                                                                  out_val, out_idx, nullptr, nullptr, 0, 0, flag_list, flag_cnt, CERT_Z);
