@@ -588,6 +588,10 @@ __global__ __launch_bounds__(256, 1) void knn_score8_kernel(const unsigned char*
         K8_STEP(4, (void)0, (void)0) K8_STEP(5, (void)0, (void)0) K8_STEP(6, (void)0, (void)0) K8_STEP(7, (void)0, (void)0)
         K8_STEP(8, (void)0, (void)0) K8_STEP(9, (void)0, (void)0) K8_STEP(10, (void)0, (void)0) K8_STEP(11, (void)0, (void)0)
 #undef K8_STEP
+        // The accumulators are next read by the fold inside the NEXT tile, and hipcc sinks the whole c1 chain down to that use:
+        // eight dependent MFMAs back to back behind the barrier, their A fragments parked in AGPRs.  An opaque use pins both
+        // chains to this tile, interleaved as written.
+        asm volatile("" : "+a"(c0), "+a"(c1));
         __syncthreads();                   // next tile landed (vmcnt(0)), this buffer free for tile + 2
     };
     auto fold_now = [&](f32x16& p0, f32x16& p1, int tile) {          // the last tile of the split has no successor to hide behind
