@@ -32,7 +32,7 @@ extern "C" {
 #define ALIVE_ERR_LAUNCH (-2)
 
 #define ALIVE_DIM 768          /* content feature width (voice_library.py:7) */
-#define ALIVE_KPRIME 16        /* bf16 candidates kept per partial list       */
+#define ALIVE_KPRIME 16        /* candidates kept per frame and library split by the bf16 stage (the fp8 stage keeps 32) */
 #define ALIVE_MAX_K 8          /* largest k accepted by the kNN entry points: the scoring kernel keeps two
                                 * lane-private half-lists of 8 bf16 candidates per frame and library split, and all
                                 * k true neighbours may fall into one of them                                  */
