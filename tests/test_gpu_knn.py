@@ -113,6 +113,25 @@ def test_knn_library_with_duplicate_rows():
         assert np.array_equal(np.sort(rows.numpy(), 1)[safe.numpy()], np.sort(want.numpy(), 1)[safe.numpy()])
 
 
+@pytest.mark.parametrize("n_frames,expect", [(900, "tier1"), (5400, "tier2")])
+def test_knn_fp8_uncertified_frames_are_researched_on_bf16(prefilter, n_frames, expect):
+    """a library whose best cosines lie closer together than the fp8 score error: the certificate fails for (nearly) every
+    frame and the call repeats them through the bf16 stage -- compacted (<= 4096 frames) or as a whole batch -- with
+    results bitwise those of the bf16 search"""
+    if prefilter != "fp8":
+        pytest.skip("fp8 candidate stage only")
+    from module.common import PackedLibrary
+    base = synthetic.gaussian("knn.base", 13, (768, 1))
+    lib = (base + 0.35 * synthetic.gaussian("fb.lib", 14, (768, 5000))).to(DEV)
+    src = (base.unsqueeze(0) + 0.35 * synthetic.gaussian("fb.src", 15, (n_frames // 450, 768, 450))).to(DEV)
+    l8, l16 = PackedLibrary(lib, prefilter="fp8"), PackedLibrary(lib, prefilter="bf16")
+    v8, i8 = l8.search(src, 4)
+    n = l8.fallback_frames()
+    v16, i16 = l16.search(src, 4)
+    assert torch.equal(i8, i16) and torch.equal(v8, v16)
+    assert (n > 0.5 * n_frames) and ((n <= 4096) == (expect == "tier1")), n
+
+
 def test_knn_sharded_merge_equals_single_shard():
     """library split into 4 contiguous shards, per-shard exact top-k, merged: same as unsharded."""
     from module.common import PackedLibrary, merge_gather
