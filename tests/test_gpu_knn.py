@@ -132,6 +132,23 @@ def test_knn_fp8_uncertified_frames_are_researched_on_bf16(prefilter, n_frames, 
     assert (n > 0.5 * n_frames) and ((n <= 4096) == (expect == "tier1")), n
 
 
+@pytest.mark.parametrize("n,t,m,k", [(1, 1, 5, 4), (1, 7, 31, 1), (3, 17, 33, 8), (1, 255, 100, 4), (2, 257, 257, 4), (1, 700, 1000, 8),
+                                     (3, 450, 4097, 4), (1, 1300, 20000, 2), (5, 450, 65537, 4), (2, 33, 8, 8)])
+def test_knn_fp8_and_bf16_stage_agree_on_ragged_shapes(prefilter, n, t, m, k):
+    """tile tails of the library (M mod 32, M < one tile, M = k), frame blocks that are mostly padding, every k up to 8, split
+    counts from 1 to 32: the two candidate stages end in the same exact rescoring and must return the same lists"""
+    if prefilter != "fp8":
+        pytest.skip("compares the fp8 stage with the bf16 stage")
+    from module.common import PackedLibrary
+    lib = synthetic.gaussian(f"rs.lib.{m}", 31, (768, m)).to(DEV)
+    src = synthetic.gaussian(f"rs.src.{n}.{t}", 32, (n, 768, t)).to(DEV)
+    v8, i8 = PackedLibrary(lib, prefilter="fp8").search(src, k)
+    v16, i16 = PackedLibrary(lib, prefilter="bf16").search(src, k)
+    assert (i8 >= 0).all() and (i8 < m).all()
+    assert torch.equal(i8, i16) and torch.equal(v8, v16)
+    assert (v8[:, :-1] >= v8[:, 1:]).all()
+
+
 def test_knn_sharded_merge_equals_single_shard():
     """library split into 4 contiguous shards, per-shard exact top-k, merged: same as unsharded."""
     from module.common import PackedLibrary, merge_gather
