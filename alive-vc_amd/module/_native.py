@@ -137,16 +137,20 @@ def stream():
 
 
 class Workspace:
-    """Grow-only device scratch, one per (device, purpose); never allocates inside a call
-    once it has reached its steady-state size (hipGraph friendly)."""
+    """Grow-only device scratch, one per (purpose, device, stream); never allocates inside a call once it has reached its
+    steady-state size (hipGraph friendly).  Keyed by the current stream: window batches that run on side streams
+    (module/pipeline.py) get scratch of their own."""
 
     def __init__(self):
-        self.buf = None
+        self.bufs = {}
 
     def get(self, nbytes, device):
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        return self.buf
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self.bufs[key] = buf
+        return buf
 
 
 def weight_names(model):

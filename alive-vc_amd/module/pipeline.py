@@ -5,6 +5,8 @@ window).  Windows are independent units (each has its own mean pitch, oscillator
 and reflect pads), so here all windows of all utterances go through the networks as one batch
 [n_windows, ...]; results are identical to per-window calls.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -83,25 +85,58 @@ class Converter:
         feat = torch.empty(n, 768, lf, device=windows.device)
         f0 = torch.empty(n, 1, lf, device=windows.device)
         rng = None if keep_frames is None else (max(0, keep_frames[0] - TRIM_LEFT), min(lf, keep_frames[1] + TRIM_RIGHT))
-        for i in range(0, n, window_batch):
+
+        # Window batches are independent before and after the match: they go round-robin onto side streams (scratch is per
+        # stream, module/_native.py::Workspace), so that the tail of one batch's kernels overlaps the next batch's -- the
+        # kernels of a batch differ widely in what bounds them.  Same kernels on the same data: results are unchanged.
+        def batches(fn):
+            cur = torch.cuda.current_stream()
+            side = self._side_streams(windows.device)
+            for j, i in enumerate(range(0, n, window_batch)):
+                if not side:
+                    fn(i)
+                    continue
+                st = side[j % len(side)]
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    fn(i)
+            for st in side:
+                cur.wait_stream(st)
+
+        def enc(i):
             feat[i:i + window_batch], f0[i:i + window_batch] = self.features(windows[i:i + window_batch], pitch_shift,
                                                                            intonation, f0_rate, frames=rng)
+        batches(enc)
         if rng is None:
             feat = self.match(feat, k, alpha)
         else:
             feat[:, :, rng[0]:rng[1]] = self.match(feat[:, :, rng[0]:rng[1]].contiguous(), k, alpha)
         if rng is None:
             out = torch.empty_like(windows)
-            for i in range(0, n, window_batch):
+
+            def dec(i):
                 out[i:i + window_batch], _ = self.dec(feat[i:i + window_batch], f0[i:i + window_batch])
+            batches(dec)
             return out
         # decode the matched range only (the oscillator still accumulates phase over the whole window); samples outside it
         # are not kept by the caller and stay zero
         out = torch.zeros_like(windows)
-        for i in range(0, n, window_batch):
+
+        def dec_range(i):
             out[i:i + window_batch, rng[0] * 320:rng[1] * 320] = self.dec.forward_range(
                 feat[i:i + window_batch, :, rng[0]:rng[1]].contiguous(), f0[i:i + window_batch], rng[0])
+        batches(dec_range)
         return out
+
+    def _side_streams(self, device):
+        """side streams of the window batches (ALIVE_STREAMS, default 3; 1 = everything on the caller's stream)"""
+        want = int(os.environ.get("ALIVE_STREAMS", "3"))
+        if want <= 1:
+            return []
+        pool = getattr(self, "_streams", None)
+        if pool is None or len(pool) != want:
+            pool = self._streams = [torch.cuda.Stream(device=device) for _ in range(want)]
+        return pool
 
     def convert(self, wf, chunk=48000, trim_context=False, **kw):
         """one utterance: wf [1, L] at 16 kHz (already normalised / mono) -> [1, L].

@@ -21,6 +21,7 @@ def spectrogram(x):
     if b is None:
         b = torch.empty(L.alive_dft_basis_bytes() // 4, dtype=torch.float32, device=dev)
         nat.check(L.alive_dft_basis(nat.ptr(b), nat.stream()), "alive_dft_basis")
+        torch.cuda.current_stream(dev).synchronize()      # once per device: other streams will read it (module/pipeline.py)
         _basis[str(dev)] = b
     out = torch.empty(n, 641, l // 320, dtype=torch.float32, device=dev)
     ws = _ws.get(L.alive_spectrogram_workspace_bytes(n, l), dev)
