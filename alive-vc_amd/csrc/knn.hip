@@ -1046,7 +1046,8 @@ static int knn_scan_launch(const float* src, int T, int64_t Tt, const float* row
 }
 
 constexpr int MAX_SPLIT8 = 1024 / KP8;
-constexpr int FCAP = 4096;                // frames the compacted (tier 1) fallback of the fp8 search takes
+constexpr int FCAP = 16384;               // frames the compacted (tier 1) fallback of the fp8 search takes
+constexpr int FPLAN = 4096;               // ... with the library split chosen for this many (blocks past the count exit at once)
 constexpr float CERT_Z = 7.0f;            // sigmas of fp8 score error the certificate allows for     // the rescoring kernel takes up to 1024 candidates per frame
 
 extern "C" size_t alive_library_fp8_bytes(int64_t M) { return (size_t)alive_library_padded_rows(M) * D; }
@@ -1070,10 +1071,10 @@ extern "C" size_t alive_knn_workspace_bytes(int64_t Tt, int64_t M) {
     b += 2 * align_up(c16 > c8 ? c16 : c8, 256);                   // candidate lists
     b += 2 * align_up((size_t)SCAN_MAX_LISTS * 64 * 4, 256);       // partial lists of the small-T scan
     const int fcap = p.Tt_pad < FCAP ? (int)p.Tt_pad : FCAP;       // fallback of the fp8 search (alive_knn_search_fp8)
-    const SearchPlan pt = make_plan(fcap, M);
+    const SearchPlan pt = make_plan(fcap < FPLAN ? fcap : FPLAN, M);
     b += align_up((size_t)p.Tt_pad * 4, 256) + 256;                // flagged frames + their count
-    b += align_up((size_t)pt.Tt_pad * D * 2, 256);                 // their compacted bf16 rows
-    b += 2 * align_up((size_t)pt.Tt_pad * pt.P * KP * 4, 256);     // their candidate lists
+    b += align_up((size_t)fcap * D * 2, 256);                      // their compacted bf16 rows
+    b += 2 * align_up((size_t)fcap * pt.P * KP * 4, 256);          // their candidate lists
     return b + 1024;
 }
 
@@ -1122,7 +1123,7 @@ extern "C" int alive_knn_search(const float* src, int N, int T, const void* lib_
 
 // The same search with the candidate stage on the fp8 MFMA (knn_score8_kernel); lib_f8 from alive_library_pack_fp8.
 // Frames whose candidate set cannot be certified (knn_rescore_kernel) are searched again through the bf16 stage:
-//   tier 1 (1 .. FCAP frames, the usual handful): their operand rows are compacted and run as a small bf16 search;
+//   tier 1 (1 .. FCAP = 16384 frames, usually a handful): their operand rows are compacted and run as a small bf16 search;
 //   tier 2 (more: a library whose best cosines lie closer together than the fp8 error): the whole call is repeated on bf16.
 // All of it is launched up front -- the kernels read the count on the device and return at once when it is not theirs.
 
@@ -1136,7 +1137,7 @@ extern "C" int alive_knn_search_fp8(const float* src, int N, int T, const void* 
     const SearchPlan p16 = make_plan((int64_t)N * T, M);
     const SearchPlan p = make_plan((int64_t)N * T, M, MAX_SPLIT8);
     const int fcap = p.Tt_pad < FCAP ? (int)p.Tt_pad : FCAP;
-    const SearchPlan pt = make_plan(fcap, M);
+    const SearchPlan pt = make_plan(fcap < FPLAN ? fcap : FPLAN, M);       // its split; the frame blocks go up to fcap
     Arena a(ws);                                       // the layout of alive_knn_search, then the fallback's own buffers
     float* s_f32 = a.take<float>((size_t)p.Tt * D);
     unsigned short* s_bf16 = a.take<unsigned short>((size_t)p.Tt_pad * D);
@@ -1148,9 +1149,9 @@ extern "C" int alive_knn_search_fp8(const float* src, int N, int T, const void* 
     int* pi = a.take<int>((size_t)SCAN_MAX_LISTS * 64);
     int* flag_list = a.take<int>((size_t)p.Tt_pad);
     int* flag_cnt = a.take<int>(64);
-    unsigned short* s_c = a.take<unsigned short>((size_t)pt.Tt_pad * D);
-    float* cv1 = a.take<float>((size_t)pt.Tt_pad * pt.P * KP);
-    int* ci1 = a.take<int>((size_t)pt.Tt_pad * pt.P * KP);
+    unsigned short* s_c = a.take<unsigned short>((size_t)fcap * D);
+    float* cv1 = a.take<float>((size_t)fcap * pt.P * KP);
+    int* ci1 = a.take<int>((size_t)fcap * pt.P * KP);
     hipStream_t s = (hipStream_t)stream;
     if (p.Tt * k <= 64 && M <= SCAN_ROWS_MAX)          // streaming ring: the exact scan, no candidate stage at all
         return knn_scan_launch(src, T, p.Tt, rows_f32, norms, M, idx_base, k, s_f32, s_bf16, pv, pi, out_val, out_idx, s);
@@ -1176,8 +1177,8 @@ extern "C" int alive_knn_search_fp8(const float* src, int N, int T, const void* 
     knn_rescore_kernel<<<(unsigned)((p.Tt + 3) / 4), 256, 0, s>>>(cv, ci, p.P, KP8, s_f32, rows_f32, norms, p.Tt, idx_base, k,
                                                                  out_val, out_idx, nullptr, nullptr, 0, 0, flag_list, flag_cnt, CERT_Z);
     // ---- tier 1: 0 < flagged <= fcap ----
-    gather_frames_kernel<<<(unsigned)pt.Tt_pad, 128, 0, s>>>(s_bf16, flag_list, flag_cnt, fcap, s_c);
-    knn_score_kernel<<<dim3((unsigned)(pt.Tt_pad / FT), pt.split), 256, SCORE_LDS, s>>>(
+    gather_frames_kernel<<<(unsigned)fcap, 128, 0, s>>>(s_bf16, flag_list, flag_cnt, fcap, s_c);
+    knn_score_kernel<<<dim3((unsigned)(fcap / FT), pt.split), 256, SCORE_LDS, s>>>(
         s_c, (const unsigned short*)lib_bf16, M, pt.tiles_total, pt.tiles_per_split, pt.P, cv1, ci1, flag_cnt, 0, fcap, 1);
     knn_rescore_kernel<<<(unsigned)((fcap + 3) / 4), 256, 0, s>>>(cv1, ci1, pt.P, KP, s_f32, rows_f32, norms, fcap, idx_base, k,
                                                                  out_val, out_idx, flag_list, flag_cnt, 0, fcap, nullptr, nullptr, 0.0f);

@@ -113,10 +113,10 @@ def test_knn_library_with_duplicate_rows():
         assert np.array_equal(np.sort(rows.numpy(), 1)[safe.numpy()], np.sort(want.numpy(), 1)[safe.numpy()])
 
 
-@pytest.mark.parametrize("n_frames,expect", [(900, "tier1"), (5400, "tier2")])
+@pytest.mark.parametrize("n_frames,expect", [(900, "tier1"), (5400, "tier1"), (18000, "tier2")])
 def test_knn_fp8_uncertified_frames_are_researched_on_bf16(prefilter, n_frames, expect):
     """a library whose best cosines lie closer together than the fp8 score error: the certificate fails for (nearly) every
-    frame and the call repeats them through the bf16 stage -- compacted (<= 4096 frames) or as a whole batch -- with
+    frame and the call repeats them through the bf16 stage -- compacted (<= 16384 frames) or as a whole batch -- with
     results bitwise those of the bf16 search"""
     if prefilter != "fp8":
         pytest.skip("fp8 candidate stage only")
@@ -129,7 +129,7 @@ def test_knn_fp8_uncertified_frames_are_researched_on_bf16(prefilter, n_frames, 
     n = l8.fallback_frames()
     v16, i16 = l16.search(src, 4)
     assert torch.equal(i8, i16) and torch.equal(v8, v16)
-    assert (n > 0.5 * n_frames) and ((n <= 4096) == (expect == "tier1")), n
+    assert (n > 0.5 * n_frames) and ((n <= 16384) == (expect == "tier1")), n
 
 
 @pytest.mark.parametrize("n,t,m,k", [(1, 1, 5, 4), (1, 7, 31, 1), (3, 17, 33, 8), (1, 255, 100, 4), (2, 257, 257, 4), (1, 700, 1000, 8),
