@@ -106,13 +106,17 @@ __global__ __launch_bounds__(64) void osc_prefix_kernel(const float* __restrict_
 }
 
 constexpr int MAX_SEG = 512;
+// samples per transpose batch of osc_synth_kernel.  The [BT][65] tile is what limits the blocks (one wave each, a serial fp64 phase
+// chain inside) per CU: 64 -> 16 takes 128 windows from 3.06 to 2.09 ms, bit for bit the same wave (8: the same, 4: slower)
+constexpr int OSC_BT = 16;
 
 __global__ __launch_bounds__(64) void osc_synth_kernel(const float* __restrict__ amps, const float* __restrict__ f0,
                                                        const float* __restrict__ phi_in, OscGeom g,
                                                        const double* __restrict__ P, const float* __restrict__ dt0,
                                                        int phi_col, int f_off, int amp_ld, float* __restrict__ wave,
                                                        float* __restrict__ phi_out) {
-    __shared__ float tile[64][65];
+    constexpr int BT = OSC_BT;
+    __shared__ float tile[BT][65];
     __shared__ uint2 coord[MAX_SEG];              // per sample of the frame: (i0 | i1 << 16, w1)
     // frame f of the WINDOW; amps / wave hold the frames [f_off, f_off + amp_ld) only (range mode; else f_off = 0, amp_ld = Lf)
     const int f = blockIdx.x + f_off, n = blockIdx.y;
@@ -137,8 +141,8 @@ __global__ __launch_bounds__(64) void osc_synth_kernel(const float* __restrict__
     const float d0 = hv ? dt0[(size_t)n * g.H + h] : 0.0f;
     const float ph = (hv && phi_in != nullptr) ? phi_in[(size_t)n * g.H + h] : 0.0f;
     __syncthreads();
-    for (int b0 = 0; b0 < g.seg; b0 += 64) {
-        const int nb = (g.seg - b0) < 64 ? (g.seg - b0) : 64;
+    for (int b0 = 0; b0 < g.seg; b0 += BT) {
+        const int nb = (g.seg - b0) < BT ? (g.seg - b0) : BT;
         for (int i = 0; i < nb; ++i) {
             const uint2 xc = coord[b0 + i];
             const int i0 = xc.x & 0xffff, i1 = xc.x >> 16;
