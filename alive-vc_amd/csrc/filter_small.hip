@@ -29,7 +29,10 @@ constexpr int NT = 512;         // 8 waves: two per SIMD
 
 template <int C>
 struct SmallCfg {
-    static constexpr int BL = 1024;                     // columns per tile incl. halo
+    static constexpr int BL = C == 8 ? 768 : 1024;      // columns per tile incl. halo.  At 8 channels the tile buffers are small
+                                                        // enough for the blocks per CU to matter more than the halo (64 windows
+                                                        // x 144 000 samples: 256 cols 1.83 ms, 512 1.67, 768 1.62, 1024 1.83; at 16
+                                                        // channels 1024 stays best: 1.32 against 1.42 / 1.52 ms)
     static constexpr int TT = BL - HALO;                // output columns per tile
     static constexpr int P = BL + 16;                   // LDS row pitch: the four k-rows of a B fragment land on disjoint banks
     static constexpr int NG = BL / 16;                  // 16-column groups per tile
