@@ -3,6 +3,10 @@
 //
 // The reference materialises cos[T][M] with an fp32 bmm and runs topk over it.
 // Here the [T][M] matrix never exists:
+//   0. knn_score8_kernel  (default candidate stage) the same structure as 1. on the block-scaled fp8 MFMA
+//      (v_mfma_scale_f32_32x32x64_f8f6f4): twice the rate, 20x the score error, so twice the candidates and a
+//      per-frame certificate in step 2; frames that fail it are searched again through 1. inside the same call
+//      (alive_knn_search_fp8).
 //   1. knn_score_kernel   bf16 MFMA (v_mfma_f32_32x32x16_bf16) over L2-normalised
 //      library rows x normalised source frames, 128x128 output tiles; each
 //      wave folds its 64x64 accumulator tile straight into per-frame top-k'
