@@ -384,17 +384,14 @@ extern "C" int alive_dwconv_norm_planes(const float* X, int N, int C, int T, con
     const size_t lds = (size_t)C * (tw + 1) * sizeof(float);
     ALIVE_CHECK_ARG(lds <= 150 * 1024, "alive_dwconv_norm_planes: C %d does not fit the LDS tile", C);
     const int64_t cols = (int64_t)N * T, cols_pad = (cols + 127) / 128 * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipSuccess;
-        const void* fns[4] = {(const void*)dwconv_norm_planes_kernel<2, 32>, (const void*)dwconv_norm_planes_kernel<3, 32>,
-                              (const void*)dwconv_norm_planes_kernel<2, 64>, (const void*)dwconv_norm_planes_kernel<3, 64>};
-        for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    {
+        static LdsOptIn optin;
+        hipError_t e = optin.ensure({(const void*)dwconv_norm_planes_kernel<2, 32>, (const void*)dwconv_norm_planes_kernel<3, 32>,
+                                     (const void*)dwconv_norm_planes_kernel<2, 64>, (const void*)dwconv_norm_planes_kernel<3, 64>}, 150 * 1024);
         if (e != hipSuccess) {
             alive_set_error("alive_dwconv_norm_planes: cannot reserve LDS: %s", hipGetErrorString(e));
             return ALIVE_ERR_LAUNCH;
         }
-        attr_set = true;
     }
     dim3 g(cdiv(T, tw), N);
 #define LAUNCH_DNP(NP_, TW_)                                                                                                   \

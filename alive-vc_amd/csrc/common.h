@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
+#include <initializer_list>
 #include "../../include/alive_vc.h"
 
 void alive_set_error(const char* fmt, ...);
@@ -24,6 +26,25 @@ void alive_set_error(const char* fmt, ...);
             return ALIVE_ERR_LAUNCH;                                  \
         }                                                             \
     } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: one opt-in flag per launch site and device
+// (a process that moves to a second GPU must opt in there too), safe against concurrent host threads.
+struct LdsOptIn {
+    std::atomic<uint64_t> done{0};
+    hipError_t ensure(std::initializer_list<const void*> fns, int bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const uint64_t bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+        for (const void* f : fns) {
+            e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return e;
+        }
+        done.fetch_or(bit, std::memory_order_release);
+        return hipSuccess;
+    }
+};
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -370,14 +370,13 @@ extern "C" int alive_filter_block64_range(const float* U, int N, int L, const vo
                     "alive_filter_block64: L must be a multiple of 4 and out / skip 16-byte aligned");
     ALIVE_CHECK_ARG(film_ld > 0 && t0 >= 0 && f0 >= 0, "alive_filter_block64: bad frame range");
     ALIVE_CHECK_ARG((double)BL * film_ld / L + 3.0 <= NFP, "alive_filter_block64: tile spans more than %d frames (L %d, frames %d)", NFP, L, film_ld);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)filter_block64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    {
+        static LdsOptIn optin;
+        hipError_t e = optin.ensure({(const void*)filter_block64_kernel}, LDS_BYTES);
         if (e != hipSuccess) {
             alive_set_error("alive_filter_block64: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(e));
             return ALIVE_ERR_LAUNCH;
         }
-        attr_set = true;
     }
     const float ratio = (float)film_ld / (float)L;       // == window frames / window samples at this rate
     dim3 g(cdiv(L, TT), N);

@@ -272,14 +272,13 @@ int launch_small(const float* U, int N, int L, const float* wpack, const float* 
                  int t0, int f0, int film_ld, const float* skip, float* out, hipStream_t s) {
     using Cfg = SmallCfg<C>;
     const int lds = (2 * C * Cfg::P + NCONV * 2 * C * NFP) * (int)sizeof(float) + Cfg::BL * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)filter_block_small_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    {
+        static LdsOptIn optin;                               // one per instantiation <C>
+        hipError_t e = optin.ensure({(const void*)filter_block_small_kernel<C>}, lds);
         if (e != hipSuccess) {
             alive_set_error("alive_filter_block_small: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
             return ALIVE_ERR_LAUNCH;
         }
-        attr_set = true;
     }
     const float ratio = (float)film_ld / (float)L;       // == window frames / window samples at this rate
     ALIVE_CHECK_ARG((double)Cfg::BL * film_ld / L + 3.0 <= NFP, "alive_filter_block_small: tile spans more than %d frames (L %d, frames %d)", NFP, L, film_ld);

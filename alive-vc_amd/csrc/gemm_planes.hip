@@ -539,15 +539,13 @@ inline int pad32(int c) { return (c + 31) & ~31; }
 template <int NP, int NS, int MINB, int ACT>
 int launch_gemm_act(const AliveGemm& d, hipStream_t s) {
     constexpr int LDS = NS * 2 * NP * PLANE_BYTES;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_planes_kernel<NP, NS, MINB, ACT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    {
+        static LdsOptIn optin;
+        hipError_t e = optin.ensure({(const void*)gemm_planes_kernel<NP, NS, MINB, ACT>}, LDS);
         if (e != hipSuccess) {
             alive_set_error("alive_gemm_planes: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return ALIVE_ERR_LAUNCH;
         }
-        configured = true;
     }
     const int64_t cols = (int64_t)d.N * d.T;
     const int n_mt = cdiv(d.Co, GM), n_ct = cdiv(cols, GN);
@@ -562,15 +560,13 @@ int launch_gemm_act(const AliveGemm& d, hipStream_t s) {
 template <int NP, int NS, int ACT>
 int launch_gemm_persistent_act(const AliveGemm& d, hipStream_t s) {
     constexpr int LDS = NS * 2 * NP * PLANE_BYTES;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_planes_persistent_kernel<NP, NS, ACT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    {
+        static LdsOptIn optin;
+        hipError_t e = optin.ensure({(const void*)gemm_planes_persistent_kernel<NP, NS, ACT>}, LDS);
         if (e != hipSuccess) {
             alive_set_error("alive_gemm_planes: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return ALIVE_ERR_LAUNCH;
         }
-        configured = true;
     }
     const int64_t cols = (int64_t)d.N * d.T;
     const int n_mt = cdiv(d.Co, GM), n_ct = cdiv(cols, GN);

@@ -404,7 +404,12 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256, 1) void knn_score8_kernel(const unsigned char* __restrict__ s_f8,
                                                             const unsigned char* __restrict__ lib, int64_t M, int tiles_total,
                                                             int tiles_per_split, int P, float* __restrict__ cand_val,
-                                                            int* __restrict__ cand_idx) {
+                                                            int* __restrict__ cand_idx, const int* __restrict__ gate_cnt,
+                                                            int gate_lo, int gate_hi) {
+    {
+        int c;
+        if (!gate_open(gate_cnt, gate_lo, gate_hi, c)) return;                       // block-uniform
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Lv = (float*)(smem + 2 * ABUF8);
     int* Li = (int*)(Lv + FT * KP8);           // both entry-major: [KH8][512 lane-columns]
@@ -662,7 +667,8 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
                                                           int64_t Tt, int64_t idx_base, int k, float* __restrict__ out_val,
                                                           int* __restrict__ out_idx, const int* __restrict__ frame_list,
                                                           const int* __restrict__ gate_cnt, int gate_lo, int gate_hi,
-                                                          int* __restrict__ flag_list, int* __restrict__ flag_cnt, float zsig) {
+                                                          int* __restrict__ flag_list, int* __restrict__ flag_cnt, float zsig,
+                                                          int list_len, float pre_scale) {
     const int lane = threadIdx.x & 63;
     const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // candidate lists are indexed by slot
     int gc;
@@ -679,9 +685,11 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
     // ---- candidate selection: this lane ends up with (at most) one candidate ----
     int my_idx = -1;
     // smallest entry of each FULL partial list (16 consecutive entries; an empty slot holds -inf): rows that never entered
+    // (list_len consecutive entries: 16 behind the fp8 stage, 8 behind the bf16 stage)
     auto list_floor = [&](float v) {
         v = fminf(v, __shfl_xor(v, 1)); v = fminf(v, __shfl_xor(v, 2));
-        v = fminf(v, __shfl_xor(v, 4)); v = fminf(v, __shfl_xor(v, 8));
+        v = fminf(v, __shfl_xor(v, 4));
+        if (list_len > 8) v = fminf(v, __shfl_xor(v, 8));
         return v;
     };
     if (R <= 64) {
@@ -775,7 +783,7 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
     float err_mu = 0.0f, err_sd = 0.0f;
     if (certify) {
         const bool okc = my_idx >= 0 && my_score > -INFINITY;
-        const float e = okc ? my_pre * (1.0f / (F8_SCALE * F8_SCALE)) - my_score : 0.0f;
+        const float e = okc ? my_pre * pre_scale - my_score : 0.0f;
         const float n = wave_sum(okc ? 1.0f : 0.0f);
         err_mu = wave_sum(e) / fmaxf(n, 1.0f);
         const float d = okc ? e - err_mu : 0.0f;
@@ -801,9 +809,10 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
     }
     // A row outside the rescored set has prefilter score <= c_cut, hence (prefilter = exact + error, error ~ (mu, sd) as
     // measured on this frame's own candidates) an exact score below c_cut - mu + z sd except in the z-sigma tail.  If the
-    // k-th exact score does not clear that, the frame goes to the bf16 candidate stage (alive_knn_search_fp8).
+    // k-th exact score does not clear that, the frame goes to the next tier: the bf16 candidate stage behind the fp8 one,
+    // the exact scan behind the bf16 one (alive_knn_search_fp8 / alive_knn_search).
     if (certify && lane == 0 && c_cut > -INFINITY) {
-        const float bound = c_cut * (1.0f / (F8_SCALE * F8_SCALE)) - err_mu + zsig * err_sd;
+        const float bound = c_cut * pre_scale - err_mu + zsig * err_sd;
         if (!(vk > bound)) flag_list[atomicAdd(flag_cnt, 1)] = (int)ft;
     }
 }
@@ -915,26 +924,28 @@ __global__ __launch_bounds__(256) void knn_scan_merge_kernel(const float* __rest
 // ----------------------------------------------------------------------------------------------
 // merge shards + gather + mean + blend.  Block = 32 consecutive frames of one window.
 // ----------------------------------------------------------------------------------------------
+// NPER = candidates per lane in the merge: S * k <= 64 * NPER (2: the usual k <= 8 over up to 16 shards; 8: k up to 64)
+template <int NPER, int KMAX>
 __global__ __launch_bounds__(256) void knn_merge_gather_kernel(const float* __restrict__ cand_val,
                                                                const int* __restrict__ cand_idx, int S, int k, float alpha,
                                                                float one_minus, const float* __restrict__ rows, const float* __restrict__ src,
                                                                int T, int64_t Tt, float* __restrict__ out,
                                                                int* __restrict__ final_idx) {
-    __shared__ int sel[32][ALIVE_MAX_K];
+    __shared__ int sel[32][KMAX];
     __shared__ float tile[32][65];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = blockIdx.y;
     const int t0 = blockIdx.x * 32;
     const int nf = (T - t0) < 32 ? (T - t0) : 32;
 
-    // phase 1: each wave merges 8 frames; S*k <= 128 candidates -> two per lane
+    // phase 1: each wave merges 8 frames; the S*k candidates of a frame sit NPER per lane
     for (int f = wv * 8; f < wv * 8 + 8; ++f) {
         if (f >= nf) break;
         const int64_t ft = (int64_t)n * T + t0 + f;
-        float v[2];
-        int id[2];
+        float v[NPER];
+        int id[NPER];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NPER; ++j) {
             int e = j * 64 + lane;
             bool in = e < S * k;
             int s = in ? e / k : 0, kk = in ? e % k : 0;
@@ -943,9 +954,15 @@ __global__ __launch_bounds__(256) void knn_merge_gather_kernel(const float* __re
             v[j] = (in && id[j] >= 0) ? cand_val[o] : -INFINITY;
         }
         for (int j = 0; j < k; ++j) {
-            bool second = (v[1] > v[0]) || (v[1] == v[0] && (unsigned)id[1] < (unsigned)id[0]);
-            float bv = second ? v[1] : v[0];
-            int bi = second ? id[1] : id[0];
+            float bv = v[0];
+            int bi = id[0], bj = 0;
+#pragma unroll
+            for (int q = 1; q < NPER; ++q) {
+                const bool better = (v[q] > bv) || (v[q] == bv && (unsigned)id[q] < (unsigned)bi);
+                bv = better ? v[q] : bv;
+                bi = better ? id[q] : bi;
+                bj = better ? q : bj;
+            }
             int win = wave_argbest(bv, bi < 0 ? 0x7fffffff : bi);
             int wi = __shfl(bi, win);
             if (lane == 0) {
@@ -953,7 +970,9 @@ __global__ __launch_bounds__(256) void knn_merge_gather_kernel(const float* __re
                 if (final_idx != nullptr && blockIdx.z == 0) final_idx[(size_t)ft * k + j] = wi;
             }
             if (lane == win) {
-                if (second) v[1] = -INFINITY; else v[0] = -INFINITY;
+#pragma unroll
+                for (int q = 0; q < NPER; ++q)
+                    if (q == bj) v[q] = -INFINITY;
             }
         }
     }
@@ -983,6 +1002,175 @@ __global__ __launch_bounds__(256) void knn_merge_gather_kernel(const float* __re
         }
         __syncthreads();
     }
+}
+
+// ----------------------------------------------------------------------------------------------
+// exact tier: brute-force fp32 scan with the rescoring arithmetic -- any number of frames, k <= 64
+// ----------------------------------------------------------------------------------------------
+// The last tier of the search (frames whose bf16 candidate set could not be certified) and the whole search for
+// k > 8 (deeper than a half-list of the candidate stages).  The streaming scan above, cut for frame lists of any
+// length: frames go in groups of G (G * k <= 64 lanes hold the sorted lists), a work item is (group, row slice w of
+// nw); a wave keeps the G normalised frames of its group in registers (12 floats per lane and frame), streams its
+// rows once and scores each against all G frames with the arithmetic of knn_rescore_kernel -- bitwise the values the
+// other tiers return.  The number of frames comes from a device counter, so the launch is unconditional: waves without
+// an item return at once.  HBM-bound for G = 16 (3 GB of rows per group at 1 M vectors, shared through L2 / MALL by the
+// groups in flight); a last resort, not a fast path.
+constexpr int EX_BLOCKS = 2048;            // launch size (x 4 waves); items are distributed by a wave-stride loop
+constexpr int EX_WAVES_TARGET = 16384;     // row slices per group are chosen so that about this many items exist
+constexpr int EX_NW_MAX = 256, EX_NW_MIN = 4;
+
+__host__ __device__ inline int exact_group(int k) { return k <= 4 ? 16 : (k <= 8 ? 8 : (k <= 16 ? 4 : (k <= 32 ? 2 : 1))); }
+__host__ __device__ inline int exact_nw(int64_t groups) {
+    int64_t nw = groups > 0 ? EX_WAVES_TARGET / groups : EX_NW_MAX;
+    nw = nw / 4 * 4;
+    return (int)(nw < EX_NW_MIN ? EX_NW_MIN : (nw > EX_NW_MAX ? EX_NW_MAX : nw));
+}
+// lists the exact tier may need for `frames` frames: groups * nw(groups) <= max(EX_WAVES_TARGET, EX_NW_MIN * groups)
+static size_t exact_lists(int64_t frames, int k) {
+    const int64_t groups = (frames + exact_group(k) - 1) / exact_group(k);
+    const int64_t a = EX_WAVES_TARGET, b = EX_NW_MIN * groups;
+    return (size_t)(a > b ? a : b) + 4;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void knn_exact_kernel(const float* __restrict__ s_f32, const float* __restrict__ rows,
+                                                        const float* __restrict__ norms, int64_t M, int64_t Tt, int k,
+                                                        const int* __restrict__ frame_list, const int* __restrict__ cnt_ptr,
+                                                        float* __restrict__ part_val, int* __restrict__ part_idx) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int64_t count = Tt;
+    if (cnt_ptr != nullptr) { const int c = *cnt_ptr; count = c < Tt ? c : Tt; }
+    if (count <= 0) return;
+    const int64_t groups = (count + G - 1) / G;
+    const int nw = exact_nw(groups);
+    const int64_t items = groups * nw;
+    const int my_t = lane / k;
+    for (int64_t item = (int64_t)blockIdx.x * 4 + wv; item < items; item += (int64_t)gridDim.x * 4) {
+        const int64_t g = item / nw;
+        const int w = (int)(item - g * nw);
+        f32x4 s0[G], s1[G], s2[G];
+#pragma unroll
+        for (int t = 0; t < G; ++t) {
+            int64_t slot = g * G + t;
+            if (slot >= count) slot = g * G;                       // padding of the last group: a copy of its first frame
+            const int64_t ft = frame_list != nullptr ? frame_list[slot] : slot;
+            const f32x4* sp = (const f32x4*)(s_f32 + (size_t)ft * D);
+            s0[t] = sp[lane]; s1[t] = sp[lane + 64]; s2[t] = sp[lane + 128];
+        }
+        const bool live = lane < G * k && g * G + my_t < count;
+        float lv = -INFINITY;
+        int li = 0x7fffffff;
+        for (int64_t r = w; r < M; r += nw) {
+            const f32x4* rp = (const f32x4*)(rows + (size_t)r * D);
+            const float nn = norms[r];
+            f32x4 q0 = rp[lane], q1 = rp[lane + 64], q2 = rp[lane + 128];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { q0[j] = q0[j] / nn; q1[j] = q1[j] / nn; q2[j] = q2[j] / nn; }
+            float p = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < G; ++t) {
+                float d = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d = fmaf(s0[t][j], q0[j], d);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d = fmaf(s1[t][j], q1[j], d);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d = fmaf(s2[t][j], q2[j], d);
+                d = wave_sum(d);
+                if (t == my_t) p = d;
+            }
+            // sorted insert inside the k lanes of this frame: entries that rank before (p, r) stay, the others move down one
+            const bool before = lv > p || (lv == p && li < (int)r);
+            const float up_v = __shfl_up(lv, 1);
+            const int up_i = __shfl_up(li, 1);
+            const bool up_before = (lane % k == 0) ? true : (up_v > p || (up_v == p && up_i < (int)r));
+            if (live && !before) {
+                lv = up_before ? p : up_v;
+                li = up_before ? (int)r : up_i;
+            }
+        }
+        part_val[(size_t)item * 64 + lane] = lv;
+        part_idx[(size_t)item * 64 + lane] = li;
+    }
+}
+
+// one block per frame (block-stride over the frame count): merge the nw partial lists of its group -> exact top-k
+template <int G>
+__global__ __launch_bounds__(256) void knn_exact_merge_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx,
+                                                              int64_t Tt, int k, int64_t idx_base, const int* __restrict__ frame_list,
+                                                              const int* __restrict__ cnt_ptr, float* __restrict__ out_val,
+                                                              int* __restrict__ out_idx) {
+    __shared__ float sv[256];
+    __shared__ int si[256], sw[256];
+    const int tid = threadIdx.x;
+    int64_t count = Tt;
+    if (cnt_ptr != nullptr) { const int c = *cnt_ptr; count = c < Tt ? c : Tt; }
+    const int64_t groups = (count + G - 1) / G;
+    const int nw = exact_nw(groups);                     // <= 256: one list per thread
+    for (int64_t slot = blockIdx.x; slot < count; slot += gridDim.x) {
+        const int64_t g = slot / G;
+        const int t = (int)(slot - g * G);
+        const int64_t ft = frame_list != nullptr ? frame_list[slot] : slot;
+        const size_t base = ((size_t)g * nw + tid) * 64 + t * k;
+        int head = 0;
+        for (int j = 0; j < k; ++j) {
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+            if (tid < nw && head < k) { bv = part_val[base + head]; bi = part_idx[base + head]; }
+            sv[tid] = bv; si[tid] = bi; sw[tid] = tid;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if (tid < o) {
+                    const float ov = sv[tid + o];
+                    const int oi = si[tid + o];
+                    if (ov > sv[tid] || (ov == sv[tid] && oi < si[tid])) { sv[tid] = ov; si[tid] = oi; sw[tid] = sw[tid + o]; }
+                }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                out_val[(size_t)ft * k + j] = sv[0];
+                out_idx[(size_t)ft * k + j] = (si[0] == 0x7fffffff || !(sv[0] > -INFINITY)) ? -1 : (int)(idx_base + si[0]);
+            }
+            if (sw[0] == tid && tid < nw) head++;
+            __syncthreads();
+        }
+    }
+}
+
+// ---- small device-side control kernels of the tiered search (no host sync anywhere) ----
+// stats[]: see alive_knn_search_stats
+enum { ST_FLAG8 = 0, ST_FLAG16 = 1, ST_PROBE_N = 2, ST_PROBE_FAIL = 3, ST_MODE = 4, ST_FIRST = 5, ST_PROBE_CNT = 6, ST_WORDS = 16 };
+
+// the sample of the probe: n frames at a fixed stride through the batch (rows of s_f8 copied, padded to a block of 256)
+__global__ __launch_bounds__(64) void probe_gather_kernel(const unsigned char* __restrict__ s_f8, int64_t Tt, int n, int n_pad,
+                                                          unsigned char* __restrict__ out, int* __restrict__ plist) {
+    const int slot = blockIdx.x;
+    if (slot >= n_pad) return;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (slot < n) {
+        const int64_t ft = (int64_t)slot * Tt / n;
+        if (threadIdx.x < D / 16) v = ((const u32x4*)(s_f8 + (size_t)ft * D))[threadIdx.x];
+        if (threadIdx.x == 0) plist[slot] = (int)ft;
+    }
+    if (threadIdx.x < D / 16) ((u32x4*)(out + (size_t)slot * D))[threadIdx.x] = v;
+}
+
+// mode = 1 (bf16 first) iff the fp8 certificate failed on more than `num / den` of the probe sample
+__global__ void probe_decide_kernel(int* __restrict__ stats, int n, int num, int den) {
+    const int fail = stats[ST_PROBE_CNT];
+    stats[ST_PROBE_N] = n;
+    stats[ST_PROBE_FAIL] = fail;
+    stats[ST_MODE] = ((int64_t)fail * den > (int64_t)n * num) ? 1 : 0;
+}
+
+// bf16-first mode: every frame goes to the bf16 tier (list = identity)
+__global__ __launch_bounds__(256) void flag_all_kernel(int* __restrict__ list, int* __restrict__ cnt, int64_t Tt,
+                                                       const int* __restrict__ gate_cnt, int gate_lo, int gate_hi) {
+    int c;
+    if (!gate_open(gate_cnt, gate_lo, gate_hi, c)) return;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < Tt) list[i] = (int)i;
+    if (i == 0) *cnt = (int)Tt;
 }
 
 // optional instrumentation: events recorded on the search stream around the scoring kernel only
@@ -1018,6 +1206,66 @@ static SearchPlan make_plan(int64_t Tt, int64_t M, int split_cap = MAX_SPLIT) {
     return p;
 }
 
+constexpr int MAX_SPLIT8 = 1024 / KP8;    // the rescoring kernel takes up to 1024 candidates per frame
+constexpr int FCAP = 16384;               // tier 1 of the bf16 re-search: up to this many flagged frames ...
+constexpr int FPLAN = 4096;               // ... with the library split chosen for this many (blocks past the count exit at once)
+constexpr float CERT_Z = 7.0f;            // sigmas of candidate-score error the certificates allow for
+constexpr int PROBE_N = 1024;             // frames of the adaptive probe (fp8 searches of >= PROBE_MIN_T frames)
+constexpr int64_t PROBE_MIN_T = 16384;
+constexpr int PROBE_NUM = 2, PROBE_DEN = 5;   // bf16 first when more than 40 % of the sample fail the fp8 certificate:
+                                              // fp8 + bf16 on a fraction f costs t8 + f t16 / eff against t16 = 2.3 t8
+
+// ---- workspace: ONE layout function for the size query, the searches and the stats pointer ----
+struct SearchWs {
+    SearchPlan p16, p8, pt, pp;            // bf16 main / fp8 main / tier-1 re-search / probe
+    int fcap, probe_n, probe_pad;
+    float* s_f32; unsigned short* s_bf16; unsigned char* s_f8;
+    float* cv; int* ci;                    // candidate lists of the main pass (and of tier 2 of the re-search)
+    float* pv; int* pi;                    // partial lists: streaming scan / exact tier
+    int* stats; int* list0; int* list1;    // counters; frames flagged by the fp8 / by the bf16 certificate
+    unsigned short* s_c;                   // compacted bf16 rows of the frames being re-searched
+    float* cv1; int* ci1;                  // tier-1 candidate lists
+    unsigned char* s_p8; float* cvp; int* cip; float* p_val; int* p_idx; int* p_list;   // probe
+    size_t bytes;
+};
+
+static SearchWs ws_layout(void* base, int64_t Tt, int64_t M, int k) {
+    SearchWs w;
+    w.p16 = make_plan(Tt, M);
+    w.p8 = make_plan(Tt, M, MAX_SPLIT8);
+    const int64_t Tp = w.p16.Tt_pad;
+    w.fcap = Tp < FCAP ? (int)Tp : FCAP;
+    w.pt = make_plan(w.fcap < FPLAN ? w.fcap : FPLAN, M);
+    w.probe_n = Tt >= PROBE_MIN_T ? PROBE_N : 0;
+    w.probe_pad = (w.probe_n + FT - 1) / FT * FT;
+    w.pp = make_plan(w.probe_n > 0 ? w.probe_n : 1, M, MAX_SPLIT8);
+    Arena a(base);
+    w.s_f32 = a.take<float>((size_t)Tt * D);
+    w.s_bf16 = a.take<unsigned short>((size_t)Tp * D);
+    w.s_f8 = a.take<unsigned char>((size_t)Tp * D);
+    const size_t c16 = (size_t)Tp * w.p16.P * KP, c8 = (size_t)Tp * w.p8.P * KP8;
+    w.cv = a.take<float>(c16 > c8 ? c16 : c8);
+    w.ci = a.take<int>(c16 > c8 ? c16 : c8);
+    size_t lists = exact_lists(Tt, k <= ALIVE_MAX_K && k >= 1 ? k : 4);
+    if (lists < (size_t)SCAN_MAX_LISTS) lists = SCAN_MAX_LISTS;
+    w.pv = a.take<float>(lists * 64);
+    w.pi = a.take<int>(lists * 64);
+    w.stats = a.take<int>(ST_WORDS);
+    w.list0 = a.take<int>((size_t)Tp);
+    w.list1 = a.take<int>((size_t)Tp);
+    w.s_c = a.take<unsigned short>((size_t)Tp * D);
+    w.cv1 = a.take<float>((size_t)w.fcap * w.pt.P * KP);
+    w.ci1 = a.take<int>((size_t)w.fcap * w.pt.P * KP);
+    w.s_p8 = a.take<unsigned char>((size_t)w.probe_pad * D + 16);
+    w.cvp = a.take<float>((size_t)w.probe_pad * w.pp.P * KP8 + 4);
+    w.cip = a.take<int>((size_t)w.probe_pad * w.pp.P * KP8 + 4);
+    w.p_val = a.take<float>((size_t)(w.probe_n + 1) * ALIVE_MAX_K);
+    w.p_idx = a.take<int>((size_t)(w.probe_n + 1) * ALIVE_MAX_K);
+    w.p_list = a.take<int>((size_t)w.probe_pad + 4);
+    w.bytes = a.used() + 1024;
+    return w;
+}
+
 }  // namespace
 
 extern "C" int64_t alive_library_padded_rows(int64_t M) { return (M + TILE - 1) / TILE * TILE; }
@@ -1049,10 +1297,48 @@ static int knn_scan_launch(const float* src, int T, int64_t Tt, const float* row
     return ALIVE_OK;
 }
 
-constexpr int MAX_SPLIT8 = 1024 / KP8;
-constexpr int FCAP = 16384;               // frames the compacted (tier 1) fallback of the fp8 search takes
-constexpr int FPLAN = 4096;               // ... with the library split chosen for this many (blocks past the count exit at once)
-constexpr float CERT_Z = 7.0f;            // sigmas of fp8 score error the certificate allows for     // the rescoring kernel takes up to 1024 candidates per frame
+// exact tier over a frame list with a device-side count (list == nullptr: all Tt frames)
+static void knn_exact_launch(const SearchWs& w, const float* rows_f32, const float* norms, int64_t M, int64_t Tt, int64_t idx_base,
+                             int k, const int* list, const int* cnt, float* out_val, int32_t* out_idx, hipStream_t s) {
+#define ALIVE_EXACT(G_)                                                                                                        \
+    {                                                                                                                          \
+        knn_exact_kernel<G_><<<EX_BLOCKS, 256, 0, s>>>(w.s_f32, rows_f32, norms, M, Tt, k, list, cnt, w.pv, w.pi);              \
+        knn_exact_merge_kernel<G_><<<1024, 256, 0, s>>>(w.pv, w.pi, Tt, k, idx_base, list, cnt, out_val, out_idx);             \
+    }
+    switch (exact_group(k)) {
+        case 16: ALIVE_EXACT(16) break;
+        case 8: ALIVE_EXACT(8) break;
+        case 4: ALIVE_EXACT(4) break;
+        case 2: ALIVE_EXACT(2) break;
+        default: ALIVE_EXACT(1) break;
+    }
+#undef ALIVE_EXACT
+}
+
+static void src_prep_launch(const SearchWs& w, const float* src, int T, int64_t Tt, hipStream_t s) {
+    if (Tt <= 512) src_prep_small_kernel<<<(unsigned)w.p16.Tt_pad, 256, 0, s>>>(src, T, Tt, w.s_f32, w.s_bf16);
+    else src_prep_kernel<<<(unsigned)(w.p16.Tt_pad / 64), 256, 0, s>>>(src, T, Tt, w.p16.Tt_pad, w.s_f32, w.s_bf16);
+}
+
+static int check_search_args(const char* what, const void* a, const void* b, int N, int T, int k, int64_t M) {
+    ALIVE_CHECK_ARG(a && b, "%s: null pointer", what);
+    ALIVE_CHECK_ARG(N > 0 && T > 0, "%s: empty source", what);
+    ALIVE_CHECK_ARG(k >= 1 && k <= ALIVE_MAX_K, "%s: k=%d outside [1,%d]", what, k, ALIVE_MAX_K);
+    ALIVE_CHECK_ARG(M >= k, "%s: library shard has %lld vectors, fewer than k=%d", what, (long long)M, k);
+    ALIVE_CHECK_ARG((int64_t)N * T < ((int64_t)1 << 31) - FT, "%s: %lld frames in one call", what, (long long)N * T);
+    return ALIVE_OK;
+}
+
+static int lds_optin(const char* what) {
+    static LdsOptIn optin8, optin16;
+    hipError_t e = optin8.ensure({(const void*)knn_score8_kernel}, SCORE8_LDS);
+    if (e == hipSuccess) e = optin16.ensure({(const void*)knn_score_kernel}, SCORE_LDS);
+    if (e != hipSuccess) {
+        alive_set_error("%s: cannot reserve %d B of LDS: %s", what, SCORE_LDS, hipGetErrorString(e));
+        return ALIVE_ERR_LAUNCH;
+    }
+    return ALIVE_OK;
+}
 
 extern "C" size_t alive_library_fp8_bytes(int64_t M) { return (size_t)alive_library_padded_rows(M) * D; }
 
@@ -1065,155 +1351,135 @@ extern "C" int alive_library_pack_fp8(const void* lib_bf16, int64_t M, void* lib
 }
 
 extern "C" size_t alive_knn_workspace_bytes(int64_t Tt, int64_t M) {
-    SearchPlan p = make_plan(Tt, M);
-    const SearchPlan p8 = make_plan(Tt, M, MAX_SPLIT8);
-    size_t b = 0;
-    b += align_up((size_t)Tt * D * 4, 256);                        // s_f32
-    b += align_up((size_t)p.Tt_pad * D * 2, 256);                  // s_bf16
-    b += align_up((size_t)p.Tt_pad * D, 256);                      // s_f8
-    const size_t c16 = (size_t)p.Tt_pad * p.P * KP * 4, c8 = (size_t)p8.Tt_pad * p8.P * KP8 * 4;
-    b += 2 * align_up(c16 > c8 ? c16 : c8, 256);                   // candidate lists
-    b += 2 * align_up((size_t)SCAN_MAX_LISTS * 64 * 4, 256);       // partial lists of the small-T scan
-    const int fcap = p.Tt_pad < FCAP ? (int)p.Tt_pad : FCAP;       // fallback of the fp8 search (alive_knn_search_fp8)
-    const SearchPlan pt = make_plan(fcap < FPLAN ? fcap : FPLAN, M);
-    b += align_up((size_t)p.Tt_pad * 4, 256) + 256;                // flagged frames + their count
-    b += align_up((size_t)fcap * D * 2, 256);                      // their compacted bf16 rows
-    b += 2 * align_up((size_t)fcap * pt.P * KP * 4, 256);          // their candidate lists
-    return b + 1024;
+    // sized for any k the entry points accept (the exact tier's partial lists grow with ceil(Tt / G(k)))
+    const size_t a = ws_layout(nullptr, Tt, M, 4).bytes, b = ws_layout(nullptr, Tt, M, ALIVE_MAX_K).bytes;
+    return a > b ? a : b;
 }
 
+// The bf16 re-search of the frames in list[0 .. *cnt) (compacted), certified, behind either first stage:
+//   tier 1 (1 .. fcap frames, usually a handful): library split chosen for few frames;
+//   tier 2 (more): the split of the whole batch; blocks past the count exit at once.
+// Frames that fail the bf16 certificate land in list1 and go through the exact scan.
+static void bf16_tiers_launch(const SearchWs& w, const void* lib_bf16, const float* rows_f32, const float* norms, int64_t M,
+                              int64_t Tt, int64_t idx_base, int k, float* out_val, int32_t* out_idx, hipStream_t s,
+                              bool time_tier2) {
+    int* cnt0 = w.stats + ST_FLAG8;
+    int* cnt1 = w.stats + ST_FLAG16;
+    const int fcap = w.fcap;
+    gather_frames_kernel<<<(unsigned)fcap, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, 0, fcap, w.s_c);
+    knn_score_kernel<<<dim3((unsigned)(fcap / FT), w.pt.split), 256, SCORE_LDS, s>>>(
+        w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.cv1, w.ci1, cnt0, 0, fcap, 1);
+    knn_rescore_kernel<<<(unsigned)((fcap + 3) / 4), 256, 0, s>>>(w.cv1, w.ci1, w.pt.P, KP, w.s_f32, rows_f32, norms, fcap, idx_base, k,
+                                                                 out_val, out_idx, w.list0, cnt0, 0, fcap, w.list1, cnt1, CERT_Z, KH, 1.0f);
+    if (w.p16.Tt_pad > fcap) {
+        gather_frames_kernel<<<(unsigned)w.p16.Tt_pad, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, fcap, 0x7fffffff, w.s_c);
+        if (time_tier2 && g_ev_start) (void)hipEventRecord(g_ev_start, s);
+        knn_score_kernel<<<dim3((unsigned)(w.p16.Tt_pad / FT), w.p16.split), 256, SCORE_LDS, s>>>(
+            w.s_c, (const unsigned short*)lib_bf16, M, w.p16.tiles_total, w.p16.tiles_per_split, w.p16.P, w.cv, w.ci, cnt0, fcap,
+            0x7fffffff, 1);
+        if (time_tier2 && g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
+        knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, w.p16.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
+                                                                   out_val, out_idx, w.list0, cnt0, fcap, 0x7fffffff, w.list1, cnt1,
+                                                                   CERT_Z, KH, 1.0f);
+    }
+    knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, w.list1, cnt1, out_val, out_idx, s);
+}
+
+// Search with the bf16 MFMA as the first candidate stage: every frame's candidate set is certified against the bf16 score
+// error measured on its own rescored candidates; frames that fail go through the exact fp32 scan.  k > 8 (deeper than a
+// half-list of the candidate stage): the exact scan for every frame.
 extern "C" int alive_knn_search(const float* src, int N, int T, const void* lib_bf16, const float* rows_f32,
                                 const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
                                 void* ws, void* stream) {
     ALIVE_CHECK_ARG(src && lib_bf16 && rows_f32 && norms && out_val && out_idx && ws, "alive_knn_search: null pointer");
-    ALIVE_CHECK_ARG(N > 0 && T > 0, "alive_knn_search: empty source");
-    ALIVE_CHECK_ARG(k >= 1 && k <= ALIVE_MAX_K, "alive_knn_search: k=%d outside [1,%d]", k, ALIVE_MAX_K);
-    ALIVE_CHECK_ARG(M >= k, "alive_knn_search: library shard has %lld vectors, fewer than k=%d", (long long)M, k);
-    const SearchPlan p = make_plan((int64_t)N * T, M);
-    Arena a(ws);
-    float* s_f32 = a.take<float>((size_t)p.Tt * D);
-    unsigned short* s_bf16 = a.take<unsigned short>((size_t)p.Tt_pad * D);
-    unsigned char* s_f8 = a.take<unsigned char>((size_t)p.Tt_pad * D);
-    (void)s_f8;
-    const SearchPlan p8w = make_plan((int64_t)N * T, M, MAX_SPLIT8);
-    const size_t c16 = (size_t)p.Tt_pad * p.P * KP, c8 = (size_t)p8w.Tt_pad * p8w.P * KP8;
-    float* cv = a.take<float>(c16 > c8 ? c16 : c8);
-    int* ci = a.take<int>(c16 > c8 ? c16 : c8);
-    float* pv = a.take<float>((size_t)SCAN_MAX_LISTS * 64);
-    int* pi = a.take<int>((size_t)SCAN_MAX_LISTS * 64);
+    if (int rc = check_search_args("alive_knn_search", src, ws, N, T, k, M)) return rc;
+    const int64_t Tt = (int64_t)N * T;
+    const SearchWs w = ws_layout(ws, Tt, M, k);
     hipStream_t s = (hipStream_t)stream;
-    if (p.Tt * k <= 64 && M <= SCAN_ROWS_MAX)          // a handful of frames: exact fp32 scan of the rows, no candidate stage
-        return knn_scan_launch(src, T, p.Tt, rows_f32, norms, M, idx_base, k, s_f32, s_bf16, pv, pi, out_val, out_idx, s);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)knn_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_LDS);
-        if (e != hipSuccess) {
-            alive_set_error("alive_knn_search: cannot reserve %d B of LDS: %s", SCORE_LDS, hipGetErrorString(e));
-            return ALIVE_ERR_LAUNCH;
-        }
-        attr_set = true;
+    if (Tt * k <= 64 && M <= SCAN_ROWS_MAX)            // a handful of frames: exact fp32 scan of the rows, no candidate stage
+        return knn_scan_launch(src, T, Tt, rows_f32, norms, M, idx_base, k, w.s_f32, w.s_bf16, w.pv, w.pi, out_val, out_idx, s);
+    if (int rc = lds_optin("alive_knn_search")) return rc;
+    (void)hipMemsetAsync(w.stats, 0, ST_WORDS * sizeof(int), s);
+    src_prep_launch(w, src, T, Tt, s);
+    if (k > KH) {
+        if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
+        knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, nullptr, nullptr, out_val, out_idx, s);
+        if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
+        ALIVE_CHECK_LAUNCH("alive_knn_search(exact)");
+        return ALIVE_OK;
     }
-    if (p.Tt <= 512) src_prep_small_kernel<<<(unsigned)p.Tt_pad, 256, 0, s>>>(src, T, p.Tt, s_f32, s_bf16);
-    else src_prep_kernel<<<(unsigned)(p.Tt_pad / 64), 256, 0, s>>>(src, T, p.Tt, p.Tt_pad, s_f32, s_bf16);
+    const SearchPlan& p = w.p16;
     if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
     knn_score_kernel<<<dim3((unsigned)(p.Tt_pad / FT), p.split), 256, SCORE_LDS, s>>>(
-        s_bf16, (const unsigned short*)lib_bf16, M, p.tiles_total, p.tiles_per_split, p.P, cv, ci, nullptr, 0, 0, 0);
+        w.s_bf16, (const unsigned short*)lib_bf16, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, nullptr, 0, 0, 0);
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
-    knn_rescore_kernel<<<(unsigned)((p.Tt + 3) / 4), 256, 0, s>>>(cv, ci, p.P, KP, s_f32, rows_f32, norms, p.Tt, idx_base, k,
-                                                                 out_val, out_idx, nullptr, nullptr, 0, 0, nullptr, nullptr, 0.0f);
+    knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, p.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
+                                                               out_val, out_idx, nullptr, nullptr, 0, 0, w.list1, w.stats + ST_FLAG16,
+                                                               CERT_Z, KH, 1.0f);
+    knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, w.list1, w.stats + ST_FLAG16, out_val, out_idx, s);
     ALIVE_CHECK_LAUNCH("alive_knn_search");
     return ALIVE_OK;
 }
 
 // The same search with the candidate stage on the fp8 MFMA (knn_score8_kernel); lib_f8 from alive_library_pack_fp8.
-// Frames whose candidate set cannot be certified (knn_rescore_kernel) are searched again through the bf16 stage:
-//   tier 1 (1 .. FCAP = 16384 frames, usually a handful): their operand rows are compacted and run as a small bf16 search;
-//   tier 2 (more: a library whose best cosines lie closer together than the fp8 error): the whole call is repeated on bf16.
-// All of it is launched up front -- the kernels read the count on the device and return at once when it is not theirs.
-
+//   probe   (batches of >= 16384 frames) the fp8 stage + its certificate on a sample of 1024 frames; when more than 40 % of
+//           them fail -- a library whose best cosines lie closer together than the fp8 error -- the fp8 pass over the
+//           batch is skipped (mode 1) and every frame goes straight to the bf16 stage;
+//   fp8     (mode 0) candidate stage on the fp8 MFMA, exact rescoring, certificate -> list0;
+//   bf16    the frames of list0 (all of them in mode 1) through the bf16 candidate stage, exact rescoring, certificate
+//           with the bf16 error statistics -> list1;
+//   exact   the frames of list1 through the brute-force fp32 scan.
+// All of it is launched up front -- the kernels read the counters on the device and return at once when a tier is empty.
 extern "C" int alive_knn_search_fp8(const float* src, int N, int T, const void* lib_f8, const void* lib_bf16, const float* rows_f32,
                                     const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
                                     void* ws, void* stream) {
     ALIVE_CHECK_ARG(src && lib_f8 && lib_bf16 && rows_f32 && norms && out_val && out_idx && ws, "alive_knn_search_fp8: null pointer");
-    ALIVE_CHECK_ARG(N > 0 && T > 0, "alive_knn_search_fp8: empty source");
-    ALIVE_CHECK_ARG(k >= 1 && k <= ALIVE_MAX_K, "alive_knn_search_fp8: k=%d outside [1,%d]", k, ALIVE_MAX_K);
-    ALIVE_CHECK_ARG(M >= k, "alive_knn_search_fp8: library shard has %lld vectors, fewer than k=%d", (long long)M, k);
-    const SearchPlan p16 = make_plan((int64_t)N * T, M);
-    const SearchPlan p = make_plan((int64_t)N * T, M, MAX_SPLIT8);
-    const int fcap = p.Tt_pad < FCAP ? (int)p.Tt_pad : FCAP;
-    const SearchPlan pt = make_plan(fcap < FPLAN ? fcap : FPLAN, M);       // its split; the frame blocks go up to fcap
-    Arena a(ws);                                       // the layout of alive_knn_search, then the fallback's own buffers
-    float* s_f32 = a.take<float>((size_t)p.Tt * D);
-    unsigned short* s_bf16 = a.take<unsigned short>((size_t)p.Tt_pad * D);
-    unsigned char* s_f8 = a.take<unsigned char>((size_t)p.Tt_pad * D);
-    const size_t c16 = (size_t)p16.Tt_pad * p16.P * KP, c8 = (size_t)p.Tt_pad * p.P * KP8;
-    float* cv = a.take<float>(c16 > c8 ? c16 : c8);
-    int* ci = a.take<int>(c16 > c8 ? c16 : c8);
-    float* pv = a.take<float>((size_t)SCAN_MAX_LISTS * 64);
-    int* pi = a.take<int>((size_t)SCAN_MAX_LISTS * 64);
-    int* flag_list = a.take<int>((size_t)p.Tt_pad);
-    int* flag_cnt = a.take<int>(64);
-    unsigned short* s_c = a.take<unsigned short>((size_t)fcap * D);
-    float* cv1 = a.take<float>((size_t)fcap * pt.P * KP);
-    int* ci1 = a.take<int>((size_t)fcap * pt.P * KP);
+    if (int rc = check_search_args("alive_knn_search_fp8", src, ws, N, T, k, M)) return rc;
+    const int64_t Tt = (int64_t)N * T;
+    if (k > KH) return alive_knn_search(src, N, T, lib_bf16, rows_f32, norms, M, idx_base, k, out_val, out_idx, ws, stream);
+    const SearchWs w = ws_layout(ws, Tt, M, k);
+    const SearchPlan& p = w.p8;
     hipStream_t s = (hipStream_t)stream;
-    if (p.Tt * k <= 64 && M <= SCAN_ROWS_MAX)          // streaming ring: the exact scan, no candidate stage at all
-        return knn_scan_launch(src, T, p.Tt, rows_f32, norms, M, idx_base, k, s_f32, s_bf16, pv, pi, out_val, out_idx, s);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)knn_score8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SCORE8_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)knn_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_LDS);
-        if (e != hipSuccess) {
-            alive_set_error("alive_knn_search_fp8: cannot reserve %d B of LDS: %s", SCORE8_LDS, hipGetErrorString(e));
-            return ALIVE_ERR_LAUNCH;
-        }
-        attr_set = true;
-    }
-    (void)hipMemsetAsync(flag_cnt, 0, sizeof(int), s);
-    if (p.Tt <= 512) src_prep_small_kernel<<<(unsigned)p.Tt_pad, 256, 0, s>>>(src, T, p.Tt, s_f32, s_bf16);
-    else src_prep_kernel<<<(unsigned)(p.Tt_pad / 64), 256, 0, s>>>(src, T, p.Tt, p.Tt_pad, s_f32, s_bf16);
+    if (Tt * k <= 64 && M <= SCAN_ROWS_MAX)            // streaming ring: the exact scan, no candidate stage at all
+        return knn_scan_launch(src, T, Tt, rows_f32, norms, M, idx_base, k, w.s_f32, w.s_bf16, w.pv, w.pi, out_val, out_idx, s);
+    if (int rc = lds_optin("alive_knn_search_fp8")) return rc;
+    (void)hipMemsetAsync(w.stats, 0, ST_WORDS * sizeof(int), s);
+    src_prep_launch(w, src, T, Tt, s);
     const int64_t n8 = p.Tt_pad * D / 8;
-    src_to_fp8_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>(s_bf16, n8, (uint2*)s_f8);
+    src_to_fp8_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>(w.s_bf16, n8, (uint2*)w.s_f8);
+    int* mode = w.stats + ST_MODE;
+    if (w.probe_n > 0) {
+        probe_gather_kernel<<<(unsigned)w.probe_pad, 64, 0, s>>>(w.s_f8, Tt, w.probe_n, w.probe_pad, w.s_p8, w.p_list);
+        knn_score8_kernel<<<dim3((unsigned)(w.probe_pad / FT), w.pp.split), 256, SCORE8_LDS, s>>>(
+            w.s_p8, (const unsigned char*)lib_f8, M, w.pp.tiles_total, w.pp.tiles_per_split, w.pp.P, w.cvp, w.cip, nullptr, 0, 0);
+        // the sample's own rescoring (results go to scratch rows, its flagged frames are only counted)
+        knn_rescore_kernel<<<(unsigned)((w.probe_n + 3) / 4), 256, 0, s>>>(w.cvp, w.cip, w.pp.P, KP8, w.s_f32, rows_f32, norms, w.probe_n,
+                                                                          idx_base, k, w.p_val, w.p_idx, w.p_list, nullptr, 0, 0,
+                                                                          w.p_list + w.probe_pad, w.stats + ST_PROBE_CNT, CERT_Z, KH8,
+                                                                          1.0f / (F8_SCALE * F8_SCALE));
+        probe_decide_kernel<<<1, 1, 0, s>>>(w.stats, w.probe_n, PROBE_NUM, PROBE_DEN);
+    }
+    // ---- mode 0: fp8 first ----
     if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
     knn_score8_kernel<<<dim3((unsigned)(p.Tt_pad / FT), p.split), 256, SCORE8_LDS, s>>>(
-        s_f8, (const unsigned char*)lib_f8, M, p.tiles_total, p.tiles_per_split, p.P, cv, ci);
+        w.s_f8, (const unsigned char*)lib_f8, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, mode, -1, 0);
+    knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, p.P, KP8, w.s_f32, rows_f32, norms, Tt, idx_base, k,
+                                                               out_val, out_idx, nullptr, mode, -1, 0, w.list0, w.stats + ST_FLAG8,
+                                                               CERT_Z, KH8, 1.0f / (F8_SCALE * F8_SCALE));
+    // ---- mode 1: bf16 first (every frame into list0) ----
+    if (w.probe_n > 0) flag_all_kernel<<<(unsigned)((Tt + 255) / 256), 256, 0, s>>>(w.list0, w.stats + ST_FLAG8, Tt, mode, 0, 1);
+    bf16_tiers_launch(w, lib_bf16, rows_f32, norms, M, Tt, idx_base, k, out_val, out_idx, s, false);
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
-    knn_rescore_kernel<<<(unsigned)((p.Tt + 3) / 4), 256, 0, s>>>(cv, ci, p.P, KP8, s_f32, rows_f32, norms, p.Tt, idx_base, k,
-                                                                 out_val, out_idx, nullptr, nullptr, 0, 0, flag_list, flag_cnt, CERT_Z);
-    // ---- tier 1: 0 < flagged <= fcap ----
-    gather_frames_kernel<<<(unsigned)fcap, 128, 0, s>>>(s_bf16, flag_list, flag_cnt, fcap, s_c);
-    knn_score_kernel<<<dim3((unsigned)(fcap / FT), pt.split), 256, SCORE_LDS, s>>>(
-        s_c, (const unsigned short*)lib_bf16, M, pt.tiles_total, pt.tiles_per_split, pt.P, cv1, ci1, flag_cnt, 0, fcap, 1);
-    knn_rescore_kernel<<<(unsigned)((fcap + 3) / 4), 256, 0, s>>>(cv1, ci1, pt.P, KP, s_f32, rows_f32, norms, fcap, idx_base, k,
-                                                                 out_val, out_idx, flag_list, flag_cnt, 0, fcap, nullptr, nullptr, 0.0f);
-    // ---- tier 2: flagged > fcap ----
-    if (p.Tt_pad > fcap) {
-        knn_score_kernel<<<dim3((unsigned)(p16.Tt_pad / FT), p16.split), 256, SCORE_LDS, s>>>(
-            s_bf16, (const unsigned short*)lib_bf16, M, p16.tiles_total, p16.tiles_per_split, p16.P, cv, ci, flag_cnt, fcap,
-            0x7fffffff, 0);
-        knn_rescore_kernel<<<(unsigned)((p.Tt + 3) / 4), 256, 0, s>>>(cv, ci, p16.P, KP, s_f32, rows_f32, norms, p.Tt, idx_base, k,
-                                                                     out_val, out_idx, nullptr, flag_cnt, fcap, 0x7fffffff, nullptr,
-                                                                     nullptr, 0.0f);
-    }
     ALIVE_CHECK_LAUNCH("alive_knn_search_fp8");
     return ALIVE_OK;
 }
 
-// number of frames the last alive_knn_search_fp8 on this workspace sent to the bf16 stage (device int, for tests / bench)
-extern "C" const int* alive_knn_fp8_fallback_count(int N, int T, int64_t M, void* ws) {
-    const SearchPlan p16 = make_plan((int64_t)N * T, M);
-    const SearchPlan p = make_plan((int64_t)N * T, M, MAX_SPLIT8);
-    Arena a(ws);
-    a.take<float>((size_t)p.Tt * D);
-    a.take<unsigned short>((size_t)p.Tt_pad * D);
-    a.take<unsigned char>((size_t)p.Tt_pad * D);
-    const size_t c16 = (size_t)p16.Tt_pad * p16.P * KP, c8 = (size_t)p.Tt_pad * p.P * KP8;
-    a.take<float>(c16 > c8 ? c16 : c8);
-    a.take<int>(c16 > c8 ? c16 : c8);
-    a.take<float>((size_t)SCAN_MAX_LISTS * 64);
-    a.take<int>((size_t)SCAN_MAX_LISTS * 64);
-    a.take<int>((size_t)p.Tt_pad);
-    return a.take<int>(64);
+// device pointer (inside ws) to the counters of the last search on this workspace, int[8]:
+//   [0] frames the fp8 certificate sent to the bf16 stage (all frames when the probe chose bf16 first)
+//   [1] frames the bf16 certificate sent to the exact scan
+//   [2] frames of the probe sample, [3] of which failed the fp8 certificate, [4] 1 = the probe chose bf16 first
+extern "C" const int* alive_knn_search_stats(int N, int T, int64_t M, void* ws) {
+    return ws_layout(ws, (int64_t)N * T, M, 4).stats;
 }
 
 extern "C" int alive_knn_set_timing_events(void* ev_start, void* ev_stop) {
@@ -1226,14 +1492,18 @@ extern "C" int alive_knn_merge_gather(const float* cand_val, const int32_t* cand
                                       const float* rows_f32_full, const float* src, int N, int T, float* out,
                                       int32_t* final_idx, void* stream) {
     ALIVE_CHECK_ARG(cand_val && cand_idx && rows_f32_full && src && out, "alive_knn_merge_gather: null pointer");
-    ALIVE_CHECK_ARG(k >= 1 && k <= ALIVE_MAX_K && n_shards >= 1 && n_shards * k <= 128,
-                    "alive_knn_merge_gather: n_shards*k = %d exceeds 128", n_shards * k);
+    ALIVE_CHECK_ARG(k >= 1 && k <= ALIVE_MAX_K && n_shards >= 1 && n_shards * k <= 512,
+                    "alive_knn_merge_gather: n_shards*k = %d exceeds 512", n_shards * k);
     ALIVE_CHECK_ARG(N > 0 && T > 0, "alive_knn_merge_gather: empty source");
     // with only a few blocks of frames the 12 feature slabs go to separate blocks (streaming: 1 block -> 12)
     const int zs = (int64_t)cdiv(T, 32) * N < 64 ? D / 64 : 1;
-    knn_merge_gather_kernel<<<dim3(cdiv(T, 32), N, zs), 256, 0, (hipStream_t)stream>>>(
-        cand_val, cand_idx, n_shards, k, (float)alpha, (float)(1.0 - alpha), rows_f32_full, src, T, (int64_t)N * T, out,
-        final_idx);
+    const dim3 g(cdiv(T, 32), N, zs);
+    if (k <= 8 && n_shards * k <= 128)
+        knn_merge_gather_kernel<2, 8><<<g, 256, 0, (hipStream_t)stream>>>(cand_val, cand_idx, n_shards, k, (float)alpha,
+                                                                       (float)(1.0 - alpha), rows_f32_full, src, T, (int64_t)N * T, out, final_idx);
+    else
+        knn_merge_gather_kernel<8, ALIVE_MAX_K><<<g, 256, 0, (hipStream_t)stream>>>(cand_val, cand_idx, n_shards, k, (float)alpha,
+                                                                                 (float)(1.0 - alpha), rows_f32_full, src, T, (int64_t)N * T, out, final_idx);
     ALIVE_CHECK_LAUNCH("alive_knn_merge_gather");
     return ALIVE_OK;
 }

@@ -32,7 +32,12 @@ class PackedNet:
 
     # --- nn.Module-like surface used by the reference's scripts ---
     def to(self, device):
-        self._device = torch.device(device)
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if device == self._device:
+            return self                                # keeps the packed table
+        self._device = device
         self._sd = OrderedDict((k, v.to(self._device)) for k, v in self._sd.items())
         self._table = None
         return self
@@ -61,4 +66,7 @@ class PackedNet:
             if self._device.type != "cuda":
                 raise RuntimeError("this network runs on the MI355X only: call .to('cuda') first (no CPU path)")
             self._table = nat.WeightTable(self.MODEL_ID, self._pack(self._sd))
+            # the packing ran as torch ops on the current stream; window batches on side streams (module/pipeline.py)
+            # read the table without any dependency on that stream, so it must be complete before it is handed out
+            torch.cuda.current_stream(self._device).synchronize()
         return self._table

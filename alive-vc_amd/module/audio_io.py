@@ -95,6 +95,7 @@ def resample(waveform, orig_freq, new_freq, pre_gain_db=0.0, post_gain_db=0.0):
     if key not in _filters:
         f = torch.empty(new * L_.alive_resample_taps(orig, new), device=waveform.device)
         nat.check(L_.alive_resample_filter(orig, new, nat.ptr(f), nat.stream()), "alive_resample_filter")
+        torch.cuda.current_stream(waveform.device).synchronize()    # once per rate pair: other streams will read it
         _filters[key] = f
     shape = waveform.shape
     x = waveform.reshape(-1, shape[-1]).contiguous().float()

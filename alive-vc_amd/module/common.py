@@ -8,6 +8,7 @@ is packed (normalised fp8 / bf16 rows + fp32 rows + norms) once per reference te
 and cached, so the per-window calls of inference.py:129 only pay for the search.
 """
 import os
+import weakref
 
 import torch
 
@@ -72,6 +73,29 @@ class PackedLibrary:
         return val, idx
 
 
+    def with_prefilter(self, prefilter):
+        """the same resident library searched through the other candidate stage (shares every tensor)"""
+        import copy
+        if prefilter not in ("bf16", "fp8"):
+            raise ValueError(prefilter)
+        other = copy.copy(self)
+        other.__dict__.pop("search", None)             # an instrumented search (bench.py) stays with the original
+        other.prefilter = prefilter
+        other._ws = nat.Workspace()
+        other._last = None
+        if prefilter == "bf16":
+            other.lib_f8 = None
+        elif self.lib_f8 is None:
+            L = nat.lib()
+            other.lib_f8 = torch.empty(L.alive_library_fp8_bytes(self.M), dtype=torch.uint8, device=self.rows.device)
+            nat.check(L.alive_library_pack_fp8(nat.ptr(self.lib_bf16), self.M, nat.ptr(other.lib_f8), nat.stream()),
+                      "alive_library_pack_fp8")
+        return other
+
+    def search_stats(self):
+        """what the tiers of the last search did (syncs; tests / bench)"""
+        return {"prefilter": self.prefilter, "frames_researched_on_bf16": self.fallback_frames() if self.lib_f8 is not None else None}
+
     def fallback_frames(self):
         """frames the last fp8 search could not certify and searched again through the bf16 stage (syncs; tests / bench)"""
         if self.lib_f8 is None or getattr(self, "_last", None) is None:
@@ -96,18 +120,31 @@ def merge_gather(cand_val, cand_idx, n_shards, k, alpha, rows_full, source, retu
     return (out, fin) if return_indices else out
 
 
-_cache = {}
+_cache = {}          # key -> (PackedLibrary, weakref to the tensor that owns the storage)
 
 
 def _packed_for(reference_DxM):
-    key = (reference_DxM.data_ptr(), tuple(reference_DxM.shape), reference_DxM._version, str(reference_DxM.device), _prefilter())
+    """Packed form of a library tensor, cached per source tensor.  The key alone (address, shape, version) cannot tell
+    a library from a later one of the same shape that the caching allocator put at the same address, so an entry also
+    holds a weak reference to the tensor that owns the storage: it is valid only while that very tensor is alive and
+    is dropped the moment it dies.  (Writes that bypass autograd's version counter -- ctypes kernels, `.data` views --
+    are invisible to it: call `forget_packed()` after such a write.)"""
+    owner = reference_DxM._base if reference_DxM._base is not None else reference_DxM
+    key = (reference_DxM.data_ptr(), tuple(reference_DxM.shape), tuple(reference_DxM.stride()), reference_DxM._version,
+           str(reference_DxM.device), _prefilter())
     hit = _cache.get(key)
-    if hit is None:
-        if len(_cache) >= 4:
-            _cache.pop(next(iter(_cache)))
-        hit = PackedLibrary(reference_DxM)
-        _cache[key] = hit
-    return hit
+    if hit is not None and hit[1]() is owner:
+        return hit[0]
+    if len(_cache) >= 4:
+        _cache.pop(next(iter(_cache)))
+    packed = PackedLibrary(reference_DxM)
+    _cache[key] = (packed, weakref.ref(owner, lambda _r, key=key: _cache.pop(key, None)))
+    return packed
+
+
+def forget_packed():
+    """drop every cached packed library (after writing into a library tensor behind torch's back)"""
+    _cache.clear()
 
 
 def match_features(source, reference, k=4, alpha=0.0, return_indices=False):

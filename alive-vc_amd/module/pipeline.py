@@ -46,6 +46,8 @@ class Converter:
         self.device = torch.device(device)
         self.ce, self.pe, self.dec = content_encoder.to(device), f0_estimator.to(device), decoder.to(device)
         self.library = None
+        for net in (self.ce, self.pe, self.dec):       # pack the weight tables now, on the caller's stream (not lazily
+            net.table()                                # inside the first window batch, which runs on a side stream)
 
     def set_library(self, tokens):
         """tokens [1, 768, M] (voice_library.pt layout) or an already packed PackedLibrary."""

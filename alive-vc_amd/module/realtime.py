@@ -17,6 +17,8 @@ class RealtimeConverter:
                  input_sr=16000, output_sr=16000, f0_rate=1.0, pitch=0.0, k=4, alpha=0.0, gain=0.0, input_gain=0.0):
         self.device = torch.device(device)
         self.ce, self.pe, self.dec = content_encoder.to(device), f0_estimator.to(device), decoder.to(device)
+        for net in (self.ce, self.pe, self.dec):
+            net.table()                                # weight tables packed up front (never inside a captured step)
         self.lib = library_tokens if isinstance(library_tokens, PackedLibrary) else PackedLibrary(library_tokens[0].to(device))
         self.chunk, self.buffersize = chunk, buffersize
         self.input_sr, self.output_sr = input_sr, output_sr

@@ -2,18 +2,27 @@
 
 1. Windows are independent units -> `partition_windows`: pure data parallelism, no collective.
 2. Library-sharded kNN (north-star option; BASELINE config 4): the bank is cut into contiguous row
-   slabs, every rank scores ALL frames against its slab and rescoring happens on the owning rank, so
-   the exchanged lists are already exact fp32 cosines: one all-gather of [Tt, k] (val fp32, idx int32
-   global) per rank -- 8*k bytes per frame per rank, latency-bound on xGMI, not link-bound -- then
-   every rank merges the S*k candidates and gathers from its replicated fp32 row table.
+   slabs and every rank scores ALL frames against its slab.  Two exchange steps:
+     a. the frames: encoders run data-parallel, so a rank only holds the content features of its own
+        windows -> one all-gather of [n, 768, T] fp32 (3 KB per frame; rescoring on the owning shard is
+        exact fp32, so the frames travel as fp32);
+     b. the lists: rescoring happens on the rank that owns the rows, so the exchanged lists are already
+        exact fp32 cosines -> one all-gather of [Tt_all, k] (val fp32 + idx int32 global: 8*k bytes per
+        frame per rank -- latency-bound on xGMI, not link-bound).
+   Every rank then merges the S*k candidates of ITS OWN frames and gathers from its replicated fp32 row
+   table; the decoder runs data-parallel again.  `ShardedLibrary.match` is the form for frames that are
+   already replicated (step b only), `match_distributed` the end-to-end form (a + b).
 
 The search / merge callables are injected so the protocol itself (bounds, index bases, gather order,
-merge inputs) is exercised by the world_size-2 gloo tests on CPU; on the GPU they are the HIP kernels.
+padding of uneven window counts, merge inputs) is exercised by the world_size-2 gloo tests on CPU; on
+the GPU they are the HIP kernels.
 """
 import time
 
 import torch
 import torch.distributed as dist
+
+from .pipeline import Converter
 
 
 def shard_bounds(M, world):
@@ -33,63 +42,165 @@ def partition_windows(n_windows, world, rank):
     return slice(b, e)
 
 
+def allgather_rows(x, group=None):
+    """[r, ...] per rank (same shape on every rank) -> [world * r, ...] in rank order."""
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo" and x.is_cuda:         # test-only path (1-GPU box): gloo moves host memory
+        return allgather_rows(x.cpu(), group).to(x.device)
+    x = x.contiguous()
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x, group=group)
+    return out
+
+
 def allgather_candidates(val, idx, group=None):
     """[Tt, k] per rank -> ([S, Tt, k], [S, Tt, k]) in rank order (the layout alive_knn_merge_gather reads)."""
     world = dist.get_world_size(group)
-    if dist.get_backend(group) == "gloo" and val.is_cuda:      # test-only path (1-GPU box): gloo moves host memory
-        gv, gi = allgather_candidates(val.cpu(), idx.cpu(), group)
-        return gv.to(val.device), gi.to(val.device)
     tt, k = val.shape
-    gv = torch.empty((world * tt, k), dtype=val.dtype, device=val.device)
-    gi = torch.empty((world * tt, k), dtype=idx.dtype, device=idx.device)
-    dist.all_gather_into_tensor(gv, val.contiguous(), group=group)
-    dist.all_gather_into_tensor(gi, idx.contiguous(), group=group)
-    return gv.view(world, tt, k), gi.view(world, tt, k)
+    return allgather_rows(val, group).view(world, tt, k), allgather_rows(idx, group).view(world, tt, k)
 
 
 class ShardedLibrary:
     """`search(source, k) -> (val, idx_global)` over this rank's slab, `merge(gv, gi, S, k, alpha, source)`
-    over the gathered lists."""
+    over the gathered lists (optionally `return_indices=True` -> (out, idx[Tt, k]))."""
 
     def __init__(self, search, merge, group=None):
         self.search, self.merge, self.group = search, merge, group
+        self.last_exchange_bytes = None
 
-    def match(self, source, k=4, alpha=0.0):
+    def match(self, source, k=4, alpha=0.0, **kw):
+        """frames replicated on every rank: search the slab, all-gather the lists, merge."""
         val, idx = self.search(source, k)
         gv, gi = allgather_candidates(val, idx, self.group)
-        return self.merge(gv, gi, dist.get_world_size(self.group), k, alpha, source)
+        return self.merge(gv, gi, dist.get_world_size(self.group), k, alpha, source, **kw)
+
+    def match_distributed(self, source_local, k=4, alpha=0.0, counts=None, **kw):
+        """frames data-parallel: `source_local` [n_r, 768, T] are this rank's windows.  counts = windows per rank in rank
+        order (None: the same on every rank); uneven counts are padded with copies of the rank's first window so that
+        both exchanges are plain equal-size all-gathers.  Returns the matched features of this rank's windows."""
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        n, d, t = source_local.shape
+        counts = [n] * world if counts is None else list(counts)
+        if counts[rank] != n:
+            raise ValueError(f"rank {rank} holds {n} windows, counts say {counts[rank]}")
+        n_max = max(counts)
+        if n_max == 0:
+            return (source_local, torch.empty(0, k, dtype=torch.int32, device=source_local.device)) if kw.get("return_indices") else source_local
+        if min(counts) == 0:
+            raise ValueError("every rank needs at least one window (pad the batch or use fewer ranks)")
+        mine = source_local.contiguous()
+        if n < n_max:
+            mine = torch.cat([mine, mine[:1].expand(n_max - n, -1, -1)], 0)
+        frames = allgather_rows(mine, self.group)                           # (a) [world * n_max, 768, T]
+        val, idx = self.search(frames, k)                                   # this slab's exact top-k of EVERY frame
+        gv, gi = allgather_candidates(val, idx, self.group)                 # (b) [S, world * n_max * T, k]
+        lo = rank * n_max * t
+        gv, gi = gv[:, lo:lo + n * t].contiguous(), gi[:, lo:lo + n * t].contiguous()
+        self.last_exchange_bytes = {"frames_allgather_received": int((world - 1) * n_max * d * t * 4),
+                                    "lists_allgather_received": int((world - 1) * world * n_max * t * k * 8)}
+        return self.merge(gv, gi, world, k, alpha, source_local, **kw)
 
 
-def make_hip_sharded_library(tokens_DxM, rank, world, group=None):
+def make_hip_sharded_library(tokens_DxM, rank, world, group=None, prefilter=None):
     """HIP instantiation: this rank packs only its slab for scoring and keeps the full fp32 row table
     (3 GB at 1 M vectors: trivial in 288 GB) for the final gather."""
     from .common import PackedLibrary, merge_gather
     M = tokens_DxM.shape[1]
     b, e = shard_bounds(M, world)[rank]
-    shard = PackedLibrary(tokens_DxM[:, b:e].contiguous(), idx_base=b)
+    shard = PackedLibrary(tokens_DxM[:, b:e].contiguous(), idx_base=b, prefilter=prefilter)
     rows_full = tokens_DxM.t().contiguous()
 
-    def merge(gv, gi, S, k, alpha, source):
-        return merge_gather(gv, gi, S, k, alpha, rows_full, source)
-    return ShardedLibrary(shard.search, merge, group)
+    def merge(gv, gi, S, k, alpha, source, return_indices=False):
+        return merge_gather(gv, gi, S, k, alpha, rows_full, source, return_indices)
+    sl = ShardedLibrary(shard.search, merge, group)
+    sl.shard, sl.rows_full = shard, rows_full
+    return sl
 
 
-def bench_sharded_knn(conv, windows, M, k, world, rank, dev, steps=3):
-    """times content features -> sharded match (search + all-gather + merge) for one window batch."""
-    g = torch.Generator(device=dev).manual_seed(1234)
-    tokens = torch.randn(768, M, device=dev, generator=g)
-    lib = make_hip_sharded_library(tokens, rank, world)
-    del tokens
-    feat, _ = conv.features(windows)
-    lib.match(feat, k)
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+class ShardedConverter(Converter):
+    """BASELINE config 4 end to end: encoders data-parallel over this rank's windows -> feature all-gather -> every rank
+    scores all frames against its library slab -> list all-gather -> merge + gather for its own frames -> decoder
+    data-parallel.  Results equal the replicated-library `Converter` on the same windows."""
+
+    def set_sharded_library(self, sharded: ShardedLibrary, counts=None):
+        self.sharded, self.counts = sharded, counts
+        return self
+
+    def match(self, feat, k=4, alpha=0.0):
+        return self.sharded.match_distributed(feat, k, alpha, self.counts)
+
+
+def _fence(dev):
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+
+
+def _max_over_ranks(x, dev):
+    t = torch.tensor([x], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()
+
+
+def _all_true(flag, dev):
+    t = torch.tensor([1.0 if flag else 0.0], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
+
+
+def bench_sharded(conv, tokens_DxM, windows_global, k, world, rank, dev, window_batch, steps=2):
+    """BASELINE config 4 on the SAME global window batch on every rank (strong scaling of one fixed batch): rank r owns a
+    contiguous block of the windows and 1/world of the library rows.  Checks, on the device and on every rank, that (i) the
+    merged top-k lists of the rank's frames equal the unsharded search of the whole library bitwise and (ii) the waveforms
+    of the end-to-end sharded conversion equal those of the replicated-library conversion bitwise; then times the
+    end-to-end sharded step (max over ranks) and the match stage alone."""
+    from .common import merge_gather
+    n_total = windows_global.shape[0]
+    counts = [e - b for b, e in shard_bounds(n_total, world)]
+    own = windows_global[partition_windows(n_total, world, rank)].contiguous()
+    sl = make_hip_sharded_library(tokens_DxM, rank, world)
+    sconv = ShardedConverter(conv.ce, conv.pe, conv.dec, dev).set_sharded_library(sl, counts)
+
+    # (i) lists: sharded merge vs unsharded search, own frames (first window batch is enough to cover every code path once
+    # per rank; every rank checks different frames)
+    feat, _ = conv.features(own[:window_batch])
+    cnt_b = [min(c, window_batch) for c in counts]
+    out_s, idx_s = sl.match_distributed(feat, k, 0.0, cnt_b, return_indices=True)
+    v1, i1 = conv.library.search(feat, k)
+    out_u, idx_u = merge_gather(v1, i1, 1, k, 0.0, conv.library.rows, feat, return_indices=True)
+    lists_equal = _all_true(torch.equal(idx_s, idx_u) and torch.equal(out_s, out_u), dev)
+    del feat, out_s, idx_s, v1, i1, out_u, idx_u
+
+    # (ii) end to end
+    ref = conv.convert_windows(own, k=k, window_batch=window_batch)
+    got = sconv.convert_windows(own, k=k, window_batch=window_batch)      # also the warm-up of the timed loop
+    waves_equal = _all_true(torch.equal(ref, got), dev)
+    del ref, got
+
+    _fence(dev)
     t0 = time.perf_counter()
     for _ in range(steps):
-        lib.match(feat, k)
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    tt = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    frames = feat.shape[0] * feat.shape[2]
-    return {"frames": frames, "ms": round(tt.item() * 1e3, 3), "frames_per_s": round(frames / tt.item(), 1),
-            "shards": world, "rows_per_shard": M // world, "exchange": "all_gather [S,Tt,k] fp32+int32"}
+        sconv.convert_windows(own, k=k, window_batch=window_batch)
+    _fence(dev)
+    dt = _max_over_ranks((time.perf_counter() - t0) / steps, dev)
+
+    feat, _ = conv.features(own)
+    sl.match_distributed(feat, k, 0.0, counts)
+    _fence(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sl.match_distributed(feat, k, 0.0, counts)
+    _fence(dev)
+    dm = _max_over_ranks((time.perf_counter() - t0) / steps, dev)
+
+    lf = windows_global.shape[1] // 320
+    M = tokens_DxM.shape[1]
+    return {"equals_unsharded": bool(lists_equal and waves_equal), "lists_equal_unsharded": lists_equal,
+            "waveforms_equal_replicated": waves_equal,
+            "ms_per_step": round(dt * 1e3, 3), "frames_per_s": round(n_total * lf / dt, 1),
+            "match_ms": round(dm * 1e3, 3), "match_scoring_tflops_aggregate": round(2.0 * 768 * M * n_total * lf / dm / 1e12, 1),
+            "global_windows": n_total, "global_frames": n_total * lf, "windows_per_rank": counts,
+            "shards": world, "rows_per_shard": [e - b for b, e in shard_bounds(M, world)],
+            "scaling": "strong (one fixed global batch; never part of `value`)",
+            "exchange": "all_gather frames [n,768,T] fp32 + all_gather lists [Tt,k] fp32+int32",
+            "exchange_bytes_received_per_rank": sl.last_exchange_bytes, "backend": dist.get_backend()}

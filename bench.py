@@ -7,16 +7,21 @@ content encoder -> kNN match against an M-vector voice library -> decoder -> wav
 Default workload = BASELINE.json config 3/4 on one GPU: 64 utterances x 10 s (384 windows,
 172 800 content frames per step) against a 1 M-vector library.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): windows are independent units, so
-ranks are pure data-parallel replicas over disjoint utterance sets ("weak" scaling, no data-path
-collective); `--shard-library` additionally times the library-sharded kNN (per-shard exact top-k,
-RCCL all-gather, merge) that the north star names as the optional mode.
+N > 1: `python bench.py --gpus N` launches its own N ranks (torch.distributed.run, one process per GPU,
+before this process has touched a GPU) unless it already runs under a launcher (RANK in the
+environment).  Windows are independent units, so the headline ranks are pure data-parallel replicas over
+disjoint utterance sets ("weak" scaling, no data-path collective).  BASELINE config 4 -- the library cut
+into N row slabs, features all-gathered, per-shard exact top-k all-gathered and merged -- runs as a
+second leg on one fixed global batch, is checked bitwise against the replicated path on every rank and
+is reported as `sharded_knn`, never as `value`.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Secondary legs (`--legs`) sit beside the headline in the same line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,24 +34,64 @@ import torch.distributed as dist                           # noqa: E402
 FRAME = 320
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_FP8_TFLOPS = 5000.0           # dense fp8 MFMA peak (block-scaled 32x32x64 e4m3), same table
+ALL_LEGS = ("uncorrelated", "bf16_prefilter", "clustered_library", "context_trim", "pcie_inclusive", "e2e_24k", "config2",
+            "streaming", "cpu_baseline")
 
 
-def synth_windows(n_utt, seconds, chunk, device, seed):
-    """n_utt synthetic utterances (noise + a few partials, peak-normalised like inference.py:92) -> all windows."""
-    from module.pipeline import make_windows
+# --------------------------------------------------------------------------------------- launch
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (one process per GPU) and pass rank 0's
+    JSON line through.  Nothing in this process has initialised a GPU (torch.cuda.device_count() does not), and the
+    children are separate processes, not an exec of this one."""
+    have = torch.cuda.device_count()
+    if not args.same_device and have < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but this node shows {have} GPU(s)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# --------------------------------------------------------------------------------------- inputs
+def synth_signals(n, L, device, seed, f_lo=90.0, f_step=7.0, f_list=None):
+    """n independent synthetic signals [n, L] at 16 kHz: noise + three partials, peak-normalised like inference.py:92"""
     g = torch.Generator(device=device).manual_seed(seed)
-    L = int(seconds * 16000)
     t = torch.arange(L, device=device, dtype=torch.float32) / 16000.0
-    wins = []
-    for u in range(n_utt):
-        f = 90.0 + 7.0 * u
+    out = torch.empty(n, L, device=device)
+    for u in range(n):
+        f = f_list[u] if f_list is not None else f_lo + f_step * u
         x = 0.1 * torch.randn(L, device=device, generator=g)
         for h in (1, 2, 3):
             x = x + 0.2 / h * torch.sin(2 * torch.pi * f * h * t)
-        x = (x / x.abs().max()).view(1, L)
-        w, _ = make_windows(x, chunk)
-        wins.append(w)
-    return torch.cat(wins, 0).contiguous()
+        out[u] = x / x.abs().max()
+    return out
+
+
+def synth_windows(n_utt, seconds, chunk, device, seed):
+    """n_utt synthetic utterances -> all of their overlapping windows (inference.py:94-101)."""
+    from module.pipeline import make_windows
+    sig = synth_signals(n_utt, int(seconds * 16000), device, seed)
+    return torch.cat([make_windows(sig[u:u + 1], chunk)[0] for u in range(n_utt)], 0).contiguous()
+
+
+def ce_derived_tokens(conv, M, device, seed=4321, L=144000):
+    """A DENSE library: M content-encoder frames of synthetic audio from the same signal family as the bench batch
+    ("also run kNN with CE-derived vectors") -- the frames of a query then have many library rows at
+    nearly the same cosine, which is what a real single-speaker library looks like to the candidate stage."""
+    from module.spectrogram import spectrogram
+    lf = L // FRAME
+    n = (M + lf - 1) // lf
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    freqs = (80.0 + 420.0 * torch.rand(n, generator=g)).tolist()
+    toks = torch.empty(768, n * lf, device=device)
+    for i in range(0, n, 128):
+        sig = synth_signals(min(128, n - i), L, device, seed + 1 + i, f_list=freqs[i:i + 128])
+        feat = conv.ce(spectrogram(sig))                                         # [b, 768, lf]
+        toks[:, i * lf:(i + sig.shape[0]) * lf] = feat.permute(1, 0, 2).reshape(768, -1)
+    return toks[:, :M].contiguous()
 
 
 def usable_cores():
@@ -90,6 +135,55 @@ def cpu_baseline(windows, rows_dev, args):
                       f"library, PyTorch-CPU oracle, {cores} threads, {t_total:.1f} s"}
 
 
+class ScoreTimer:
+    """per-launch HIP-event timing of the dominant kernel (the MFMA candidate scoring) on the stream it is launched on"""
+
+    def __init__(self, nat):
+        self.nat, self.pairs = nat, []
+
+    def wrap(self, library):
+        orig = library.search
+
+        def timed(src, k):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); b.record()                               # materialise the handles
+            self.nat.lib().alive_knn_set_timing_events(a.cuda_event, b.cuda_event)
+            self.pairs.append((a, b, src.shape[0] * src.shape[2], library.M))
+            try:
+                return orig(src, k)
+            finally:
+                self.nat.lib().alive_knn_set_timing_events(None, None)
+        library.search = timed
+        return orig
+
+    @staticmethod
+    def unwrap(library):
+        library.__dict__.pop("search", None)
+
+    def totals(self):
+        """(ms, flop, launches) of everything recorded since the last clear (call after a synchronize)"""
+        ms = sum(a.elapsed_time(b) for a, b, _, _ in self.pairs)
+        flop = sum(2.0 * 768 * m * t for _, _, t, m in self.pairs)
+        return ms, flop, len(self.pairs)
+
+
+def guarded(fn):
+    """a secondary leg must never cost the headline line"""
+    try:
+        return fn()
+    except Exception as e:                                    # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+def timed_steps(fn, reps):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps, r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,18 +196,22 @@ def main():
     ap.add_argument("-k", type=int, default=4)
     ap.add_argument("--window-batch", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-oracle leg (0 = skip)")
-    ap.add_argument("--shard-library", action="store_true", help="(default when --gpus > 1) also time the library-sharded kNN + all-gather")
-    ap.add_argument("--no-shard-library", action="store_true", help="skip the library-sharded kNN leg of a multi-GPU run")
+    ap.add_argument("--legs", default="all", help="comma list of secondary legs (N = 1): " + ",".join(ALL_LEGS) + " | all | none")
+    ap.add_argument("--stream-steps", type=int, default=1000, help="steps of the streaming leg (BASELINE config 5)")
+    ap.add_argument("--no-shard-library", action="store_true", help="skip the library-sharded leg (config 4) of a multi-GPU run")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real thing); gloo + --same-device only exercise the multi-rank code path on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true", help="test only: every rank uses cuda:0")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args))
+
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", 0 if args.same_device else local)
     torch.cuda.set_device(dev)
     if world > 1:
@@ -121,6 +219,11 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+    legs = set(ALL_LEGS) if args.legs == "all" else set(x for x in args.legs.split(",") if x and x != "none")
+    if args.cpu_seconds <= 0:
+        legs.discard("cpu_baseline")
+    if rank != 0 or world > 1:
+        legs = set()
 
     from module import _native as nat
     from module.common import PackedLibrary
@@ -135,27 +238,16 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234)         # same library on every rank
     tokens = torch.randn(768, M, device=dev, generator=g)
     library = PackedLibrary(tokens)
-    del tokens
+    if world == 1 or args.no_shard_library:
+        del tokens
     conv = Converter(ContentEncoder(seed=2), F0Estimator(seed=2), Decoder(seed=2), dev).set_library(library)
     windows = synth_windows(args.utterances, args.seconds, args.chunk, dev, seed=100 + rank)
     n_win, L = windows.shape
     frames_per_step = n_win * (L // FRAME)
     useful_frames = args.utterances * int(args.seconds * 16000) // FRAME
 
-    # ---- per-launch timing of the dominant kernel (the MFMA candidate scoring) with events on its stream ----
-    ev_pairs = []
-    orig_search = library.search
-
-    def timed_search(src, k):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); b.record()                               # materialise the handles
-        nat.lib().alive_knn_set_timing_events(a.cuda_event, b.cuda_event)
-        ev_pairs.append((a, b, src.shape[0] * src.shape[2]))
-        try:
-            return orig_search(src, k)
-        finally:
-            nat.lib().alive_knn_set_timing_events(None, None)
-    library.search = timed_search
+    timer = ScoreTimer(nat)
+    timer.wrap(library)
 
     def step():
         return conv.convert_windows(windows, k=args.k, window_batch=args.window_batch)
@@ -168,7 +260,7 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
-    ev_pairs.clear()
+    timer.pairs.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -180,13 +272,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     assert torch.isfinite(out).all(), "non-finite waveform"
-    researched = library.fallback_frames() if library.prefilter == "fp8" else None     # of the last timed step's search
+    stats = library.search_stats()                            # of the last timed step's search
 
     # ---- roofline of the scoring kernel ----
-    flops, ms = 0.0, 0.0
-    for a, b, tt_frames in ev_pairs:
-        ms += a.elapsed_time(b)
-        flops += 2.0 * 768 * M * tt_frames
+    ms, flops, launches = timer.totals()
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     traffic = None
     fp8 = library.prefilter == "fp8"
@@ -197,82 +286,198 @@ def main():
     roofline = {"kernel": "knn_score8_kernel" if fp8 else "knn_score_kernel", "bound": "mfma", "achieved": round(achieved, 1),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "mfma_dtype": "fp8 e4m3, block-scaled 32x32x64" if fp8 else "bf16 32x32x16",
-                "launches": len(ev_pairs), "avg_launch_ms": round(ms / max(1, len(ev_pairs)), 3),
-                "kernel_share_of_step": round(ms * 1e-3 / dt, 3)}
+                "launches": launches, "avg_launch_ms": round(ms / max(1, launches), 3),
+                "kernel_share_of_step": round(ms * 1e-3 / dt, 3), "search_tiers_last_step": stats}
 
+    extra = {}
     # Data dependence of the scoring kernel: the candidate-list path is taken more often when the frames of a wave
     # are uncorrelated.  The batch above comes from one synthetic signal family (correlated frames); time the same
     # kernel once on i.i.d. Gaussian frames so both ends are on record (real speech lies in between).
-    ev_pairs.clear()
-    rnd = torch.randn(n_win, 768, L // FRAME, device=dev, generator=torch.Generator(device=dev).manual_seed(77 + rank))
-    library.search(rnd, args.k)
-    torch.cuda.synchronize()
-    a, b, tt_frames = ev_pairs[-1]
-    roofline["achieved_uncorrelated_frames"] = round(2.0 * 768 * M * tt_frames / (a.elapsed_time(b) * 1e-3) / 1e12, 1)
-    del rnd
-    if fp8:            # frames of the last timed batch whose fp8 candidate set was not certified and went through the bf16 stage
-        roofline["frames_researched_on_bf16"] = {"timed_batch": researched, "uncorrelated_batch": library.fallback_frames(),
-                                                 "of": frames_per_step}
+    if "uncorrelated" in legs:
+        def leg():
+            timer.pairs.clear()
+            rnd = torch.randn(n_win, 768, L // FRAME, device=dev, generator=torch.Generator(device=dev).manual_seed(77))
+            library.search(rnd, args.k)
+            torch.cuda.synchronize()
+            ms_u, fl_u, _ = timer.totals()
+            roofline["achieved_uncorrelated_frames"] = round(fl_u / (ms_u * 1e-3) / 1e12, 1)
+            roofline["search_tiers_uncorrelated"] = library.search_stats()
+            return None
+        err = guarded(leg)
+        if err:
+            roofline["uncorrelated_error"] = err
+    timer.unwrap(library)
+
+    # The same step with the bf16 candidate stage (ALIVE_KNN_PREFILTER=bf16): same library object, fp8 image unused
+    if "bf16_prefilter" in legs:
+        def leg():
+            lib16 = library.with_prefilter("bf16")
+            t16 = ScoreTimer(nat)
+            t16.wrap(lib16)
+            conv.set_library(lib16)
+            try:
+                conv.convert_windows(windows, k=args.k, window_batch=args.window_batch)
+                t16.pairs.clear()
+                tb, o16 = timed_steps(step, 2)
+                ms16, fl16, n16 = t16.totals()
+                return {"ms_per_step": round(tb * 1e3, 2), "frames_per_s": round(frames_per_step / tb, 1),
+                        "scoring_tflops": round(fl16 / (ms16 * 1e-3) / 1e12, 1), "scoring_ms_per_launch": round(ms16 / n16, 3),
+                        "frac_of_bf16_peak": round(fl16 / (ms16 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                        "waveforms_equal_default_stage": bool(torch.equal(o16, out)), "search_tiers": lib16.search_stats()}
+            finally:
+                conv.set_library(library)
+        extra["bf16_prefilter"] = guarded(leg)
+
+    # A dense, CE-derived 1 M-vector library (every query frame has many rows at nearly its best cosine): the case in
+    # which a candidate stage on fp8 cannot be certified and the search has to fall through its tiers.
+    if "clustered_library" in legs:
+        def leg():
+            toks = ce_derived_tokens(conv, M, dev)
+            res = {}
+            outs = {}
+            for pf in ("fp8", "bf16"):
+                libc = PackedLibrary(toks, prefilter=pf)
+                tc = ScoreTimer(nat)
+                tc.wrap(libc)
+                conv.set_library(libc)
+                conv.convert_windows(windows, k=args.k, window_batch=args.window_batch)
+                tc.pairs.clear()
+                tb, outs[pf] = timed_steps(step, 2)
+                msc, flc, nc = tc.totals()
+                res[pf] = {"ms_per_step": round(tb * 1e3, 2), "frames_per_s": round(frames_per_step / tb, 1),
+                           "first_stage_scoring_tflops": round(flc / (msc * 1e-3) / 1e12, 1),
+                           "search_tiers": libc.search_stats()}
+                del libc
+            res["default_vs_bf16_prefilter"] = round(res["fp8"]["ms_per_step"] / res["bf16"]["ms_per_step"], 4)
+            res["waveforms_equal_across_stages"] = bool(torch.equal(outs["fp8"], outs["bf16"]))
+            res["library"] = f"{M} content-encoder frames of synthetic audio of the bench batch's signal family (dense: SURVEY 8(d))"
+            return res
+        try:
+            extra["clustered_library"] = guarded(leg)
+        finally:
+            conv.set_library(library)
 
     # Optional mode of the build, reported beside the headline and never as `value`: inference.py keeps the centre third of
     # every window, so only the frames that can reach it through the decoder need the kNN match (Converter(keep_frames=...),
-    # `--trim-context`).  The kept samples are bitwise those of the full computation (checked here on the whole batch: kept_samples_bitwise_equal).
-    trim = None
-    if rank == 0 and world == 1:
-        try:                                                  # a failure here must not cost the headline line
-            library.search = orig_search
+    # `--trim-context`).  The kept samples are bitwise those of the full computation (checked here on the whole batch).
+    if "context_trim" in legs:
+        def leg():
             cf = (L // FRAME) // 3
             ref_out = out[:, cf * FRAME:2 * cf * FRAME].clone()
-            conv.convert_windows(windows, k=args.k, window_batch=args.window_batch, keep_frames=(cf, 2 * cf))    # warm-up (scratch sizes)
-            torch.cuda.synchronize()
-            tt0 = time.perf_counter()
-            for _ in range(2):
-                out_t = conv.convert_windows(windows, k=args.k, window_batch=args.window_batch, keep_frames=(cf, 2 * cf))
-            torch.cuda.synchronize()
-            tt0 = (time.perf_counter() - tt0) / 2
+            trim_step = lambda: conv.convert_windows(windows, k=args.k, window_batch=args.window_batch, keep_frames=(cf, 2 * cf))  # noqa: E731
+            trim_step()                                           # warm-up (scratch sizes)
+            tt0, out_t = timed_steps(trim_step, 2)
             same = bool(torch.equal(out_t[:, cf * FRAME:2 * cf * FRAME], ref_out))
-            trim = {"ms_per_step": round(tt0 * 1e3, 2), "windows_per_s": round(n_win / tt0, 1),
+            return {"ms_per_step": round(tt0 * 1e3, 2), "windows_per_s": round(n_win / tt0, 1),
                     "useful_frames_per_s": round(useful_frames / tt0, 1), "kept_samples_bitwise_equal": same,
                     "note": "kNN match and decoder on frames [cf-32, 2cf+16) of each window (oscillator phase over the whole window), content encoder on that range +-16; spectrogram and f0 estimator on the whole window"}
-            del out_t, ref_out
-        except Exception as e:
-            trim = {"error": f"{type(e).__name__}: {e}"[:300]}
+        extra["context_trim"] = guarded(leg)
 
     # PCIe-inclusive rate (never `value`): the same step with the windows arriving from pinned host memory and the
     # waveforms returned to it, as the CLI edge does (inference.py:88-94,134)
-    pcie = None
-    if rank == 0 and world == 1:
-        try:
-            library.search = orig_search
+    if "pcie_inclusive" in legs:
+        def leg():
             host_in = windows.cpu().pin_memory()
             host_out = torch.empty_like(host_in).pin_memory()
-            torch.cuda.synchronize()
-            tp = time.perf_counter()
-            for _ in range(2):
+
+            def s():
                 wdev = host_in.to(dev, non_blocking=True)
                 host_out.copy_(conv.convert_windows(wdev, k=args.k, window_batch=args.window_batch), non_blocking=True)
-            torch.cuda.synchronize()
-            tp = (time.perf_counter() - tp) / 2
-            pcie = {"value": round(frames_per_step / tp, 1), "unit": "frames/s", "ms_per_step": round(tp * 1e3, 2),
+            tp, _ = timed_steps(s, 2)
+            return {"value": round(frames_per_step / tp, 1), "unit": "frames/s", "ms_per_step": round(tp * 1e3, 2),
                     "bytes_per_step": int(2 * host_in.numel() * 4)}
-            del host_in, host_out, wdev
-        except Exception as e:
-            pcie = {"error": f"{type(e).__name__}: {e}"[:300]}
+        extra["pcie_inclusive"] = guarded(leg)
+
+    # The metric says "@24 kHz": 24 kHz utterances in pinned host memory -> device -> resample to 16 kHz -> peak
+    # normalise -> windows -> the step -> centre thirds stitched -> resample to 24 kHz -> host (inference.py:86-142
+    # without the file I/O).  Never `value`.
+    if "e2e_24k" in legs:
+        def leg():
+            from module import audio_io
+            from module.pipeline import make_windows, stitch
+            sr = 24000
+            sig16 = synth_signals(args.utterances, int(args.seconds * 16000), dev, seed=100)
+            host_in = audio_io.resample(sig16, 16000, sr).cpu().pin_memory()          # [U, seconds * 24000]
+            host_out = torch.empty_like(host_in).pin_memory()
+
+            def s():
+                wf = audio_io.resample(host_in.to(dev, non_blocking=True), sr, 16000)
+                wf = wf / wf.abs().amax(dim=1, keepdim=True)
+                wins, total = [], 0
+                for u in range(wf.shape[0]):
+                    w, total = make_windows(wf[u:u + 1], args.chunk)
+                    wins.append(w)
+                per = wins[0].shape[0]
+                o = conv.convert_windows(torch.cat(wins, 0), k=args.k, window_batch=args.window_batch)
+                utt = torch.cat([stitch(o[u * per:(u + 1) * per], total, args.chunk) for u in range(wf.shape[0])], 0)
+                host_out.copy_(audio_io.resample(utt, 16000, sr)[:, :host_out.shape[1]], non_blocking=True)
+            s()
+            te, _ = timed_steps(s, 2)
+            audio_s = args.utterances * args.seconds
+            return {"ms_per_step": round(te * 1e3, 2), "frames_per_s": round(frames_per_step / te, 1),
+                    "useful_frames_per_s": round(useful_frames / te, 1), "rtf": round(te / audio_s, 6),
+                    "finite": bool(torch.isfinite(host_out).all()),
+                    "path": "24 kHz pinned host -> H2D -> resample 24k->16k -> normalise -> windows -> step -> stitch -> resample 16k->24k -> D2H"}
+        extra["e2e_24k"] = guarded(leg)
+
+    small_tokens = None
+    if "config2" in legs or "streaming" in legs:
+        small_tokens = torch.randn(1, 768, 50_000, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+
+    # BASELINE config 2: one 10 s utterance at a time (batch 1) against a ~50 k-vector single-speaker library: latency
+    if "config2" in legs:
+        def leg():
+            c2 = Converter(conv.ce, conv.pe, conv.dec, dev).set_library(small_tokens)
+            wf = synth_signals(1, 160000, dev, seed=5)
+            lat = []
+            for i in range(12):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                o = c2.convert(wf, chunk=args.chunk, k=args.k, window_batch=args.window_batch)
+                torch.cuda.synchronize()
+                lat.append((time.perf_counter() - t1) * 1e3)
+            lat = sorted(lat[2:])
+            return {"ms_per_utterance_p50": round(lat[len(lat) // 2], 3), "ms_per_utterance_max": round(lat[-1], 3),
+                    "rtf": round(lat[len(lat) // 2] * 1e-3 / 10.0, 6), "finite": bool(torch.isfinite(o).all()),
+                    "workload": "one 10 s utterance (6 windows = 2700 frames), 50 000-vector library, batch 1"}
+        extra["config2"] = guarded(leg)
+
+    # BASELINE config 5: streaming, 10 ms chunks (-c 160 -b 16: 8-frame ring), per-step device pipeline in one hipGraph
+    if "streaming" in legs:
+        def leg():
+            import numpy as np
+            from module.realtime import RealtimeConverter
+            chunk, bs, steps = 160, 16, args.stream_steps
+            rt = RealtimeConverter(conv.ce, conv.pe, conv.dec, small_tokens, dev, chunk=chunk, buffersize=bs).enable_graph()
+            pcm = (np.random.default_rng(0).standard_normal(chunk * (steps + bs + 60)) * 3000).astype(np.int16)
+            lat = []
+            for s_ in range(steps + bs + 50):
+                t1 = time.perf_counter()
+                o = rt.step(pcm[s_ * chunk:(s_ + 1) * chunk])       # includes H2D of the ring and D2H of the result
+                d = time.perf_counter() - t1
+                if o is not None and s_ >= bs + 50:
+                    lat.append(d * 1e3)
+            lat = np.array(lat)
+            return {"p50_ms": round(float(np.percentile(lat, 50)), 3), "p99_ms": round(float(np.percentile(lat, 99)), 3),
+                    "mean_ms": round(float(lat.mean()), 3), "rtf": round(float(np.percentile(lat, 50)) / (chunk / 16.0), 4),
+                    "steps": int(lat.size), "hipgraph": True,
+                    "workload": f"int16 chunks of {chunk} samples (10 ms), ring of {bs} chunks = {chunk * bs // FRAME} frames, 50 000-vector library, host in / host out per step"}
+        extra["streaming"] = guarded(leg)
+    del small_tokens
 
     sharded = None
     if world > 1 and not args.no_shard_library:
-        # BASELINE config 4 (never part of `value`): the library cut into `world` row slabs, every rank scores one window
-        # batch against its slab, exact per-shard top-k merged after one all-gather over RCCL
-        from module.sharded import bench_sharded_knn
-        library.search = orig_search
-        try:
-            sharded = bench_sharded_knn(conv, windows[: args.window_batch], M, args.k, world, rank, dev)
-        except Exception as e:                                # keep the headline line even if this leg fails
-            sharded = {"error": f"{type(e).__name__}: {e}"[:300]}
+        # BASELINE config 4 (never part of `value`): one fixed global batch (same seed on every rank), windows partitioned
+        # over the ranks, the library cut into `world` row slabs -- checked bitwise against the replicated path
+        from module.sharded import bench_sharded
+
+        def leg():
+            wg = synth_windows(args.utterances, args.seconds, args.chunk, dev, seed=100)
+            return bench_sharded(conv, tokens, wg, args.k, world, rank, dev, args.window_batch)
+        sharded = guarded(leg)
 
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        library.search = orig_search
+    if "cpu_baseline" in legs:
         cpu = cpu_baseline(windows, library.rows, args)
 
     if rank == 0:
@@ -297,13 +502,16 @@ def main():
             "rtf": round((dt / args.steps) / audio_s, 6),
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "pcie_inclusive": pcie,
-            "context_trim": trim,
         }
+        if world > 1:
+            line["ranks"] = {"backend": dist.get_backend(), "rccl_ranks" if args.backend == "nccl" else "gloo_ranks": dist.get_world_size(),
+                             "same_device": bool(args.same_device)}
+        line.update(extra)
         if sharded is not None:
             line["sharded_knn"] = sharded
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

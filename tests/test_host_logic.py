@@ -150,14 +150,15 @@ def _cpu_search_factory(lib_DxM, begin, end):
 
 
 def _cpu_merge_factory(lib_DxM):
-    def merge(gv, gi, S, k, alpha, source):
+    def merge(gv, gi, S, k, alpha, source, return_indices=False):
         n, d, t = source.shape
         v = gv.permute(1, 0, 2).reshape(n * t, S * k)
         i = gi.permute(1, 0, 2).reshape(n * t, S * k).long()
         best = torch.topk(v, k, dim=1).indices
         sel = torch.gather(i, 1, best)                                    # [Tt, k]
         picked = lib_DxM.t()[sel].mean(dim=1).view(n, t, d).transpose(1, 2)
-        return picked * (1 - alpha) + source * alpha
+        out = picked * (1 - alpha) + source * alpha
+        return (out, sel) if return_indices else out
     return merge
 
 
@@ -176,7 +177,21 @@ def _worker(rank, world, port, q):
         parts = [None] * world
         dist.all_gather_object(parts, out[mine])
         whole = torch.cat(parts, 0)
-        q.put((rank, float((out - ref).abs().max()), float((whole - ref).abs().max())))
+        # BASELINE config 4 end to end: frames are data-parallel too (uneven window counts: 3 + 2), so the protocol
+        # all-gathers the features first, every rank searches ALL frames in its slab, and merges only its own
+        src5 = synthetic.gaussian("sh.src5", 33, (5, 768, 9))
+        counts = [e_ - b_ for b_, e_ in shard_bounds(5, world)]
+        own = src5[partition_windows(5, world, rank)]
+        got, gidx = sl.match_distributed(own, k=3, alpha=0.1, counts=counts, return_indices=True)
+        ref5, ridx5, _ = O.match_features(src5, lib.unsqueeze(0).expand(5, -1, -1), 3, 0.1, return_indices=True)
+        want = ref5[partition_windows(5, world, rank)]
+        widx = ridx5[partition_windows(5, world, rank)].reshape(-1, 3)
+        e3 = float((got - want).abs().max())
+        same_idx = bool((torch.sort(gidx, 1).values == torch.sort(widx, 1).values).all())
+        xb = sl.last_exchange_bytes
+        ok_bytes = xb["frames_allgather_received"] == (world - 1) * 3 * 768 * 9 * 4 and \
+            xb["lists_allgather_received"] == (world - 1) * world * 3 * 9 * 3 * 8
+        q.put((rank, float((out - ref).abs().max()), float((whole - ref).abs().max()), e3, same_idx and ok_bytes))
     finally:
         dist.destroy_process_group()
 
@@ -192,5 +207,5 @@ def test_sharded_knn_protocol_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, e1, e2 in res:
-        assert e1 < 1e-5 and e2 < 1e-5, res
+    for rank, e1, e2, e3, ok in res:
+        assert e1 < 1e-5 and e2 < 1e-5 and e3 < 1e-5 and ok, res
