@@ -300,7 +300,9 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
             modulate_store(Fc, dst, ct * 16 + c16, v);
             // The fence is load-bearing: with the 16 column bodies merged into one scheduling region hipcc (ROCm 7.2) produced a
             // schedule whose results differed from run to run (1.5e-2 off); with one region per column tile they are exact.
+#ifndef ALIVE_NO_TILE_FENCE          // diagnostic build only (tools/stress_filter_block.py): see DESIGN.md 3.2b'
             __builtin_amdgcn_sched_barrier(0);
+#endif
             p0 = n0;
             p1 = n1;
             Fc = Fn;

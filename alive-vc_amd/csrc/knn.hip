@@ -220,9 +220,9 @@ __device__ __forceinline__ bool gate_open(const int* cnt, int lo, int hi, int& c
 
 // compacts the bf16 operand rows of the flagged frames: out[slot] = s_bf16[list[slot]], zero rows up to the next 256
 __global__ __launch_bounds__(128) void gather_frames_kernel(const unsigned short* __restrict__ s_bf16, const int* __restrict__ list,
-                                                            const int* __restrict__ cnt, int cap, unsigned short* __restrict__ out) {
+                                                            const int* __restrict__ cnt, int lo, int hi, unsigned short* __restrict__ out) {
     int c;
-    if (!gate_open(cnt, 0, cap, c)) return;
+    if (!gate_open(cnt, lo, hi, c)) return;
     const int slot = blockIdx.x;
     if (slot >= (c + 255) / 256 * 256) return;
     if (threadIdx.x >= 96) return;
@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(256) void knn_merge_gather_kernel(const float* __re
 // groups in flight); a last resort, not a fast path.
 constexpr int EX_BLOCKS = 2048;            // launch size (x 4 waves); items are distributed by a wave-stride loop
 constexpr int EX_WAVES_TARGET = 16384;     // row slices per group are chosen so that about this many items exist
-constexpr int EX_NW_MAX = 256, EX_NW_MIN = 4;
+constexpr int EX_NW_MAX = 1024, EX_NW_MIN = 4;
 
 __host__ __device__ inline int exact_group(int k) { return k <= 4 ? 16 : (k <= 8 ? 8 : (k <= 16 ? 4 : (k <= 32 ? 2 : 1))); }
 __host__ __device__ inline int exact_nw(int64_t groups) {
@@ -1032,8 +1032,42 @@ static size_t exact_lists(int64_t frames, int k) {
     return (size_t)(a > b ? a : b) + 4;
 }
 
+// Wave sums of G per-lane partials at once, bitwise equal to G calls of wave_sum (the xor tree 32, 16, 8, 4, 2, 1):
+// in the first log2(G) levels a lane keeps half of its values and hands the other half to its partner (own + partner's,
+// the operands of wave_sum's add at that level), so G values cost G - 1 + (6 - log2 G) shuffles instead of 6 G.
+// Returns the total of frame t = lane / (64 / G) (the 64 / G lanes of that group all hold it).
 template <int G>
-__global__ __launch_bounds__(256) void knn_exact_kernel(const float* __restrict__ s_f32, const float* __restrict__ rows,
+__device__ __forceinline__ float wave_sum_frames(float (&d)[G], int lane) {
+    if constexpr (G >= 16) {
+        const bool up = lane & 32;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = (up ? d[8 + j] : d[j]) + __shfl_xor(up ? d[j] : d[8 + j], 32);
+    }
+    if constexpr (G >= 8) {
+        constexpr int o = G >= 16 ? 16 : 32;
+        const bool up = lane & o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = (up ? d[4 + j] : d[j]) + __shfl_xor(up ? d[j] : d[4 + j], o);
+    }
+    if constexpr (G >= 4) {
+        constexpr int o = G >= 16 ? 8 : (G >= 8 ? 16 : 32);
+        const bool up = lane & o;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) d[j] = (up ? d[2 + j] : d[j]) + __shfl_xor(up ? d[j] : d[2 + j], o);
+    }
+    if constexpr (G >= 2) {
+        constexpr int o = G >= 16 ? 4 : (G >= 8 ? 8 : (G >= 4 ? 16 : 32));
+        const bool up = lane & o;
+        d[0] = (up ? d[1] : d[0]) + __shfl_xor(up ? d[0] : d[1], o);
+    }
+    float v = d[0];
+#pragma unroll
+    for (int o = 32 / G; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int G>
+__global__ __launch_bounds__(256, 2) void knn_exact_kernel(const float* __restrict__ s_f32, const float* __restrict__ rows,
                                                         const float* __restrict__ norms, int64_t M, int64_t Tt, int k,
                                                         const int* __restrict__ frame_list, const int* __restrict__ cnt_ptr,
                                                         float* __restrict__ part_val, int* __restrict__ part_idx) {
@@ -1044,7 +1078,8 @@ __global__ __launch_bounds__(256) void knn_exact_kernel(const float* __restrict_
     const int64_t groups = (count + G - 1) / G;
     const int nw = exact_nw(groups);
     const int64_t items = groups * nw;
-    const int my_t = lane / k;
+    const int my_t = lane / k;                                    // lists: lane = frame * k + slot
+    const int src_lane = (my_t < G ? my_t : G - 1) * (64 / G);    // where wave_sum_frames leaves that frame's total
     for (int64_t item = (int64_t)blockIdx.x * 4 + wv; item < items; item += (int64_t)gridDim.x * 4) {
         const int64_t g = item / nw;
         const int w = (int)(item - g * nw);
@@ -1060,25 +1095,37 @@ __global__ __launch_bounds__(256) void knn_exact_kernel(const float* __restrict_
         const bool live = lane < G * k && g * G + my_t < count;
         float lv = -INFINITY;
         int li = 0x7fffffff;
+        f32x4 q0, q1, q2;
+        float nn = 1.0f;
+        if (w < M) {
+            const f32x4* rp = (const f32x4*)(rows + (size_t)w * D);
+            q0 = rp[lane]; q1 = rp[lane + 64]; q2 = rp[lane + 128];
+            nn = norms[w];
+        }
         for (int64_t r = w; r < M; r += nw) {
-            const f32x4* rp = (const f32x4*)(rows + (size_t)r * D);
-            const float nn = norms[r];
-            f32x4 q0 = rp[lane], q1 = rp[lane + 64], q2 = rp[lane + 128];
+            f32x4 n0 = q0, n1 = q1, n2 = q2;                       // the next row is requested before this one is scored
+            float nnn = nn;                                        // (G = 16: no registers left for it; the SIMD's other wave covers the latency)
+            if (G < 16 && r + nw < M) {
+                const f32x4* rp = (const f32x4*)(rows + (size_t)(r + nw) * D);
+                n0 = rp[lane]; n1 = rp[lane + 64]; n2 = rp[lane + 128];
+                nnn = norms[r + nw];
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) { q0[j] = q0[j] / nn; q1[j] = q1[j] / nn; q2[j] = q2[j] / nn; }
-            float p = -INFINITY;
+            float d[G];
 #pragma unroll
             for (int t = 0; t < G; ++t) {
-                float d = 0.0f;
+                float a = 0.0f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d = fmaf(s0[t][j], q0[j], d);
+                for (int j = 0; j < 4; ++j) a = fmaf(s0[t][j], q0[j], a);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d = fmaf(s1[t][j], q1[j], d);
+                for (int j = 0; j < 4; ++j) a = fmaf(s1[t][j], q1[j], a);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d = fmaf(s2[t][j], q2[j], d);
-                d = wave_sum(d);
-                if (t == my_t) p = d;
+                for (int j = 0; j < 4; ++j) a = fmaf(s2[t][j], q2[j], a);
+                d[t] = a;
             }
+            const float tot = wave_sum_frames<G>(d, lane);
+            const float p = __shfl(tot, src_lane);
             // sorted insert inside the k lanes of this frame: entries that rank before (p, r) stay, the others move down one
             const bool before = lv > p || (lv == p && li < (int)r);
             const float up_v = __shfl_up(lv, 1);
@@ -1087,6 +1134,13 @@ __global__ __launch_bounds__(256) void knn_exact_kernel(const float* __restrict_
             if (live && !before) {
                 lv = up_before ? p : up_v;
                 li = up_before ? (int)r : up_i;
+            }
+            if (G < 16) {
+                q0 = n0; q1 = n1; q2 = n2; nn = nnn;
+            } else if (r + nw < M) {
+                const f32x4* rp = (const f32x4*)(rows + (size_t)(r + nw) * D);
+                q0 = rp[lane]; q1 = rp[lane + 64]; q2 = rp[lane + 128];
+                nn = norms[r + nw];
             }
         }
         part_val[(size_t)item * 64 + lane] = lv;
@@ -1106,17 +1160,28 @@ __global__ __launch_bounds__(256) void knn_exact_merge_kernel(const float* __res
     int64_t count = Tt;
     if (cnt_ptr != nullptr) { const int c = *cnt_ptr; count = c < Tt ? c : Tt; }
     const int64_t groups = (count + G - 1) / G;
-    const int nw = exact_nw(groups);                     // <= 256: one list per thread
+    const int nw = exact_nw(groups);                     // <= 1024: up to four sorted lists per thread
+    constexpr int NL = EX_NW_MAX / 256;
     for (int64_t slot = blockIdx.x; slot < count; slot += gridDim.x) {
         const int64_t g = slot / G;
         const int t = (int)(slot - g * G);
         const int64_t ft = frame_list != nullptr ? frame_list[slot] : slot;
-        const size_t base = ((size_t)g * nw + tid) * 64 + t * k;
-        int head = 0;
+        int head[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) head[i] = 0;
         for (int j = 0; j < k; ++j) {
             float bv = -INFINITY;
-            int bi = 0x7fffffff;
-            if (tid < nw && head < k) { bv = part_val[base + head]; bi = part_idx[base + head]; }
+            int bi = 0x7fffffff, bl = -1;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int w = tid + 256 * i;
+                if (w < nw && head[i] < k) {
+                    const size_t o = ((size_t)g * nw + w) * 64 + t * k + head[i];
+                    const float v = part_val[o];
+                    const int id = part_idx[o];
+                    if (v > bv || (v == bv && id < bi)) { bv = v; bi = id; bl = i; }
+                }
+            }
             sv[tid] = bv; si[tid] = bi; sw[tid] = tid;
             __syncthreads();
             for (int o = 128; o > 0; o >>= 1) {
@@ -1131,7 +1196,11 @@ __global__ __launch_bounds__(256) void knn_exact_merge_kernel(const float* __res
                 out_val[(size_t)ft * k + j] = sv[0];
                 out_idx[(size_t)ft * k + j] = (si[0] == 0x7fffffff || !(sv[0] > -INFINITY)) ? -1 : (int)(idx_base + si[0]);
             }
-            if (sw[0] == tid && tid < nw) head++;
+            if (sw[0] == tid && bl >= 0) {
+#pragma unroll
+                for (int i = 0; i < NL; ++i)
+                    if (i == bl) head[i]++;
+            }
             __syncthreads();
         }
     }
@@ -1361,8 +1430,7 @@ extern "C" size_t alive_knn_workspace_bytes(int64_t Tt, int64_t M) {
 //   tier 2 (more): the split of the whole batch; blocks past the count exit at once.
 // Frames that fail the bf16 certificate land in list1 and go through the exact scan.
 static void bf16_tiers_launch(const SearchWs& w, const void* lib_bf16, const float* rows_f32, const float* norms, int64_t M,
-                              int64_t Tt, int64_t idx_base, int k, float* out_val, int32_t* out_idx, hipStream_t s,
-                              bool time_tier2) {
+                              int64_t Tt, int64_t idx_base, int k, float* out_val, int32_t* out_idx, hipStream_t s) {
     int* cnt0 = w.stats + ST_FLAG8;
     int* cnt1 = w.stats + ST_FLAG16;
     const int fcap = w.fcap;
@@ -1373,11 +1441,9 @@ static void bf16_tiers_launch(const SearchWs& w, const void* lib_bf16, const flo
                                                                  out_val, out_idx, w.list0, cnt0, 0, fcap, w.list1, cnt1, CERT_Z, KH, 1.0f);
     if (w.p16.Tt_pad > fcap) {
         gather_frames_kernel<<<(unsigned)w.p16.Tt_pad, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, fcap, 0x7fffffff, w.s_c);
-        if (time_tier2 && g_ev_start) (void)hipEventRecord(g_ev_start, s);
         knn_score_kernel<<<dim3((unsigned)(w.p16.Tt_pad / FT), w.p16.split), 256, SCORE_LDS, s>>>(
             w.s_c, (const unsigned short*)lib_bf16, M, w.p16.tiles_total, w.p16.tiles_per_split, w.p16.P, w.cv, w.ci, cnt0, fcap,
             0x7fffffff, 1);
-        if (time_tier2 && g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
         knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, w.p16.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                    out_val, out_idx, w.list0, cnt0, fcap, 0x7fffffff, w.list1, cnt1,
                                                                    CERT_Z, KH, 1.0f);
@@ -1463,13 +1529,13 @@ extern "C" int alive_knn_search_fp8(const float* src, int N, int T, const void* 
     if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
     knn_score8_kernel<<<dim3((unsigned)(p.Tt_pad / FT), p.split), 256, SCORE8_LDS, s>>>(
         w.s_f8, (const unsigned char*)lib_f8, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, mode, -1, 0);
+    if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
     knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, p.P, KP8, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                out_val, out_idx, nullptr, mode, -1, 0, w.list0, w.stats + ST_FLAG8,
                                                                CERT_Z, KH8, 1.0f / (F8_SCALE * F8_SCALE));
     // ---- mode 1: bf16 first (every frame into list0) ----
     if (w.probe_n > 0) flag_all_kernel<<<(unsigned)((Tt + 255) / 256), 256, 0, s>>>(w.list0, w.stats + ST_FLAG8, Tt, mode, 0, 1);
-    bf16_tiers_launch(w, lib_bf16, rows_f32, norms, M, Tt, idx_base, k, out_val, out_idx, s, false);
-    if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
+    bf16_tiers_launch(w, lib_bf16, rows_f32, norms, M, Tt, idx_base, k, out_val, out_idx, s);
     ALIVE_CHECK_LAUNCH("alive_knn_search_fp8");
     return ALIVE_OK;
 }

@@ -52,7 +52,7 @@ PROTOTYPES = {
     "alive_library_fp8_bytes": (_SZ, [_I64]),
     "alive_library_pack_fp8": (_I, [_VP, _I64, _VP, _VP]),
     "alive_knn_search_fp8": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP]),
-    "alive_knn_fp8_fallback_count": (_VP, [_I, _I, _I64, _VP]),
+    "alive_knn_search_stats": (_VP, [_I, _I, _I64, _VP]),
     "alive_knn_set_timing_events": (_I, [_VP, _VP]),
     "alive_knn_merge_gather": (_I, [_VP, _VP, _I, _I, _D, _VP, _VP, _I, _I, _VP, _VP, _VP]),
     "alive_conv1d": (_I, [C.POINTER(AliveConv), _VP]),

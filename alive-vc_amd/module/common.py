@@ -70,6 +70,7 @@ class PackedLibrary:
         nat.check(L.alive_knn_search(nat.ptr(source), n, t, nat.ptr(self.lib_bf16), nat.ptr(self.rows),
                                      nat.ptr(self.norms), self.M, self.idx_base, k, nat.ptr(val), nat.ptr(idx),
                                      nat.ptr(ws), nat.stream()), "alive_knn_search")
+        self._last = (n, t, k, ws)
         return val, idx
 
 
@@ -93,20 +94,29 @@ class PackedLibrary:
         return other
 
     def search_stats(self):
-        """what the tiers of the last search did (syncs; tests / bench)"""
-        return {"prefilter": self.prefilter, "frames_researched_on_bf16": self.fallback_frames() if self.lib_f8 is not None else None}
+        """what the tiers of the last search on the current stream did (syncs; tests / bench)"""
+        last = getattr(self, "_last", None)
+        if last is None:
+            return None
+        n, t, k, ws = last
+        torch.cuda.synchronize()
+        st = {"prefilter": self.prefilter}
+        if n * t * k <= 64 and self.M <= 262144:        # the streaming scan: exact, no candidate stage
+            return dict(st, tier="exact scan of every row (streaming)")
+        if k > 8:
+            return dict(st, tier="exact scan of every row (k > 8)")
+        off = nat.lib().alive_knn_search_stats(n, t, self.M, nat.ptr(ws)) - ws.data_ptr()
+        c = ws[off:off + 32].view(torch.int32).tolist()
+        if self.lib_f8 is not None:
+            st.update(frames_researched_on_bf16=c[0], probe_sample=c[2], probe_failed_fp8_certificate=c[3],
+                      probe_chose_bf16_first=bool(c[4]))
+        st.update(frames_searched_exactly=c[1], frames=n * t)
+        return st
 
     def fallback_frames(self):
-        """frames the last fp8 search could not certify and searched again through the bf16 stage (syncs; tests / bench)"""
-        if self.lib_f8 is None or getattr(self, "_last", None) is None:
-            return 0
-        n, t, k, ws = self._last
-        p = nat.lib().alive_knn_fp8_fallback_count(n, t, self.M, nat.ptr(ws))
-        if n * t * k <= 64 and self.M <= 262144:     # the streaming scan has no candidate stage
-            return 0
-        torch.cuda.synchronize()
-        off = (p - ws.data_ptr())
-        return int(ws[off:off + 4].view(torch.int32).item())
+        """frames the last fp8 search sent to the bf16 stage (syncs; tests / bench)"""
+        st = self.search_stats()
+        return 0 if st is None else int(st.get("frames_researched_on_bf16") or 0)
 
 
 def merge_gather(cand_val, cand_idx, n_shards, k, alpha, rows_full, source, return_indices=False):

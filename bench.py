@@ -139,7 +139,7 @@ class ScoreTimer:
     """per-launch HIP-event timing of the dominant kernel (the MFMA candidate scoring) on the stream it is launched on"""
 
     def __init__(self, nat):
-        self.nat, self.pairs = nat, []
+        self.nat, self.pairs, self.whole = nat, [], []      # kernel events; events around the whole tiered search
 
     def wrap(self, library):
         orig = library.search
@@ -149,9 +149,13 @@ class ScoreTimer:
             a.record(); b.record()                               # materialise the handles
             self.nat.lib().alive_knn_set_timing_events(a.cuda_event, b.cuda_event)
             self.pairs.append((a, b, src.shape[0] * src.shape[2], library.M))
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.whole.append((s0, s1))
+            s0.record()
             try:
                 return orig(src, k)
             finally:
+                s1.record()
                 self.nat.lib().alive_knn_set_timing_events(None, None)
         library.search = timed
         return orig
@@ -159,6 +163,14 @@ class ScoreTimer:
     @staticmethod
     def unwrap(library):
         library.__dict__.pop("search", None)
+
+    def clear(self):
+        self.pairs.clear()
+        self.whole.clear()
+
+    def search_ms(self):
+        """whole tiered search (all tiers, rescoring included), per call (after a synchronize)"""
+        return sum(a.elapsed_time(b) for a, b in self.whole) / max(1, len(self.whole))
 
     def totals(self):
         """(ms, flop, launches) of everything recorded since the last clear (call after a synchronize)"""
@@ -260,7 +272,7 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
-    timer.pairs.clear()
+    timer.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -287,7 +299,8 @@ def main():
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "mfma_dtype": "fp8 e4m3, block-scaled 32x32x64" if fp8 else "bf16 32x32x16",
                 "launches": launches, "avg_launch_ms": round(ms / max(1, launches), 3),
-                "kernel_share_of_step": round(ms * 1e-3 / dt, 3), "search_tiers_last_step": stats}
+                "kernel_share_of_step": round(ms * 1e-3 / dt, 3), "search_ms": round(timer.search_ms(), 2),
+                "search_tiers_last_step": stats}
 
     extra = {}
     # Data dependence of the scoring kernel: the candidate-list path is taken more often when the frames of a wave
@@ -295,7 +308,7 @@ def main():
     # kernel once on i.i.d. Gaussian frames so both ends are on record (real speech lies in between).
     if "uncorrelated" in legs:
         def leg():
-            timer.pairs.clear()
+            timer.clear()
             rnd = torch.randn(n_win, 768, L // FRAME, device=dev, generator=torch.Generator(device=dev).manual_seed(77))
             library.search(rnd, args.k)
             torch.cuda.synchronize()
@@ -317,12 +330,13 @@ def main():
             conv.set_library(lib16)
             try:
                 conv.convert_windows(windows, k=args.k, window_batch=args.window_batch)
-                t16.pairs.clear()
+                t16.clear()
                 tb, o16 = timed_steps(step, 2)
                 ms16, fl16, n16 = t16.totals()
                 return {"ms_per_step": round(tb * 1e3, 2), "frames_per_s": round(frames_per_step / tb, 1),
                         "scoring_tflops": round(fl16 / (ms16 * 1e-3) / 1e12, 1), "scoring_ms_per_launch": round(ms16 / n16, 3),
                         "frac_of_bf16_peak": round(fl16 / (ms16 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                        "search_ms": round(t16.search_ms(), 2),
                         "waveforms_equal_default_stage": bool(torch.equal(o16, out)), "search_tiers": lib16.search_stats()}
             finally:
                 conv.set_library(library)
@@ -341,11 +355,12 @@ def main():
                 tc.wrap(libc)
                 conv.set_library(libc)
                 conv.convert_windows(windows, k=args.k, window_batch=args.window_batch)
-                tc.pairs.clear()
+                tc.clear()
                 tb, outs[pf] = timed_steps(step, 2)
                 msc, flc, nc = tc.totals()
                 res[pf] = {"ms_per_step": round(tb * 1e3, 2), "frames_per_s": round(frames_per_step / tb, 1),
-                           "first_stage_scoring_tflops": round(flc / (msc * 1e-3) / 1e12, 1),
+                           "search_ms": round(tc.search_ms(), 2),
+                           "search_effective_tflops": round(flc / nc / (tc.search_ms() * 1e-3) / 1e12, 1),
                            "search_tiers": libc.search_stats()}
                 del libc
             res["default_vs_bf16_prefilter"] = round(res["fp8"]["ms_per_step"] / res["bf16"]["ms_per_step"], 4)

@@ -33,9 +33,10 @@ extern "C" {
 
 #define ALIVE_DIM 768          /* content feature width (voice_library.py:7) */
 #define ALIVE_KPRIME 16        /* candidates kept per frame and library split by the bf16 stage (the fp8 stage keeps 32) */
-#define ALIVE_MAX_K 8          /* largest k accepted by the kNN entry points: the scoring kernel keeps two
-                                * lane-private half-lists of 8 bf16 candidates per frame and library split, and all
-                                * k true neighbours may fall into one of them                                  */
+#define ALIVE_MAX_K 64         /* largest k accepted by the kNN entry points (the reference takes any k <= M, inference.py:34 /
+                                * common.py:105).  k <= 8 runs through the MFMA candidate stages (a half-list of the bf16
+                                * stage is 8 deep, and all k true neighbours may fall into one of them); 8 < k <= 64 runs the
+                                * exact fp32 scan for every frame                                              */
 
 const char* alive_last_error(void);
 int alive_version(void);
@@ -55,10 +56,15 @@ int64_t alive_library_padded_rows(int64_t M);
 int alive_library_pack(const float* tokens_DxM, int64_t M, int D,
                        void* lib_bf16, float* rows_f32, float* norms, void* stream);
 
-/* alive_knn_search: exact top-k of one library shard.
+/* alive_knn_search: exact top-k of one library shard, bf16 MFMA candidate stage first.
  *   src[N][D][T] fp32 source frames; frames are flattened to Tt = N*T.
- *   bf16 MFMA cosine scoring with per-wave top-k' lists in LDS, then exact
- *   fp32 rescoring (normalise-then-dot, as the reference) of every candidate.
+ *   bf16 MFMA cosine scoring with lane-private top-k' lists in LDS, then exact fp32 rescoring (normalise-then-dot, as
+ *   the reference) of every candidate.  Every frame is then CERTIFIED: a row outside its rescored set has a candidate
+ *   score <= c (the floor of the partial list it failed to enter, or the best candidate the selection of 64 dropped),
+ *   hence an exact cosine <= c - mu + 7 sigma with (mu, sigma) the candidate-score error measured on that frame's own
+ *   rescored candidates; the frame passes if its k-th exact cosine clears that.  Frames that do not pass are searched
+ *   again by the exact tier inside the same call: a brute-force fp32 scan of the whole shard with the rescoring
+ *   arithmetic (launched up front, sized on the device, no sync).  k > 8: the exact scan for every frame.
  *   out_val[Tt][k] fp32 cosine, descending; out_idx[Tt][k] = idx_base + row.
  *   ws: alive_knn_workspace_bytes(Tt, M) bytes.
  */
@@ -68,29 +74,32 @@ int alive_knn_search(const float* src, int N, int T,
                      int64_t M, int64_t idx_base, int k,
                      float* out_val, int32_t* out_idx, void* ws, void* stream);
 
-/* The same search with the candidate stage on the block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, OCP e4m3
+/* The same search with the first candidate stage on the block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, OCP e4m3
  * operands = normalised rows x 2^8, scales 2^0): about twice the scoring rate at ~20x the score error of bf16, so the
  * lists hold twice as many candidates (32 per frame and library split) in front of the same exact fp32 rescoring.
  *   lib_f8[M_pad][D]: alive_library_fp8_bytes(M) bytes, made from lib_bf16 by alive_library_pack_fp8.
  *   Same workspace, same outputs and the same contract as alive_knn_search.
- * Exactness does not rest on the fp8 scores: after the exact rescoring every frame is CERTIFIED -- a row outside its
- * rescored set has an fp8 score <= c (the floor of the partial list it failed to enter, or the best candidate the
- * selection of 64 dropped), so an exact cosine <= c - mu + 7 sigma with (mu, sigma) the fp8 error measured on that
- * frame's own rescored candidates; the frame passes if its k-th exact cosine clears that.  Frames that do not pass are
- * searched again through the bf16 stage inside the same call (compacted when they are few; the whole batch when the
- * library's best cosines lie closer together than the fp8 error) -- launched up front, decided on the device, no sync.
- * alive_knn_fp8_fallback_count: device pointer (inside ws) to the number of frames the last call re-searched. */
+ * Tiers, all launched up front and decided on the device (no sync, graph-capturable):
+ *   probe  batches of >= 16384 frames: the fp8 stage and its certificate on a sample of 1024 frames; when more than 40 %
+ *          of the sample fail (a library whose best cosines lie closer together than the fp8 error) the fp8 pass over
+ *          the batch is skipped and every frame starts at the bf16 stage;
+ *   fp8    candidates, exact rescoring, certificate (fp8 error statistics);
+ *   bf16   the frames that failed, compacted, through the bf16 stage: candidates, rescoring, certificate (bf16 statistics);
+ *   exact  the frames that failed again: brute-force fp32 scan.
+ * alive_knn_search_stats: device pointer (inside ws) to int[8] counters of the last search on that workspace:
+ *   [0] frames sent to the bf16 stage  [1] frames sent to the exact scan  [2] probe sample size  [3] probe failures
+ *   [4] 1 = the probe chose bf16 first.  (alive_knn_search fills [1] only.) */
 size_t alive_library_fp8_bytes(int64_t M);
 int alive_library_pack_fp8(const void* lib_bf16, int64_t M, void* lib_f8, void* stream);
 int alive_knn_search_fp8(const float* src, int N, int T,
                          const void* lib_f8, const void* lib_bf16, const float* rows_f32, const float* norms,
                          int64_t M, int64_t idx_base, int k,
                          float* out_val, int32_t* out_idx, void* ws, void* stream);
-const int* alive_knn_fp8_fallback_count(int N, int T, int64_t M, void* ws);
+const int* alive_knn_search_stats(int N, int T, int64_t M, void* ws);
 
 /* Measurement hook (bench.py): when both are non-NULL hipEvent_t handles, every following
- * alive_knn_search on this host thread records them on its stream immediately before / after the
- * bf16 scoring kernel (the dominant kernel).  Pass NULLs to switch off. */
+ * alive_knn_search / alive_knn_search_fp8 on this host thread records them on its stream immediately before / after the
+ * first-stage scoring kernel of the whole batch (the dominant kernel).  Pass NULLs to switch off. */
 int alive_knn_set_timing_events(void* ev_start, void* ev_stop);
 
 /* alive_knn_merge_gather: merge n_shards exact top-k lists ([S][Tt][k], e.g.

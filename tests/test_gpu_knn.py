@@ -130,6 +130,8 @@ def test_knn_fp8_uncertified_frames_are_researched_on_bf16(prefilter, n_frames, 
     v16, i16 = l16.search(src, 4)
     assert torch.equal(i8, i16) and torch.equal(v8, v16)
     assert (n > 0.5 * n_frames) and ((n <= 16384) == (expect == "tier1")), n
+    st = l8.search_stats()
+    assert st["probe_chose_bf16_first"] == (n_frames >= 16384), st          # batches of >= 16384 frames are probed first
 
 
 @pytest.mark.parametrize("n,t,m,k", [(1, 1, 5, 4), (1, 7, 31, 1), (3, 17, 33, 8), (1, 255, 100, 4), (2, 257, 257, 4), (1, 700, 1000, 8),
@@ -233,3 +235,142 @@ def test_knn_full_size_properties(prefilter):
         del pl
         v16, i16 = PackedLibrary(lib, prefilter="bf16").search(src, k)
         assert torch.equal(idx.view(N * T, k), i16) and torch.equal(val.view(N * T, k), v16)
+
+
+def _brute_force_topk(src_frames, lib_DxM, k, chunk=100_000):
+    """fp32 brute force on the device, chunked over the library: (values[F, k+1] desc, indices[F, k+1])"""
+    qn = src_frames / src_frames.norm(dim=1, keepdim=True)
+    bv = torch.full((qn.shape[0], k + 1), -2.0, device=qn.device)
+    bi = torch.zeros(qn.shape[0], k + 1, dtype=torch.long, device=qn.device)
+    for c in range(0, lib_DxM.shape[1], chunk):
+        blk = lib_DxM[:, c:c + chunk]
+        sc = qn @ (blk / blk.norm(dim=0, keepdim=True))
+        v, i = torch.topk(sc, min(k + 1, sc.shape[1]), dim=1)
+        allv, alli = torch.cat([bv, v], 1), torch.cat([bi, i + c], 1)
+        bv, o = torch.topk(allv, k + 1, dim=1)
+        bi = torch.gather(alli, 1, o)
+    return bv, bi
+
+
+def _assert_equals_brute_force(val, idx, bv, bi, k, min_safe):
+    safe = (bv[:, k - 1] - bv[:, k]) > 1e-5
+    got = torch.sort(idx.long(), dim=1).values[safe]
+    want = torch.sort(bi[:, :k], dim=1).values[safe]
+    assert int(safe.sum()) >= min_safe, int(safe.sum())
+    bad = int((got != want).any(dim=1).sum())
+    assert bad == 0, f"{bad} of {int(safe.sum())} frames have a different top-{k} set"
+    assert float((val - bv[:, :k]).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("kind", ["randn", "clustered"])
+def test_knn_full_size_against_brute_force_on_10k_frames(prefilter, kind):
+    """M = 1 M, >= 10 000 frames, the default tiered search against a chunked fp32 brute-force scan of the whole library:
+    same top-k set in every frame outside near-ties (gap < 1e-5), values within 2e-6 (module/common.py:100-105).
+    randn: i.i.d. Gaussian rows and frames.  clustered: a DENSE library of content-encoder frames and query frames from
+    the same signal family -- the case in which the fp8 certificate fails for half of the frames."""
+    import bench
+    from module.common import PackedLibrary
+    M, k = 1_000_000, 4
+    g = torch.Generator(device=DEV).manual_seed(31)
+    if kind == "randn":
+        lib = torch.randn(768, M, device=DEV, generator=g)
+        src = torch.randn(24, 768, 450, device=DEV, generator=g)
+    else:
+        from module.content_encoder import ContentEncoder
+        from module.decoder import Decoder
+        from module.f0_estimator import F0Estimator
+        from module.pipeline import Converter
+        conv = Converter(ContentEncoder(seed=2), F0Estimator(seed=2), Decoder(seed=2), DEV)
+        lib = bench.ce_derived_tokens(conv, M, torch.device(DEV))
+        src, _ = conv.features(bench.synth_windows(4, 10.0, 48000, torch.device(DEV), seed=100))       # [24, 768, 450]
+    pl = PackedLibrary(lib)
+    val, idx = pl.search(src, k)
+    st = pl.search_stats()
+    flat = src.permute(0, 2, 1).reshape(-1, 768)
+    assert flat.shape[0] >= 10_000
+    bv, bi = _brute_force_topk(flat, lib, k)
+    _assert_equals_brute_force(val, idx, bv, bi, k, min_safe=int(0.9 * flat.shape[0]))
+    assert st["frames"] == flat.shape[0]
+    if kind == "clustered" and prefilter == "fp8":
+        assert st["frames_researched_on_bf16"] > 0          # the dense library does trip the fp8 certificate
+
+
+def test_knn_exact_tier_on_a_library_of_near_duplicates(prefilter):
+    """A library made of clusters of 40 near-copies whose cosines to a query differ by a few 1e-4: the bf16 certificate (and
+    the fp8 one in front of it) cannot tell whether a neighbour was lost, so frames fall through to the exact fp32 scan.
+    The result must still be the brute-force one, and the counters must say which tier produced it."""
+    from module.common import PackedLibrary
+    g = torch.Generator(device=DEV).manual_seed(41)
+    base = torch.randn(768, 300, device=DEV, generator=g)
+    lib = (base.repeat_interleave(40, dim=1) + 0.02 * torch.randn(768, 12000, device=DEV, generator=g)).contiguous()
+    src = (base[:, torch.randint(0, 300, (3 * 200,), device=DEV, generator=g)]
+           + 0.3 * torch.randn(768, 600, device=DEV, generator=g)).view(768, 3, 200).permute(1, 0, 2).contiguous()
+    pl = PackedLibrary(lib)
+    val, idx = pl.search(src, 4)
+    st = pl.search_stats()
+    assert st["frames_searched_exactly"] > 0, st
+    flat = src.permute(0, 2, 1).reshape(-1, 768)
+    bv, bi = _brute_force_topk(flat, lib, 4)
+    _assert_equals_brute_force(val, idx, bv, bi, 4, min_safe=300)
+
+
+@pytest.mark.parametrize("n,t,m,k", [(1, 40, 500, 9), (2, 33, 3000, 16), (1, 7, 100, 64), (1, 450, 20000, 12)])
+def test_knn_k_above_8_runs_the_exact_scan(n, t, m, k):
+    """the reference accepts any k <= M (inference.py:34, common.py:105); k > 8 is deeper than the candidate lists and runs
+    the exact fp32 scan for every frame.  Checked against the oracle, and bitwise against the candidate path: the first 4
+    columns of a k-deep search are the k = 4 search (same arithmetic in every tier)."""
+    from module.common import PackedLibrary, match_features
+    src = synthetic.gaussian(f"k16.src.{n}.{t}", 51, (n, 768, t))
+    lib = synthetic.make_library(m, 52)
+    out, idx = match_features(src.to(DEV), lib.to(DEV), k=k, alpha=0.25, return_indices=True)
+    ref, ridx, cos = O.match_features(src, lib.expand(n, -1, -1), k, 0.25, return_indices=True)
+    top = torch.topk(cos, k + 1, dim=2).values.reshape(n * t, k + 1)
+    safe = ((top[:, k - 1] - top[:, k]) > 1e-5).numpy()
+    assert np.array_equal(np.sort(idx.cpu().numpy(), 1)[safe], np.sort(ridx.reshape(n * t, k).numpy(), 1)[safe])
+    safe3 = torch.from_numpy(safe).view(n, t)
+    for i in range(n):
+        torch.testing.assert_close(out[i].cpu()[:, safe3[i]], ref[i][:, safe3[i]], rtol=1e-5, atol=2e-6)
+    pl = PackedLibrary(lib[0].to(DEV))
+    vk, ik = pl.search(src.to(DEV), k)
+    v4, i4 = pl.search(src.to(DEV), 4)
+    assert torch.equal(vk[:, :4], v4) and torch.equal(ik[:, :4], i4)
+    assert (vk[:, :-1] >= vk[:, 1:]).all()
+
+
+def test_match_features_cache_tells_same_shaped_libraries_apart():
+    """two different libraries of the same shape passed as temporaries (the caching allocator hands the second one the
+    address of the first): the packed form must not be reused"""
+    from module.common import match_features
+    src = synthetic.gaussian("cache.src", 61, (1, 768, 50)).to(DEV)
+    outs = []
+    for seed in (62, 63, 62):
+        outs.append(match_features(src, synthetic.make_library(700, seed).to(DEV), k=4))
+        torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[2])
+    assert not torch.equal(outs[0], outs[1])
+    ref = O.match_features(src.cpu(), synthetic.make_library(700, 63), 4)
+    torch.testing.assert_close(outs[1].cpu(), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_knn_eight_shards_of_a_1m_library_equal_the_unsharded_search():
+    """BASELINE config 4 in one process: 8 contiguous shards x 125 000 rows, per-shard exact top-k, merged -- bitwise the
+    unsharded result (lists and regressed features)"""
+    from module.common import PackedLibrary, merge_gather
+    from module.sharded import shard_bounds
+    M, k = 1_000_000, 4
+    g = torch.Generator(device=DEV).manual_seed(71)
+    lib = torch.randn(768, M, device=DEV, generator=g)
+    src = torch.randn(8, 768, 450, device=DEV, generator=g)
+    full = PackedLibrary(lib)
+    v0, i0 = full.search(src, k)
+    ref, fin_ref = merge_gather(v0, i0, 1, k, 0.0, full.rows, src, return_indices=True)
+    vs, is_ = [], []
+    for b, e in shard_bounds(M, 8):
+        sh = PackedLibrary(lib[:, b:e].contiguous(), idx_base=b)
+        v, i = sh.search(src, k)
+        vs.append(v)
+        is_.append(i)
+        del sh
+    out, fin = merge_gather(torch.stack(vs).contiguous(), torch.stack(is_).contiguous(), 8, k, 0.0, full.rows, src,
+                            return_indices=True)
+    assert torch.equal(fin, fin_ref) and torch.equal(out, ref)
