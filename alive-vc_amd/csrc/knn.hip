@@ -1242,6 +1242,27 @@ __global__ __launch_bounds__(256) void flag_all_kernel(int* __restrict__ list, i
     if (i == 0) *cnt = (int)Tt;
 }
 
+// ---- greedy de-duplication of a library (generate_voice_library.py --dedup): keep[i] = no KEPT earlier frame among its
+// k nearest has cosine > threshold.  The sequential definition is a recursion over a DAG (edges point to lower indices),
+// evaluated by passes: a frame is decided once all its earlier near neighbours are.  state: 0 undecided, 1 kept, 2 dropped;
+// transitions are monotone, so in-place reads of a neighbour decided in the same pass are harmless.
+__global__ __launch_bounds__(256) void dedup_pass_kernel(const float* __restrict__ val, const int* __restrict__ idx, int64_t M, int k,
+                                                         float threshold, int* __restrict__ state, int* __restrict__ undecided) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M || state[i] != 0) return;
+    bool any_kept = false, all_dropped = true;
+    for (int q = 0; q < k; ++q) {
+        const int j = idx[i * k + q];
+        if (j < 0 || j >= i || !(val[i * k + q] > threshold)) continue;
+        const int sj = ((volatile int*)state)[j];
+        any_kept |= sj == 1;
+        all_dropped &= sj == 2;
+    }
+    if (any_kept) state[i] = 2;
+    else if (all_dropped) state[i] = 1;
+    else atomicAdd(undecided, 1);
+}
+
 // optional instrumentation: events recorded on the search stream around the scoring kernel only
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 
@@ -1571,5 +1592,13 @@ extern "C" int alive_knn_merge_gather(const float* cand_val, const int32_t* cand
         knn_merge_gather_kernel<8, ALIVE_MAX_K><<<g, 256, 0, (hipStream_t)stream>>>(cand_val, cand_idx, n_shards, k, (float)alpha,
                                                                                  (float)(1.0 - alpha), rows_f32_full, src, T, (int64_t)N * T, out, final_idx);
     ALIVE_CHECK_LAUNCH("alive_knn_merge_gather");
+    return ALIVE_OK;
+}
+
+extern "C" int alive_dedup_pass(const float* val, const int32_t* idx, int64_t M, int k, double threshold, int32_t* state,
+                                int32_t* undecided, void* stream) {
+    ALIVE_CHECK_ARG(val && idx && state && undecided && M >= 1 && k >= 1, "alive_dedup_pass: bad arguments");
+    dedup_pass_kernel<<<(unsigned)((M + 255) / 256), 256, 0, (hipStream_t)stream>>>(val, idx, M, k, (float)threshold, state, undecided);
+    ALIVE_CHECK_LAUNCH("alive_dedup_pass");
     return ALIVE_OK;
 }

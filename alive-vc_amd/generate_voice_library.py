@@ -46,20 +46,31 @@ def collect_clips(root, max_clips, rng):
     return clips[order[:max_clips]]
 
 
-def dedup_mask(tokens_DxM, threshold, k=8):
-    """keep[m] = False when some kept frame m' < m has cos(m, m') > threshold.  Greedy in index order; neighbours come
-    from the HIP kNN search of the library against itself (k nearest, the frame itself included)."""
+def dedup_mask(tokens_DxM, threshold, k=8, chunk=65536):
+    """keep[m] = False when some KEPT frame m' < m has cos(m, m') > threshold (greedy in index order).  Neighbours come
+    from the HIP kNN search of the library against itself (k nearest, the frame itself included), in chunks of frames;
+    the greedy recursion is resolved on the device by passes (alive_dedup_pass): a frame is decided once all of its
+    earlier near neighbours are -- as many passes as the longest chain of near-duplicates, no per-row host loop."""
+    from module import _native as nat
     from module.common import PackedLibrary
     m = tokens_DxM.shape[1]
     k = min(k, m)
-    val, idx = PackedLibrary(tokens_DxM.contiguous()).search(tokens_DxM.unsqueeze(0).contiguous(), k)
-    val, idx = val.cpu(), idx.cpu().long()
-    keep = torch.ones(m, dtype=torch.bool)
-    for i in range(m):
-        near = idx[i][(val[i] > threshold) & (idx[i] < i) & (idx[i] >= 0)]
-        if near.numel() and keep[near].any():
-            keep[i] = False
-    return keep
+    dev = tokens_DxM.device
+    lib = PackedLibrary(tokens_DxM.contiguous())
+    val = torch.empty(m, k, dtype=torch.float32, device=dev)
+    idx = torch.empty(m, k, dtype=torch.int32, device=dev)
+    for s in range(0, m, chunk):
+        v, i = lib.search(tokens_DxM[:, s:s + chunk].unsqueeze(0).contiguous(), k)
+        val[s:s + chunk], idx[s:s + chunk] = v, i
+    state = torch.zeros(m, dtype=torch.int32, device=dev)
+    undecided = torch.zeros(1, dtype=torch.int32, device=dev)
+    for _ in range(m + 1):
+        undecided.zero_()
+        nat.check(nat.lib().alive_dedup_pass(nat.ptr(val), nat.ptr(idx), m, k, float(threshold), nat.ptr(state), nat.ptr(undecided),
+                                             nat.stream()), "alive_dedup_pass")
+        if int(undecided.item()) == 0:
+            break
+    return (state == 1).cpu()
 
 
 def main(argv=None):

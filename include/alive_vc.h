@@ -111,6 +111,13 @@ int alive_knn_merge_gather(const float* cand_val, const int32_t* cand_idx, int n
                            double alpha, const float* rows_f32_full, const float* src,
                            int N, int T, float* out, int32_t* final_idx, void* stream);
 
+/* alive_dedup_pass: one pass of the greedy de-duplication of a library (generate_voice_library.py of this build, --dedup):
+ * frame i is dropped iff a KEPT earlier frame among its k nearest (val / idx[M][k] = alive_knn_search of the library
+ * against itself) has cosine > threshold.  state[M]: 0 undecided, 1 kept, 2 dropped (zero it before the first pass);
+ * *undecided (zero it before each pass) counts the frames still waiting for an earlier neighbour; repeat until it is 0. */
+int alive_dedup_pass(const float* val, const int32_t* idx, int64_t M, int k, double threshold, int32_t* state,
+                     int32_t* undecided, void* stream);
+
 /* ----------------------------------------------------------- operators ----
  * Building blocks, exported so that every kernel has its own parity test.
  *

@@ -1,0 +1,89 @@
+"""BASELINE config 3 at batch scale through the whole path: 128 and 384 windows in one `convert_windows`, window batches of
+64 / 128 on three side streams (9 GB of scratch per stream), a 200 000-vector library -- against per-window calls
+(bitwise) and against the CPU oracle on sampled windows (waveform RMS < 1e-3).  Reference loop: inference.py:96-135."""
+import pytest
+import torch
+
+import alive_oracle as O
+import bench
+from module import schema, synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+M = 200_000
+
+
+@pytest.fixture(scope="module")
+def rig():
+    from module.content_encoder import ContentEncoder
+    from module.decoder import Decoder
+    from module.f0_estimator import F0Estimator
+    from module.pipeline import Converter
+    g = torch.Generator(device=DEV).manual_seed(200)
+    tokens = torch.randn(1, 768, M, device=DEV, generator=g)
+    conv = Converter(ContentEncoder(seed=2), F0Estimator(seed=2), Decoder(seed=2), DEV).set_library(tokens)
+    windows = bench.synth_windows(64, 10.0, 48000, DEV, seed=300)                   # 384 windows x 144 000 samples
+    return conv, tokens, windows
+
+
+@pytest.mark.parametrize("n_win,window_batch,streams", [(128, 64, "3"), (128, 128, "3"), (384, 128, "3"), (384, 64, "3"),
+                                                        (384, 128, "1"), (130, 64, "2")])
+def test_batched_conversion_equals_per_window_calls(rig, monkeypatch, n_win, window_batch, streams):
+    """a window's waveform must not depend on how many windows share its launch, on the batch it falls into or on the side
+    stream that batch runs on (130 windows: a ragged last batch of 2)"""
+    conv, _, windows = rig
+    monkeypatch.setenv("ALIVE_STREAMS", streams)
+    w = windows[:n_win]
+    out = conv.convert_windows(w, k=4, alpha=0.1, window_batch=window_batch)
+    assert torch.isfinite(out).all()
+    monkeypatch.setenv("ALIVE_STREAMS", "1")
+    for i in sorted({0, 1, window_batch - 1, window_batch % n_win, n_win // 2, n_win - 2, n_win - 1}):
+        single = conv.convert_windows(w[i:i + 1].contiguous(), k=4, alpha=0.1, window_batch=1)
+        assert torch.equal(single[0], out[i]), f"window {i} differs between the batched and the single launch"
+
+
+def test_repeated_batched_conversion_is_deterministic(rig, monkeypatch):
+    """the same 384-window step five times on three streams: bitwise the same waveforms (scratch reuse across streams,
+    weight tables shared by the streams)"""
+    conv, _, windows = rig
+    monkeypatch.setenv("ALIVE_STREAMS", "3")
+    first = conv.convert_windows(windows, k=4, window_batch=128)
+    for _ in range(4):
+        assert torch.equal(conv.convert_windows(windows, k=4, window_batch=128), first)
+
+
+def test_batched_conversion_against_the_oracle(rig, monkeypatch):
+    """three windows of the 384-window batch through the CPU oracle with the same 200 k-vector library:
+    waveform RMS error < 1e-3 (the north-star bar), f0 identical"""
+    conv, tokens, windows = rig
+    monkeypatch.setenv("ALIVE_STREAMS", "3")
+    out = conv.convert_windows(windows, k=4, window_batch=128).cpu()
+    cpu = [synthetic.make_state_dict(s, 2, p) for s, p in ((schema.content_encoder_schema(), "ce."),
+                                                          (schema.f0_estimator_schema(), "pe."),
+                                                          (schema.decoder_schema(), "dec."))]
+    lib = tokens.cpu()
+    torch.set_num_threads(16)
+    for i in (0, 200, 383):
+        ref = O.convert_window(cpu[0], cpu[1], cpu[2], windows[i:i + 1].cpu(), lib, k=4, alpha=0.0)
+        err = (out[i:i + 1] - ref).pow(2).mean().sqrt().item()
+        assert err < 1e-3, f"window {i}: RMS error {err:.3e} against the oracle (signal RMS {ref.pow(2).mean().sqrt().item():.3f})"
+
+
+def test_match_at_200k_vectors_against_brute_force(rig):
+    """the kNN half of config 3: all 172 800 frames of the batch against the 200 k-vector library, 12 000 of them checked
+    against a brute-force fp32 scan"""
+    conv, tokens, windows = rig
+    feat = torch.cat([conv.features(windows[i:i + 128])[0] for i in range(0, 384, 128)], 0)
+    val, idx = conv.library.search(feat, 4)
+    assert tuple(val.shape) == (172_800, 4)
+    flat = feat.permute(0, 2, 1).reshape(-1, 768)
+    sel = torch.randperm(flat.shape[0], device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))[:12_000]
+    q = flat[sel]
+    qn = q / q.norm(dim=1, keepdim=True)
+    ln = tokens[0] / tokens[0].norm(dim=0, keepdim=True)
+    top = torch.topk(qn @ ln, 5, dim=1)
+    safe = (top.values[:, 3] - top.values[:, 4]) > 1e-5
+    got = torch.sort(idx[sel].long(), dim=1).values[safe]
+    want = torch.sort(top.indices[:, :4], dim=1).values[safe]
+    assert int(safe.sum()) > 11_000 and torch.equal(got, want)
+    assert float((val[sel] - top.values[:, :4]).abs().max()) <= 2e-6

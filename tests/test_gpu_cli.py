@@ -131,6 +131,30 @@ def test_voice_library_dedup_drops_later_near_duplicates():
     assert gvl.dedup_mask(toks.to("cuda"), 1.5).all()                 # nothing is above an impossible threshold
 
 
+def test_voice_library_dedup_at_scale_equals_the_sequential_definition():
+    """60 000 frames with chains of near-duplicates (a copy of a copy of a copy ...): the device passes must reproduce the
+    greedy index-order definition, evaluated here row by row on the host from the same neighbour lists"""
+    import generate_voice_library as gvl
+    from module.common import PackedLibrary
+    g = torch.Generator(device="cuda").manual_seed(9)
+    base = torch.randn(768, 20000, device="cuda", generator=g)
+    parts = [base]
+    for gen in range(2):                                           # generation g + 1 copies generation g (chains of length 3)
+        parts.append(parts[-1] + 0.02 * torch.randn(768, 20000, device="cuda", generator=g))
+    toks = torch.cat(parts, 1)[:, torch.randperm(60000, device="cuda", generator=g)].contiguous()
+    thr, k = 0.9995, 8
+    keep = gvl.dedup_mask(toks, thr, k=k, chunk=16384)
+    val, idx = PackedLibrary(toks).search(toks.unsqueeze(0), k)
+    val, idx = val.cpu().numpy(), idx.cpu().numpy()
+    want = np.ones(60000, dtype=bool)
+    for i in range(60000):
+        near = idx[i][(val[i] > thr) & (idx[i] < i) & (idx[i] >= 0)]
+        if near.size and want[near].any():
+            want[i] = False
+    assert np.array_equal(keep.numpy(), want)
+    assert 15000 < int(want.sum()) < 45000                          # chains really occur: neither all kept nor all dropped
+
+
 def test_realtime_graph_capture_equals_eager(workdir):
     """the whole per-step device pipeline captured into one hipGraph replays to the same samples as eager execution"""
     from module.content_encoder import ContentEncoder

@@ -600,3 +600,40 @@ def test_dwconv_norm_planes_single_pass(planes, n, c, t, adaptive, dw):
                                cond.to(DEV) if adaptive else None, 5, 5 + c, planes=planes)
     got = ops.planes_to_float(P, n, c, t, planes)
     assert relerr(got, ref) < (1e-5 if planes == 2 else 2e-6)
+
+
+@pytest.mark.parametrize("c,l", [(64, 36000), (16, 72000), (8, 144000)])
+def test_fused_filter_blocks_are_deterministic_at_batch_scale(c, l):
+    """128 windows (the bench's window batch), 100 launches on the same inputs: every output bitwise the first one
+    (the scheduling fence of filter_block64_kernel was guarded by 3 repetitions on tiny shapes only)"""
+    from module import _native as nat
+    N, lf = 128, 450
+    L_ = nat.lib()
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    film = torch.randn(N, 4128, lf, device=DEV, generator=gen)
+    x = torch.randn(N, c, l, device=DEV, generator=gen)
+    skip = torch.randn(N, c, l, device=DEV, generator=gen)
+    out = torch.empty_like(x)
+    st = torch.cuda.current_stream().cuda_stream
+    if c == 64:
+        w = (torch.randn(L_.alive_filter_block64_weights(), device=DEV, generator=gen) * 0.05).to(torch.bfloat16)
+        b = torch.randn(7, 64, device=DEV, generator=gen) * 0.1
+
+        def run():
+            nat.check(L_.alive_filter_block64(x.data_ptr(), N, l, w.data_ptr(), b.data_ptr(), film.data_ptr(), 4128, lf, 3072,
+                                              skip.data_ptr(), out.data_ptr(), st))
+    else:
+        w = torch.randn(L_.alive_filter_block_small_weights(c), device=DEV, generator=gen) * 0.1
+
+        def run():
+            nat.check(L_.alive_filter_block_small(x.data_ptr(), N, c, l, w.data_ptr(), film.data_ptr(), 4128, lf, 100,
+                                                  skip.data_ptr(), out.data_ptr(), st))
+    first = None
+    for rep in range(100):
+        out.zero_()
+        run()
+        if first is None:
+            first = out.clone()
+            assert torch.isfinite(first).all()
+        else:
+            assert torch.equal(out, first), f"launch {rep} differs from the first"
