@@ -300,8 +300,14 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
             modulate_store(Fc, dst, ct * 16 + c16, v);
             // The fence is load-bearing: with the 16 column bodies merged into one scheduling region hipcc (ROCm 7.2) produced a
             // schedule whose results differed from run to run (1.5e-2 off); with one region per column tile they are exact.
-#ifndef ALIVE_NO_TILE_FENCE          // diagnostic build only (tools/stress_filter_block.py): see DESIGN.md 3.2b'
+#if !defined(ALIVE_NO_TILE_FENCE)    // -DALIVE_NO_TILE_FENCE[=n]: diagnostic builds only (tools/diag_filter_nofence.py, DESIGN.md 3.2b')
             __builtin_amdgcn_sched_barrier(0);
+#elif ALIVE_NO_TILE_FENCE == 1       // compiler-level memory clobber instead of the scheduling fence
+            asm volatile("" ::: "memory");
+#elif ALIVE_NO_TILE_FENCE == 2       // fence only behind the last four column tiles
+            if (ct >= 12) __builtin_amdgcn_sched_barrier(0);
+#elif ALIVE_NO_TILE_FENCE == 3       // fence only behind the first twelve
+            if (ct < 12) __builtin_amdgcn_sched_barrier(0);
 #endif
             p0 = n0;
             p1 = n1;

@@ -52,6 +52,8 @@ def build_parser():
     parser.add_argument('-lsr', '--loopback-sr', default=16000, type=int)
     parser.add_argument('--input-wav', default=None, help="stream this file instead of an audio device (this build only)")
     parser.add_argument('--output-wav', default=None, help="write the converted stream here (this build only)")
+    parser.add_argument('--no-graph', action='store_true',
+                        help="launch the per-chunk device pipeline kernel by kernel instead of replaying one captured hipGraph (this build only)")
     return parser
 
 
@@ -84,6 +86,8 @@ def main(argv=None):
     rt = RealtimeConverter(CE, PE, Dec, tgt.contiguous(), device, chunk=args.chunk, buffersize=args.buffersize,
                            input_sr=args.input_sr, output_sr=args.output_sr, f0_rate=args.f0_rate, pitch=args.pitch,
                            k=args.k, alpha=args.alpha, gain=args.gain, input_gain=args.input_gain)
+    if not args.no_graph:
+        rt.enable_graph()        # the whole per-chunk device pipeline (~150 launches) captured once, replayed per chunk: same samples
     print("converting voice...")
     if args.input_wav is not None:
         wf, sr = audio_io.load(args.input_wav)

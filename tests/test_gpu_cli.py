@@ -91,6 +91,21 @@ def test_realtime_converter_matches_oracle(workdir):
     assert np.sqrt(np.mean((got - want) ** 2)) / 32768 < 1e-3
 
 
+def test_realtime_cli_replays_a_hipgraph_with_the_same_samples(workdir):
+    """realtime_inference.py (BASELINE config 5: -c 160 -b 16, hipGraph-captured per-chunk pipeline) streaming a 24 kHz file:
+    the default (captured graph) and --no-graph runs write identical files"""
+    import realtime_inference as rti
+    d, _, _ = workdir
+    base = ["-dep", str(d / "decoder.pt"), "-cep", str(d / "content_encoder.pt"), "-f0ep", str(d / "f0_estimator.pt"),
+            "-lib", str(d / "voice_library.pt"), "-d", "cuda", "-c", "160", "-b", "16", "-f0", "0.5",
+            "--input-wav", str(d / "inputs" / "utt.wav")]
+    rti.main(base + ["--output-wav", str(d / "rt_graph.wav")])
+    rti.main(base + ["--output-wav", str(d / "rt_eager.wav"), "--no-graph"])
+    a, sra = audio_io.load(str(d / "rt_graph.wav"))
+    b, _ = audio_io.load(str(d / "rt_eager.wav"))
+    assert sra == 16000 and a.shape[1] >= 160 * 50 and torch.equal(a, b)
+
+
 def test_realtime_rejects_rings_shorter_than_five_frames(workdir):
     from module.content_encoder import ContentEncoder
     from module.decoder import Decoder
