@@ -41,6 +41,18 @@ TRIM_LEFT, TRIM_RIGHT = 32, 16
 CE_MARGIN = 16          # ContentEncoder: four k7 depthwise convs (+-12 frames) between the spectrogram and its output
 
 
+# Overlap sharing.  Consecutive windows of one utterance overlap by two chunks, and a content / f0 frame at least EDGE frames
+# from both edges of its window depends on nothing but the samples around it (spectrogram frame +-640 samples, four k7
+# depthwise convs +-12 frames): it has the same value in every window that contains it, and so has its kNN match.  With
+# `share_overlap` the front end (spectrogram, f0 estimator, content encoder, match) therefore runs ONCE per utterance on the
+# padded signal plus, per window, on its two edge blocks; every window's matched features and raw f0 are then assembled by
+# copies.  The pitch transform (per-window mean pitch) and the whole decoder still run per window.  Results are bitwise those
+# of the per-window front end (tests/test_gpu_batch.py); at the reference's 3-chunk windows it launches ~51 % of the frames.
+EDGE = 14            # 12 frames of ConvNeXt context + 2 of STFT reflect padding (module/realtime.py uses the same numbers)
+NET_MARGIN = 16
+SPEC_MARGIN = 2
+
+
 class Converter:
     def __init__(self, content_encoder: ContentEncoder, f0_estimator: F0Estimator, decoder: Decoder, device="cuda"):
         self.device = torch.device(device)
@@ -70,12 +82,56 @@ class Converter:
         feat[:, :, a:b] = self.ce(spec[:, :, a:b].contiguous())
         return feat, f0
 
+    def features_shared(self, windows, group, k=4, alpha=0.0, utt_batch=32):
+        """(matched content features [n, 768, lf], raw f0 [n, 1, lf]) of n = m * group windows, every `group` consecutive ones
+        being the windows of one signal at hop = a third of the window (make_windows): the front end runs once per signal."""
+        n, L = windows.shape
+        c = L // 3
+        lf, cf = L // 320, c // 320
+        if n % group or c % 320 or lf < 2 * (EDGE + NET_MARGIN + SPEC_MARGIN):
+            raise ValueError(f"share_overlap needs groups of {group} windows of 3 chunks, chunk a multiple of 320 and >= "
+                             f"{2 * (EDGE + NET_MARGIN + SPEC_MARGIN)} frames per window")
+        m = n // group
+        w3 = windows.view(m, group, L)
+        # the padded signal of every group: first chunk of each window, then the last two chunks of the last one
+        sig = torch.cat([w3[:, :, :c].reshape(m, group * c), w3[:, -1, c:]], dim=1).contiguous()      # [m, (group + 2) c]
+        dev = windows.device
+        feat = torch.empty(n, 768, lf, device=dev)
+        f0 = torch.empty(n, 1, lf, device=dev)
+        fu = torch.empty(m, 768, (group + 2) * cf, device=dev)
+        pu = torch.empty(m, 1, (group + 2) * cf, device=dev)
+        for i in range(0, m, utt_batch):                       # interior frames: one pass over each signal
+            spec = spectrogram(sig[i:i + utt_batch])
+            pu[i:i + utt_batch] = self.pe.estimate(spec)
+            fu[i:i + utt_batch] = self.ce(spec)
+        nl = EDGE + NET_MARGIN
+        fe = torch.empty(n, 768, 2 * EDGE, device=dev)         # edge frames of every window: [0, EDGE) and [lf - EDGE, lf)
+        pe_ = torch.empty(n, 1, 2 * EDGE, device=dev)
+        for i in range(0, n, 8 * utt_batch):
+            w = windows[i:i + 8 * utt_batch]
+            sl = spectrogram(w[:, :(nl + SPEC_MARGIN) * 320].contiguous())[:, :, :nl].contiguous()
+            sr = spectrogram(w[:, L - (nl + SPEC_MARGIN) * 320:].contiguous())[:, :, SPEC_MARGIN:].contiguous()
+            fe[i:i + 8 * utt_batch, :, :EDGE] = self.ce(sl)[:, :, :EDGE]
+            fe[i:i + 8 * utt_batch, :, EDGE:] = self.ce(sr)[:, :, NET_MARGIN:]
+            pe_[i:i + 8 * utt_batch, :, :EDGE] = self.pe.estimate(sl)[:, :, :EDGE]
+            pe_[i:i + 8 * utt_batch, :, EDGE:] = self.pe.estimate(sr)[:, :, NET_MARGIN:]
+        fu = self.match(fu, k, alpha)                          # the match: once per distinct frame
+        fe = self.match(fe, k, alpha)
+        f4, p4 = feat.view(m, group, 768, lf), f0.view(m, group, 1, lf)
+        for g in range(group):                                 # window g of a signal = frames [g cf, g cf + lf) of it
+            f4[:, g, :, EDGE:lf - EDGE] = fu[:, :, g * cf + EDGE:g * cf + lf - EDGE]
+            p4[:, g, :, EDGE:lf - EDGE] = pu[:, :, g * cf + EDGE:g * cf + lf - EDGE]
+        feat[:, :, :EDGE], feat[:, :, lf - EDGE:] = fe[:, :, :EDGE], fe[:, :, EDGE:]
+        f0[:, :, :EDGE], f0[:, :, lf - EDGE:] = pe_[:, :, :EDGE], pe_[:, :, EDGE:]
+        self.last_front_end_frames = m * (group + 2) * cf + n * 2 * EDGE           # frames that went through the match
+        return feat, f0
+
     def match(self, feat, k=4, alpha=0.0):
         val, idx = self.library.search(feat, k)
         return merge_gather(val, idx, 1, k, alpha, self.library.rows, feat)
 
     def convert_windows(self, windows, k=4, alpha=0.0, pitch_shift=0.0, intonation=1.0, f0_rate=1.0, window_batch=64,
-                        keep_frames=None):
+                        keep_frames=None, share_overlap=None):
         """windows [n, L] on the device -> waveforms [n, L]; L a multiple of 320.
         Networks run in batches of `window_batch` windows (bounded scratch); the kNN match runs ONCE over the frames
         of all windows, so every library tile streamed from L2 is used by as many frames as possible.
@@ -84,6 +140,27 @@ class Converter:
         samples are bitwise the same as without it (the other frames of the window decode from unmatched features)."""
         n, L = windows.shape
         lf = L // 320
+        # (the edge blocks of all windows form one launch of n x 30 frame columns: below 96 columns the library would switch
+        # to its streaming kernels, which round differently from the plane GEMMs the windows themselves run on -- then the
+        # per-window front end is used, so that the result never depends on the flag)
+        if share_overlap and keep_frames is None and n * (EDGE + NET_MARGIN) >= 96:
+            # share_overlap = windows per signal (make_windows order): front end once per signal, decoder per window
+            feat, f0 = self.features_shared(windows, int(share_overlap), k, alpha)
+            f0 = ops.pitch_transform_(f0, 0, f0_rate=f0_rate, pitch_shift=pitch_shift, intonation=intonation)
+            out = torch.empty_like(windows)
+            cur = torch.cuda.current_stream()
+            side = self._side_streams(windows.device)
+            for j, i in enumerate(range(0, n, window_batch)):
+                st = side[j % len(side)] if side else None
+                if st is None:
+                    out[i:i + window_batch], _ = self.dec(feat[i:i + window_batch], f0[i:i + window_batch])
+                    continue
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    out[i:i + window_batch], _ = self.dec(feat[i:i + window_batch], f0[i:i + window_batch])
+            for st in side:
+                cur.wait_stream(st)
+            return out
         feat = torch.empty(n, 768, lf, device=windows.device)
         f0 = torch.empty(n, 1, lf, device=windows.device)
         rng = None if keep_frames is None else (max(0, keep_frames[0] - TRIM_LEFT), min(lf, keep_frames[1] + TRIM_RIGHT))
@@ -145,4 +222,7 @@ class Converter:
         trim_context: match only the frames that can reach the kept centre third (same samples, ~44 % of the kNN work)"""
         windows, total = make_windows(wf.to(self.device), chunk)
         keep = (chunk // 320, 2 * chunk // 320) if trim_context else None
+        if kw.get("share_overlap") is True:                       # one utterance: all of its windows form one group
+            ok = chunk % 320 == 0 and 3 * chunk // 320 >= 2 * (EDGE + NET_MARGIN + SPEC_MARGIN) and keep is None
+            kw["share_overlap"] = windows.shape[0] if ok else None
         return stitch(self.convert_windows(windows, keep_frames=keep, **kw), total, chunk)

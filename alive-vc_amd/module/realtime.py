@@ -12,9 +12,38 @@ from .common import PackedLibrary, merge_gather
 from .spectrogram import spectrogram
 
 
+# Interior reuse.  A content / f0 frame t of the ring depends on spectrogram frames [t - 12, t + 12] (four k7
+# depthwise convs in ContentEncoder and F0Estimator) and those on samples [320 t - 640, 320 t + 640): frames at least EDGE from
+# both ring edges do not see the reflect padding, so when the ring advances by a whole number of frames they are the SAME
+# values one step later, s frames further left -- and so are their matched features (the kNN is per frame).  What cannot be
+# carried over: the oscillator (its phase is a running sum from the ring's first sample, re-anchored every step) and with it
+# the whole Filter, i.e. the decoder always runs on the full ring.
+# One more condition makes the reuse EXACT rather than merely close: the library picks its kernels by problem size (below 96
+# frame columns the fp32-activation streaming kernels, from 96 the plane-packed split-bf16 GEMMs; the norm kernel has a
+# per-frame form for T <= 32), and the two families round differently (1e-5).  A recomputed edge block must therefore go
+# through the same kernels as the full ring would: blocks of 33 frames under a ring shorter than 96 frames, blocks of 96
+# frames under a longer one.
+EDGE = 14            # 12 frames of ConvNeXt context + 2 of STFT reflect padding
+SPEC_MARGIN = 2      # STFT frames spoiled by the reflect padding of a slice
+PLANES_MIN_COLS = 96  # csrc/networks.hip: use_planes()
+NORM_SMALL_MAX_T = 32  # csrc/blocks.hip: alive_dwconv_norm's per-frame kernel
+
+
+def reuse_block(frames, shift):
+    """frames of a recomputed edge block (EDGE new frames + margin) under a ring of `frames`, or None where no block size keeps
+    the edge blocks on the full ring's kernels"""
+    if frames < PLANES_MIN_COLS:
+        blk = NORM_SMALL_MAX_T + 1
+        ok = blk + shift < PLANES_MIN_COLS
+    else:
+        blk, ok = PLANES_MIN_COLS, True
+    return blk if ok and frames >= 2 * (blk + SPEC_MARGIN) + shift else None
+
+
 class RealtimeConverter:
     def __init__(self, content_encoder, f0_estimator, decoder, library_tokens, device="cuda", chunk=960, buffersize=8,
-                 input_sr=16000, output_sr=16000, f0_rate=1.0, pitch=0.0, k=4, alpha=0.0, gain=0.0, input_gain=0.0):
+                 input_sr=16000, output_sr=16000, f0_rate=1.0, pitch=0.0, k=4, alpha=0.0, gain=0.0, input_gain=0.0,
+                 reuse_interior="auto"):
         self.device = torch.device(device)
         self.ce, self.pe, self.dec = content_encoder.to(device), f0_estimator.to(device), decoder.to(device)
         for net in (self.ce, self.pe, self.dec):
@@ -36,10 +65,26 @@ class RealtimeConverter:
         self.phi = 0
         self._graph = None
         self.last_f0 = None
+        # interior reuse: only where it is exact -- no resampling in front (the ring IS the 16 kHz signal), a shift of whole
+        # frames, and a ring long enough that the two recomputed edge blocks do not meet.  "auto": on when that holds.
+        self.frames, self.shift = frames, chunk // 320
+        self._blk = reuse_block(frames, self.shift) if (input_sr == 16000 and chunk % 320 == 0 and
+                                                        (chunk * buffersize) % 320 == 0) else None
+        fits = self._blk is not None
+        if reuse_interior is True and not fits:
+            raise ValueError("interior reuse needs input_sr 16000, chunk a multiple of 320 and a ring of 70 + chunk .. 95 frames "
+                             f"or of at least 196 + chunk frames (got {frames} frames): see module/realtime.py")
+        self.reuse = bool(fits and reuse_interior in (True, "auto"))
+        self._cache_valid = False
+        if self.reuse:
+            self._c_feat = torch.zeros(1, 768, frames, device=self.device)      # matched features of the ring's frames
+            self._c_f0 = torch.zeros(1, 1, frames, device=self.device)          # transformed f0
 
     # ------------------------------------------------------------------ device part of one step
     def _device_step(self, data, phi):
         """data float32 [1, ring samples at input_sr] on the device, phi [1, 64] -> (wave at output_sr [L], phi_next [1, 64])"""
+        if self.reuse:
+            return self._device_step_reuse(data, phi)
         data = audio_io.resample(data, self.input_sr, 16000, post_gain_db=self.input_gain)     # resample, then gain (:146-147)
         spec = spectrogram(data)
         content = self.ce(spec)
@@ -51,6 +96,54 @@ class RealtimeConverter:
         self.last_f0 = f0
         wave = audio_io.resample(wave, 16000, self.output_sr, pre_gain_db=self.gain)[0]         # gain, then resample (:173-175)
         return wave, phi_out[:, :, self.end_of_output]
+
+    def _front_end(self, data):
+        """16 kHz ring [1, n] -> (matched content [1, 768, F], transformed f0 [1, 1, F]) for every frame"""
+        spec = spectrogram(data)
+        content = self.ce(spec)
+        f0 = self.pe.estimate(spec)
+        f0 = ops.pitch_transform_(f0, 1, f0_rate=self.f0_rate, pitch_shift=self.pitch)
+        val, idx = self.lib.search(content, self.k)
+        return merge_gather(val, idx, 1, self.k, self.alpha, self.lib.rows, content), f0
+
+    def _device_step_reuse(self, data, phi):
+        """the same step with the front end computed for the two edge blocks only; interior frames come from the previous
+        step's ring, `shift` frames further right.  Bitwise the full computation (tests/test_gpu_cli.py)."""
+        F_, s = self.frames, self.shift
+        data = data if self.input_gain == 0 else audio_io.gain(data, self.input_gain)
+        if not self._cache_valid:
+            feat, f0 = self._front_end(data)
+            self._c_feat.copy_(feat)
+            self._c_f0.copy_(f0)
+            self._cache_valid = True
+        else:
+            keep_f, keep_p = self._c_feat[:, :, s:].clone(), self._c_f0[:, :, s:].clone()
+            self._c_feat[:, :, :F_ - s].copy_(keep_f)
+            self._c_f0[:, :, :F_ - s].copy_(keep_p)
+            nl = self._blk                                            # left block: frames [0, EDGE) from a slice of nl frames
+            margin = nl - EDGE                                        # >= 19 > the 12 frames of context
+            feat, f0 = self._front_end_slice(data[:, :(nl + SPEC_MARGIN) * 320], 0, nl)
+            self._c_feat[:, :, :EDGE].copy_(feat[:, :, :EDGE])
+            self._c_f0[:, :, :EDGE].copy_(f0[:, :, :EDGE])
+            a = F_ - EDGE - s                                         # right block: frames [a, F)
+            lo = a - margin
+            feat, f0 = self._front_end_slice(data[:, (lo - SPEC_MARGIN) * 320:], SPEC_MARGIN, SPEC_MARGIN + F_ - lo)
+            self._c_feat[:, :, a:].copy_(feat[:, :, margin:])
+            self._c_f0[:, :, a:].copy_(f0[:, :, margin:])
+        wave, phi_out = self.dec(self._c_feat, f0=self._c_f0, phi=phi, crop=(self.begin_of_output, self.end_of_output))
+        self.last_f0 = self._c_f0
+        wave = audio_io.resample(wave, 16000, self.output_sr, pre_gain_db=self.gain)[0]
+        return wave, phi_out[:, :, self.end_of_output]
+
+    def _front_end_slice(self, samples, f_lo, f_hi):
+        """front end on a slice of the ring: spectrogram of `samples`, frames [f_lo, f_hi) of it through the networks and the
+        match (the frames outside are spoiled by the slice's own reflect padding)"""
+        spec = spectrogram(samples.contiguous())[:, :, f_lo:f_hi].contiguous()
+        content = self.ce(spec)
+        f0 = self.pe.estimate(spec)
+        f0 = ops.pitch_transform_(f0, 1, f0_rate=self.f0_rate, pitch_shift=self.pitch)
+        val, idx = self.lib.search(content, self.k)
+        return merge_gather(val, idx, 1, self.k, self.alpha, self.lib.rows, content), f0
 
     def enable_graph(self):
         """Capture the whole per-step device pipeline (~150 launches) into one hipGraph: the C ABI never allocates or
@@ -71,11 +164,16 @@ class RealtimeConverter:
             self._g_phi.copy_(phi_next)
             self._g_out = wave
         self._g_phi.zero_()
+        self._cache_valid = False          # interior reuse: the captured step is the incremental one; the first real step runs in full
         return self
 
     def step_device(self, ring_f32):
         """ring float32 [1, buffersize*chunk] already on the device -> wave [L] (device); phase carried internally."""
         if getattr(self, "_graph", None) is not None:
+            if self.reuse and not self._cache_valid:             # fills the frame caches the captured (incremental) step reads
+                wave, phi_next = self._device_step(ring_f32, self._g_phi)
+                self._g_phi.copy_(phi_next)
+                return wave
             self._g_in.copy_(ring_f32)
             self._graph.replay()
             return self._g_out

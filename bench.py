@@ -34,7 +34,7 @@ import torch.distributed as dist                           # noqa: E402
 FRAME = 320
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_FP8_TFLOPS = 5000.0           # dense fp8 MFMA peak (block-scaled 32x32x64 e4m3), same table
-ALL_LEGS = ("uncorrelated", "bf16_prefilter", "clustered_library", "context_trim", "pcie_inclusive", "e2e_24k", "config2",
+ALL_LEGS = ("uncorrelated", "bf16_prefilter", "clustered_library", "overlap_shared", "context_trim", "pcie_inclusive", "e2e_24k", "config2",
             "streaming", "cpu_baseline")
 
 
@@ -371,6 +371,23 @@ def main():
             extra["clustered_library"] = guarded(leg)
         finally:
             conv.set_library(library)
+
+    # Optional mode of the build, reported beside the headline and never as `value`: the windows of an utterance overlap by two
+    # thirds, and a content / f0 frame away from its window's edges has the same value in every window that holds it -- so
+    # the front end (spectrogram, f0 estimator, content encoder, kNN match) can run once per utterance instead of once per
+    # window.  Every waveform sample is bitwise that of the headline step (checked here on the whole batch).
+    if "overlap_shared" in legs:
+        def leg():
+            per = n_win // args.utterances
+            sh_step = lambda: conv.convert_windows(windows, k=args.k, window_batch=args.window_batch, share_overlap=per)  # noqa: E731
+            sh_step()
+            ts, out_s = timed_steps(sh_step, 2)
+            return {"ms_per_step": round(ts * 1e3, 2), "frames_per_s": round(frames_per_step / ts, 1),
+                    "useful_frames_per_s": round(useful_frames / ts, 1), "rtf": round(ts / (args.utterances * args.seconds), 6),
+                    "waveforms_bitwise_equal_headline": bool(torch.equal(out_s, out)),
+                    "frames_through_front_end_and_match": conv.last_front_end_frames, "of": frames_per_step,
+                    "note": "front end once per utterance + the two 14-frame edge blocks of every window; pitch transform and decoder per window"}
+        extra["overlap_shared"] = guarded(leg)
 
     # Optional mode of the build, reported beside the headline and never as `value`: inference.py keeps the centre third of
     # every window, so only the frames that can reach it through the decoder need the kNN match (Converter(keep_frames=...),

@@ -87,3 +87,27 @@ def test_match_at_200k_vectors_against_brute_force(rig):
     want = torch.sort(top.indices[:, :4], dim=1).values[safe]
     assert int(safe.sum()) > 11_000 and torch.equal(got, want)
     assert float((val[sel] - top.values[:, :4]).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("n_utt,window_batch", [(8, 64), (64, 128)])
+def test_overlap_sharing_equals_the_per_window_front_end(rig, monkeypatch, n_utt, window_batch):
+    """the windows of an utterance overlap by two thirds (inference.py:94-101): with share_overlap the spectrogram, the f0
+    estimator, the content encoder and the kNN match run once per utterance (+ the two edge blocks of every window) and the
+    windows are assembled by copies -- every waveform sample bitwise as before, ~51 % of the frames through the match"""
+    conv, _, windows = rig
+    monkeypatch.setenv("ALIVE_STREAMS", "3")
+    w = windows[:n_utt * 6]
+    ref = conv.convert_windows(w, k=4, alpha=0.1, pitch_shift=1.0, intonation=1.2, window_batch=window_batch)
+    got = conv.convert_windows(w, k=4, alpha=0.1, pitch_shift=1.0, intonation=1.2, window_batch=window_batch, share_overlap=6)
+    assert torch.equal(got, ref)
+    assert conv.last_front_end_frames == n_utt * (8 * 150 + 6 * 28)
+    assert conv.last_front_end_frames < 0.52 * w.shape[0] * 450
+
+
+def test_overlap_sharing_of_one_utterance(rig):
+    """Converter.convert(share_overlap=True): odd window counts, short chunks (50 frames per chunk), a chunk that is too short
+    falls back to the per-window front end"""
+    conv, _, _ = rig
+    wf = (0.3 * synthetic.make_waveform(16000 * 7 + 123, 41)).to(DEV)
+    for chunk in (48000, 16000, 4800):
+        assert torch.equal(conv.convert(wf, chunk=chunk, k=4, share_overlap=True), conv.convert(wf, chunk=chunk, k=4))

@@ -60,6 +60,20 @@ def test_inference_cli_trim_context_writes_the_same_file(workdir):
     assert torch.equal(a, b)
 
 
+def test_inference_cli_overlap_sharing_writes_the_same_file(workdir):
+    """the CLI shares the front end between the overlapping windows of an utterance by default; --no-share-overlap (the
+    reference's per-window order) must write the same samples"""
+    import inference
+    d, _, _ = workdir
+    base = ["-i", str(d / "inputs"), "-dep", str(d / "decoder.pt"), "-cep", str(d / "content_encoder.pt"), "-f0ep", str(d / "f0_estimator.pt"),
+            "-lib", str(d / "voice_library.pt"), "-d", "cuda", "-c", "16000", "-p", "1.5", "-a", "0.05"]      # 50 frames per chunk
+    inference.main(base + ["-o", str(d / "out_shared")])
+    inference.main(base + ["-o", str(d / "out_per_window"), "--no-share-overlap"])
+    a, _ = audio_io.load(str(d / "out_shared" / "0_utt.wav"))
+    b, _ = audio_io.load(str(d / "out_per_window" / "0_utt.wav"))
+    assert torch.equal(a, b)
+
+
 def test_realtime_converter_matches_oracle(workdir):
     from module.content_encoder import ContentEncoder
     from module.decoder import Decoder
@@ -104,6 +118,40 @@ def test_realtime_cli_replays_a_hipgraph_with_the_same_samples(workdir):
     a, sra = audio_io.load(str(d / "rt_graph.wav"))
     b, _ = audio_io.load(str(d / "rt_eager.wav"))
     assert sra == 16000 and a.shape[1] >= 160 * 50 and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("graph,bs", [(False, 26), (True, 26), (False, 70)])
+def test_realtime_interior_reuse_equals_full_recomputation(graph, bs):
+    """a ring of 78 frames advancing by 3 frames per step.  With interior reuse only the two edge blocks of
+    the ring go through spectrogram / content encoder / f0 estimator / kNN again; the emitted samples must be bitwise those
+    of the step that recomputes the whole ring (realtime_inference.py:130-167), eagerly and from the captured hipGraph."""
+    from module.content_encoder import ContentEncoder
+    from module.decoder import Decoder
+    from module.f0_estimator import F0Estimator
+    from module.realtime import RealtimeConverter
+    lib = synthetic.make_library(3000, 1)
+    chunk, steps = 960, 7                    # bs 26: ring of 78 frames (streaming kernels, 33-frame edge blocks); 70: 210 frames (plane GEMMs, 96-frame blocks)
+    pcm = (synthetic.make_waveform(chunk * (bs + steps), 64)[0].numpy() * 20000).astype(np.int16)
+    outs = {}
+    for reuse in (False, True):
+        rt = RealtimeConverter(ContentEncoder(seed=2), F0Estimator(seed=2), Decoder(seed=2), lib, "cuda", chunk=chunk,
+                               buffersize=bs, f0_rate=0.5, pitch=1.0, alpha=0.1, reuse_interior=reuse)
+        assert rt.reuse == reuse and rt.frames == 3 * bs
+        if graph:
+            rt.enable_graph()
+        waves = []
+        for s in range(steps):                                          # the float waveform of the whole ring, not only its int16 centre
+            ring = torch.from_numpy(pcm[s * chunk:(s + bs) * chunk].astype(np.float32) / 32768)[None].to("cuda")
+            waves.append(rt.step_device(ring).clone())
+        outs[reuse] = torch.stack(waves)
+    assert outs[True].shape[0] == steps and torch.isfinite(outs[True]).all()
+    assert torch.equal(outs[True], outs[False])
+    with pytest.raises(ValueError):                                     # the reference's default ring (24 frames) is too short for it
+        RealtimeConverter(ContentEncoder(seed=2), F0Estimator(seed=2), Decoder(seed=2), lib, "cuda", chunk=960, buffersize=8,
+                          reuse_interior=True)
+    with pytest.raises(ValueError):                                     # 120 frames: no block size stays on the full ring's kernels
+        RealtimeConverter(ContentEncoder(seed=2), F0Estimator(seed=2), Decoder(seed=2), lib, "cuda", chunk=960, buffersize=40,
+                          reuse_interior=True)
 
 
 def test_realtime_rejects_rings_shorter_than_five_frames(workdir):
