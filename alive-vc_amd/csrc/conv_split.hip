@@ -16,6 +16,7 @@
 // buffered per k-step.  Block = 4 waves, tile BM x 128 (BM = 128: 2x2 waves of 64x64; BM = 64: 1x4 waves
 // of 64x32), v_mfma_f32_32x32x16_bf16.
 #include "conv_epilogue.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -30,18 +31,22 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p) { return *(const bf16x8*)p; }
 
 // NP = number of bf16 planes per operand: 2 -> 3 MFMAs per product (~2^-16), 3 -> 6 MFMAs per product (~2^-24, fp32-grade)
+// BM = 256: all 256 output channels of the filter's coarsest scale in ONE block -- a wave owns 64 rows x 128 columns (2 x 4 MFMA
+// tiles, 128 accumulator registers, one block per CU).  Against two 128-row blocks per column tile that stages the X tile
+// (global loads, split, LDS writes) once instead of twice, reads every activation fragment for two row tiles instead of one
+// (0.33 instead of 0.67 LDS fragment reads per MFMA) and halves the X traffic from L2 / HBM.
 template <int BM, int NP>
-__global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float film_ratio) {
-    // wave tile: 32 rows x (128 | 64) columns.  BM = 128: four waves stacked along the rows; BM = 64: 2 x 2.
-    constexpr int NR = BM == 128 ? 4 : 2;         // 32-column MFMA tiles per wave
-    constexpr int MR = 1;
+__global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(AliveConv p, float film_ratio) {
+    // wave tile: (32 | 64) rows x (128 | 64) columns.  BM = 256 / 128: four waves stacked along the rows; BM = 64: 2 x 2.
+    constexpr int NR = BM >= 128 ? 4 : 2;         // 32-column MFMA tiles per wave
+    constexpr int MR = BM == 256 ? 2 : 1;         // 32-row MFMA tiles per wave
 
     // X tile, double buffered: [2 buffers][2 planes][XROWS][PITCH]
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NP * XPLANE];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wrow = BM == 128 ? wid : (wid >> 1);          // 32-row block of this wave
-    const int wcol = BM == 128 ? 0 : (wid & 1) * 64;        // first column of this wave
+    const int wrow = BM >= 128 ? wid : (wid >> 1);          // row block of this wave (32 * MR rows)
+    const int wcol = BM >= 128 ? 0 : (wid & 1) * 64;        // first column of this wave
     const int lr = lane & 31, lh = lane >> 5;
     const int n = blockIdx.z, m0 = blockIdx.y * BM, t0 = blockIdx.x * BN;
     const int co_pad = (p.Co + 15) & ~15;
@@ -55,18 +60,23 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
     // lane (row lr, half lh) loads the 16 B of k-step s, plane pl it feeds to the MFMA.  No LDS staging of the weights,
     // hence no block barrier per k-step: the only barrier left is the one that publishes the next X tile, once per
     // 32-channel block (KW taps x 24 MFMAs per wave).  One k-step is prefetched in registers.
-    int grow = m0 + wrow * 32 + lr;
-    grow = grow < co_pad ? grow : co_pad - 1;
-    const unsigned short* Wrow[NP];
+    const unsigned short* Wrow[MR][NP];
 #pragma unroll
-    for (int pl = 0; pl < NP; ++pl) Wrow[pl] = W16 + ((size_t)pl * co_pad + grow) * K2 + lh * 8;
-    bf16x8 a_cur[2][NP], a_nxt[2][NP];            // [k16 step][plane]
-    auto load_A = [&](int cb, int j, bf16x8 (&a)[2][NP]) {
+    for (int mr = 0; mr < MR; ++mr) {
+        int grow = m0 + wrow * 32 * MR + mr * 32 + lr;
+        grow = grow < co_pad ? grow : co_pad - 1;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) Wrow[mr][pl] = W16 + ((size_t)pl * co_pad + grow) * K2 + lh * 8;
+    }
+    bf16x8 a_cur[MR][2][NP], a_nxt[MR][2][NP];    // [row tile][k16 step][plane]
+    auto load_A = [&](int cb, int j, bf16x8 (&a)[MR][2][NP]) {
         const int kcol = j * p.Ci_pad + cb * BKC;
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+        for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) a[s2][pl] = *(const bf16x8*)(Wrow[pl] + kcol + s2 * 16);
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) a[mr][s2][pl] = *(const bf16x8*)(Wrow[mr][pl] + kcol + s2 * 16);
     };
 
     // ---- X staging: 9 (row, channel-pair) items per thread per 32-channel block.  Everything that does not depend on
@@ -130,19 +140,20 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
 
     // ---- accumulators start at the bias ----
     f32x16 acc[MR][NR];
-    {
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
         f32x16 b16;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            int row = m0 + wrow * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            int row = m0 + wrow * 32 * MR + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             b16[r] = (p.bias != nullptr && row < p.Co) ? p.bias[row] : 0.0f;
         }
 #pragma unroll
-        for (int nn = 0; nn < NR; ++nn) acc[0][nn] = b16;
+        for (int nn = 0; nn < NR; ++nn) acc[mr][nn] = b16;
     }
 
     // weights are prefetched TWO k-steps ahead (fragment-shaped L2 reads have a long tail under load)
-    bf16x8 a_nx2[2][NP];
+    bf16x8 a_nx2[MR][2][NP];
     int pcb = 0, pj = 0;                                       // (block, tap) of the next fragment set to fetch
     auto advance = [&]() { if (++pj == p.KW) { pj = 0; ++pcb; } };
     load_X(0);
@@ -172,16 +183,20 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
 #pragma unroll
                 for (int nn = 0; nn < NR; ++nn) {
 #pragma unroll
-                    for (int sum = NP - 1; sum >= 0; --sum)
+                    for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-                        for (int i = 0; i <= sum; ++i)
-                            acc[0][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[s2][i], bf[sum - i][nn], acc[0][nn], 0, 0, 0);
+                        for (int sum = NP - 1; sum >= 0; --sum)
+#pragma unroll
+                            for (int i = 0; i <= sum; ++i)
+                                acc[mr][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[mr][s2][i], bf[sum - i][nn], acc[mr][nn], 0, 0, 0);
                 }
             }
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
+            for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl) { a_cur[s2][pl] = a_nxt[s2][pl]; a_nxt[s2][pl] = a_nx2[s2][pl]; }
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) { a_cur[mr][s2][pl] = a_nxt[mr][s2][pl]; a_nxt[mr][s2][pl] = a_nx2[mr][s2][pl]; }
         }
         if (more_cb) store_X((cb + 1) & 1);
         __syncthreads();          // next X tile visible; this one is free to be overwritten one block later
@@ -203,12 +218,14 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(AliveConv p, float f
     const bool upvec = p.up >= 4 && (p.up & (p.up - 1)) == 0 && p.up <= PR && (p.Co & (p.up - 1)) == 0;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-        if ((wrow >> 1) == ps) {                     // wave-uniform: the two 32-row waves of this pass deposit their tiles
+        if ((MR == 2 ? wrow : (wrow >> 1)) == ps) {  // wave-uniform: the wave(s) that own the 64 rows of this pass deposit their tiles
 #pragma unroll
-            for (int nn = 0; nn < NR; ++nn)
+            for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    Ct[((wrow & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CP + wcol + nn * 32 + lr] = acc[0][nn][r];
+                for (int nn = 0; nn < NR; ++nn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        Ct[((MR == 2 ? mr : (wrow & 1)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CP + wcol + nn * 32 + lr] = acc[mr][nn][r];
         }
         if (p.Z != nullptr) {
             for (int e = tid; e < PR * 2 * FILM_NF; e += 256) {
@@ -358,7 +375,15 @@ int alive_conv_split_launch(const AliveConv* d, float ratio, hipStream_t s) {
     }
     ALIVE_CHECK_ARG(d->act >= 0 && d->act <= 2, "alive_conv1d(split): activation %d not available on the split kernel", d->act);
     ALIVE_CHECK_ARG(d->Tout <= d->Tin + d->pad_left, "alive_conv1d(split): Tout");
-    if (d->Co > 64) {
+    // measured (tools/bench_conv256.py, 128 windows x 4500 columns): the 256-row tile is 12 - 37 % SLOWER than two 128-row blocks
+    // (k5 + FiLM + residual 2.11 against 1.72 ms, 1x1 1.15 against 0.84): at one block per CU nothing covers the LDS / L2
+    // latencies of the single wave per SIMD, and no other block's main loop runs under the four epilogue passes.  Off by
+    // default; ALIVE_CONV_TILE256=1 selects it (same results bit for bit).
+    static const bool tile256 = getenv("ALIVE_CONV_TILE256") != nullptr && atoi(getenv("ALIVE_CONV_TILE256")) != 0;
+    if (d->Co > 128 && d->Co % 256 == 0 && d->precision == 1 && tile256) {
+        dim3 g(cdiv(d->Tout, BN), d->Co / 256, d->N);
+        conv_split_kernel<256, 2><<<g, 256, 0, s>>>(*d, ratio);
+    } else if (d->Co > 64) {
         dim3 g(cdiv(d->Tout, BN), cdiv(d->Co, 128), d->N);
         if (d->precision == 2) conv_split_kernel<128, 3><<<g, 256, 0, s>>>(*d, ratio);
         else conv_split_kernel<128, 2><<<g, 256, 0, s>>>(*d, ratio);

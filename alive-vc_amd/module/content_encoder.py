@@ -13,14 +13,17 @@ class ContentEncoder(PackedNet):
     _schema = staticmethod(schema.content_encoder_schema)
     _pack = staticmethod(pack_content_encoder)
 
-    def forward(self, x):
-        """x [N, 641, T] -> [N, 768, T]"""
+    def forward(self, x, out=None):
+        """x [N, 641, T] -> [N, 768, T]   (out: a contiguous [N, 768, T] tensor to write into, e.g. a batch slice)"""
         x = x.contiguous().float()
         n, c, t = x.shape
         if c != schema.N_BINS:
             raise ValueError(f"ContentEncoder expects 641 spectrogram bins, got {c}")
         L = nat.lib()
-        out = torch.empty(n, schema.CONTENT_DIM, t, device=x.device)
+        if out is None:
+            out = torch.empty(n, schema.CONTENT_DIM, t, device=x.device)
+        elif tuple(out.shape) != (n, schema.CONTENT_DIM, t) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("ContentEncoder: out must be a contiguous fp32 [N, 768, T] tensor")
         ws = self._ws.get(L.alive_content_encoder_workspace_bytes(n, t), x.device)
         nat.check(L.alive_content_encoder(self.table().array, nat.ptr(x), n, t, nat.ptr(out), nat.ptr(ws), nat.stream()),
                   "alive_content_encoder")

@@ -35,7 +35,7 @@ class Decoder(PackedNet):
     _schema = staticmethod(schema.decoder_schema)
     _pack = staticmethod(pack_decoder)
 
-    def forward(self, x, f0, phi=0, harmonics_scale=1, crop=(0, -1), phi_col=None):
+    def forward(self, x, f0, phi=0, harmonics_scale=1, crop=(0, -1), phi_col=None, out=None):
         if harmonics_scale != 1:
             # the reference multiplies the oscillator's return TUPLE by this value (decoder.py:207):
             # any value other than the int 1 raises there as well
@@ -60,7 +60,9 @@ class Decoder(PackedNet):
             phi_col = crop[1]
         if phi_col < 0:
             phi_col += lw
-        wave = torch.empty(n, lw, device=x.device)
+        wave = out if out is not None else torch.empty(n, lw, device=x.device)         # out: e.g. a slice of the batch's output
+        if tuple(wave.shape) != (n, lw) or wave.dtype != torch.float32 or not wave.is_contiguous():
+            raise ValueError("Decoder: out must be a contiguous fp32 [N, 320 * Lf] tensor")
         phi_out = torch.empty(n, schema.NUM_HARMONICS, device=x.device)
         ws = self._ws.get(L.alive_decoder_workspace_bytes(n, lf), x.device)
         nat.check(L.alive_decoder_forward(self.table().array, nat.ptr(x), nat.ptr(f0), nat.ptr(phi_in), int(crop[0]),

@@ -13,14 +13,16 @@ class F0Estimator(PackedNet):
     _schema = staticmethod(schema.f0_estimator_schema)
     _pack = staticmethod(pack_f0_estimator)
 
-    def estimate(self, x, downsample_factor=1):
-        """x [N, 641, T] -> f0 [N, 1, T]"""
+    def estimate(self, x, downsample_factor=1, out=None):
+        """x [N, 641, T] -> f0 [N, 1, T]   (out: a contiguous [N, 1, T] tensor to write into)"""
         x = x.contiguous().float()
         n, c, t = x.shape
         if c != schema.N_BINS:
             raise ValueError(f"F0Estimator expects 641 spectrogram bins, got {c}")
         L = nat.lib()
-        f0 = torch.empty(n, 1, t, device=x.device)
+        f0 = out if out is not None else torch.empty(n, 1, t, device=x.device)
+        if tuple(f0.shape) != (n, 1, t) or f0.dtype != torch.float32 or not f0.is_contiguous():
+            raise ValueError("F0Estimator: out must be a contiguous fp32 [N, 1, T] tensor")
         ws = self._ws.get(L.alive_f0_estimate_workspace_bytes(n, t), x.device)
         nat.check(L.alive_f0_estimate(self.table().array, nat.ptr(x), n, t, nat.ptr(f0), nat.ptr(ws), nat.stream()),
                   "alive_f0_estimate")

@@ -66,16 +66,16 @@ class Converter:
         self.library = tokens if isinstance(tokens, PackedLibrary) else PackedLibrary(tokens[0].to(self.device))
         return self
 
-    def features(self, windows, pitch_shift=0.0, intonation=1.0, f0_rate=1.0, frames=None):
+    def features(self, windows, pitch_shift=0.0, intonation=1.0, f0_rate=1.0, frames=None, out=None):
         """spectrogram -> f0 (+ per-window pitch transform) and content features   (inference.py:112-128).
         frames = (lo, hi): content features are only needed on [lo, hi) (context trimming): the encoder runs on that range
         plus its own receptive field; the other frames come back as zeros.  f0 always covers the whole window (the pitch
         transform uses the window's mean pitch, the oscillator accumulates phase from the first frame)."""
         spec = spectrogram(windows)
-        f0 = self.pe.estimate(spec)
+        f0 = self.pe.estimate(spec, out=None if out is None else out[1])     # out = (feat, f0) batch slices to write into
         f0 = ops.pitch_transform_(f0, 0, f0_rate=f0_rate, pitch_shift=pitch_shift, intonation=intonation)
         if frames is None:
-            return self.ce(spec), f0
+            return self.ce(spec, out=None if out is None else out[0]), f0
         lf = spec.shape[2]
         a, b = max(0, frames[0] - CE_MARGIN), min(lf, frames[1] + CE_MARGIN)
         feat = torch.zeros(spec.shape[0], 768, lf, device=spec.device)
@@ -153,11 +153,11 @@ class Converter:
             for j, i in enumerate(range(0, n, window_batch)):
                 st = side[j % len(side)] if side else None
                 if st is None:
-                    out[i:i + window_batch], _ = self.dec(feat[i:i + window_batch], f0[i:i + window_batch])
+                    self.dec(feat[i:i + window_batch], f0[i:i + window_batch], out=out[i:i + window_batch])
                     continue
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
-                    out[i:i + window_batch], _ = self.dec(feat[i:i + window_batch], f0[i:i + window_batch])
+                    self.dec(feat[i:i + window_batch], f0[i:i + window_batch], out=out[i:i + window_batch])
             for st in side:
                 cur.wait_stream(st)
             return out
@@ -183,6 +183,10 @@ class Converter:
                 cur.wait_stream(st)
 
         def enc(i):
+            if rng is None:                                 # the networks write straight into the batch's slices
+                self.features(windows[i:i + window_batch], pitch_shift, intonation, f0_rate,
+                              out=(feat[i:i + window_batch], f0[i:i + window_batch]))
+                return
             feat[i:i + window_batch], f0[i:i + window_batch] = self.features(windows[i:i + window_batch], pitch_shift,
                                                                            intonation, f0_rate, frames=rng)
         batches(enc)
@@ -194,7 +198,7 @@ class Converter:
             out = torch.empty_like(windows)
 
             def dec(i):
-                out[i:i + window_batch], _ = self.dec(feat[i:i + window_batch], f0[i:i + window_batch])
+                self.dec(feat[i:i + window_batch], f0[i:i + window_batch], out=out[i:i + window_batch])
             batches(dec)
             return out
         # decode the matched range only (the oscillator still accumulates phase over the whole window); samples outside it
