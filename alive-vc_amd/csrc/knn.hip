@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
                                                           int* __restrict__ out_idx, const int* __restrict__ frame_list,
                                                           const int* __restrict__ gate_cnt, int gate_lo, int gate_hi,
                                                           int* __restrict__ flag_list, int* __restrict__ flag_cnt, float zsig,
-                                                          int list_len, float pre_scale) {
+                                                          int list_len, float pre_scale, float sd_prior) {
     const int lane = threadIdx.x & 63;
     const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // candidate lists are indexed by slot
     int gc;
@@ -692,11 +692,35 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
         if (list_len > 8) v = fminf(v, __shfl_xor(v, 8));
         return v;
     };
+    // Pruning (certified searches only): a candidate whose prefilter score lies more than 2 z sigma below the k-th best
+    // prefilter score cannot reach the exact top-k unless two score errors beyond z sigma coincide; it is not rescored (a
+    // 3-KB row gather saved: the kernel is bound by them) and counts, like every row that was never a candidate, into c_cut --
+    // so the certificate below still decides whether the frame's result stands.  At least MIN_RESCORE candidates are kept for
+    // the error statistics.
+    constexpr int MIN_RESCORE = 16;
+    const float prune = certify ? 2.0f * zsig * sd_prior / pre_scale : INFINITY;     // in prefilter-score units
     if (R <= 64) {
         if (lane < R) my_idx = ci[lane];
         if (certify) {
-            my_pre = lane < R ? cv[lane] : -INFINITY;
-            c_cut = list_floor((lane < R && my_idx >= 0) ? my_pre : -INFINITY);
+            my_pre = (lane < R && my_idx >= 0) ? cv[lane] : -INFINITY;
+            c_cut = list_floor(my_pre);
+            // k-th and MIN_RESCORE-th largest prefilter score of the frame (wave-wide, by removal)
+            float rest = my_pre, sk = -INFINITY, s16 = -INFINITY;
+            for (int j = 0; j < MIN_RESCORE; ++j) {
+                float m = rest;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+                if (j == k - 1) sk = m;
+                s16 = m;
+                const unsigned long long hit = __builtin_amdgcn_ballot_w64(rest == m && m > -INFINITY);
+                if (hit == 0) break;                                   // fewer candidates than that
+                if (lane == (int)__builtin_ctzll(hit)) rest = -INFINITY;
+            }
+            const float cut = fminf(sk - prune, s16);                  // keep everything down to the cut, and at least 16
+            if (my_pre < cut) {
+                c_cut = fmaxf(c_cut, my_pre);
+                my_idx = -1;
+            }
         }
     } else {
         // keep the 64 best bf16 scores: R/64 candidates per lane in registers (R <= 1024)
@@ -712,6 +736,7 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
             if (id[j] < 0) v[j] = -INFINITY;
             if (certify) c_cut = fmaxf(c_cut, list_floor(v[j]));
         }
+        float sk = -INFINITY;              // k-th best prefilter score of the frame
         for (int sel = 0; sel < 64; ++sel) {
             float bv = v[0];
             int bj = 0;
@@ -725,6 +750,8 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
             int win = wave_argbest(bv, bid);
             int widx = __shfl(bid, win);
             float wval = __shfl(bv, win);
+            if (sel == k - 1) sk = wval;
+            if (sel >= MIN_RESCORE && wval < sk - prune) break;        // wave-uniform: the rest stays in v[] and counts into c_cut
             if (lane == sel) { my_idx = (wval > -INFINITY) ? widx : -1; my_pre = wval; }
             if (lane == win) {
 #pragma unroll
@@ -787,7 +814,7 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
         const float n = wave_sum(okc ? 1.0f : 0.0f);
         err_mu = wave_sum(e) / fmaxf(n, 1.0f);
         const float d = okc ? e - err_mu : 0.0f;
-        err_sd = sqrtf(wave_sum(d * d) / fmaxf(n, 1.0f));
+        err_sd = fmaxf(sqrtf(wave_sum(d * d) / fmaxf(n, 1.0f)), sd_prior);      // never below the stage's typical error
         c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 16));
         c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 32));
         c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 1)); c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 2));
@@ -1300,6 +1327,8 @@ constexpr int MAX_SPLIT8 = 1024 / KP8;    // the rescoring kernel takes up to 10
 constexpr int FCAP = 16384;               // tier 1 of the bf16 re-search: up to this many flagged frames ...
 constexpr int FPLAN = 4096;               // ... with the library split chosen for this many (blocks past the count exit at once)
 constexpr float CERT_Z = 7.0f;            // sigmas of candidate-score error the certificates allow for
+constexpr float SD_PRIOR8 = 1.5e-3f;      // typical error (cosine units) of an fp8 / a bf16 candidate score: floor of the per-frame estimate
+constexpr float SD_PRIOR16 = 8.0e-5f;
 constexpr int PROBE_N = 1024;             // frames of the adaptive probe (fp8 searches of >= PROBE_MIN_T frames)
 constexpr int64_t PROBE_MIN_T = 16384;
 constexpr int PROBE_NUM = 2, PROBE_DEN = 5;   // bf16 first when more than 40 % of the sample fail the fp8 certificate:
@@ -1459,7 +1488,7 @@ static void bf16_tiers_launch(const SearchWs& w, const void* lib_bf16, const flo
     knn_score_kernel<<<dim3((unsigned)(fcap / FT), w.pt.split), 256, SCORE_LDS, s>>>(
         w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.cv1, w.ci1, cnt0, 0, fcap, 1);
     knn_rescore_kernel<<<(unsigned)((fcap + 3) / 4), 256, 0, s>>>(w.cv1, w.ci1, w.pt.P, KP, w.s_f32, rows_f32, norms, fcap, idx_base, k,
-                                                                 out_val, out_idx, w.list0, cnt0, 0, fcap, w.list1, cnt1, CERT_Z, KH, 1.0f);
+                                                                 out_val, out_idx, w.list0, cnt0, 0, fcap, w.list1, cnt1, CERT_Z, KH, 1.0f, SD_PRIOR16);
     if (w.p16.Tt_pad > fcap) {
         gather_frames_kernel<<<(unsigned)w.p16.Tt_pad, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, fcap, 0x7fffffff, w.s_c);
         knn_score_kernel<<<dim3((unsigned)(w.p16.Tt_pad / FT), w.p16.split), 256, SCORE_LDS, s>>>(
@@ -1467,7 +1496,7 @@ static void bf16_tiers_launch(const SearchWs& w, const void* lib_bf16, const flo
             0x7fffffff, 1);
         knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, w.p16.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                    out_val, out_idx, w.list0, cnt0, fcap, 0x7fffffff, w.list1, cnt1,
-                                                                   CERT_Z, KH, 1.0f);
+                                                                   CERT_Z, KH, 1.0f, SD_PRIOR16);
     }
     knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, w.list1, cnt1, out_val, out_idx, s);
 }
@@ -1502,7 +1531,7 @@ extern "C" int alive_knn_search(const float* src, int N, int T, const void* lib_
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
     knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, p.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                out_val, out_idx, nullptr, nullptr, 0, 0, w.list1, w.stats + ST_FLAG16,
-                                                               CERT_Z, KH, 1.0f);
+                                                               CERT_Z, KH, 1.0f, SD_PRIOR16);
     knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, w.list1, w.stats + ST_FLAG16, out_val, out_idx, s);
     ALIVE_CHECK_LAUNCH("alive_knn_search");
     return ALIVE_OK;
@@ -1543,7 +1572,7 @@ extern "C" int alive_knn_search_fp8(const float* src, int N, int T, const void* 
         knn_rescore_kernel<<<(unsigned)((w.probe_n + 3) / 4), 256, 0, s>>>(w.cvp, w.cip, w.pp.P, KP8, w.s_f32, rows_f32, norms, w.probe_n,
                                                                           idx_base, k, w.p_val, w.p_idx, w.p_list, nullptr, 0, 0,
                                                                           w.p_list + w.probe_pad, w.stats + ST_PROBE_CNT, CERT_Z, KH8,
-                                                                          1.0f / (F8_SCALE * F8_SCALE));
+                                                                          1.0f / (F8_SCALE * F8_SCALE), SD_PRIOR8);
         probe_decide_kernel<<<1, 1, 0, s>>>(w.stats, w.probe_n, PROBE_NUM, PROBE_DEN);
     }
     // ---- mode 0: fp8 first ----
@@ -1553,7 +1582,7 @@ extern "C" int alive_knn_search_fp8(const float* src, int N, int T, const void* 
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
     knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, p.P, KP8, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                out_val, out_idx, nullptr, mode, -1, 0, w.list0, w.stats + ST_FLAG8,
-                                                               CERT_Z, KH8, 1.0f / (F8_SCALE * F8_SCALE));
+                                                               CERT_Z, KH8, 1.0f / (F8_SCALE * F8_SCALE), SD_PRIOR8);
     // ---- mode 1: bf16 first (every frame into list0) ----
     if (w.probe_n > 0) flag_all_kernel<<<(unsigned)((Tt + 255) / 256), 256, 0, s>>>(w.list0, w.stats + ST_FLAG8, Tt, mode, 0, 1);
     bf16_tiers_launch(w, lib_bf16, rows_f32, norms, M, Tt, idx_base, k, out_val, out_idx, s);

@@ -237,3 +237,26 @@ def test_realtime_graph_capture_equals_eager(workdir):
         outs[mode] = np.concatenate([o for o in got if o is not None])
     assert outs["eager"].shape == (6 * chunk,)
     assert np.array_equal(outs["eager"], outs["graph"])
+
+
+def test_bench_two_ranks_gloo_same_device():
+    """`python bench.py --gpus 2` launches its own ranks (torch.distributed.run) and prints ONE JSON line; with
+    --backend gloo --same-device both ranks share the box's single GPU, which exercises the whole multi-rank path: weak-scaling
+    headline (max over ranks) and BASELINE config 4 end to end -- feature all-gather, library-sharded match, list all-gather,
+    merge -- checked on the device against the unsharded search and the replicated path (bitwise)."""
+    import json
+    import subprocess
+    env = dict(os.environ, ALIVE_STREAMS="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device",
+                        "--library-size", "30000", "--utterances", "3", "--seconds", "4", "--steps", "1", "--warmup", "1",
+                        "--window-batch", "8"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["ranks"] == {"backend": "gloo", "gloo_ranks": 2, "same_device": True}
+    sk = d["sharded_knn"]
+    assert sk["equals_unsharded"] is True and sk["lists_equal_unsharded"] and sk["waveforms_equal_replicated"], sk
+    assert sk["shards"] == 2 and sk["rows_per_shard"] == [15000, 15000] and sum(sk["windows_per_rank"]) == sk["global_windows"]
+    assert sk["exchange_bytes_received_per_rank"]["frames_allgather_received"] > 0
