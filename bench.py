@@ -52,7 +52,14 @@ def launch_ranks(args):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    # stdout of this process is the contract's ONE JSON line: everything else the ranks (or their libraries: gloo announces
+    # its peers on stdout) print goes to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        ok = line.startswith("{") and line.rstrip().endswith("}")
+        (sys.stdout if ok else sys.stderr).write(line)
+        (sys.stdout if ok else sys.stderr).flush()
+    return proc.wait()
 
 
 # --------------------------------------------------------------------------------------- inputs
