@@ -105,6 +105,44 @@ def test_realtime_converter_matches_oracle(workdir):
     assert np.sqrt(np.mean((got - want) ** 2)) / 32768 < 1e-3
 
 
+def test_realtime_converter_with_resampling_and_gains_matches_oracle(workdir):
+    """the streaming loop at 24 kHz in / 24 kHz out with input and output gains (realtime_inference.py:139-187): device
+    resampler on both edges of every step (csrc/audio.hip), gain order as in the reference (resample -> gain on the way in,
+    gain -> resample on the way out), centre chunk cut at the output rate"""
+    from module.content_encoder import ContentEncoder
+    from module.decoder import Decoder
+    from module.f0_estimator import F0Estimator
+    from module.realtime import RealtimeConverter
+    d, sds, _ = workdir
+    lib = synthetic.make_library(1000, 1)
+    chunk, bs, sr = 480, 12, 24000                       # 20 ms chunks; ring of 5760 samples at 24 kHz = 12 frames at 16 kHz
+    rt = RealtimeConverter(ContentEncoder(seed=2), F0Estimator(seed=2), Decoder(seed=2), lib, "cuda", chunk=chunk, buffersize=bs,
+                           input_sr=sr, output_sr=sr, f0_rate=0.5, pitch=1.0, gain=-2.0, input_gain=3.0)
+    pcm = (synthetic.make_waveform(chunk * (bs + 3), 65)[0].numpy() * 12000).astype(np.int16)
+    internal_chunk = int(chunk * (16000 / sr))
+    center16 = int(internal_chunk * bs) // 2
+    begin, end = center16 - internal_chunk // 2, center16 + internal_chunk // 2
+    assert (begin, end) == (rt.begin_of_output, rt.end_of_output)
+    phi, outs, refs = 0, [], []
+    for s in range(bs + 3):
+        o = rt.step(pcm[s * chunk:(s + 1) * chunk])
+        if s < bs:
+            assert o is None
+            continue
+        ring = torch.from_numpy(pcm[(s - bs + 1) * chunk:(s + 1) * chunk].astype(np.float32) / 32768)[None]
+        x = O.gain(O.resample(ring, sr, 16000), 3.0)
+        wave, phi = O.realtime_step(sds["content_encoder.pt"], sds["f0_estimator.pt"], sds["decoder.pt"], x, lib, phi,
+                                    begin, end, f0_rate=0.5, pitch_shift=1.0)
+        y = O.resample(O.gain(wave, -2.0), 16000, sr)[0]
+        ref = (y.numpy() * 32768).astype(np.int16)
+        c = bs * chunk // 2
+        refs.append(ref[c - chunk // 2: c + chunk // 2])
+        outs.append(o)
+    got, want = np.concatenate(outs).astype(np.float64), np.concatenate(refs).astype(np.float64)
+    assert got.shape == want.shape == (3 * chunk,)
+    assert np.sqrt(np.mean((got - want) ** 2)) / 32768 < 1e-3
+
+
 def test_realtime_cli_replays_a_hipgraph_with_the_same_samples(workdir):
     """realtime_inference.py (BASELINE config 5: -c 160 -b 16, hipGraph-captured per-chunk pipeline) streaming a 24 kHz file:
     the default (captured graph) and --no-graph runs write identical files"""
