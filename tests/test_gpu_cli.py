@@ -48,6 +48,34 @@ def test_inference_cli_matches_oracle(workdir):
     assert err < 1e-3, err
 
 
+def test_inference_cli_target_utterance_stereo_input_gain_and_normalize(workdir):
+    """inference.py:69-84,88-93,136-142: a target utterance (-t) whose content frames join the library in front of the -lib
+    tokens, a stereo 22.05 kHz input (normalised over both channels, then averaged), output gain and -norm"""
+    import inference
+    d, sds, _ = workdir
+    os.makedirs(d / "in_st", exist_ok=True)
+    st = torch.cat([synthetic.make_waveform(22050, 92) * 0.4, synthetic.make_waveform(22050, 93) * 0.7], 0)      # [2, 1 s]
+    audio_io.save(str(d / "in_st" / "pair.wav"), st, 22050)
+    tgt_wav = synthetic.make_waveform(16000 * 2, 94) * 0.6                                                       # 2 s at 16 kHz
+    audio_io.save(str(d / "target.wav"), tgt_wav, 16000)
+    inference.main(["-i", str(d / "in_st"), "-o", str(d / "out_st"), "-dep", str(d / "decoder.pt"), "-cep", str(d / "content_encoder.pt"),
+                    "-f0ep", str(d / "f0_estimator.pt"), "-lib", str(d / "voice_library.pt"), "-t", str(d / "target.wav"),
+                    "-d", "cuda", "-c", "6400", "-g", "-3.0", "-norm", "True", "-k", "5"])
+    out, sr = audio_io.load(str(d / "out_st" / "0_pair.wav"))
+    assert sr == 22050 and out.shape == (1, 22050)
+    ce, pe, dec = sds["content_encoder.pt"], sds["f0_estimator.pt"], sds["decoder.pt"]
+    tw = tgt_wav / tgt_wav.abs().max()
+    lib = torch.cat([O.content_encoder(ce, O.spectrogram(tw[:1])), synthetic.make_library(512, 5)], dim=2)
+    wf = O.resample(st, 22050, 16000)
+    wf = (wf / wf.abs().max()).mean(dim=0, keepdim=True)
+    ref = O.convert_utterance(ce, pe, dec, wf, lib, chunk=6400, k=5, alpha=0.0)
+    ref = O.gain(O.resample(ref, 16000, 22050), -3.0)
+    peak = ref.abs().max().item()
+    ref = ref / peak
+    err = (out - ref).pow(2).mean().sqrt().item()
+    assert err < 1e-3 / peak, (err, peak)        # -norm rescales the waveform to peak 1: the 1e-3 bar scales with it
+
+
 def test_inference_cli_trim_context_writes_the_same_file(workdir):
     import inference
     d, _, _ = workdir
