@@ -47,8 +47,7 @@ void convnext_names(Names& n, const std::string& p, bool adaptive) {
 
 const Names& names_of(int model) {
     static Names ce, pe, dec;
-    static bool init = false;
-    if (!init) {
+    static const bool init = [&]() {                  // function-local static: initialised once, thread-safe (C++11)
         ce.add("input.W"); ce.add("input.b");
         for (int i = 0; i < 4; ++i) convnext_names(ce, "mid" + std::to_string(i), false);
         ce.add("output.W"); ce.add("output.b");
@@ -80,8 +79,9 @@ const Names& names_of(int model) {
                 }
         }
         dec.add("flt.out.W"); dec.add("flt.out.b");
-        init = true;
-    }
+        return true;
+    }();
+    (void)init;
     return model == 0 ? ce : (model == 1 ? pe : dec);
 }
 
