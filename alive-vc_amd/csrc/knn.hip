@@ -1399,8 +1399,8 @@ __global__ __launch_bounds__(256) void dedup_pass_kernel(const float* __restrict
     else atomicAdd(undecided, 1);
 }
 
-// optional instrumentation: events recorded on the search stream around the scoring kernel only
-static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+// optional instrumentation (the *_timed entry points): events recorded on the search stream around the first-stage scoring
+// kernel only; passed down explicitly, no state in the library
 
 struct SearchPlan {
     int64_t Tt, Tt_pad;
@@ -1512,7 +1512,7 @@ extern "C" int alive_library_pack(const float* tokens, int64_t M, int Dd, void* 
 
 static int knn_scan_launch(const float* src, int T, int64_t Tt, const float* rows_f32, const float* norms, int64_t M,
                            int64_t idx_base, int k, float* s_f32, unsigned short* s_bf16, float* pv, int* pi, float* out_val,
-                           int32_t* out_idx, hipStream_t s) {
+                           int32_t* out_idx, hipStream_t s, hipEvent_t g_ev_start, hipEvent_t g_ev_stop) {
     src_prep_small_kernel<<<(unsigned)Tt, 256, 0, s>>>(src, T, Tt, s_f32, s_bf16);
     int blocks = (int)((M + 4 * SCAN_WAVES - 1) / (4 * SCAN_WAVES));          // >= 4 rows per wave
     if (blocks > SCAN_MAX_LISTS / SCAN_WAVES) blocks = SCAN_MAX_LISTS / SCAN_WAVES;
@@ -1613,16 +1613,16 @@ static void bf16_tiers_launch(const SearchWs& w, const void* lib_bf16, const flo
 // Search with the bf16 MFMA as the first candidate stage: every frame's candidate set is certified against the bf16 score
 // error measured on its own rescored candidates; frames that fail go through the exact fp32 scan.  k > 8 (deeper than a
 // half-list of the candidate stage): the exact scan for every frame.
-extern "C" int alive_knn_search(const float* src, int N, int T, const void* lib_bf16, const float* rows_f32,
-                                const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
-                                void* ws, void* stream) {
+static int knn_search_impl(const float* src, int N, int T, const void* lib_bf16, const float* rows_f32,
+                           const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
+                           void* ws, void* stream, hipEvent_t g_ev_start, hipEvent_t g_ev_stop) {
     ALIVE_CHECK_ARG(src && lib_bf16 && rows_f32 && norms && out_val && out_idx && ws, "alive_knn_search: null pointer");
     if (int rc = check_search_args("alive_knn_search", src, ws, N, T, k, M)) return rc;
     const int64_t Tt = (int64_t)N * T;
     const SearchWs w = ws_layout(ws, Tt, M, k);
     hipStream_t s = (hipStream_t)stream;
     if (Tt * k <= 64 && M <= SCAN_ROWS_MAX)            // a handful of frames: exact fp32 scan of the rows, no candidate stage
-        return knn_scan_launch(src, T, Tt, rows_f32, norms, M, idx_base, k, w.s_f32, w.s_bf16, w.pv, w.pi, out_val, out_idx, s);
+        return knn_scan_launch(src, T, Tt, rows_f32, norms, M, idx_base, k, w.s_f32, w.s_bf16, w.pv, w.pi, out_val, out_idx, s, g_ev_start, g_ev_stop);
     if (int rc = lds_optin("alive_knn_search")) return rc;
     (void)hipMemsetAsync(w.stats, 0, ST_WORDS * sizeof(int), s);
     src_prep_launch(w, src, T, Tt, s);
@@ -1655,18 +1655,31 @@ extern "C" int alive_knn_search(const float* src, int N, int T, const void* lib_
 //           with the bf16 error statistics -> list1;
 //   exact   the frames of list1 through the brute-force fp32 scan.
 // All of it is launched up front -- the kernels read the counters on the device and return at once when a tier is empty.
-extern "C" int alive_knn_search_fp8(const float* src, int N, int T, const void* lib_f8, const void* lib_bf16, const float* rows_f32,
-                                    const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
-                                    void* ws, void* stream) {
+extern "C" int alive_knn_search(const float* src, int N, int T, const void* lib_bf16, const float* rows_f32,
+                                const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
+                                void* ws, void* stream) {
+    return knn_search_impl(src, N, T, lib_bf16, rows_f32, norms, M, idx_base, k, out_val, out_idx, ws, stream, nullptr, nullptr);
+}
+extern "C" int alive_knn_search_timed(const float* src, int N, int T, const void* lib_bf16, const float* rows_f32,
+                                      const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
+                                      void* ws, void* stream, void* ev_start, void* ev_stop) {
+    return knn_search_impl(src, N, T, lib_bf16, rows_f32, norms, M, idx_base, k, out_val, out_idx, ws, stream,
+                           (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
+}
+
+static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f8, const void* lib_bf16, const float* rows_f32,
+                               const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
+                               void* ws, void* stream, hipEvent_t g_ev_start, hipEvent_t g_ev_stop) {
     ALIVE_CHECK_ARG(src && lib_f8 && lib_bf16 && rows_f32 && norms && out_val && out_idx && ws, "alive_knn_search_fp8: null pointer");
     if (int rc = check_search_args("alive_knn_search_fp8", src, ws, N, T, k, M)) return rc;
     const int64_t Tt = (int64_t)N * T;
-    if (k > KH) return alive_knn_search(src, N, T, lib_bf16, rows_f32, norms, M, idx_base, k, out_val, out_idx, ws, stream);
+    if (k > KH)
+        return knn_search_impl(src, N, T, lib_bf16, rows_f32, norms, M, idx_base, k, out_val, out_idx, ws, stream, g_ev_start, g_ev_stop);
     const SearchWs w = ws_layout(ws, Tt, M, k);
     const SearchPlan& p = w.p8;
     hipStream_t s = (hipStream_t)stream;
     if (Tt * k <= 64 && M <= SCAN_ROWS_MAX)            // streaming ring: the exact scan, no candidate stage at all
-        return knn_scan_launch(src, T, Tt, rows_f32, norms, M, idx_base, k, w.s_f32, w.s_bf16, w.pv, w.pi, out_val, out_idx, s);
+        return knn_scan_launch(src, T, Tt, rows_f32, norms, M, idx_base, k, w.s_f32, w.s_bf16, w.pv, w.pi, out_val, out_idx, s, g_ev_start, g_ev_stop);
     if (int rc = lds_optin("alive_knn_search_fp8")) return rc;
     (void)hipMemsetAsync(w.stats, 0, ST_WORDS * sizeof(int), s);
     src_prep_launch(w, src, T, Tt, s);
@@ -1699,18 +1712,24 @@ extern "C" int alive_knn_search_fp8(const float* src, int N, int T, const void* 
     return ALIVE_OK;
 }
 
+extern "C" int alive_knn_search_fp8(const float* src, int N, int T, const void* lib_f8, const void* lib_bf16, const float* rows_f32,
+                                    const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
+                                    void* ws, void* stream) {
+    return knn_search_fp8_impl(src, N, T, lib_f8, lib_bf16, rows_f32, norms, M, idx_base, k, out_val, out_idx, ws, stream, nullptr, nullptr);
+}
+extern "C" int alive_knn_search_fp8_timed(const float* src, int N, int T, const void* lib_f8, const void* lib_bf16, const float* rows_f32,
+                                          const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
+                                          void* ws, void* stream, void* ev_start, void* ev_stop) {
+    return knn_search_fp8_impl(src, N, T, lib_f8, lib_bf16, rows_f32, norms, M, idx_base, k, out_val, out_idx, ws, stream,
+                               (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
+}
+
 // device pointer (inside ws) to the counters of the last search on this workspace, int[8]:
 //   [0] frames the fp8 certificate sent to the bf16 stage (all frames when the probe chose bf16 first)
 //   [1] frames the bf16 certificate sent to the exact scan
 //   [2] frames of the probe sample, [3] of which failed the fp8 certificate, [4] 1 = the probe chose bf16 first
 extern "C" const int* alive_knn_search_stats(int N, int T, int64_t M, void* ws) {
     return ws_layout(ws, (int64_t)N * T, M, 4).stats;
-}
-
-extern "C" int alive_knn_set_timing_events(void* ev_start, void* ev_stop) {
-    g_ev_start = (hipEvent_t)ev_start;
-    g_ev_stop = (hipEvent_t)ev_stop;
-    return ALIVE_OK;
 }
 
 extern "C" int alive_knn_merge_gather(const float* cand_val, const int32_t* cand_idx, int n_shards, int k, double alpha,

@@ -54,22 +54,23 @@ class PackedLibrary:
                       "alive_library_pack_fp8")
         self._ws = nat.Workspace()
 
-    def search(self, source, k):
-        """exact top-k of this shard: (val[Tt,k] fp32 desc, idx[Tt,k] int32 global)."""
+    def search(self, source, k, events=None):
+        """exact top-k of this shard: (val[Tt,k] fp32 desc, idx[Tt,k] int32 global).
+        events = (start, stop): torch.cuda.Event pair recorded around the first-stage scoring kernel (measurement)."""
         n, d, t = source.shape
         L = nat.lib()
         val = torch.empty(n * t, k, dtype=torch.float32, device=source.device)
         idx = torch.empty(n * t, k, dtype=torch.int32, device=source.device)
         ws = self._ws.get(L.alive_knn_workspace_bytes(n * t, self.M), source.device)
+        ev = (None, None) if events is None else (events[0].cuda_event, events[1].cuda_event)
         if self.lib_f8 is not None:
-            nat.check(L.alive_knn_search_fp8(nat.ptr(source), n, t, nat.ptr(self.lib_f8), nat.ptr(self.lib_bf16),
-                                             nat.ptr(self.rows), nat.ptr(self.norms), self.M, self.idx_base, k,
-                                             nat.ptr(val), nat.ptr(idx), nat.ptr(ws), nat.stream()), "alive_knn_search_fp8")
-            self._last = (n, t, k, ws)
-            return val, idx
-        nat.check(L.alive_knn_search(nat.ptr(source), n, t, nat.ptr(self.lib_bf16), nat.ptr(self.rows),
-                                     nat.ptr(self.norms), self.M, self.idx_base, k, nat.ptr(val), nat.ptr(idx),
-                                     nat.ptr(ws), nat.stream()), "alive_knn_search")
+            nat.check(L.alive_knn_search_fp8_timed(nat.ptr(source), n, t, nat.ptr(self.lib_f8), nat.ptr(self.lib_bf16),
+                                                   nat.ptr(self.rows), nat.ptr(self.norms), self.M, self.idx_base, k,
+                                                   nat.ptr(val), nat.ptr(idx), nat.ptr(ws), nat.stream(), *ev), "alive_knn_search_fp8")
+        else:
+            nat.check(L.alive_knn_search_timed(nat.ptr(source), n, t, nat.ptr(self.lib_bf16), nat.ptr(self.rows),
+                                               nat.ptr(self.norms), self.M, self.idx_base, k, nat.ptr(val), nat.ptr(idx),
+                                               nat.ptr(ws), nat.stream(), *ev), "alive_knn_search")
         self._last = (n, t, k, ws)
         return val, idx
 

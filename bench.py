@@ -154,16 +154,14 @@ class ScoreTimer:
         def timed(src, k):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(); b.record()                               # materialise the handles
-            self.nat.lib().alive_knn_set_timing_events(a.cuda_event, b.cuda_event)
             self.pairs.append((a, b, src.shape[0] * src.shape[2], library.M))
             s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             self.whole.append((s0, s1))
             s0.record()
             try:
-                return orig(src, k)
+                return orig(src, k, events=(a, b))               # recorded by the library around the scoring kernel, on its stream
             finally:
                 s1.record()
-                self.nat.lib().alive_knn_set_timing_events(None, None)
         library.search = timed
         return orig
 

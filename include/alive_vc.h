@@ -97,14 +97,20 @@ int alive_knn_search_fp8(const float* src, int N, int T,
                          float* out_val, int32_t* out_idx, void* ws, void* stream);
 const int* alive_knn_search_stats(int N, int T, int64_t M, void* ws);
 
-/* Measurement hook (bench.py): when both are non-NULL hipEvent_t handles, every following
- * alive_knn_search / alive_knn_search_fp8 on this host thread records them on its stream immediately before / after the
- * first-stage scoring kernel of the whole batch (the dominant kernel).  Pass NULLs to switch off. */
-int alive_knn_set_timing_events(void* ev_start, void* ev_stop);
+/* Measurement forms (bench.py): the same searches; ev_start / ev_stop are hipEvent_t handles (or NULL) recorded on `stream`
+ * immediately before / after the first-stage scoring kernel of the whole batch -- the dominant kernel of the path. */
+int alive_knn_search_timed(const float* src, int N, int T,
+                           const void* lib_bf16, const float* rows_f32, const float* norms,
+                           int64_t M, int64_t idx_base, int k,
+                           float* out_val, int32_t* out_idx, void* ws, void* stream, void* ev_start, void* ev_stop);
+int alive_knn_search_fp8_timed(const float* src, int N, int T,
+                               const void* lib_f8, const void* lib_bf16, const float* rows_f32, const float* norms,
+                               int64_t M, int64_t idx_base, int k,
+                               float* out_val, int32_t* out_idx, void* ws, void* stream, void* ev_start, void* ev_stop);
 
 /* alive_knn_merge_gather: merge n_shards exact top-k lists ([S][Tt][k], e.g.
  * after an RCCL all-gather), pick the global top-k, gather those rows from the
- * full fp32 row table, mean over k, alpha-blend with the source.
+ * full fp32 row table, mean over k, alpha-blend with the source.  n_shards * k <= 512.
  *   out[N][D][T];  final_idx[Tt][k] (may be NULL).
  */
 int alive_knn_merge_gather(const float* cand_val, const int32_t* cand_idx, int n_shards, int k,

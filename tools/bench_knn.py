@@ -19,8 +19,7 @@ a.record(); b.record()
 lib.search(src, 4)
 tot = 0.0
 for _ in range(reps):
-    nat.lib().alive_knn_set_timing_events(a.cuda_event, b.cuda_event)
-    lib.search(src, 4)
+    lib.search(src, 4, events=(a, b))
     torch.cuda.synchronize()
     tot += a.elapsed_time(b)
 ms = tot / reps

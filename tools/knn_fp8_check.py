@@ -25,10 +25,8 @@ a.record(); b.record()
 res = {}
 for name, lib in (("bf16", lib16), ("fp8", lib8)):
     lib.search(src, 4)
-    nat.lib().alive_knn_set_timing_events(a.cuda_event, b.cuda_event)
-    v, i = lib.search(src, 4)
+    v, i = lib.search(src, 4, events=(a, b))
     torch.cuda.synchronize()
-    nat.lib().alive_knn_set_timing_events(None, None)
     ms = a.elapsed_time(b)
     res[name] = (v, i)
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
