@@ -209,3 +209,36 @@ def test_sharded_knn_protocol_world2_gloo():
         assert p.exitcode == 0
     for rank, e1, e2, e3, ok in res:
         assert e1 < 1e-5 and e2 < 1e-5 and e3 < 1e-5 and ok, res
+
+
+def test_overlap_sharing_geometry_against_the_oracle():
+    """The index arithmetic of Converter.features_shared (module/pipeline.py) restated with the CPU oracle's networks: content
+    frames of a window that are >= EDGE frames from its edges equal the frames of ONE pass over the padded signal, and the
+    edge frames equal those of a 30-frame slice of the window -- i.e. EDGE = 12 (ConvNeXt context) + 2 (STFT reflect padding)
+    and NET_MARGIN = 16 are enough for the REFERENCE's arithmetic, not only for this build's kernels."""
+    from module.pipeline import EDGE, NET_MARGIN, SPEC_MARGIN
+    ce = synthetic.make_state_dict(schema.content_encoder_schema(), 2, "ce.")
+    chunk = 16000                                                     # 50 frames per chunk, windows of 150 frames
+    wf = 0.3 * synthetic.make_waveform(16000 * 3 + 77, 71)
+    windows, _ = make_windows(wf, chunk)                              # [n, 48000]
+    n, L = windows.shape
+    lf, cf = L // 320, chunk // 320
+    per_window = torch.cat([O.content_encoder(ce, O.spectrogram(windows[i:i + 1])) for i in range(n)], 0)      # the reference's order
+    sig = torch.cat([windows[:, :chunk].reshape(1, n * chunk), windows[-1:, chunk:]], dim=1)                  # padded signal, (n + 2) chunks
+    assert sig.shape[1] == (n + 2) * chunk
+    whole = O.content_encoder(ce, O.spectrogram(sig))
+    nl = EDGE + NET_MARGIN
+    for g in range(n):
+        shared = torch.empty(1, 768, lf)
+        shared[:, :, EDGE:lf - EDGE] = whole[:, :, g * cf + EDGE:g * cf + lf - EDGE]
+        w = windows[g:g + 1]
+        left = O.content_encoder(ce, O.spectrogram(w[:, :(nl + SPEC_MARGIN) * 320])[:, :, :nl])
+        right = O.content_encoder(ce, O.spectrogram(w[:, L - (nl + SPEC_MARGIN) * 320:])[:, :, SPEC_MARGIN:])
+        shared[:, :, :EDGE] = left[:, :, :EDGE]
+        shared[:, :, lf - EDGE:] = right[:, :, NET_MARGIN:]
+        torch.testing.assert_close(shared, per_window[g:g + 1], rtol=1e-4, atol=1e-5)
+    # ... while frames near the window edge do differ from the whole-signal pass (they see the window's own padding): the edge
+    # blocks are needed
+    g = 1
+    near = whole[:, :, g * cf + 4] - per_window[g, :, 4]
+    assert near.abs().max() > 1e-3
