@@ -252,7 +252,10 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
                 const int t = t0 + c4;
                 if (row >= p.Co || t >= p.Tout) continue;
                 f32x4 v = *(const f32x4*)&Ct[pr * CP + c4];
-                if (p.act == 1) { for (int q = 0; q < 4; ++q) v[q] = gelu_fast(v[q]); }
+                if (p.act == 1) {                                  // two values per instruction on the packed fp32 pipe
+                    const f32x2 g0 = gelu_fast2(f32x2{v[0], v[1]}), g1 = gelu_fast2(f32x2{v[2], v[3]});
+                    v = f32x4{g0[0], g0[1], g1[0], g1[1]};
+                }
                 else if (p.act == 2) { for (int q = 0; q < 4; ++q) v[q] = expf(v[q]); }
                 if (p.post_add != nullptr) v = v + p.post_add[row];
                 if (p.ch_scale != nullptr) v = v * p.ch_scale[row];
@@ -263,12 +266,14 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
                 if (p.Z != nullptr) {
                     const float* fs = Ft + pr * 2 * FILM_NF - f_lo;
                     f32x4 z;
+                    const f32x2 g0 = gelu_fast2(f32x2{v[0], v[1]}), g1 = gelu_fast2(f32x2{v[2], v[3]});
+                    const float gv[4] = {g0[0], g0[1], g1[0], g1[1]};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         Lerp lp = lerp_coord(t + q + p.film_t0, film_ratio, p.Lf);
                         float sc = lerp_apply(lp, fs[lp.i0], fs[lp.i1]);
                         float sh = lerp_apply(lp, fs[FILM_NF + lp.i0], fs[FILM_NF + lp.i1]);
-                        z[q] = gelu_fast(v[q]) * sc + sh;
+                        z[q] = gv[q] * sc + sh;
                     }
                     *(f32x4*)(p.Z + o) = z;
                 }
