@@ -1453,7 +1453,7 @@ struct SearchWs {
     int* stats; int* list0; int* list1;    // counters; frames flagged by the fp8 / by the bf16 certificate
     unsigned short* s_c;                   // compacted bf16 rows of the frames being re-searched
     float* cv1; int* ci1;                  // tier-1 candidate lists
-    unsigned char* s_p8; float* cvp; int* cip; float* p_val; int* p_idx; int* p_list;   // probe
+    unsigned char* s_p8; float* cvp; int* cip; int* p_list;   // probe: sample rows, lists, [frame of slot | flagged frames]
     size_t bytes;
 };
 
@@ -1487,9 +1487,7 @@ static SearchWs ws_layout(void* base, int64_t Tt, int64_t M, int k) {
     w.s_p8 = a.take<unsigned char>((size_t)w.probe_pad * D + 16);
     w.cvp = a.take<float>((size_t)w.probe_pad * w.pp.P * KP8 + 4);
     w.cip = a.take<int>((size_t)w.probe_pad * w.pp.P * KP8 + 4);
-    w.p_val = a.take<float>((size_t)(w.probe_n + 1) * ALIVE_MAX_K);
-    w.p_idx = a.take<int>((size_t)(w.probe_n + 1) * ALIVE_MAX_K);
-    w.p_list = a.take<int>((size_t)w.probe_pad + 4);
+    w.p_list = a.take<int>((size_t)2 * w.probe_pad + 8);
     w.bytes = a.used() + 1024;
     return w;
 }
@@ -1690,9 +1688,11 @@ static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f
         probe_gather_kernel<<<(unsigned)w.probe_pad, 64, 0, s>>>(w.s_f8, Tt, w.probe_n, w.probe_pad, w.s_p8, w.p_list);
         knn_score8_kernel<<<dim3((unsigned)(w.probe_pad / FT), w.pp.split), 256, SCORE8_LDS, s>>>(
             w.s_p8, (const unsigned char*)lib_f8, M, w.pp.tiles_total, w.pp.tiles_per_split, w.pp.P, w.cvp, w.cip, nullptr, 0, 0);
-        // the sample's own rescoring (results go to scratch rows, its flagged frames are only counted)
+        // the sample's own rescoring.  The kernel writes a frame's result to the frame's own output rows (out[frame]), so
+        // the sample's exact lists land in the caller's outputs and are overwritten by the pass over the batch; its flagged
+        // frames (second half of p_list) are only counted
         knn_rescore_kernel<<<(unsigned)((w.probe_n + 3) / 4), 256, 0, s>>>(w.cvp, w.cip, w.pp.P, KP8, w.s_f32, rows_f32, norms, w.probe_n,
-                                                                          idx_base, k, w.p_val, w.p_idx, w.p_list, nullptr, 0, 0,
+                                                                          idx_base, k, out_val, out_idx, w.p_list, nullptr, 0, 0,
                                                                           w.p_list + w.probe_pad, w.stats + ST_PROBE_CNT, CERT_Z, KH8,
                                                                           1.0f / (F8_SCALE * F8_SCALE), SD_PRIOR8);
         probe_decide_kernel<<<1, 1, 0, s>>>(w.stats, w.probe_n, PROBE_NUM, PROBE_DEN);

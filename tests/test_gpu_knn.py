@@ -375,3 +375,36 @@ def test_knn_eight_shards_of_a_1m_library_equal_the_unsharded_search():
     out, fin = merge_gather(torch.stack(vs).contiguous(), torch.stack(is_).contiguous(), 8, k, 0.0, full.rows, src,
                             return_indices=True)
     assert torch.equal(fin, fin_ref) and torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("n,t,m,k", [(45, 450, 30000, 4), (1, 300, 5000, 4), (2, 40, 1000, 16), (40, 450, 4096, 8)])
+def test_knn_search_stays_inside_its_workspace_and_outputs(prefilter, n, t, m, k):
+    """the C ABI works in caller-owned memory only: workspace of alive_knn_workspace_bytes, outputs [Tt, k].  Guard bands
+    behind the workspace and around the outputs must come back untouched (20 250 frames: the probe tier is active; a
+    regression test for a probe that once wrote its sample's results at the frames' own row offsets of a sample-sized buffer)"""
+    from module import _native as nat
+    from module.common import PackedLibrary
+    L = nat.lib()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    lib = PackedLibrary(torch.randn(768, m, device=DEV, generator=g), prefilter=prefilter)
+    src = torch.randn(n, 768, t, device=DEV, generator=g)
+    tt = n * t
+    need = L.alive_knn_workspace_bytes(tt, m)
+    guard = 8 << 20
+    ws = torch.full((need + guard,), 0xAB, dtype=torch.uint8, device=DEV)
+    outv = torch.full((tt * k + 2048,), 12345.0, device=DEV)
+    outi = torch.full((tt * k + 2048,), 54321, dtype=torch.int32, device=DEV)
+    v, i = outv[1024:1024 + tt * k], outi[1024:1024 + tt * k]
+    if prefilter == "fp8":
+        rc = L.alive_knn_search_fp8(nat.ptr(src), n, t, nat.ptr(lib.lib_f8), nat.ptr(lib.lib_bf16), nat.ptr(lib.rows), nat.ptr(lib.norms),
+                                    m, 0, k, v.data_ptr(), i.data_ptr(), ws.data_ptr(), nat.stream())
+    else:
+        rc = L.alive_knn_search(nat.ptr(src), n, t, nat.ptr(lib.lib_bf16), nat.ptr(lib.rows), nat.ptr(lib.norms), m, 0, k,
+                                v.data_ptr(), i.data_ptr(), ws.data_ptr(), nat.stream())
+    nat.check(rc, "search")
+    torch.cuda.synchronize()
+    assert bool((ws[need:] == 0xAB).all()), "the search wrote behind its workspace"
+    assert bool((outv[:1024] == 12345.0).all() and (outv[1024 + tt * k:] == 12345.0).all())
+    assert bool((outi[:1024] == 54321).all() and (outi[1024 + tt * k:] == 54321).all())
+    rv, ri = lib.search(src, k)
+    assert torch.equal(v.view(tt, k), rv) and torch.equal(i.view(tt, k), ri)
