@@ -188,3 +188,57 @@ def test_decoder_forward_range_is_bitwise_inside_its_margins(nets):
     assert torch.equal(head[:, :180 * 320], full[:, :180 * 320])
     with pytest.raises(ValueError):
         dec.forward_range(x[:, :, :10].contiguous(), f0, 445)
+
+
+@pytest.mark.parametrize("n,t", [(3, 450), (1, 8), (2, 97)])
+def test_network_entry_points_stay_inside_their_workspaces(nets, n, t):
+    """alive_spectrogram / alive_content_encoder / alive_f0_estimate / alive_decoder_forward on caller-owned memory with guard
+    bands behind every workspace and output: nothing outside `*_workspace_bytes` and the documented output shapes is written
+    (batch kernels at 3 x 450 and 2 x 97 frames, streaming kernels at 8 frames)"""
+    from module import _native as nat
+    from module import spectrogram as sp
+    ce, pe, dec, _ = nets
+    L = nat.lib()
+    st = nat.stream()
+    G = 1 << 20
+
+    def banded(nbytes, dtype=torch.uint8, fill=0xAB):
+        return torch.full((int(nbytes) + G,), fill, dtype=dtype, device=DEV)
+
+    def intact(buf, nbytes, fill=0xAB):
+        return bool((buf[int(nbytes):] == fill).all())
+
+    wav = (0.3 * synthetic.make_waveform(t * 320, 77)).repeat(n, 1).to(DEV).contiguous()
+    sp.spectrogram(wav[:1])                                             # builds the cached DFT basis
+    basis = sp._basis[str(wav.device)]
+    need = L.alive_spectrogram_workspace_bytes(n, t * 320)
+    ws = banded(need)
+    spec = torch.full((n * 641 * t + 4096,), 7.0, device=DEV)
+    nat.check(L.alive_spectrogram(nat.ptr(basis), nat.ptr(wav), n, t * 320, spec.data_ptr(), ws.data_ptr(), st), "spectrogram")
+    torch.cuda.synchronize()
+    assert intact(ws, need) and bool((spec[n * 641 * t:] == 7.0).all())
+    spec = spec[:n * 641 * t].view(n, 641, t).contiguous()
+    assert torch.equal(spec, sp.spectrogram(wav))
+
+    for net, fn, wsq, ch in ((ce, L.alive_content_encoder, L.alive_content_encoder_workspace_bytes, 768),
+                             (pe, L.alive_f0_estimate, L.alive_f0_estimate_workspace_bytes, 1)):
+        need = wsq(n, t)
+        ws = banded(need)
+        out = torch.full((n * ch * t + 4096,), 7.0, device=DEV)
+        nat.check(fn(net.table().array, nat.ptr(spec), n, t, out.data_ptr(), ws.data_ptr(), st), "net")
+        torch.cuda.synchronize()
+        assert intact(ws, need), "network wrote behind its workspace"
+        assert bool((out[n * ch * t:] == 7.0).all())
+
+    need = L.alive_decoder_workspace_bytes(n, t)
+    ws = banded(need)
+    x = synthetic.gaussian("gb.x", 4, (n, 768, t)).to(DEV)
+    f0 = torch.full((n, 1, t), 150.0, device=DEV)
+    wave = torch.full((n * t * 320 + 4096,), 7.0, device=DEV)
+    phi = torch.full((n * 64 + 4096,), 7.0, device=DEV)
+    nat.check(L.alive_decoder_forward(dec.table().array, nat.ptr(x), nat.ptr(f0), None, 0, t * 320 - 1, n, t, wave.data_ptr(),
+                                      phi.data_ptr(), ws.data_ptr(), st), "decoder")
+    torch.cuda.synchronize()
+    assert intact(ws, need), "decoder wrote behind its workspace"
+    assert bool((wave[n * t * 320:] == 7.0).all() and (phi[n * 64:] == 7.0).all())
+    assert torch.isfinite(wave[:n * t * 320]).all()
