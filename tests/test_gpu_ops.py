@@ -637,3 +637,72 @@ def test_fused_filter_blocks_are_deterministic_at_batch_scale(c, l):
             assert torch.isfinite(first).all()
         else:
             assert torch.equal(out, first), f"launch {rep} differs from the first"
+
+
+def test_operators_write_only_their_outputs(monkeypatch):
+    """every tensor an operator wrapper allocates for the C ABI (module/ops.py: outputs and plane buffers) is placed between
+    two guard bands; after a battery of ragged shapes through alive_conv1d (fp32 / split / transposed / strided / skinny),
+    alive_gemm_planes, alive_to_planes, alive_dwconv_norm(_planes), alive_channel_norm, alive_argmax_channels, alive_oscillator,
+    the fused FilterBlocks and the filter edges, every band must be untouched"""
+    from module import ops
+    bands = []
+    real_empty = torch.empty
+
+    def guarded_empty(*shape, **kw):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+            shape = tuple(shape[0])
+        dev = kw.get("device", None)
+        if dev is None or not str(dev).startswith("cuda"):
+            return real_empty(*shape, **kw)
+        dtype = kw.get("dtype", torch.float32)
+        numel = 1
+        for d in shape:
+            numel *= int(d)
+        esz = torch.empty(0, dtype=dtype).element_size()
+        pad = 4096 // esz                                   # 4 KB either side keeps the 16-byte alignment of the payload
+        buf = torch.zeros(numel + 2 * pad, dtype=dtype, device=dev)
+        raw = buf.view(torch.uint8)
+        raw[:4096] = 0x5A
+        raw[raw.numel() - 4096:] = 0x5A
+        bands.append(raw)
+        return buf[pad:pad + numel].view(*shape)
+    monkeypatch.setattr(ops.torch, "empty", guarded_empty)
+
+    def t(name, shape, scale=1.0):
+        return g(name, shape, scale=scale).to(DEV)
+
+    # conv1d: exact fp32, split bf16 (2 / 3 planes), ragged Co / Ci / T, causal reflect padding with the FiLM second output
+    for prec in ("fp32", "bf16x3", "bf16x6"):
+        ops.conv1d(t("g1", (2, 37, 131)), t("g1w", (45, 37, 5), 0.1), t("g1b", (45,)), dilation=2, pad_left=8, pad_mode=1, out_len=131,
+                   precision=prec)
+        ops.conv1d(t("g2", (3, 64, 257)), t("g2w", (64, 64, 1), 0.1), t("g2b", (64,)), act="gelu", precision=prec)
+    film, _ = ops.conv1d(t("gc", (2, 24, 19)), t("gcw", (128, 24, 1), 0.1), t("gcb", (128,)))
+    ops.conv1d(t("g3", (2, 64, 190)), t("g3w", (64, 64, 5), 0.1), t("g3b", (64,)), dilation=1, pad_left=4, pad_mode=1, out_len=190,
+               residual=t("g3r", (2, 64, 190)), film=film, film_scale_row=0, film_shift_row=64, precision="bf16x3")
+    ops.conv1d(t("g4", (2, 16, 301)), t("g4w", (16, 8, 2), 0.1), t("g4b", (8,)), transposed=True)                    # ConvTranspose r = 2
+    ops.conv1d(t("g5", (2, 64, 45)), t("g5w", (64, 16, 8), 0.1), t("g5b", (16,)), transposed=True, precision="bf16x3")   # r = 8
+    ops.conv1d(t("g6", (2, 16, 800)), t("g6w", (64, 16, 8), 0.1), t("g6b", (64,)), stride=8)                          # strided down
+    ops.conv1d(t("g7", (1, 256, 9)), t("g7w", (256, 256, 5), 0.05), t("g7b", (256,)), pad_left=4, pad_mode=1, out_len=9,
+               precision="bf16x3")                                                                                     # skinny (streaming)
+    # plane GEMMs, plane conversion, norms, argmax
+    for planes in (2, 3):
+        x = t("g8", (3, 77, 131))
+        P = ops.to_planes(x, planes)
+        ops.gemm_planes(P, 3, 131, t("g8w", (150, 77, 1), 0.1), t("g8b", (150,)), planes=planes, act="gelu", want_planes=True)
+        if planes == 3:                                     # the argmax epilogue exists for the 3-plane classifier GEMM
+            ops.gemm_planes_argmax(P, 3, 131, t("g8a", (300, 77, 1), 0.1), t("g8c", (300,)), planes=planes)
+        ops.dwconv_norm_planes(t("g9", (2, 64, 101)), t("g9w", (64, 1, 7), 0.3), t("g9b", (64,)), t("g9g", (64,)) + 1.0, t("g9o", (64,)),
+                               planes=planes)
+    ops.dwconv_norm(t("ga", (2, 48, 33)), t("gaw", (48, 1, 7), 0.3), t("gab", (48,)), gain=t("gag", (1, 48, 1)), offset=t("gao", (1, 48, 1)))
+    ops.dwconv_norm(t("ga", (2, 48, 7)), t("gaw", (48, 1, 7), 0.3), t("gab", (48,)), gain=t("gag", (1, 48, 1)), offset=t("gao", (1, 48, 1)))
+    ops.channel_norm(t("gb", (2, 256, 45)), t("gbg", (1, 256, 1)), t("gbo", (1, 256, 1)))
+    ops.argmax_channels(t("gd", (2, 4096, 13)))
+    # oscillator, filter edges
+    amps = t("ge", (2, 64, 11)).abs()
+    ops.oscillator(amps, torch.full((2, 1, 11), 140.0, device=DEV), phi_col=11 * 320 - 1)
+    ops.filter_source_in(t("gf", (2, 1, 2000)), t("gfw", (8, 1, 7), 0.2), t("gfb", (8,)), t("gfd", (16, 8, 2), 0.2), t("gfe", (16,)))
+    ops.filter_source_out(t("gh", (2, 8, 2000)), t("ghw", (1, 8, 7), 0.2), t("ghb", (1,)))
+    torch.cuda.synchronize()
+    assert len(bands) >= 25
+    for raw in bands:
+        assert bool((raw[:4096] == 0x5A).all() and (raw[raw.numel() - 4096:] == 0x5A).all()), "an operator wrote outside its output"
