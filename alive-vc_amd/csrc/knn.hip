@@ -609,24 +609,64 @@ __global__ __launch_bounds__(256, 1) void knn_score8_kernel(const unsigned char*
 #ifdef ALIVE_KNN_ABL_NORARE            // ablation build (tools/bench_knn.py): the fold's fast path only -- results are WRONG, timing only
         return;
 #endif
+        // Rare path (wave-uniform; by ablation ~1500 cycles with the matrix pipe idle, 15 % of the kernel on the bench batch and
+        // 30 % on uncorrelated frames), cut for the common case of ONE admitted row per lane:
+        //  * every lane's list minimum and its quarter are known from the register caches, so the quarter is read from LDS
+        //    first and arrives under the packing / top-2 work below (the rescan used to wait behind the entry write);
+        //  * the register index r goes into the 4 low mantissa bits of every score (2^-19 relative, far below the fp8 error):
+        //    the 16 values of a lane are distinct and the row of a score is score & 15;
+        //  * best and runner-up come out of one v_med3 / v_max chain; the runner-up (and whatever lies below it) is only
+        //    looked at by the loop form when some lane's runner-up is admitted too.
         const int64_t row0 = (int64_t)tile * LT;
-        const bool ragged = row0 + LT > M;
-        // Rare path (wave-uniform).  The register index r is packed into the 4 low mantissa bits of every score (2^-19
-        // relative, far below the fp8 error), so the 16 values of a lane are distinct, the row of a maximum is mx & 15 and
-        // "the next candidate" is the largest value below the current one: no search for the index, no retiring.
+        float* lv = Lv + lc0 + ni * 64;
+        int* li = Li + lc0 + ni * 64;
+        const bool b01 = qv[ni][1] < qv[ni][0], b23 = qv[ni][3] < qv[ni][2];
+        const float m01 = b01 ? qv[ni][1] : qv[ni][0], m23 = b23 ? qv[ni][3] : qv[ni][2];
+        const int p01 = b01 ? qp[ni][1] : qp[ni][0], p23 = b23 ? qp[ni][3] : qp[ni][2];
+        const int tpos = m23 < m01 ? p23 : p01;                 // entry to overwrite: the list minimum
+        const int tq = tpos >> 2, te = tpos & 3;
+        const float* qb = lv + (tq * 4) * 512;
+        float x0 = qb[0], x1 = qb[512], x2 = qb[1024], x3 = qb[1536];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = __uint_as_float((__float_as_uint(acc[r]) & ~15u) | (unsigned)r);
-        if (ragged) {                                   // -inf with index bits is a NaN: put the rows beyond M back to -inf
+        if (row0 + LT > M) {                            // -inf with index bits is a NaN: put the rows beyond M back to -inf
             asm volatile("" ::: "memory");
             const int left = (int)(M - row0);
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (4 * lh >= left - ((r & 3) + 8 * (r >> 2))) acc[r] = -INFINITY;
         }
-        mx = acc[0];
+        float m1 = -INFINITY, m2 = -INFINITY;
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
-        fold_loop(acc, ni, tile, mx);
+        for (int r = 0; r < 16; ++r) {
+            m2 = __builtin_amdgcn_fmed3f(m1, m2, acc[r]);       // m1 >= m2: the median is the new runner-up
+            m1 = fmaxf(m1, acc[r]);
+        }
+        const bool has = m1 > thr[ni];
+        if (has) {
+            const unsigned u = __float_as_uint(m1);
+            lv[tpos * 512] = m1;
+            li[tpos * 512] = (int)(row0 + ((u & 3u) + 8u * ((u >> 2) & 3u)) + 4 * lh);
+        }
+        // the quarter as it stands after the write: the new entry in place of the old minimum
+        x0 = (has && te == 0) ? m1 : x0;
+        x1 = (has && te == 1) ? m1 : x1;
+        x2 = (has && te == 2) ? m1 : x2;
+        x3 = (has && te == 3) ? m1 : x3;
+        const bool c1 = x1 < x0, c3 = x3 < x2;
+        const float n01 = c1 ? x1 : x0, n23 = c3 ? x3 : x2;
+        const int e01 = c1 ? 1 : 0, e23 = c3 ? 3 : 2;
+        const bool c = n23 < n01;
+        const float nq = c ? n23 : n01;
+        const int np = tq * 4 + (c ? e23 : e01);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool hit = has && tq == q;
+            qv[ni][q] = hit ? nq : qv[ni][q];
+            qp[ni][q] = hit ? np : qp[ni][q];
+        }
+        thr[ni] = fminf(fminf(qv[ni][0], qv[ni][1]), fminf(qv[ni][2], qv[ni][3]));
+        fold_loop(acc, ni, tile, m2);                           // returns at once unless some lane's runner-up is admitted too
     };
 #ifdef ALIVE_KNN_FOLD_PIPELINED
     auto fold_second = [&](f32x16& acc, int ni, int tile, FoldSt& f) {    // a lane's runner-up is admitted too: the loop form, rarely
