@@ -315,7 +315,8 @@ def test_knn_exact_tier_on_a_library_of_near_duplicates(prefilter, k):
     _assert_equals_brute_force(val, idx, bv, bi, k, min_safe=250)
 
 
-@pytest.mark.parametrize("n,t,m,k", [(1, 40, 500, 9), (2, 33, 3000, 16), (1, 7, 100, 64), (1, 450, 20000, 12)])
+@pytest.mark.parametrize("n,t,m,k", [(1, 40, 500, 9), (2, 33, 3000, 16), (1, 7, 100, 64), (1, 450, 20000, 12), (1, 5, 16, 16),
+                                     (1, 1, 64, 64), (3, 2, 33, 32)])
 def test_knn_k_above_8_runs_the_exact_scan(n, t, m, k):
     """the reference accepts any k <= M (inference.py:34, common.py:105); k > 8 is deeper than the candidate lists and runs
     the exact fp32 scan for every frame.  Checked against the oracle, and bitwise against the candidate path: the first 4
@@ -325,8 +326,11 @@ def test_knn_k_above_8_runs_the_exact_scan(n, t, m, k):
     lib = synthetic.make_library(m, 52)
     out, idx = match_features(src.to(DEV), lib.to(DEV), k=k, alpha=0.25, return_indices=True)
     ref, ridx, cos = O.match_features(src, lib.expand(n, -1, -1), k, 0.25, return_indices=True)
-    top = torch.topk(cos, k + 1, dim=2).values.reshape(n * t, k + 1)
-    safe = ((top[:, k - 1] - top[:, k]) > 1e-5).numpy()
+    if m > k:
+        top = torch.topk(cos, k + 1, dim=2).values.reshape(n * t, k + 1)
+        safe = ((top[:, k - 1] - top[:, k]) > 1e-5).numpy()
+    else:
+        safe = np.ones(n * t, dtype=bool)                     # M == k: every row is selected
     assert np.array_equal(np.sort(idx.cpu().numpy(), 1)[safe], np.sort(ridx.reshape(n * t, k).numpy(), 1)[safe])
     safe3 = torch.from_numpy(safe).view(n, t)
     for i in range(n):
