@@ -52,8 +52,9 @@ def build_parser():
     parser.add_argument('--trim-context', action='store_true',
                         help="match only the frames that can reach the kept centre third of each window (same samples, ~44 %% of the kNN work)")
     parser.add_argument('--no-share-overlap', action='store_true',
-                        help="run spectrogram / f0 estimator / content encoder / kNN match per window as the reference does, instead of "
-                             "once per utterance with the windows assembled from it (same samples either way; this build only)")
+                        help="always run spectrogram / f0 estimator / content encoder / kNN match per window as the reference does; by "
+                             "default long utterances run them once per utterance with the windows assembled from it (same samples "
+                             "either way; this build only)")
     parser.add_argument('--pcm16', action='store_true', help="write 16-bit PCM instead of float32 WAV (this build only)")
     return parser
 
@@ -97,7 +98,8 @@ def main(argv=None):
         print(f"converting {path}")
         out = conv.convert(wf, chunk=args.chunk, k=args.k, alpha=args.alpha, pitch_shift=args.pitch,
                            intonation=args.intonation, f0_rate=args.f0_rate, window_batch=args.window_batch,
-                           trim_context=args.trim_context, share_overlap=not (args.no_share_overlap or args.trim_context))
+                           trim_context=args.trim_context,
+                           share_overlap=None if (args.no_share_overlap or args.trim_context) else "auto")
         out = audio_io.resample(out, 16000, sr, post_gain_db=args.gain).cpu()      # resample, then gain (:136-137)
         if args.normalize:
             out = out / out.abs().max()

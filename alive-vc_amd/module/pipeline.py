@@ -226,7 +226,13 @@ class Converter:
         trim_context: match only the frames that can reach the kept centre third (same samples, ~44 % of the kNN work)"""
         windows, total = make_windows(wf.to(self.device), chunk)
         keep = (chunk // 320, 2 * chunk // 320) if trim_context else None
-        if kw.get("share_overlap") is True:                       # one utterance: all of its windows form one group
+        share = kw.get("share_overlap")
+        if share is True or share == "auto":                      # one utterance: all of its windows form one group
+            n = windows.shape[0]
             ok = chunk % 320 == 0 and 3 * chunk // 320 >= 2 * (EDGE + NET_MARGIN + SPEC_MARGIN) and keep is None
-            kw["share_overlap"] = windows.shape[0] if ok else None
+            # "auto": sharing adds ~2.5 ms of small launches (one more encoder pass, edge blocks, copies) and saves about half
+            # of the front end, most of it in the kNN match -- measured break-even: 43 windows at a 50 k-vector library, 18 at 1 M
+            if share == "auto" and self.library is not None:
+                ok = ok and n * (1.0 + self.library.M / 5e5) >= 45.0
+            kw["share_overlap"] = n if ok else None
         return stitch(self.convert_windows(windows, keep_frames=keep, **kw), total, chunk)

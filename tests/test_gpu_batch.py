@@ -111,3 +111,10 @@ def test_overlap_sharing_of_one_utterance(rig):
     wf = (0.3 * synthetic.make_waveform(16000 * 7 + 123, 41)).to(DEV)
     for chunk in (48000, 16000, 4800):
         assert torch.equal(conv.convert(wf, chunk=chunk, k=4, share_overlap=True), conv.convert(wf, chunk=chunk, k=4))
+    # "auto" (the CLI's setting): 7 s at chunk 16000 = 10 windows against 200 k vectors stays per window, 60 s is shared
+    conv.last_front_end_frames = None
+    conv.convert(wf, chunk=16000, k=4, share_overlap="auto")
+    assert conv.last_front_end_frames is None
+    long = (0.3 * synthetic.make_waveform(16000 * 60, 42)).to(DEV)
+    out = conv.convert(long, chunk=16000, k=4, share_overlap="auto")
+    assert conv.last_front_end_frames is not None and torch.equal(out, conv.convert(long, chunk=16000, k=4))

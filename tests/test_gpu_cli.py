@@ -89,8 +89,9 @@ def test_inference_cli_trim_context_writes_the_same_file(workdir):
 
 
 def test_inference_cli_overlap_sharing_writes_the_same_file(workdir):
-    """the CLI shares the front end between the overlapping windows of an utterance by default; --no-share-overlap (the
-    reference's per-window order) must write the same samples"""
+    """the CLI shares the front end between the overlapping windows of a long utterance (share_overlap="auto": a 1 s file
+    stays on the per-window order, a 60 s file against a 1 M library is shared); --no-share-overlap (the reference's
+    per-window order) must write the same samples either way"""
     import inference
     d, _, _ = workdir
     base = ["-i", str(d / "inputs"), "-dep", str(d / "decoder.pt"), "-cep", str(d / "content_encoder.pt"), "-f0ep", str(d / "f0_estimator.pt"),
