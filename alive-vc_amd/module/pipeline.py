@@ -115,8 +115,13 @@ class Converter:
             fe[i:i + 8 * utt_batch, :, EDGE:] = self.ce(sr)[:, :, NET_MARGIN:]
             pe_[i:i + 8 * utt_batch, :, :EDGE] = self.pe.estimate(sl)[:, :, :EDGE]
             pe_[i:i + 8 * utt_batch, :, EDGE:] = self.pe.estimate(sr)[:, :, NET_MARGIN:]
-        fu = self.match(fu, k, alpha)                          # the match: once per distinct frame
-        fe = self.match(fe, k, alpha)
+        # the match: once per distinct frame, and ONE search for the signals' frames and the windows' edge frames together
+        # (a search of its own for the 28 edge frames per window would run the scoring kernel at a fraction of its rate)
+        tu = fu.shape[2]
+        src = torch.cat([fu.permute(1, 0, 2).reshape(768, m * tu), fe.permute(1, 0, 2).reshape(768, n * 2 * EDGE)], dim=1)
+        matched = self.match(src.unsqueeze(0).contiguous(), k, alpha)[0]
+        fu = matched[:, :m * tu].view(768, m, tu).permute(1, 0, 2)
+        fe = matched[:, m * tu:].view(768, n, 2 * EDGE).permute(1, 0, 2)
         f4, p4 = feat.view(m, group, 768, lf), f0.view(m, group, 1, lf)
         for g in range(group):                                 # window g of a signal = frames [g cf, g cf + lf) of it
             f4[:, g, :, EDGE:lf - EDGE] = fu[:, :, g * cf + EDGE:g * cf + lf - EDGE]
