@@ -2,21 +2,19 @@
 // (/root/reference/module/common.py:96-109) and VoiceLibrary.match (voice_library.py:15-33).
 //
 // The reference materialises cos[T][M] with an fp32 bmm and runs topk over it.
-// Here the [T][M] matrix never exists:
-//   0. knn_score8_kernel  (default candidate stage) the same structure as 1. on the block-scaled fp8 MFMA
-//      (v_mfma_scale_f32_32x32x64_f8f6f4): twice the rate, 20x the score error, so twice the candidates and a
-//      per-frame certificate in step 2; frames that fail it are searched again through 1. inside the same call
-//      (alive_knn_search_fp8).
-//   1. knn_score_kernel   bf16 MFMA (v_mfma_f32_32x32x16_bf16) over L2-normalised
-//      library rows x normalised source frames, 128x128 output tiles; each
-//      wave folds its 64x64 accumulator tile straight into per-frame top-k'
-//      candidate lists kept in LDS (a register threshold rejects almost every
-//      score with one v_max3 chain; insertions are rare after the first tiles).
-//   2. knn_rescore_kernel every surviving candidate is re-scored in fp32 with the
-//      reference's arithmetic (normalise-then-dot) and the exact top-k is taken,
-//      so the bf16 pass only has to be a superset generator.
-//   3. knn_merge_gather_kernel merges per-shard exact lists (after an RCCL
-//      all-gather when the library is sharded), gathers the k rows, mean, blend.
+// Here the [T][M] matrix never exists.  A search is a chain of tiers, launched up front and gated by device-side counters:
+//   probe  (big batches) the fp8 stage + its certificate on 1 024 sample frames decides whether the batch starts on fp8 or bf16.
+//   0. knn_score8_kernel  candidate stage on the block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4): frames
+//      stationary in registers, library tiles streamed through LDS by LDS-DMA, lane-private top-16 lists per half-wave.
+//   1. knn_score_kernel   the same structure on the bf16 MFMA (v_mfma_f32_32x32x16_bf16), lists of 8: first stage of
+//      alive_knn_search, and the re-search of the frames whose fp8 candidate set could not be certified.
+//   2. knn_rescore_kernel every surviving candidate is re-scored in fp32 with the reference's arithmetic
+//      (normalise-then-dot), the exact top-k is taken, and the frame is CERTIFIED against the candidate stage's score
+//      error measured on its own candidates (the MFMA passes only have to be superset generators).
+//   3. knn_exact_kernel   frames neither certificate passes, and every search with k > 8: brute-force fp32 scan with the
+//      rescoring arithmetic.  knn_scan_kernel is its streaming form (a handful of frames, no candidate stage at all).
+//   4. knn_merge_gather_kernel merges per-shard exact lists (after an RCCL all-gather when the library is sharded),
+//      gathers the k rows, mean, blend.
 //
 // Layout: frames on the MFMA column/lane axis (B operand), library rows on the
 // row/register axis (A operand): a lane owns two frame columns and sees 32
