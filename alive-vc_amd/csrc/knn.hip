@@ -399,11 +399,11 @@ constexpr int ABUF8 = NPIECE8 * PIECE;     // 27648 B per tile buffer
 constexpr int SCORE8_LDS = 2 * ABUF8 + FT * KP8 * 8;   // 120832 B
 typedef int v8i __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(256, 1) void knn_score8_kernel(const unsigned char* __restrict__ s_f8,
-                                                            const unsigned char* __restrict__ lib, int64_t M, int tiles_total,
-                                                            int tiles_per_split, int P, float* __restrict__ cand_val,
-                                                            int* __restrict__ cand_idx, const int* __restrict__ gate_cnt,
-                                                            int gate_lo, int gate_hi) {
+__device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict__ s_f8,
+                                                const unsigned char* __restrict__ lib, int64_t M, int tiles_total,
+                                                int tiles_per_split, int P, float* __restrict__ cand_val,
+                                                int* __restrict__ cand_idx, const int* __restrict__ gate_cnt,
+                                                int gate_lo, int gate_hi) {
     {
         int c;
         if (!gate_open(gate_cnt, gate_lo, gate_hi, c)) return;                       // block-uniform
@@ -781,6 +781,19 @@ __global__ __launch_bounds__(256, 1) void knn_score8_kernel(const unsigned char*
         cand_val[o] = Lv[(k % KH8) * 512 + lc];
         cand_idx[o] = Li[(k % KH8) * 512 + lc];
     }
+}
+
+// two entry points of the same body, so that a kernel trace tells the pass over the batch from the 1 024-frame probe
+__global__ __launch_bounds__(256, 1) void knn_score8_kernel(const unsigned char* __restrict__ s_f8, const unsigned char* __restrict__ lib,
+                                                            int64_t M, int tiles_total, int tiles_per_split, int P,
+                                                            float* __restrict__ cand_val, int* __restrict__ cand_idx,
+                                                            const int* __restrict__ gate_cnt, int gate_lo, int gate_hi) {
+    knn_score8_body(s_f8, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, gate_cnt, gate_lo, gate_hi);
+}
+__global__ __launch_bounds__(256, 1) void knn_probe8_kernel(const unsigned char* __restrict__ s_f8, const unsigned char* __restrict__ lib,
+                                                            int64_t M, int tiles_total, int tiles_per_split, int P,
+                                                            float* __restrict__ cand_val, int* __restrict__ cand_idx) {
+    knn_score8_body(s_f8, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, nullptr, 0, 0);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1595,7 +1608,7 @@ static int check_search_args(const char* what, const void* a, const void* b, int
 
 static int lds_optin(const char* what) {
     static LdsOptIn optin8, optin16;
-    hipError_t e = optin8.ensure({(const void*)knn_score8_kernel}, SCORE8_LDS);
+    hipError_t e = optin8.ensure({(const void*)knn_score8_kernel, (const void*)knn_probe8_kernel}, SCORE8_LDS);
     if (e == hipSuccess) e = optin16.ensure({(const void*)knn_score_kernel}, SCORE_LDS);
     if (e != hipSuccess) {
         alive_set_error("%s: cannot reserve %d B of LDS: %s", what, SCORE_LDS, hipGetErrorString(e));
@@ -1724,8 +1737,8 @@ static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f
     int* mode = w.stats + ST_MODE;
     if (w.probe_n > 0) {
         probe_gather_kernel<<<(unsigned)w.probe_pad, 64, 0, s>>>(w.s_f8, Tt, w.probe_n, w.probe_pad, w.s_p8, w.p_list);
-        knn_score8_kernel<<<dim3((unsigned)(w.probe_pad / FT), w.pp.split), 256, SCORE8_LDS, s>>>(
-            w.s_p8, (const unsigned char*)lib_f8, M, w.pp.tiles_total, w.pp.tiles_per_split, w.pp.P, w.cvp, w.cip, nullptr, 0, 0);
+        knn_probe8_kernel<<<dim3((unsigned)(w.probe_pad / FT), w.pp.split), 256, SCORE8_LDS, s>>>(
+            w.s_p8, (const unsigned char*)lib_f8, M, w.pp.tiles_total, w.pp.tiles_per_split, w.pp.P, w.cvp, w.cip);
         // the sample's own rescoring.  The kernel writes a frame's result to the frame's own output rows (out[frame]), so
         // the sample's exact lists land in the caller's outputs and are overwritten by the pass over the batch; its flagged
         // frames (second half of p_list) are only counted
