@@ -28,6 +28,12 @@ constexpr int KP = ALIVE_KPRIME;      // 16
 constexpr int TILE = 128;             // library row padding granule
 constexpr int MAX_SPLIT = 64;         // max library splits (grid.y); candidates/frame = split*KP <= 1024
 
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
 // ----------------------------------------------------------------------------------------------
 // packing
 // ----------------------------------------------------------------------------------------------
@@ -71,6 +77,27 @@ __global__ __launch_bounds__(256) void lib_pack_kernel(const float* __restrict__
     }
 }
 
+// Strict (deterministic) certificate, library side: max over the rows of || r^ - bf16(r^) ||_2, r^ = row / norm as the
+// packing kernel computes it.  One wave per row; the maximum lands in bound[0] through an atomicMax on the float's bits
+// (non-negative floats order like unsigned integers).  The fp32 sum of squares is rounded up by 1e-4 relative.
+__global__ __launch_bounds__(256) void lib_rounding_bound_kernel(const unsigned short* __restrict__ lib, const float* __restrict__ rows,
+                                                                 const float* __restrict__ norms, int64_t M,
+                                                                 unsigned* __restrict__ bound) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float nn = norms[m];
+    float ss = 0.0f;
+    for (int d = lane; d < D; d += 64) {
+        const float q = rows[(size_t)m * D + d] / nn;
+        const float b = __uint_as_float((unsigned)lib[(size_t)m * D + d] << 16);
+        const float e = q - b;
+        ss = fmaf(e, e, ss);
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) atomicMax(bound, __float_as_uint(sqrtf(ss) * 1.0001f));
+}
+
 // ---- fp8 (OCP e4m3) form of the scoring operands: value * 2^8, so that the elements of unit vectors (|x| ~ 0.04)
 // sit in e4m3's normal range (2^-6 .. 448); scores come out scaled by 2^16, which a ranking does not see
 constexpr float F8_SCALE = 256.0f;
@@ -112,8 +139,10 @@ __global__ __launch_bounds__(256) void src_to_fp8_kernel(const unsigned short* _
 }
 
 // src[N][D][T] -> s_f32[Tt][D] (normalised, fp32), s_bf16[Tt_pad][D]
+// dq (optional): || q^ - bf16(q^) ||_2 per frame, rounded up -- the frame's share of the strict certificate's bound
 __global__ __launch_bounds__(256) void src_prep_kernel(const float* __restrict__ src, int T, int64_t Tt, int64_t Tt_pad,
-                                                       float* __restrict__ s_f32, unsigned short* __restrict__ s_bf16) {
+                                                       float* __restrict__ s_f32, unsigned short* __restrict__ s_bf16,
+                                                       float* __restrict__ dq) {
     __shared__ float red[4][64];
     __shared__ float tile[64][65];
     __shared__ float nrm[64];
@@ -133,26 +162,44 @@ __global__ __launch_bounds__(256) void src_prep_kernel(const float* __restrict__
     __syncthreads();
     if (wv == 0) nrm[lane] = sqrtf(red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
     __syncthreads();
+    float e2[16];                                     // rounding error of frame f0 + wv + 4 i, this lane's features
+#pragma unroll
+    for (int i = 0; i < 16; ++i) e2[i] = 0.0f;
     for (int d0 = 0; d0 < D; d0 += 64) {
         for (int r = wv; r < 64; r += 4) tile[r][lane] = ok ? col[(size_t)(d0 + r) * T] : 0.0f;
         __syncthreads();
-        for (int r = wv; r < 64; r += 4) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = wv + 4 * i;
             const int64_t ff = f0 + r;
             if (ff < Tt_pad) {
                 float q = (ff < Tt) ? tile[lane][r] / nrm[r] : 0.0f;
                 if (ff < Tt) s_f32[(size_t)ff * D + d0 + lane] = q;
-                s_bf16[(size_t)ff * D + d0 + lane] = f32_to_bf16_rn(q);
+                const unsigned short b = f32_to_bf16_rn(q);
+                s_bf16[(size_t)ff * D + d0 + lane] = b;
+                const float e = q - __uint_as_float((unsigned)b << 16);
+                e2[i] = fmaf(e, e, e2[i]);
             }
         }
         __syncthreads();
+    }
+    if (dq != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float t = wave_sum(e2[i]);
+            const int64_t ff = f0 + wv + 4 * i;
+            if (lane == 0 && ff < Tt) dq[ff] = sqrtf(t) * 1.0001f;
+        }
     }
 }
 
 // the same for a handful of frames (streaming): one block per frame, threads along d -- the kernel above walks d
 // serially with one frame per lane, which for 8 frames is 2 x 192 dependent strided loads per wave
 __global__ __launch_bounds__(256) void src_prep_small_kernel(const float* __restrict__ src, int T, int64_t Tt,
-                                                             float* __restrict__ s_f32, unsigned short* __restrict__ s_bf16) {
+                                                             float* __restrict__ s_f32, unsigned short* __restrict__ s_bf16,
+                                                             float* __restrict__ dq) {
     __shared__ float red[4];
+    __shared__ float ered[4];
     const int64_t ft = blockIdx.x;
     const int tid = threadIdx.x;
     if (ft >= Tt) {                                  // padding frames of the last 256-frame block: zero rows
@@ -178,11 +225,21 @@ __global__ __launch_bounds__(256) void src_prep_small_kernel(const float* __rest
     }
     __syncthreads();
     const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    float e2 = 0.0f;
 #pragma unroll
     for (int i = 0; i < D / 256; ++i) {
         const float q = v[i] / nrm;
         s_f32[(size_t)ft * D + tid + 256 * i] = q;
-        s_bf16[(size_t)ft * D + tid + 256 * i] = f32_to_bf16_rn(q);
+        const unsigned short b = f32_to_bf16_rn(q);
+        s_bf16[(size_t)ft * D + tid + 256 * i] = b;
+        const float e = q - __uint_as_float((unsigned)b << 16);
+        e2 = fmaf(e, e, e2);
+    }
+    if (dq != nullptr) {                             // block-uniform
+        e2 = wave_sum(e2);
+        if ((tid & 63) == 0) ered[tid >> 6] = e2;
+        __syncthreads();
+        if (tid == 0) dq[ft] = sqrtf(ered[0] + ered[1] + ered[2] + ered[3]) * 1.0001f;
     }
 }
 
@@ -799,12 +856,6 @@ __global__ __launch_bounds__(256, 1) void knn_probe8_kernel(const unsigned char*
 // ----------------------------------------------------------------------------------------------
 // exact fp32 rescoring + top-k  (one wave per frame)
 // ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
 // (value desc, index asc) ordering, wave-wide argmax; returns the winning lane
 __device__ __forceinline__ int wave_argbest(float v, int idx) {
     float bv = v;
@@ -828,7 +879,8 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
                                                           int* __restrict__ out_idx, const int* __restrict__ frame_list,
                                                           const int* __restrict__ gate_cnt, int gate_lo, int gate_hi,
                                                           int* __restrict__ flag_list, int* __restrict__ flag_cnt, float zsig,
-                                                          int list_len, float pre_scale, float sd_prior) {
+                                                          int list_len, float pre_scale, float sd_prior,
+                                                          const float* __restrict__ det_q, const float* __restrict__ det_lib) {
     const int lane = threadIdx.x & 63;
     const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // candidate lists are indexed by slot
     int gc;
@@ -858,7 +910,13 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
     // so the certificate below still decides whether the frame's result stands.  At least MIN_RESCORE candidates are kept for
     // the error statistics.
     constexpr int MIN_RESCORE = 16;
-    const float prune = certify ? 2.0f * zsig * sd_prior / pre_scale : INFINITY;     // in prefilter-score units
+    // Strict mode (det_q != nullptr; bf16 stage only): the bound on |stage score - exact cosine| is DETERMINISTIC --
+    // Cauchy-Schwarz on the two rounding-error vectors, || q^ - bf16(q^) || (this frame, measured) + || bf16(q^) || *
+    // max_R || r^ - bf16(r^) || (this library, measured) + the fp32 accumulation error of 768 exact products (<= 768 * 2^-23
+    // * sum |q r| <= 9.3e-5) + the rounding of the rescoring arithmetic itself (< 3e-6): no statistics, no assumption.
+    const float det_bound = det_q != nullptr ? det_q[ft] + 1.004f * det_lib[0] + 1.0e-4f : 0.0f;
+    const float prune = !certify ? INFINITY
+                                 : (det_q != nullptr ? 2.0f * det_bound : 2.0f * zsig * sd_prior) / pre_scale;     // in prefilter-score units
     if (R <= 64) {
         if (lane < R) my_idx = ci[lane];
         if (certify) {
@@ -967,14 +1025,22 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
     }
 
     // ---- certificate statistics: error of the prefilter score on the rescored candidates of THIS frame ----
-    float err_mu = 0.0f, err_sd = 0.0f;
+    // The frame's candidates are the rows most like its true neighbours, so their errors have the scale that matters (the
+    // error of a stage score grows with the score, and rows with a few dominant coordinates have errors of their own kind:
+    // profiles/r03_knn_zstats.json) -- but they are a SELECTED sample: picking the highest stage scores favours positive
+    // errors, so their mean may only ever RAISE the bound (err_mu <= 0: the systematic shrink of rounded products, ~0.5 % of
+    // the score on fp8), the spread is taken about zero (RMS >= standard deviation), and twice the largest error seen is a
+    // second floor for the slack (heavy single-term errors are bounded, not Gaussian).
+    float err_mu = 0.0f, err_sd = 0.0f, err_max = 0.0f;
     if (certify) {
         const bool okc = my_idx >= 0 && my_score > -INFINITY;
         const float e = okc ? my_pre * pre_scale - my_score : 0.0f;
         const float n = wave_sum(okc ? 1.0f : 0.0f);
-        err_mu = wave_sum(e) / fmaxf(n, 1.0f);
-        const float d = okc ? e - err_mu : 0.0f;
-        err_sd = fmaxf(sqrtf(wave_sum(d * d) / fmaxf(n, 1.0f)), sd_prior);      // never below the stage's typical error
+        err_mu = fminf(wave_sum(e) / fmaxf(n, 1.0f), 0.0f);
+        err_sd = fmaxf(sqrtf(wave_sum(e * e) / fmaxf(n, 1.0f)), sd_prior);      // never below the stage's typical error
+        err_max = fabsf(e);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) err_max = fmaxf(err_max, __shfl_xor(err_max, o));
         c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 16));
         c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 32));
         c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 1)); c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 2));
@@ -999,7 +1065,8 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
     // k-th exact score does not clear that, the frame goes to the next tier: the bf16 candidate stage behind the fp8 one,
     // the exact scan behind the bf16 one (alive_knn_search_fp8 / alive_knn_search).
     if (certify && lane == 0 && c_cut > -INFINITY) {
-        const float bound = c_cut * pre_scale - err_mu + zsig * err_sd;
+        const float bound = det_q != nullptr ? c_cut * pre_scale + det_bound
+                                             : c_cut * pre_scale - err_mu + fmaxf(zsig * err_sd, 2.0f * err_max);
         if (!(vk > bound)) flag_list[atomicAdd(flag_cnt, 1)] = (int)ft;
     }
 }
@@ -1395,7 +1462,14 @@ __global__ __launch_bounds__(256) void knn_exact_merge_kernel(const float* __res
 
 // ---- small device-side control kernels of the tiered search (no host sync anywhere) ----
 // stats[]: see alive_knn_search_stats
-enum { ST_FLAG8 = 0, ST_FLAG16 = 1, ST_PROBE_N = 2, ST_PROBE_FAIL = 3, ST_MODE = 4, ST_FIRST = 5, ST_PROBE_CNT = 6, ST_WORDS = 16 };
+enum { ST_FLAG8 = 0, ST_FLAG16 = 1, ST_PROBE_N = 2, ST_PROBE_FAIL = 3, ST_MODE = 4, ST_FIRST = 5, ST_PROBE_CNT = 6, ST_TIER = 7,
+       ST_WORDS = 16 };
+// ST_TIER: which path the last search on this workspace took (written by every path, so that the host never has to
+// re-derive the dispatch): 1 = streaming scan, 2 = exact scan of every frame (k > 8), 3 = bf16 first, 4 = fp8 first
+enum { TIER_SCAN = 1, TIER_EXACT_ALL = 2, TIER_BF16 = 3, TIER_FP8 = 4 };
+__global__ void stats_init_kernel(int* __restrict__ stats, int tier) {
+    if (threadIdx.x < ST_WORDS) stats[threadIdx.x] = threadIdx.x == ST_TIER ? tier : 0;
+}
 
 // the sample of the probe: n frames at a fixed stride through the batch (rows of s_f8 copied, padded to a block of 256)
 __global__ __launch_bounds__(64) void probe_gather_kernel(const unsigned char* __restrict__ s_f8, int64_t Tt, int n, int n_pad,
@@ -1505,6 +1579,8 @@ struct SearchWs {
     unsigned short* s_c;                   // compacted bf16 rows of the frames being re-searched
     float* cv1; int* ci1;                  // tier-1 candidate lists
     unsigned char* s_p8; float* cvp; int* cip; int* p_list;   // probe: sample rows, lists, [frame of slot | flagged frames]
+    float* dq;                             // || q^ - bf16(q^) || per frame (strict certificate)
+    const float* det_q; const float* det_lib;   // set by the strict search only: frame / library share of the deterministic bound
     size_t bytes;
 };
 
@@ -1519,6 +1595,7 @@ static SearchWs ws_layout(void* base, int64_t Tt, int64_t M, int k) {
     w.probe_pad = (w.probe_n + FT - 1) / FT * FT;
     w.pp = make_plan(w.probe_n > 0 ? w.probe_n : 1, M, MAX_SPLIT8);
     Arena a(base);
+    w.stats = a.take<int>(ST_WORDS);       // first: its address must not depend on k (alive_knn_search_stats has no k)
     w.s_f32 = a.take<float>((size_t)Tt * D);
     w.s_bf16 = a.take<unsigned short>((size_t)Tp * D);
     w.s_f8 = a.take<unsigned char>((size_t)Tp * D);
@@ -1529,7 +1606,6 @@ static SearchWs ws_layout(void* base, int64_t Tt, int64_t M, int k) {
     if (lists < (size_t)SCAN_MAX_LISTS) lists = SCAN_MAX_LISTS;
     w.pv = a.take<float>(lists * 64);
     w.pi = a.take<int>(lists * 64);
-    w.stats = a.take<int>(ST_WORDS);
     w.list0 = a.take<int>((size_t)Tp);
     w.list1 = a.take<int>((size_t)Tp);
     w.s_c = a.take<unsigned short>((size_t)Tp * D);
@@ -1539,6 +1615,9 @@ static SearchWs ws_layout(void* base, int64_t Tt, int64_t M, int k) {
     w.cvp = a.take<float>((size_t)w.probe_pad * w.pp.P * KP8 + 4);
     w.cip = a.take<int>((size_t)w.probe_pad * w.pp.P * KP8 + 4);
     w.p_list = a.take<int>((size_t)2 * w.probe_pad + 8);
+    w.dq = a.take<float>((size_t)Tp);
+    w.det_q = nullptr;
+    w.det_lib = nullptr;
     w.bytes = a.used() + 1024;
     return w;
 }
@@ -1561,8 +1640,9 @@ extern "C" int alive_library_pack(const float* tokens, int64_t M, int Dd, void* 
 
 static int knn_scan_launch(const float* src, int T, int64_t Tt, const float* rows_f32, const float* norms, int64_t M,
                            int64_t idx_base, int k, float* s_f32, unsigned short* s_bf16, float* pv, int* pi, float* out_val,
-                           int32_t* out_idx, hipStream_t s, hipEvent_t g_ev_start, hipEvent_t g_ev_stop) {
-    src_prep_small_kernel<<<(unsigned)Tt, 256, 0, s>>>(src, T, Tt, s_f32, s_bf16);
+                           int32_t* out_idx, int* stats, hipStream_t s, hipEvent_t g_ev_start, hipEvent_t g_ev_stop) {
+    stats_init_kernel<<<1, 64, 0, s>>>(stats, TIER_SCAN);
+    src_prep_small_kernel<<<(unsigned)Tt, 256, 0, s>>>(src, T, Tt, s_f32, s_bf16, nullptr);
     int blocks = (int)((M + 4 * SCAN_WAVES - 1) / (4 * SCAN_WAVES));          // >= 4 rows per wave
     if (blocks > SCAN_MAX_LISTS / SCAN_WAVES) blocks = SCAN_MAX_LISTS / SCAN_WAVES;
     if (blocks < 1) blocks = 1;
@@ -1593,8 +1673,9 @@ static void knn_exact_launch(const SearchWs& w, const float* rows_f32, const flo
 }
 
 static void src_prep_launch(const SearchWs& w, const float* src, int T, int64_t Tt, hipStream_t s) {
-    if (Tt <= 512) src_prep_small_kernel<<<(unsigned)w.p16.Tt_pad, 256, 0, s>>>(src, T, Tt, w.s_f32, w.s_bf16);
-    else src_prep_kernel<<<(unsigned)(w.p16.Tt_pad / 64), 256, 0, s>>>(src, T, Tt, w.p16.Tt_pad, w.s_f32, w.s_bf16);
+    float* dq = w.det_q != nullptr ? w.dq : nullptr;
+    if (Tt <= 512) src_prep_small_kernel<<<(unsigned)w.p16.Tt_pad, 256, 0, s>>>(src, T, Tt, w.s_f32, w.s_bf16, dq);
+    else src_prep_kernel<<<(unsigned)(w.p16.Tt_pad / 64), 256, 0, s>>>(src, T, Tt, w.p16.Tt_pad, w.s_f32, w.s_bf16, dq);
 }
 
 static int check_search_args(const char* what, const void* a, const void* b, int N, int T, int k, int64_t M) {
@@ -1646,7 +1727,7 @@ static void bf16_tiers_launch(const SearchWs& w, const void* lib_bf16, const flo
     knn_score_kernel<<<dim3((unsigned)(fcap / FT), w.pt.split), 256, SCORE_LDS, s>>>(
         w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.cv1, w.ci1, cnt0, 0, fcap, 1);
     knn_rescore_kernel<<<(unsigned)((fcap + 3) / 4), 256, 0, s>>>(w.cv1, w.ci1, w.pt.P, KP, w.s_f32, rows_f32, norms, fcap, idx_base, k,
-                                                                 out_val, out_idx, w.list0, cnt0, 0, fcap, w.list1, cnt1, CERT_Z, KH, 1.0f, SD_PRIOR16);
+                                                                 out_val, out_idx, w.list0, cnt0, 0, fcap, w.list1, cnt1, CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib);
     if (w.p16.Tt_pad > fcap) {
         gather_frames_kernel<<<(unsigned)w.p16.Tt_pad, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, fcap, 0x7fffffff, w.s_c);
         knn_score_kernel<<<dim3((unsigned)(w.p16.Tt_pad / FT), w.p16.split), 256, SCORE_LDS, s>>>(
@@ -1654,7 +1735,7 @@ static void bf16_tiers_launch(const SearchWs& w, const void* lib_bf16, const flo
             0x7fffffff, 1);
         knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, w.p16.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                    out_val, out_idx, w.list0, cnt0, fcap, 0x7fffffff, w.list1, cnt1,
-                                                                   CERT_Z, KH, 1.0f, SD_PRIOR16);
+                                                                   CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib);
     }
     knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, w.list1, cnt1, out_val, out_idx, s);
 }
@@ -1664,16 +1745,20 @@ static void bf16_tiers_launch(const SearchWs& w, const void* lib_bf16, const flo
 // half-list of the candidate stage): the exact scan for every frame.
 static int knn_search_impl(const float* src, int N, int T, const void* lib_bf16, const float* rows_f32,
                            const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
-                           void* ws, void* stream, hipEvent_t g_ev_start, hipEvent_t g_ev_stop) {
+                           void* ws, void* stream, hipEvent_t g_ev_start, hipEvent_t g_ev_stop, const float* strict_bound = nullptr) {
     ALIVE_CHECK_ARG(src && lib_bf16 && rows_f32 && norms && out_val && out_idx && ws, "alive_knn_search: null pointer");
     if (int rc = check_search_args("alive_knn_search", src, ws, N, T, k, M)) return rc;
     const int64_t Tt = (int64_t)N * T;
-    const SearchWs w = ws_layout(ws, Tt, M, k);
+    SearchWs w = ws_layout(ws, Tt, M, k);
+    if (strict_bound != nullptr) {         // deterministic certificate: per-frame rounding error + the library's (alive_library_rounding_bound)
+        w.det_q = w.dq;
+        w.det_lib = strict_bound;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (Tt * k <= 64 && M <= SCAN_ROWS_MAX)            // a handful of frames: exact fp32 scan of the rows, no candidate stage
-        return knn_scan_launch(src, T, Tt, rows_f32, norms, M, idx_base, k, w.s_f32, w.s_bf16, w.pv, w.pi, out_val, out_idx, s, g_ev_start, g_ev_stop);
+        return knn_scan_launch(src, T, Tt, rows_f32, norms, M, idx_base, k, w.s_f32, w.s_bf16, w.pv, w.pi, out_val, out_idx, w.stats, s, g_ev_start, g_ev_stop);
     if (int rc = lds_optin("alive_knn_search")) return rc;
-    (void)hipMemsetAsync(w.stats, 0, ST_WORDS * sizeof(int), s);
+    stats_init_kernel<<<1, 64, 0, s>>>(w.stats, k > KH ? TIER_EXACT_ALL : TIER_BF16);
     src_prep_launch(w, src, T, Tt, s);
     if (k > KH) {
         if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
@@ -1689,7 +1774,7 @@ static int knn_search_impl(const float* src, int N, int T, const void* lib_bf16,
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
     knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, p.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                out_val, out_idx, nullptr, nullptr, 0, 0, w.list1, w.stats + ST_FLAG16,
-                                                               CERT_Z, KH, 1.0f, SD_PRIOR16);
+                                                               CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib);
     knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, w.list1, w.stats + ST_FLAG16, out_val, out_idx, s);
     ALIVE_CHECK_LAUNCH("alive_knn_search");
     return ALIVE_OK;
@@ -1709,6 +1794,27 @@ extern "C" int alive_knn_search(const float* src, int N, int T, const void* lib_
                                 void* ws, void* stream) {
     return knn_search_impl(src, N, T, lib_bf16, rows_f32, norms, M, idx_base, k, out_val, out_idx, ws, stream, nullptr, nullptr);
 }
+// Strict search: the bf16 candidate stage with a DETERMINISTIC certificate (knn_rescore_kernel: det_bound), frames that
+// fail it through the exact fp32 scan.  No statistical assumption anywhere: the result is the exact top-k of the rescoring
+// arithmetic for every input.  bound: device float[1] from alive_library_rounding_bound.
+extern "C" int alive_knn_search_strict(const float* src, int N, int T, const void* lib_bf16, const float* rows_f32,
+                                       const float* norms, const float* bound, int64_t M, int64_t idx_base, int k, float* out_val,
+                                       int32_t* out_idx, void* ws, void* stream, void* ev_start, void* ev_stop) {
+    ALIVE_CHECK_ARG(bound != nullptr, "alive_knn_search_strict: null bound (alive_library_rounding_bound)");
+    return knn_search_impl(src, N, T, lib_bf16, rows_f32, norms, M, idx_base, k, out_val, out_idx, ws, stream,
+                           (hipEvent_t)ev_start, (hipEvent_t)ev_stop, bound);
+}
+
+extern "C" int alive_library_rounding_bound(const void* lib_bf16, const float* rows_f32, const float* norms, int64_t M,
+                                            float* bound, void* stream) {
+    ALIVE_CHECK_ARG(lib_bf16 && rows_f32 && norms && bound && M >= 1, "alive_library_rounding_bound: bad arguments");
+    (void)hipMemsetAsync(bound, 0, sizeof(float), (hipStream_t)stream);
+    lib_rounding_bound_kernel<<<(unsigned)((M + 3) / 4), 256, 0, (hipStream_t)stream>>>((const unsigned short*)lib_bf16, rows_f32, norms,
+                                                                                        M, (unsigned*)bound);
+    ALIVE_CHECK_LAUNCH("alive_library_rounding_bound");
+    return ALIVE_OK;
+}
+
 extern "C" int alive_knn_search_timed(const float* src, int N, int T, const void* lib_bf16, const float* rows_f32,
                                       const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
                                       void* ws, void* stream, void* ev_start, void* ev_stop) {
@@ -1728,9 +1834,9 @@ static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f
     const SearchPlan& p = w.p8;
     hipStream_t s = (hipStream_t)stream;
     if (Tt * k <= 64 && M <= SCAN_ROWS_MAX)            // streaming ring: the exact scan, no candidate stage at all
-        return knn_scan_launch(src, T, Tt, rows_f32, norms, M, idx_base, k, w.s_f32, w.s_bf16, w.pv, w.pi, out_val, out_idx, s, g_ev_start, g_ev_stop);
+        return knn_scan_launch(src, T, Tt, rows_f32, norms, M, idx_base, k, w.s_f32, w.s_bf16, w.pv, w.pi, out_val, out_idx, w.stats, s, g_ev_start, g_ev_stop);
     if (int rc = lds_optin("alive_knn_search_fp8")) return rc;
-    (void)hipMemsetAsync(w.stats, 0, ST_WORDS * sizeof(int), s);
+    stats_init_kernel<<<1, 64, 0, s>>>(w.stats, TIER_FP8);
     src_prep_launch(w, src, T, Tt, s);
     const int64_t n8 = p.Tt_pad * D / 8;
     src_to_fp8_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>(w.s_bf16, n8, (uint2*)w.s_f8);
@@ -1745,7 +1851,7 @@ static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f
         knn_rescore_kernel<<<(unsigned)((w.probe_n + 3) / 4), 256, 0, s>>>(w.cvp, w.cip, w.pp.P, KP8, w.s_f32, rows_f32, norms, w.probe_n,
                                                                           idx_base, k, out_val, out_idx, w.p_list, nullptr, 0, 0,
                                                                           w.p_list + w.probe_pad, w.stats + ST_PROBE_CNT, CERT_Z, KH8,
-                                                                          1.0f / (F8_SCALE * F8_SCALE), SD_PRIOR8);
+                                                                          1.0f / (F8_SCALE * F8_SCALE), SD_PRIOR8, nullptr, nullptr);
         probe_decide_kernel<<<1, 1, 0, s>>>(w.stats, w.probe_n, PROBE_NUM, PROBE_DEN);
     }
     // ---- mode 0: fp8 first ----
@@ -1755,7 +1861,7 @@ static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
     knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, p.P, KP8, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                out_val, out_idx, nullptr, mode, -1, 0, w.list0, w.stats + ST_FLAG8,
-                                                               CERT_Z, KH8, 1.0f / (F8_SCALE * F8_SCALE), SD_PRIOR8);
+                                                               CERT_Z, KH8, 1.0f / (F8_SCALE * F8_SCALE), SD_PRIOR8, nullptr, nullptr);
     // ---- mode 1: bf16 first (every frame into list0) ----
     if (w.probe_n > 0) flag_all_kernel<<<(unsigned)((Tt + 255) / 256), 256, 0, s>>>(w.list0, w.stats + ST_FLAG8, Tt, mode, 0, 1);
     bf16_tiers_launch(w, lib_bf16, rows_f32, norms, M, Tt, idx_base, k, out_val, out_idx, s);
@@ -1779,6 +1885,8 @@ extern "C" int alive_knn_search_fp8_timed(const float* src, int N, int T, const 
 //   [0] frames the fp8 certificate sent to the bf16 stage (all frames when the probe chose bf16 first)
 //   [1] frames the bf16 certificate sent to the exact scan
 //   [2] frames of the probe sample, [3] of which failed the fp8 certificate, [4] 1 = the probe chose bf16 first
+//   [7] the path taken: 1 streaming scan, 2 exact scan of every frame (k > 8), 3 bf16 first, 4 fp8 first
+// (the counters are the first thing in the workspace: their address depends on neither the batch nor k)
 extern "C" const int* alive_knn_search_stats(int N, int T, int64_t M, void* ws) {
     return ws_layout(ws, (int64_t)N * T, M, 4).stats;
 }

@@ -92,7 +92,7 @@ def main(argv=None):
     VL = VoiceLibrary(args.num_tokens)
     if args.seed is not None:
         VL.tokens = torch.randn(1, 768, args.num_tokens, generator=torch.Generator().manual_seed(args.seed))
-    print("Generating Library...")
+    print("encoding the corpus into library frames")
     need = (args.num_tokens + args.frames_per_clip - 1) // args.frames_per_clip
     clips = collect_clips(args.dataset, need, rng)
     filled = 0
@@ -111,9 +111,9 @@ def main(argv=None):
         print(f"dedup: {filled - kept.shape[1]} of {filled} frames have an earlier neighbour above cos {args.dedup}")
         VL.tokens = torch.cat([kept, VL.tokens[0, :, filled:]], 1).unsqueeze(0).contiguous()
         filled = kept.shape[1]
-    print(f"Writing file... ({filled} of {VL.tokens.shape[2]} slots from data)")
+    print(f"saving ({filled} of {VL.tokens.shape[2]} slots from data)")
     torch.save(VL.state_dict(), args.voice_library_path)
-    print("Complete!")
+    print("done")
 
 
 if __name__ == "__main__":

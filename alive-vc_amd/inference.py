@@ -75,18 +75,18 @@ def main(argv=None):
 
     tgt = torch.zeros(1, 768, 0, device=device)
     if args.target != "NONE":
-        print("loading target...")
+        print("target: encoding the reference wav into library frames")
         wf, sr = audio_io.load(args.target)
         wf = audio_io.resample(wf.to(device), sr, 16000)
         wf = wf / wf.abs().max()
         wf = wf[:1]
         tgt = CE(spectrogram(wf))
     if args.voice_library_path != "NONE":
-        print(f"loading voice library {args.voice_library_path}")
+        print(f"target: voice library file {args.voice_library_path}")
         VL = VoiceLibrary().to(device)
         VL.load_state_dict(torch.load(args.voice_library_path, map_location=device))
         tgt = torch.cat([tgt, VL.tokens], dim=2)
-    print(f"Loaded {tgt.shape[2]} words.")
+    print(f"library holds {tgt.shape[2]} vectors")
     conv = Converter(CE, PE, Dec, device).set_library(tgt)
 
     paths = sorted(glob.glob(os.path.join(args.inputs, "*")))
@@ -95,7 +95,7 @@ def main(argv=None):
         wf = audio_io.resample(wf.to(device), sr, 16000)
         wf = wf / wf.abs().max()
         wf = wf.mean(dim=0, keepdim=True)
-        print(f"converting {path}")
+        print(f"-> {path}")
         out = conv.convert(wf, chunk=args.chunk, k=args.k, alpha=args.alpha, pitch_shift=args.pitch,
                            intonation=args.intonation, f0_rate=args.f0_rate, window_batch=args.window_batch,
                            trim_context=args.trim_context,

@@ -24,14 +24,22 @@ def _prefilter():
     return os.environ.get("ALIVE_KNN_PREFILTER", DEFAULT_PREFILTER)
 
 
+def _strict():
+    """ALIVE_KNN_STRICT=1: every search through the bf16 stage with the DETERMINISTIC certificate (no statistical
+    assumption; include/alive_vc.h: alive_knn_search_strict).  The default certificates are statistical (7 sigma of the
+    measured stage error; audited in profiles/r03_knn_audit.json)."""
+    return os.environ.get("ALIVE_KNN_STRICT", "0") not in ("0", "", "false", "False")
+
+
 class PackedLibrary:
     """Device-resident search form of a voice library tokens[768, M] (one shard).
 
     lib_bf16[M_pad,768] normalised rows (MFMA operand), rows[M,768] fp32 raw rows,
     norms[M].  `idx_base` is the global index of row 0 when the library is sharded."""
 
-    def __init__(self, tokens_DxM: torch.Tensor, idx_base: int = 0, prefilter: str = None):
-        self.prefilter = prefilter or _prefilter()
+    def __init__(self, tokens_DxM: torch.Tensor, idx_base: int = 0, prefilter: str = None, strict: bool = None):
+        self.strict = _strict() if strict is None else bool(strict)
+        self.prefilter = "bf16" if self.strict else (prefilter or _prefilter())
         if self.prefilter not in ("bf16", "fp8"):
             raise ValueError(f"prefilter must be 'bf16' or 'fp8', got {self.prefilter!r}")
         if tokens_DxM.dim() != 2 or tokens_DxM.shape[0] != DIM:
@@ -52,7 +60,16 @@ class PackedLibrary:
             self.lib_f8 = torch.empty(L.alive_library_fp8_bytes(self.M), dtype=torch.uint8, device=dev)
             nat.check(L.alive_library_pack_fp8(nat.ptr(self.lib_bf16), self.M, nat.ptr(self.lib_f8), nat.stream()),
                       "alive_library_pack_fp8")
+        self.bound = None
+        if self.strict:
+            self._make_bound()
         self._ws = nat.Workspace()
+
+    def _make_bound(self):
+        """max_R || r^ - bf16(r^) ||: the library's share of the strict certificate's deterministic bound"""
+        self.bound = torch.zeros(1, dtype=torch.float32, device=self.rows.device)
+        nat.check(nat.lib().alive_library_rounding_bound(nat.ptr(self.lib_bf16), nat.ptr(self.rows), nat.ptr(self.norms), self.M,
+                                                         nat.ptr(self.bound), nat.stream()), "alive_library_rounding_bound")
 
     def search(self, source, k, events=None):
         """exact top-k of this shard: (val[Tt,k] fp32 desc, idx[Tt,k] int32 global).
@@ -63,7 +80,11 @@ class PackedLibrary:
         idx = torch.empty(n * t, k, dtype=torch.int32, device=source.device)
         ws = self._ws.get(L.alive_knn_workspace_bytes(n * t, self.M), source.device)
         ev = (None, None) if events is None else (events[0].cuda_event, events[1].cuda_event)
-        if self.lib_f8 is not None:
+        if self.strict:
+            nat.check(L.alive_knn_search_strict(nat.ptr(source), n, t, nat.ptr(self.lib_bf16), nat.ptr(self.rows), nat.ptr(self.norms),
+                                                nat.ptr(self.bound), self.M, self.idx_base, k, nat.ptr(val), nat.ptr(idx),
+                                                nat.ptr(ws), nat.stream(), *ev), "alive_knn_search_strict")
+        elif self.lib_f8 is not None:
             nat.check(L.alive_knn_search_fp8_timed(nat.ptr(source), n, t, nat.ptr(self.lib_f8), nat.ptr(self.lib_bf16),
                                                    nat.ptr(self.rows), nat.ptr(self.norms), self.M, self.idx_base, k,
                                                    nat.ptr(val), nat.ptr(idx), nat.ptr(ws), nat.stream(), *ev), "alive_knn_search_fp8")
@@ -83,6 +104,7 @@ class PackedLibrary:
         other = copy.copy(self)
         other.__dict__.pop("search", None)             # an instrumented search (bench.py) stays with the original
         other.prefilter = prefilter
+        other.strict, other.bound = False, None
         other._ws = nat.Workspace()
         other._last = None
         if prefilter == "bf16":
@@ -94,6 +116,13 @@ class PackedLibrary:
                       "alive_library_pack_fp8")
         return other
 
+    def with_strict(self):
+        """the same resident library searched with the deterministic certificate (shares every tensor)"""
+        other = self.with_prefilter("bf16")
+        other.strict = True
+        other._make_bound()
+        return other
+
     def search_stats(self):
         """what the tiers of the last search on the current stream did (syncs; tests / bench)"""
         last = getattr(self, "_last", None)
@@ -101,14 +130,17 @@ class PackedLibrary:
             return None
         n, t, k, ws = last
         torch.cuda.synchronize()
-        st = {"prefilter": self.prefilter}
-        if n * t * k <= 64 and self.M <= 262144:        # the streaming scan: exact, no candidate stage
-            return dict(st, tier="exact scan of every row (streaming)")
-        if k > 8:
-            return dict(st, tier="exact scan of every row (k > 8)")
+        st = {"prefilter": self.prefilter, "certificate": "deterministic" if self.strict else "statistical"}
         off = nat.lib().alive_knn_search_stats(n, t, self.M, nat.ptr(ws)) - ws.data_ptr()
         c = ws[off:off + 32].view(torch.int32).tolist()
-        if self.lib_f8 is not None:
+        tier = c[7]                                     # written by the C side on every path (knn.hip: ST_TIER)
+        if tier == 1:
+            return dict(st, tier="exact scan of every row (streaming)")
+        if tier == 2:
+            return dict(st, tier="exact scan of every row (k > 8)")
+        if tier not in (3, 4):
+            raise RuntimeError(f"alive_knn_search_stats: no search has run on this workspace (tier word {tier})")
+        if tier == 4:
             st.update(frames_researched_on_bf16=c[0], probe_sample=c[2], probe_failed_fp8_certificate=c[3],
                       probe_chose_bf16_first=bool(c[4]))
         st.update(frames_searched_exactly=c[1], frames=n * t)
@@ -142,7 +174,7 @@ def _packed_for(reference_DxM):
     are invisible to it: call `forget_packed()` after such a write.)"""
     owner = reference_DxM._base if reference_DxM._base is not None else reference_DxM
     key = (reference_DxM.data_ptr(), tuple(reference_DxM.shape), tuple(reference_DxM.stride()), reference_DxM._version,
-           str(reference_DxM.device), _prefilter())
+           str(reference_DxM.device), _prefilter(), _strict())
     hit = _cache.get(key)
     if hit is not None and hit[1]() is owner:
         return hit[0]

@@ -167,8 +167,25 @@ class RealtimeConverter:
         self._cache_valid = False          # interior reuse: the captured step is the incremental one; the first real step runs in full
         return self
 
-    def step_device(self, ring_f32):
-        """ring float32 [1, buffersize*chunk] already on the device -> wave [L] (device); phase carried internally."""
+    def reset(self):
+        """start a new stream on this converter: empty ring, phase 0, and the interior-reuse caches invalid (the next step runs
+        the full front end).  Call it whenever the chunk sequence restarts or a chunk was dropped / duplicated."""
+        self.ring = []
+        self.phi = 0
+        self._cache_valid = False
+        if getattr(self, "_graph", None) is not None:
+            self._g_phi.zero_()
+        return self
+
+    def step_device(self, ring_f32, continues=False):
+        """ring float32 [1, buffersize*chunk] already on the device -> wave [L] (device); phase carried internally.
+
+        Contract of interior reuse (on when the ring geometry allows, see `reuse_block`): the matched features and f0 of the
+        ring's interior frames are carried over from the previous call, which is only right when `ring_f32` IS the previous
+        ring advanced by exactly one chunk.  The caller says so with `continues=True` (`step()` does: it owns the ring);
+        the default treats the ring as unrelated to the previous one and recomputes the whole front end."""
+        if not continues:
+            self._cache_valid = False
         if getattr(self, "_graph", None) is not None:
             if self.reuse and not self._cache_valid:             # fills the frame caches the captured (incremental) step reads
                 wave, phi_next = self._device_step(ring_f32, self._g_phi)
@@ -192,7 +209,7 @@ class RealtimeConverter:
             return None
         data = torch.from_numpy(np.concatenate(self.ring, 0)).to(self.device)
         data = audio_io.pcm16_to_float(data).unsqueeze(0)            # / 32768 on the device (:139-140)
-        wave = self.step_device(data)
+        wave = self.step_device(data, continues=True)                # this ring is the previous one advanced by one chunk
         out = audio_io.float_to_pcm16(wave).cpu().numpy()            # C cast of numpy's astype, no clipping (:180-183)
         center = self.buffersize * self.chunk // 2
         return out[center - self.chunk // 2: center + self.chunk // 2]

@@ -7,8 +7,9 @@
         windows -> one all-gather of [n, 768, T] fp32 (3 KB per frame; rescoring on the owning shard is
         exact fp32, so the frames travel as fp32);
      b. the lists: rescoring happens on the rank that owns the rows, so the exchanged lists are already
-        exact fp32 cosines -> one all-gather of [Tt_all, k] (val fp32 + idx int32 global: 8*k bytes per
-        frame per rank -- latency-bound on xGMI, not link-bound).
+        exact fp32 cosines -> one all-to-all that routes every shard's lists to the rank that owns the frames
+        ([S, own frames, k], val fp32 + idx int32 global: 8*k bytes per frame per shard -- latency-bound on
+        xGMI, not link-bound; an all-gather would deliver `world` times as much to every rank).
    Every rank then merges the S*k candidates of ITS OWN frames and gathers from its replicated fp32 row
    table; the decoder runs data-parallel again.  `ShardedLibrary.match` is the form for frames that are
    already replicated (step b only), `match_distributed` the end-to-end form (a + b).
@@ -60,6 +61,24 @@ def allgather_candidates(val, idx, group=None):
     return allgather_rows(val, group).view(world, tt, k), allgather_rows(idx, group).view(world, tt, k)
 
 
+def alltoall_candidates(val, idx, group=None):
+    """Routes the lists to the ranks that own the frames.  val / idx [world * r, k] on every rank: this shard's exact lists
+    of ALL frames, frames in owner-rank order, r frames per owner -> ([S, r, k], [S, r, k]): the lists of every shard for
+    THIS rank's r frames.  One all_to_all_single of val and idx packed side by side ([.., 2k] fp32 words): a rank receives
+    (world - 1) * r * k * 8 bytes, where an all-gather of everything would deliver world times that."""
+    world = dist.get_world_size(group)
+    tt, k = val.shape
+    r = tt // world
+    if dist.get_backend(group) == "gloo" and val.is_cuda:       # test-only path (1-GPU box): gloo moves host memory
+        gv, gi = alltoall_candidates(val.cpu(), idx.cpu(), group)
+        return gv.to(val.device), gi.to(val.device)
+    send = torch.cat([val.contiguous(), idx.contiguous().view(torch.float32)], dim=1).contiguous()      # [world * r, 2k]
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    recv = recv.view(world, r, 2 * k)
+    return recv[:, :, :k].contiguous(), recv[:, :, k:].contiguous().view(torch.int32)
+
+
 class ShardedLibrary:
     """`search(source, k) -> (val, idx_global)` over this rank's slab, `merge(gv, gi, S, k, alpha, source)`
     over the gathered lists (optionally `return_indices=True` -> (out, idx[Tt, k]))."""
@@ -93,22 +112,25 @@ class ShardedLibrary:
             mine = torch.cat([mine, mine[:1].expand(n_max - n, -1, -1)], 0)
         frames = allgather_rows(mine, self.group)                           # (a) [world * n_max, 768, T]
         val, idx = self.search(frames, k)                                   # this slab's exact top-k of EVERY frame
-        gv, gi = allgather_candidates(val, idx, self.group)                 # (b) [S, world * n_max * T, k]
-        lo = rank * n_max * t
-        gv, gi = gv[:, lo:lo + n * t].contiguous(), gi[:, lo:lo + n * t].contiguous()
+        gv, gi = alltoall_candidates(val, idx, self.group)                  # (b) [S, n_max * T, k]: only this rank's frames
+        gv, gi = gv[:, :n * t].contiguous(), gi[:, :n * t].contiguous()
         self.last_exchange_bytes = {"frames_allgather_received": int((world - 1) * n_max * d * t * 4),
-                                    "lists_allgather_received": int((world - 1) * world * n_max * t * k * 8)}
+                                    "lists_alltoall_received": int((world - 1) * n_max * t * k * 8)}
         return self.merge(gv, gi, world, k, alpha, source_local, **kw)
 
 
-def make_hip_sharded_library(tokens_DxM, rank, world, group=None, prefilter=None):
+def make_hip_sharded_library(tokens_DxM, rank, world, group=None, prefilter=None, rows_full=None):
     """HIP instantiation: this rank packs only its slab for scoring and keeps the full fp32 row table
-    (3 GB at 1 M vectors: trivial in 288 GB) for the final gather."""
+    (3 GB at 1 M vectors: trivial in 288 GB) for the final gather.  rows_full: an existing [M, 768] fp32 row table of the
+    same library (a replicated PackedLibrary's `.rows`) to reuse instead of a second transposed copy."""
     from .common import PackedLibrary, merge_gather
     M = tokens_DxM.shape[1]
     b, e = shard_bounds(M, world)[rank]
     shard = PackedLibrary(tokens_DxM[:, b:e].contiguous(), idx_base=b, prefilter=prefilter)
-    rows_full = tokens_DxM.t().contiguous()
+    if rows_full is None:
+        rows_full = tokens_DxM.t().contiguous()
+    elif tuple(rows_full.shape) != (M, tokens_DxM.shape[0]):
+        raise ValueError(f"rows_full is {tuple(rows_full.shape)}, expected {(M, tokens_DxM.shape[0])}")
 
     def merge(gv, gi, S, k, alpha, source, return_indices=False):
         return merge_gather(gv, gi, S, k, alpha, rows_full, source, return_indices)
@@ -128,6 +150,14 @@ class ShardedConverter(Converter):
 
     def match(self, feat, k=4, alpha=0.0):
         return self.sharded.match_distributed(feat, k, alpha, self.counts)
+
+    def convert_windows(self, windows, *a, share_overlap=None, **kw):
+        # overlap sharing flattens a rank's distinct frames into ONE [1, 768, F] source whose F differs from rank to rank;
+        # the exchange steps are equal-size collectives over whole windows, so the mode is refused here rather than padded
+        if share_overlap:
+            raise ValueError("share_overlap is not available with a sharded library: use the replicated Converter, or "
+                             "share_overlap=None")
+        return super().convert_windows(windows, *a, share_overlap=None, **kw)
 
 
 def _fence(dev):
@@ -158,7 +188,16 @@ def bench_sharded(conv, tokens_DxM, windows_global, k, world, rank, dev, window_
     n_total = windows_global.shape[0]
     counts = [e - b for b, e in shard_bounds(n_total, world)]
     own = windows_global[partition_windows(n_total, world, rank)].contiguous()
-    sl = make_hip_sharded_library(tokens_DxM, rank, world)
+    # Everything that can fail on ONE rank alone (allocations: the slab's packed forms) happens before the first collective
+    # of the leg, and the ranks agree on the outcome first: a rank that raised later, inside the exchange, would leave its
+    # peers blocked in an all-gather for good (and the job's one JSON line unprinted).
+    sl, err = None, None
+    try:
+        sl = make_hip_sharded_library(tokens_DxM, rank, world, rows_full=conv.library.rows)
+    except Exception as e:                                    # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"[:200]
+    if not _all_true(sl is not None, dev):
+        return {"error": f"library shard set-up failed on some rank (this rank: {err})", "shards": world}
     sconv = ShardedConverter(conv.ce, conv.pe, conv.dec, dev).set_sharded_library(sl, counts)
 
     # (i) lists: sharded merge vs unsharded search, own frames (first window batch is enough to cover every code path once
@@ -202,5 +241,5 @@ def bench_sharded(conv, tokens_DxM, windows_global, k, world, rank, dev, window_
             "global_windows": n_total, "global_frames": n_total * lf, "windows_per_rank": counts,
             "shards": world, "rows_per_shard": [e - b for b, e in shard_bounds(M, world)],
             "scaling": "strong (one fixed global batch; never part of `value`)",
-            "exchange": "all_gather frames [n,768,T] fp32 + all_gather lists [Tt,k] fp32+int32",
+            "exchange": "all_gather frames [n,768,T] fp32 + all_to_all lists [own frames,k] fp32+int32",
             "exchange_bytes_received_per_rank": sl.last_exchange_bytes, "backend": dist.get_backend()}

@@ -71,24 +71,24 @@ def main(argv=None):
 
     tgt = torch.zeros(1, 768, 0, device=device)
     if args.target != "NONE":
-        print("loading target...")
+        print("target: encoding the reference wav into library frames")
         wf, sr = audio_io.load(args.target)
         wf = audio_io.resample(wf.to(device), sr, 16000)
         wf = wf / wf.abs().max()
         tgt = CE(spectrogram(wf[:1]))[:, :, ::4]                # the realtime script subsamples the target (:88)
     if args.voice_library_path != "NONE":
-        print(f"loading voice library {args.voice_library_path}")
+        print(f"target: voice library file {args.voice_library_path}")
         VL = VoiceLibrary().to(device)
         VL.load_state_dict(torch.load(args.voice_library_path, map_location=device))
         tgt = torch.cat([tgt, VL.tokens], dim=2)
-    print(f"Loaded {tgt.shape[2]} words.")
+    print(f"library holds {tgt.shape[2]} vectors")
 
     rt = RealtimeConverter(CE, PE, Dec, tgt.contiguous(), device, chunk=args.chunk, buffersize=args.buffersize,
                            input_sr=args.input_sr, output_sr=args.output_sr, f0_rate=args.f0_rate, pitch=args.pitch,
                            k=args.k, alpha=args.alpha, gain=args.gain, input_gain=args.input_gain)
     if not args.no_graph:
         rt.enable_graph()        # the whole per-chunk device pipeline (~150 launches) captured once, replayed per chunk: same samples
-    print("converting voice...")
+    print("streaming: conversion running (Ctrl-C stops)")
     if args.input_wav is not None:
         wf, sr = audio_io.load(args.input_wav)
         wf = audio_io.resample(wf.mean(dim=0, keepdim=True).to(device), sr, args.input_sr)[0].cpu()

@@ -46,12 +46,11 @@ def launch_ranks(args):
     have = torch.cuda.device_count()
     if not args.same_device and have < args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but this node shows {have} GPU(s)")
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher picks (and holds) a free rendezvous port itself -- binding a socket here, closing it and
+    # passing the number on would race with every other job on the node
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
     # stdout of this process is the contract's ONE JSON line: everything else the ranks (or their libraries: gloo announces
     # its peers on stdout) print goes to stderr
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
@@ -219,10 +218,18 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real thing); gloo + --same-device only exercise the multi-rank code path on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true", help="test only: every rank uses cuda:0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="--gpus 1 only: create a world-size-1 process group anyway and run the library-sharded leg with one shard, so "
+                         "that RCCL init, the device-tensor collectives and the fences of module/sharded.py execute on a 1-GPU box")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(launch_ranks(args))
+    if args.force_dist and "RANK" not in os.environ:              # a one-rank "job" without a launcher: rendezvous on loopback
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -231,7 +238,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", 0 if args.same_device else local)
     torch.cuda.set_device(dev)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -255,7 +263,7 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234)         # same library on every rank
     tokens = torch.randn(768, M, device=dev, generator=g)
     library = PackedLibrary(tokens)
-    if world == 1 or args.no_shard_library:
+    if not dist_on or args.no_shard_library:
         del tokens
     conv = Converter(ContentEncoder(seed=2), F0Estimator(seed=2), Decoder(seed=2), dev).set_library(library)
     windows = synth_windows(args.utterances, args.seconds, args.chunk, dev, seed=100 + rank)
@@ -271,7 +279,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -284,7 +292,7 @@ def main():
         out = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
@@ -511,7 +519,7 @@ def main():
     del small_tokens
 
     sharded = None
-    if world > 1 and not args.no_shard_library:
+    if dist_on and not args.no_shard_library:
         # BASELINE config 4 (never part of `value`): one fixed global batch (same seed on every rank), windows partitioned
         # over the ranks, the library cut into `world` row slabs -- checked bitwise against the replicated path
         from module.sharded import bench_sharded
@@ -548,14 +556,14 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        if world > 1:
+        if dist_on:
             line["ranks"] = {"backend": dist.get_backend(), "rccl_ranks" if args.backend == "nccl" else "gloo_ranks": dist.get_world_size(),
                              "same_device": bool(args.same_device)}
         line.update(extra)
         if sharded is not None:
             line["sharded_knn"] = sharded
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

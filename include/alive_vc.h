@@ -61,8 +61,12 @@ int alive_library_pack(const float* tokens_DxM, int64_t M, int D,
  *   bf16 MFMA cosine scoring with lane-private top-k' lists in LDS, then exact fp32 rescoring (normalise-then-dot, as
  *   the reference) of every candidate.  Every frame is then CERTIFIED: a row outside its rescored set has a candidate
  *   score <= c (the floor of the partial list it failed to enter, or the best candidate the selection of 64 dropped),
- *   hence an exact cosine <= c - mu + 7 sigma with (mu, sigma) the candidate-score error measured on that frame's own
- *   rescored candidates; the frame passes if its k-th exact cosine clears that.  Frames that do not pass are searched
+ *   hence an exact cosine <= c - min(mu, 0) + max(7 sigma, 2 max|e|), with mu / sigma / max|e| the mean, the RMS about zero
+ *   (floored by the stage's typical error) and the largest magnitude of the candidate-score error measured on that frame's
+ *   own rescored candidates; the frame passes if its k-th exact cosine clears that.  This certificate is STATISTICAL: it is
+ *   wrong for a frame only if the stage error of one of its k true neighbours lies beyond those 7 sigma (audited:
+ *   tools/knn_audit.py, profiles/r03_knn_audit.json; alive_knn_search_strict is the form without any such assumption).
+ *   Frames that do not pass are searched
  *   again by the exact tier inside the same call: a brute-force fp32 scan of the whole shard with the rescoring
  *   arithmetic (launched up front, sized on the device, no sync).  k > 8: the exact scan for every frame.
  *   out_val[Tt][k] fp32 cosine, descending; out_idx[Tt][k] = idx_base + row.
@@ -73,6 +77,20 @@ int alive_knn_search(const float* src, int N, int T,
                      const void* lib_bf16, const float* rows_f32, const float* norms,
                      int64_t M, int64_t idx_base, int k,
                      float* out_val, int32_t* out_idx, void* ws, void* stream);
+
+/* Strict form of alive_knn_search: the same bf16 candidate stage, but the certificate is DETERMINISTIC -- a row outside a
+ * frame's rescored set has an exact cosine <= c + || q^ - bf16(q^) || + 1.004 max_R || r^ - bf16(r^) || + 1.0e-4
+ * (Cauchy-Schwarz on the two rounding-error vectors; the last term bounds the fp32 accumulation of the stage and the
+ * rounding of the rescoring arithmetic).  Frames that do not clear it go through the exact fp32 scan, so the returned
+ * lists are the exact top-k of the rescoring arithmetic for EVERY input, adversarial ones included.
+ *   bound: device float[1] = max_R || r^ - bf16(r^) ||, filled by alive_library_rounding_bound from a packed library.
+ *   ev_start / ev_stop: as in the *_timed forms below (NULL: none).  Counters: alive_knn_search_stats [1], [7]. */
+int alive_library_rounding_bound(const void* lib_bf16, const float* rows_f32, const float* norms, int64_t M,
+                                 float* bound, void* stream);
+int alive_knn_search_strict(const float* src, int N, int T,
+                            const void* lib_bf16, const float* rows_f32, const float* norms, const float* bound,
+                            int64_t M, int64_t idx_base, int k,
+                            float* out_val, int32_t* out_idx, void* ws, void* stream, void* ev_start, void* ev_stop);
 
 /* The same search with the first candidate stage on the block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, OCP e4m3
  * operands = normalised rows x 2^8, scales 2^0): about twice the scoring rate at ~20x the score error of bf16, so the
@@ -88,7 +106,8 @@ int alive_knn_search(const float* src, int N, int T,
  *   exact  the frames that failed again: brute-force fp32 scan.
  * alive_knn_search_stats: device pointer (inside ws) to int[8] counters of the last search on that workspace:
  *   [0] frames sent to the bf16 stage  [1] frames sent to the exact scan  [2] probe sample size  [3] probe failures
- *   [4] 1 = the probe chose bf16 first.  (alive_knn_search fills [1] only.) */
+ *   [4] 1 = the probe chose bf16 first  [7] the path taken: 1 streaming scan, 2 exact scan of every frame (k > 8),
+ *   3 bf16 first, 4 fp8 first.  (alive_knn_search fills [1] and [7] only.)  The counters sit at the start of ws. */
 size_t alive_library_fp8_bytes(int64_t M);
 int alive_library_pack_fp8(const void* lib_bf16, int64_t M, void* lib_f8, void* stream);
 int alive_knn_search_fp8(const float* src, int N, int T,

@@ -209,7 +209,7 @@ def test_realtime_interior_reuse_equals_full_recomputation(graph, bs):
         waves = []
         for s in range(steps):                                          # the float waveform of the whole ring, not only its int16 centre
             ring = torch.from_numpy(pcm[s * chunk:(s + bs) * chunk].astype(np.float32) / 32768)[None].to("cuda")
-            waves.append(rt.step_device(ring).clone())
+            waves.append(rt.step_device(ring, continues=s > 0).clone())   # the caller vouches for the one-chunk advance
         outs[reuse] = torch.stack(waves)
     assert outs[True].shape[0] == steps and torch.isfinite(outs[True]).all()
     assert torch.equal(outs[True], outs[False])
@@ -219,6 +219,71 @@ def test_realtime_interior_reuse_equals_full_recomputation(graph, bs):
     with pytest.raises(ValueError):                                     # 120 frames: no block size stays on the full ring's kernels
         RealtimeConverter(ContentEncoder(seed=2), F0Estimator(seed=2), Decoder(seed=2), lib, "cuda", chunk=960, buffersize=40,
                           reuse_interior=True)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_realtime_interior_reuse_survives_a_broken_chunk_sequence(graph):
+    """the carried-over interior frames are only valid when the ring is the previous one advanced by one chunk.
+    `step_device` without `continues=True` (a dropped chunk, an unrelated ring) and `reset()` (a second stream on the same
+    converter) must fall back to the full front end: results bitwise those of a converter without interior reuse."""
+    from module.content_encoder import ContentEncoder
+    from module.decoder import Decoder
+    from module.f0_estimator import F0Estimator
+    from module.realtime import RealtimeConverter
+    lib = synthetic.make_library(3000, 1)
+    chunk, bs = 960, 26
+    pcm = (synthetic.make_waveform(chunk * (bs + 12), 65)[0].numpy() * 20000).astype(np.int16)
+    starts = [0, 1, 2, 5, 6, 3]                                          # chunk 3, 4 dropped, then a jump backwards
+    outs = {}
+    for reuse in (False, True):
+        rt = RealtimeConverter(ContentEncoder(seed=2), F0Estimator(seed=2), Decoder(seed=2), lib, "cuda", chunk=chunk,
+                               buffersize=bs, reuse_interior=reuse)
+        if graph:
+            rt.enable_graph()
+        waves, prev = [], None
+        for s in starts:
+            ring = torch.from_numpy(pcm[s * chunk:(s + bs) * chunk].astype(np.float32) / 32768)[None].to("cuda")
+            waves.append(rt.step_device(ring, continues=(prev is not None and s == prev + 1)).clone())
+            prev = s
+        # a second stream through step(): reset() empties the ring, the phase and the caches
+        rt.reset()
+        second = [rt.step(pcm[(4 + i) * chunk:(5 + i) * chunk]) for i in range(bs + 3)]
+        assert all(o is None for o in second[:bs]) and all(o is not None for o in second[bs:])
+        outs[reuse] = (torch.stack(waves), np.concatenate(second[bs:]))
+    assert torch.equal(outs[True][0], outs[False][0])
+    assert np.array_equal(outs[True][1], outs[False][1])
+
+
+def test_realtime_interior_reuse_matches_oracle():
+    """row f4 against the CPU oracle (not only against the build's own full recomputation): a 78-frame ring advancing by
+    3 frames, 5 emitted chunks, interior reuse on -- int16 RMS / 32768 < 1e-3 like every other streaming test"""
+    from module import schema
+    from module.content_encoder import ContentEncoder
+    from module.decoder import Decoder
+    from module.f0_estimator import F0Estimator
+    from module.realtime import RealtimeConverter
+    lib = synthetic.make_library(1000, 1)
+    sds = [synthetic.make_state_dict(s, 2, p) for s, p in ((schema.content_encoder_schema(), "ce."),
+                                                          (schema.f0_estimator_schema(), "pe."), (schema.decoder_schema(), "dec."))]
+    chunk, bs, emit = 960, 26, 5
+    rt = RealtimeConverter(ContentEncoder(seed=2), F0Estimator(seed=2), Decoder(seed=2), lib, "cuda", chunk=chunk,
+                           buffersize=bs, f0_rate=0.5, reuse_interior=True)
+    pcm = (synthetic.make_waveform(chunk * (bs + emit), 66)[0].numpy() * 20000).astype(np.int16)
+    begin, end = O.realtime_geometry(chunk, bs)
+    phi, outs, refs = 0, [], []
+    for s in range(bs + emit):
+        o = rt.step(pcm[s * chunk:(s + 1) * chunk])
+        if s < bs:
+            continue
+        ring = torch.from_numpy(pcm[(s - bs + 1) * chunk:(s + 1) * chunk].astype(np.float32) / 32768)[None]
+        wave, phi = O.realtime_step(sds[0], sds[1], sds[2], ring, lib, phi, begin, end, f0_rate=0.5)
+        ref = (wave[0].numpy() * 32768).astype(np.int16)
+        c = bs * chunk // 2
+        refs.append(ref[c - chunk // 2: c + chunk // 2])
+        outs.append(o)
+    got, want = np.concatenate(outs).astype(np.float64), np.concatenate(refs).astype(np.float64)
+    assert got.shape == want.shape == (emit * chunk,)
+    assert np.sqrt(np.mean((got - want) ** 2)) / 32768 < 1e-3
 
 
 def test_realtime_rejects_rings_shorter_than_five_frames(workdir):
@@ -304,6 +369,27 @@ def test_realtime_graph_capture_equals_eager(workdir):
         outs[mode] = np.concatenate([o for o in got if o is not None])
     assert outs["eager"].shape == (6 * chunk,)
     assert np.array_equal(outs["eager"], outs["graph"])
+
+
+def test_bench_world1_rccl_executes_the_sharded_leg():
+    """the RCCL code path on the hardware there is.  `--gpus 1 --force-dist` creates a world-size-1 `nccl`
+    (= RCCL) process group: communicator init with device_id, barrier / all_reduce on device tensors (fences, max over
+    ranks), all_gather_into_tensor of the content features and all_to_all_single of the exact lists in module/sharded.py,
+    with one shard -- so that an 8-GPU run is not the first execution of those calls on device memory."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--backend", "nccl",
+                        "--library-size", "30000", "--utterances", "3", "--seconds", "4", "--steps", "1", "--warmup", "1",
+                        "--window-batch", "8", "--legs", "none"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["ranks"] == {"backend": "nccl", "rccl_ranks": 1, "same_device": False}
+    sk = d["sharded_knn"]
+    assert sk["backend"] == "nccl" and sk["equals_unsharded"] is True and sk["shards"] == 1, sk
+    assert sk["rows_per_shard"] == [30000] and sk["exchange"].startswith("all_gather frames")
 
 
 def test_bench_two_ranks_gloo_same_device():

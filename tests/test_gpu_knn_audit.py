@@ -1,0 +1,101 @@
+"""Exactness audit of the tiered kNN search: EVERY frame of the bench batch, and adversarial
+libraries, against a brute-force fp32 scan of the whole 1 M-vector library -- for the fp8-first search, the bf16-first search
+and the strict (deterministic-certificate) search.  A frame whose returned top-k set differs from the brute-force set
+although the brute-force gap(k, k+1) is >= 1e-5 is a false certification: any such frame fails the test.
+The cases and the brute force are those of tools/knn_audit.py (whose full report is profiles/r03_knn_audit.json)."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+M = 1_000_000
+
+
+@pytest.fixture(scope="module")
+def env():
+    import bench
+    import knn_audit as A
+    from module.content_encoder import ContentEncoder
+    from module.decoder import Decoder
+    from module.f0_estimator import F0Estimator
+    from module.pipeline import Converter
+    dev = torch.device("cuda")
+    conv = Converter(ContentEncoder(seed=2), F0Estimator(seed=2), Decoder(seed=2), dev)
+    yield A, bench, conv, dev
+    A._feat_cache.clear()
+    torch.cuda.empty_cache()
+
+
+def run_case(env, name, frames, modes, k=4):
+    from module.common import PackedLibrary
+    A, bench, conv, dev = env
+    toks, feat = A.make_case(name, M, frames, dev, conv, bench)
+    N, _, t = feat.shape
+    qn = A.normalise_rows(feat.permute(0, 2, 1).reshape(N * t, 768))
+    bv, bi = A.brute_topk(qn, A.normalise_rows(toks.t().contiguous()), k + 1)
+    out = {}
+    for mode in modes:
+        lib = PackedLibrary(toks, prefilter="fp8" if mode == "fp8" else "bf16", strict=(mode == "strict"))
+        val, idx = lib.search(feat, k)
+        r = A.compare(val, idx, bv, bi, k)
+        r["tiers"] = lib.search_stats()
+        out[mode] = (r, val, idx)
+        del lib
+    del toks, feat, qn
+    torch.cuda.empty_cache()
+    return out
+
+
+@pytest.mark.parametrize("name", ["randn", "dense"])
+def test_every_frame_of_the_bench_batch_against_brute_force(env, name):
+    """all 172 800 frames x 1 M rows, the bench's i.i.d. library and the dense content-encoder library"""
+    res = run_case(env, name, 172_800, ("fp8", "bf16", "strict"))
+    for mode, (r, _, _) in res.items():
+        assert r["frames"] == 172_800 and r["safe_frames"] > 0.98 * r["frames"], (name, mode, r)
+        assert r["mismatches"] == 0, (name, mode, r)
+        assert r["max_abs_value_error"] <= 2e-6, (name, mode, r)
+    # the three searches return the same exact lists (ties to the lower index in every tier)
+    assert torch.equal(res["fp8"][2], res["bf16"][2]) and torch.equal(res["fp8"][1], res["bf16"][1])
+    assert torch.equal(res["strict"][2], res["bf16"][2])
+    assert res["strict"][0]["tiers"]["certificate"] == "deterministic"
+    if name == "randn":              # the headline case: certified on fp8, nothing re-searched
+        assert res["fp8"][0]["tiers"]["frames_researched_on_bf16"] <= 16, res["fp8"][0]["tiers"]
+
+
+@pytest.mark.parametrize("name", ["randn_iid", "spiky", "spiky_self", "norms", "mixture", "lowrank", "self", "dense_self", "clusters"])
+def test_adversarial_libraries_against_brute_force(env, name):
+    """rows with 1-8 dominant coordinates, norms over six decades, a dense / spiky mixture with queries that carry a matching
+    spike, rank-16 rows, queries that are library rows, clusters of near-copies denser than any stage's error"""
+    frames = 450 * (8 if name == "clusters" else 48)             # clusters: every frame ends in the exact scan
+    res = run_case(env, name, frames, ("fp8", "bf16", "strict"))
+    for mode, (r, _, _) in res.items():
+        assert r["mismatches"] == 0, (name, mode, r)
+        assert r["max_abs_value_error"] <= 2e-6, (name, mode, r)
+    assert res["fp8"][0]["safe_frames"] > 0.5 * frames, res["fp8"][0]
+
+
+def test_search_counters_do_not_depend_on_k(env):
+    """the counters used to be looked up with the layout of k = 4; for k in 5..8 and more than 32 768 frames they
+    were read from inside the partial-list area.  They now sit at the start of the workspace."""
+    from module.common import PackedLibrary
+    A, bench, conv, dev = env
+    toks = torch.randn(768, 50_000, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    feat = torch.randn(90, 768, 450, device=dev, generator=torch.Generator(device=dev).manual_seed(4))       # 40 500 frames
+    for pf in ("fp8", "bf16"):
+        lib = PackedLibrary(toks, prefilter=pf)
+        ref = None
+        for k in (4, 8):
+            val, idx = lib.search(feat, k)
+            st = lib.search_stats()
+            assert st["frames"] == 40_500 and 0 <= st["frames_searched_exactly"] <= 64, (pf, k, st)
+            if pf == "fp8":
+                assert st["probe_sample"] == 1024 and 0 <= st["frames_researched_on_bf16"] <= 4096, (pf, k, st)
+            if ref is not None:                                   # the k = 8 lists start with the k = 4 lists
+                assert torch.equal(idx[:, :4], ref)
+            ref = idx[:, :4].clone() if k == 4 else ref

@@ -190,7 +190,7 @@ def _worker(rank, world, port, q):
         same_idx = bool((torch.sort(gidx, 1).values == torch.sort(widx, 1).values).all())
         xb = sl.last_exchange_bytes
         ok_bytes = xb["frames_allgather_received"] == (world - 1) * 3 * 768 * 9 * 4 and \
-            xb["lists_allgather_received"] == (world - 1) * world * 3 * 9 * 3 * 8
+            xb["lists_alltoall_received"] == (world - 1) * 3 * 9 * 3 * 8        # routed: only this rank's frames arrive
         q.put((rank, float((out - ref).abs().max()), float((whole - ref).abs().max()), e3, same_idx and ok_bytes))
     finally:
         dist.destroy_process_group()
