@@ -18,6 +18,14 @@
 // HBM traffic drops to the input, the U-Net skip and the output (3 tensor passes instead of ~18).
 #include "conv_epilogue.h"
 
+// With hipcc's SLP vectorizer on, filter_block64_kernel comes out as a binary whose last column tiles differ from run to run
+// (DESIGN.md 3.2b'; a static scan of that binary, tools/mfma_hazard_scan.py, finds no MFMA operand / result distance below
+// the gfx950 tables, so the defect is not one the listed software hazards explain).  The Makefile compiles this file with
+// -fno-slp-vectorize and says so with the macro; any other recipe fails here instead of shipping that binary.
+#ifndef ALIVE_FILTER_MID_NO_SLP
+#error "filter_mid.hip must be compiled with -fno-slp-vectorize -DALIVE_FILTER_MID_NO_SLP (see csrc/Makefile)"
+#endif
+
 namespace {
 
 constexpr int C = 64;

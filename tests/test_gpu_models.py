@@ -48,7 +48,13 @@ def test_networks_against_reference_fixtures(golden_dir, nets, T):
     wave, phi = dec(full_feat.to(DEV), torch.from_numpy(z["f0_dec"]).to(DEV))
     err = rms(wave, torch.from_numpy(z["wave"]))
     assert err < RMS_BAR, f"waveform RMS error {err:.3e} vs reference fixture"
-    torch.testing.assert_close(phi[:, :, -1].cpu(), torch.from_numpy(z["phi_last"]), rtol=0, atol=5e-2)
+    # the carried phase is asin(sin(theta)): ill-conditioned where |sin| -> 1 (d asin = d sin / cos), so it is compared away
+    # from the fold, at the tolerance the long-horizon streaming test measures (7e-4 rad after 300 carried steps)
+    ref_phi = torch.from_numpy(z["phi_last"])
+    ok = ref_phi.abs() < 1.45
+    assert ok.float().mean() > 0.8
+    torch.testing.assert_close(phi[:, :, -1].cpu()[ok], ref_phi[ok], rtol=0, atol=5e-3)
+    torch.testing.assert_close(torch.sin(phi[:, :, -1].cpu()), torch.sin(ref_phi), rtol=0, atol=2e-3)      # everywhere: sin is what is carried
 
 
 def test_decoder_stage_errors_are_small(nets):
@@ -83,7 +89,10 @@ def test_realtime_two_steps(golden_dir, nets):
         data, phi_out = dec(content, f0=f0, phi=phi, crop=(begin, end))
         phi = phi_out[:, :, end].unsqueeze(2)
         assert rms(data, torch.from_numpy(z[f"wave{step}"])) < RMS_BAR
-        torch.testing.assert_close(phi.cpu(), torch.from_numpy(z[f"phi{step}"]), rtol=0, atol=2e-2)
+        ref_phi = torch.from_numpy(z[f"phi{step}"])
+        ok = ref_phi.abs() < 1.45                                # away from the fold of asin (see the fixture test above)
+        torch.testing.assert_close(phi.cpu()[ok], ref_phi[ok], rtol=0, atol=5e-3)
+        torch.testing.assert_close(torch.sin(phi.cpu()), torch.sin(ref_phi), rtol=0, atol=2e-3)
 
 
 def test_decoder_rejects_short_input_and_bad_scale(nets):

@@ -75,7 +75,7 @@ def test_streaming_300_steps_hipgraph_matches_oracle_with_carried_phase():
         json.dump(report, open(os.path.join(out_dir, "streaming_long_horizon.json"), "w"), indent=1)
     assert resync <= 3, report                                       # the comparison must cover (nearly) the whole stream
     assert drift.size >= steps - 3
-    assert rms < 1e-3, report                                        # the whole emitted stream, not three chunks
-    # the carried phase does not walk away: the last 50 steps are as close to the oracle as the first 50 (to 5 mrad)
-    assert drift.max() < 2e-2, report
-    assert drift[-50:].max() < drift[:50].max() + 5e-3, report
+    assert rms < 1e-4, report                                        # the whole emitted stream (bar 1e-3; measured 3.8e-6)
+    # the carried phase does not walk away (measured: 4.9e-4 rad over the first 50 steps, 7.3e-4 over the last 50 of 300)
+    assert drift.max() < 5e-3, report
+    assert drift[-50:].max() < drift[:50].max() + 2e-3, report

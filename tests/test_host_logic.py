@@ -242,3 +242,15 @@ def test_overlap_sharing_geometry_against_the_oracle():
     g = 1
     near = whole[:, :, g * cf + 4] - per_window[g, :, 4]
     assert near.abs().max() > 1e-3
+
+
+def test_filter_mid_is_built_without_the_slp_vectorizer():
+    """csrc/Makefile must compile filter_mid.hip with -fno-slp-vectorize (DESIGN.md 3.2b': with SLP on, the fused 64-channel
+    FilterBlock is not deterministic); the source refuses to compile without the macro that accompanies the flag"""
+    mk = open(os.path.join(ROOT, "alive-vc_amd", "csrc", "Makefile")).read()
+    line = [ln for ln in mk.splitlines() if ln.startswith("FLAGS_filter_mid")]
+    assert len(line) == 1 and "-fno-slp-vectorize" in line[0] and "-DALIVE_FILTER_MID_NO_SLP" in line[0], line
+    assert "$(FLAGS_$*)" in mk
+    src = open(os.path.join(ROOT, "alive-vc_amd", "csrc", "filter_mid.hip")).read()
+    assert "#ifndef ALIVE_FILTER_MID_NO_SLP" in src and "#error" in src
+    assert "diag.hip" not in [w for ln in mk.splitlines() if ln.startswith("SRCS") for w in ln.split()]      # measurement kernels stay out of the product .so

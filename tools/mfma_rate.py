@@ -2,7 +2,7 @@
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "alive-vc_amd"))
 from module import _native as nat
-L_ = nat.lib()
+L_ = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libalive_diag.so"))    # built by csrc/Makefile next to this file
 fn = L_.alive_debug_mfma_rate
 fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 dev = "cuda"
