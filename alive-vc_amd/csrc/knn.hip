@@ -289,15 +289,22 @@ __global__ __launch_bounds__(128) void gather_frames_kernel(const unsigned short
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// COLLECT = true is the collect tier's form of the same kernel: instead of keeping the best 8 rows of every half-list it
+// keeps EVERY row whose score reaches the frame's fixed threshold thr_in[slot] (= the frame's exact k-th cosine so far minus
+// the slack of its failed certificate, knn_rescore_kernel), up to 8 per half-list; a half-list that would need more marks
+// the frame as overflowed (index -2 in its first entry).  Same tiles, same MFMA loop, same output layout.
+template <bool COLLECT>
 __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short* __restrict__ s_bf16,
                                                            const unsigned short* __restrict__ lib, int64_t M, int tiles_total,
                                                            int tiles_per_split, int P, float* __restrict__ cand_val,
                                                            int* __restrict__ cand_idx, const int* __restrict__ gate_cnt,
-                                                           int gate_lo, int gate_hi, int by_count) {
+                                                           int gate_lo, int gate_hi, int by_count, const float* __restrict__ thr_in) {
+    int n_slots = 0x7fffffff;
     {
         int c;
         if (!gate_open(gate_cnt, gate_lo, gate_hi, c)) return;                       // block-uniform
         if (by_count && (int64_t)blockIdx.x * 256 >= c) return;                      // compacted frames: only c of them
+        if (by_count) n_slots = c;
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Lv = (float*)(smem + 2 * ABUF);
@@ -343,6 +350,14 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
 
     // lane-column id = w*128 + ni*64 + lane; entry e of its list lives at [e*512 + id]
     float thr[2] = {-INFINITY, -INFINITY};
+    int cnt[2] = {0, 0};                               // COLLECT: rows kept so far by this lane's half-list
+    if (COLLECT) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int64_t slot = frame0 + 64 * w + 32 * ni + lr;
+            thr[ni] = slot < n_slots ? thr_in[slot] : INFINITY;        // padding slots collect nothing
+        }
+    }
     const int lc0 = w * 128 + lane;
     __syncthreads();                                   // lists initialised, tile_begin landed (vmcnt(0) + barrier)
 
@@ -392,6 +407,30 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
                 if (ragged && row0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= M) acc[r] = -INFINITY;
                 mx = fmaxf(mx, acc[r]);
             }
+            if (COLLECT) {
+                // every row at or above the fixed threshold is kept (rows, not a ranking: no minimum to maintain)
+                while (__builtin_amdgcn_ballot_w64(mx >= thr[ni]) != 0) {
+                    const bool has = mx >= thr[ni];
+                    int rsel = 0;
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) rsel = (acc[r] == mx) ? r : rsel;
+                    if (has) {
+                        if (cnt[ni] < KH) {
+                            Lv[(size_t)cnt[ni] * 512 + lc0 + ni * 64] = mx;
+                            Li[(size_t)cnt[ni] * 512 + lc0 + ni * 64] = (int)(row0 + (rsel & 3) + 8 * (rsel >> 2) + 4 * lh);
+                        }
+                        ++cnt[ni];
+                    }
+                    float nmx = -INFINITY;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (has && r == rsel) acc[r] = -INFINITY;
+                        nmx = fmaxf(nmx, acc[r]);
+                    }
+                    mx = nmx;
+                }
+                continue;
+            }
             // Rare path (wave-uniform branch): some lane's best new score beats its list minimum.  The whole wave
             // runs it converged: every lane scans its own 8-entry list (entry-major LDS: conflict-free), lanes with a
             // candidate replace their minimum; repeated while any lane still holds a second candidate in this tile.
@@ -430,6 +469,12 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
         __syncthreads();                               // next tile landed (vmcnt(0)), this buffer free for tile+2
     }
 
+    if (COLLECT) {                                     // a half-list that met more than 8 rows above the threshold: overflow mark
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+            if (cnt[ni] > KH) Li[lc0 + ni * 64] = -2;
+        __syncthreads();
+    }
     // ---- write this block's lists: cand[frame][P][KP]; entries 0..7 from the lower half-wave, 8..15 from the upper ----
     for (int e = tid; e < FT * KP; e += 256) {
         const int k = e % KP, col = e / KP;
@@ -880,7 +925,8 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
                                                           const int* __restrict__ gate_cnt, int gate_lo, int gate_hi,
                                                           int* __restrict__ flag_list, int* __restrict__ flag_cnt, float zsig,
                                                           int list_len, float pre_scale, float sd_prior,
-                                                          const float* __restrict__ det_q, const float* __restrict__ det_lib) {
+                                                          const float* __restrict__ det_q, const float* __restrict__ det_lib,
+                                                          float* __restrict__ thr_list, int collect) {
     const int lane = threadIdx.x & 63;
     const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // candidate lists are indexed by slot
     int gc;
@@ -890,7 +936,11 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
     const int R = P * kp;                  // kp candidates per frame and split: KP (bf16 scoring) or KP8 (fp8 scoring)
     const float* cv = cand_val + (size_t)slot * R;
     const int* ci = cand_idx + (size_t)slot * R;
-    const bool certify = flag_list != nullptr;
+    // collect != 0: the candidates are the rows the collect tier kept (knn_score_kernel<true>: EVERY row at or above the
+    // frame's threshold, so nothing is pruned and there is no certificate to compute); a frame whose rows did not fit -- an
+    // overflowed half-list, or more than 64 rows together with its current top-k -- is flagged for the exact scan instead.
+    const bool certify = flag_list != nullptr && !collect;
+    bool overflow = false;
     float c_cut = -INFINITY;               // certificate: the best prefilter score a row OUTSIDE the rescored set can have
     float my_pre = 0.0f;                   // prefilter score of this lane's candidate
 
@@ -919,6 +969,10 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
                                  : (det_q != nullptr ? 2.0f * det_bound : 2.0f * zsig * sd_prior) / pre_scale;     // in prefilter-score units
     if (R <= 64) {
         if (lane < R) my_idx = ci[lane];
+        if (collect) {
+            overflow = __builtin_amdgcn_ballot_w64(my_idx == -2) != 0;
+            my_idx = my_idx < 0 ? -1 : my_idx;
+        }
         if (certify) {
             my_pre = (lane < R && my_idx >= 0) ? cv[lane] : -INFINITY;
             c_cut = list_floor(my_pre);
@@ -951,6 +1005,7 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
             bool in = (j < per) && (e < R);
             v[j] = in ? cv[e] : -INFINITY;
             id[j] = in ? ci[e] : -1;
+            if (collect && id[j] == -2) overflow = true;
             if (id[j] < 0) v[j] = -INFINITY;
             if (certify) c_cut = fmaxf(c_cut, list_floor(v[j]));
         }
@@ -969,6 +1024,7 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
             int widx = __shfl(bid, win);
             float wval = __shfl(bv, win);
             if (sel == k - 1) sk = wval;
+            if (!(wval > -INFINITY)) break;                            // wave-uniform: no candidate left
             if (sel >= MIN_RESCORE && wval < sk - prune) break;        // wave-uniform: the rest stays in v[] and counts into c_cut
             if (lane == sel) { my_idx = (wval > -INFINITY) ? widx : -1; my_pre = wval; }
             if (lane == win) {
@@ -980,6 +1036,27 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
         if (certify) {                     // candidates the selection of 64 left behind
 #pragma unroll
             for (int j = 0; j < 16; ++j) c_cut = fmaxf(c_cut, v[j]);
+        }
+        if (collect) {                     // collected rows that did not fit the 64 lanes: the frame goes to the exact scan
+            float left = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) left = fmaxf(left, v[j]);
+            overflow = __builtin_amdgcn_ballot_w64(overflow || left > -INFINITY) != 0;
+        }
+    }
+    if (collect) {
+        // the frame's current exact top-k joins the candidates (its rows lie at or above the threshold and are collected again
+        // in all but a z-sigma tail of the statistical mode; joining them makes that tail harmless), without duplicates
+        unsigned long long free_mask = ~__builtin_amdgcn_ballot_w64(my_idx >= 0);
+        for (int j = 0; j < k; ++j) {
+            const int g = out_idx[(size_t)ft * k + j];
+            if (g < 0) continue;                                       // wave-uniform
+            const int el = (int)(g - idx_base);
+            if (__builtin_amdgcn_ballot_w64(my_idx == el) != 0) continue;
+            if (free_mask == 0) { overflow = true; break; }
+            const int l = (int)__builtin_ctzll(free_mask);
+            if (lane == l) { my_idx = el; my_pre = INFINITY; }
+            free_mask &= free_mask - 1;
         }
     }
 
@@ -1067,8 +1144,15 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
     if (certify && lane == 0 && c_cut > -INFINITY) {
         const float bound = det_q != nullptr ? c_cut * pre_scale + det_bound
                                              : c_cut * pre_scale - err_mu + fmaxf(zsig * err_sd, 2.0f * err_max);
-        if (!(vk > bound)) flag_list[atomicAdd(flag_cnt, 1)] = (int)ft;
+        if (!(vk > bound)) {
+            // the frame goes to the next tier; for the collect tier it takes along the threshold below which no row can
+            // belong to its top-k: its k-th exact cosine so far minus the slack it was just tested with (stage-score units)
+            const int pos = atomicAdd(flag_cnt, 1);
+            flag_list[pos] = (int)ft;
+            if (thr_list != nullptr) thr_list[pos] = (vk - (bound - c_cut * pre_scale)) / pre_scale;
+        }
     }
+    if (collect && lane == 0 && overflow) flag_list[atomicAdd(flag_cnt, 1)] = (int)ft;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1462,7 +1546,7 @@ __global__ __launch_bounds__(256) void knn_exact_merge_kernel(const float* __res
 
 // ---- small device-side control kernels of the tiered search (no host sync anywhere) ----
 // stats[]: see alive_knn_search_stats
-enum { ST_FLAG8 = 0, ST_FLAG16 = 1, ST_PROBE_N = 2, ST_PROBE_FAIL = 3, ST_MODE = 4, ST_FIRST = 5, ST_PROBE_CNT = 6, ST_TIER = 7,
+enum { ST_FLAG8 = 0, ST_FLAG16 = 1, ST_PROBE_N = 2, ST_PROBE_FAIL = 3, ST_MODE = 4, ST_FIRST = 5, ST_PROBE_CNT = 6, ST_TIER = 7, ST_FLAGC = 8,
        ST_WORDS = 16 };
 // ST_TIER: which path the last search on this workspace took (written by every path, so that the host never has to
 // re-derive the dispatch): 1 = streaming scan, 2 = exact scan of every frame (k > 8), 3 = bf16 first, 4 = fp8 first
@@ -1579,6 +1663,7 @@ struct SearchWs {
     unsigned short* s_c;                   // compacted bf16 rows of the frames being re-searched
     float* cv1; int* ci1;                  // tier-1 candidate lists
     unsigned char* s_p8; float* cvp; int* cip; int* p_list;   // probe: sample rows, lists, [frame of slot | flagged frames]
+    float* thr1; int* list2;               // collect tier: thresholds of the frames in list1; frames that overflowed it
     float* dq;                             // || q^ - bf16(q^) || per frame (strict certificate)
     const float* det_q; const float* det_lib;   // set by the strict search only: frame / library share of the deterministic bound
     size_t bytes;
@@ -1615,6 +1700,8 @@ static SearchWs ws_layout(void* base, int64_t Tt, int64_t M, int k) {
     w.cvp = a.take<float>((size_t)w.probe_pad * w.pp.P * KP8 + 4);
     w.cip = a.take<int>((size_t)w.probe_pad * w.pp.P * KP8 + 4);
     w.p_list = a.take<int>((size_t)2 * w.probe_pad + 8);
+    w.thr1 = a.take<float>((size_t)Tp);
+    w.list2 = a.take<int>((size_t)Tp);
     w.dq = a.take<float>((size_t)Tp);
     w.det_q = nullptr;
     w.det_lib = nullptr;
@@ -1690,7 +1777,7 @@ static int check_search_args(const char* what, const void* a, const void* b, int
 static int lds_optin(const char* what) {
     static LdsOptIn optin8, optin16;
     hipError_t e = optin8.ensure({(const void*)knn_score8_kernel, (const void*)knn_probe8_kernel}, SCORE8_LDS);
-    if (e == hipSuccess) e = optin16.ensure({(const void*)knn_score_kernel}, SCORE_LDS);
+    if (e == hipSuccess) e = optin16.ensure({(const void*)knn_score_kernel<false>, (const void*)knn_score_kernel<true>}, SCORE_LDS);
     if (e != hipSuccess) {
         alive_set_error("%s: cannot reserve %d B of LDS: %s", what, SCORE_LDS, hipGetErrorString(e));
         return ALIVE_ERR_LAUNCH;
@@ -1714,6 +1801,36 @@ extern "C" size_t alive_knn_workspace_bytes(int64_t Tt, int64_t M) {
     return a > b ? a : b;
 }
 
+// The collect tier: the frames whose bf16 certificate failed (list1, with the thresholds thr1 the rescoring kernel recorded
+// for them) go through the bf16 scoring kernel once more, in its COLLECT form -- every row whose stage score reaches the
+// frame's threshold is kept and rescored exactly, together with the frame's current top-k.  A row below the threshold
+// cannot belong to the top-k (by the same slack the certificate was tested with: 7 sigma of the measured stage error, or
+// the deterministic bound of the strict search), so the result is final; frames with more rows above the threshold than
+// the lists hold (dense clusters: more rows inside the stage's error than any candidate list can keep) are the only ones
+// left for the exact scan.  Same two launch plans as the re-search: few frames (<= fcap) / the whole batch.
+static void collect_tier_launch(const SearchWs& w, const void* lib_bf16, const float* rows_f32, const float* norms, int64_t M,
+                                int64_t Tt, int64_t idx_base, int k, float* out_val, int32_t* out_idx, hipStream_t s) {
+    int* cnt1 = w.stats + ST_FLAG16;
+    int* cnt2 = w.stats + ST_FLAGC;
+    const int fcap = w.fcap;
+    gather_frames_kernel<<<(unsigned)fcap, 128, 0, s>>>(w.s_bf16, w.list1, cnt1, 0, fcap, w.s_c);
+    knn_score_kernel<true><<<dim3((unsigned)(fcap / FT), w.pt.split), 256, SCORE_LDS, s>>>(
+        w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.cv1, w.ci1, cnt1, 0, fcap, 1, w.thr1);
+    knn_rescore_kernel<<<(unsigned)((fcap + 3) / 4), 256, 0, s>>>(w.cv1, w.ci1, w.pt.P, KP, w.s_f32, rows_f32, norms, fcap, idx_base, k,
+                                                                 out_val, out_idx, w.list1, cnt1, 0, fcap, w.list2, cnt2, CERT_Z, KH, 1.0f,
+                                                                 SD_PRIOR16, nullptr, nullptr, nullptr, 1);
+    if (w.p16.Tt_pad > fcap) {
+        gather_frames_kernel<<<(unsigned)w.p16.Tt_pad, 128, 0, s>>>(w.s_bf16, w.list1, cnt1, fcap, 0x7fffffff, w.s_c);
+        knn_score_kernel<true><<<dim3((unsigned)(w.p16.Tt_pad / FT), w.p16.split), 256, SCORE_LDS, s>>>(
+            w.s_c, (const unsigned short*)lib_bf16, M, w.p16.tiles_total, w.p16.tiles_per_split, w.p16.P, w.cv, w.ci, cnt1, fcap,
+            0x7fffffff, 1, w.thr1);
+        knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, w.p16.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
+                                                                   out_val, out_idx, w.list1, cnt1, fcap, 0x7fffffff, w.list2, cnt2,
+                                                                   CERT_Z, KH, 1.0f, SD_PRIOR16, nullptr, nullptr, nullptr, 1);
+    }
+    knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, w.list2, cnt2, out_val, out_idx, s);
+}
+
 // The bf16 re-search of the frames in list[0 .. *cnt) (compacted), certified, behind either first stage:
 //   tier 1 (1 .. fcap frames, usually a handful): library split chosen for few frames;
 //   tier 2 (more): the split of the whole batch; blocks past the count exit at once.
@@ -1724,20 +1841,20 @@ static void bf16_tiers_launch(const SearchWs& w, const void* lib_bf16, const flo
     int* cnt1 = w.stats + ST_FLAG16;
     const int fcap = w.fcap;
     gather_frames_kernel<<<(unsigned)fcap, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, 0, fcap, w.s_c);
-    knn_score_kernel<<<dim3((unsigned)(fcap / FT), w.pt.split), 256, SCORE_LDS, s>>>(
-        w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.cv1, w.ci1, cnt0, 0, fcap, 1);
+    knn_score_kernel<false><<<dim3((unsigned)(fcap / FT), w.pt.split), 256, SCORE_LDS, s>>>(
+        w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.cv1, w.ci1, cnt0, 0, fcap, 1, nullptr);
     knn_rescore_kernel<<<(unsigned)((fcap + 3) / 4), 256, 0, s>>>(w.cv1, w.ci1, w.pt.P, KP, w.s_f32, rows_f32, norms, fcap, idx_base, k,
-                                                                 out_val, out_idx, w.list0, cnt0, 0, fcap, w.list1, cnt1, CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib);
+                                                                 out_val, out_idx, w.list0, cnt0, 0, fcap, w.list1, cnt1, CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0);
     if (w.p16.Tt_pad > fcap) {
         gather_frames_kernel<<<(unsigned)w.p16.Tt_pad, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, fcap, 0x7fffffff, w.s_c);
-        knn_score_kernel<<<dim3((unsigned)(w.p16.Tt_pad / FT), w.p16.split), 256, SCORE_LDS, s>>>(
+        knn_score_kernel<false><<<dim3((unsigned)(w.p16.Tt_pad / FT), w.p16.split), 256, SCORE_LDS, s>>>(
             w.s_c, (const unsigned short*)lib_bf16, M, w.p16.tiles_total, w.p16.tiles_per_split, w.p16.P, w.cv, w.ci, cnt0, fcap,
-            0x7fffffff, 1);
+            0x7fffffff, 1, nullptr);
         knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, w.p16.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                    out_val, out_idx, w.list0, cnt0, fcap, 0x7fffffff, w.list1, cnt1,
-                                                                   CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib);
+                                                                   CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0);
     }
-    knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, w.list1, cnt1, out_val, out_idx, s);
+    collect_tier_launch(w, lib_bf16, rows_f32, norms, M, Tt, idx_base, k, out_val, out_idx, s);
 }
 
 // Search with the bf16 MFMA as the first candidate stage: every frame's candidate set is certified against the bf16 score
@@ -1769,13 +1886,13 @@ static int knn_search_impl(const float* src, int N, int T, const void* lib_bf16,
     }
     const SearchPlan& p = w.p16;
     if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
-    knn_score_kernel<<<dim3((unsigned)(p.Tt_pad / FT), p.split), 256, SCORE_LDS, s>>>(
-        w.s_bf16, (const unsigned short*)lib_bf16, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, nullptr, 0, 0, 0);
+    knn_score_kernel<false><<<dim3((unsigned)(p.Tt_pad / FT), p.split), 256, SCORE_LDS, s>>>(
+        w.s_bf16, (const unsigned short*)lib_bf16, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, nullptr, 0, 0, 0, nullptr);
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
     knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, p.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                out_val, out_idx, nullptr, nullptr, 0, 0, w.list1, w.stats + ST_FLAG16,
-                                                               CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib);
-    knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, w.list1, w.stats + ST_FLAG16, out_val, out_idx, s);
+                                                               CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0);
+    collect_tier_launch(w, lib_bf16, rows_f32, norms, M, Tt, idx_base, k, out_val, out_idx, s);
     ALIVE_CHECK_LAUNCH("alive_knn_search");
     return ALIVE_OK;
 }
@@ -1851,7 +1968,7 @@ static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f
         knn_rescore_kernel<<<(unsigned)((w.probe_n + 3) / 4), 256, 0, s>>>(w.cvp, w.cip, w.pp.P, KP8, w.s_f32, rows_f32, norms, w.probe_n,
                                                                           idx_base, k, out_val, out_idx, w.p_list, nullptr, 0, 0,
                                                                           w.p_list + w.probe_pad, w.stats + ST_PROBE_CNT, CERT_Z, KH8,
-                                                                          1.0f / (F8_SCALE * F8_SCALE), SD_PRIOR8, nullptr, nullptr);
+                                                                          1.0f / (F8_SCALE * F8_SCALE), SD_PRIOR8, nullptr, nullptr, nullptr, 0);
         probe_decide_kernel<<<1, 1, 0, s>>>(w.stats, w.probe_n, PROBE_NUM, PROBE_DEN);
     }
     // ---- mode 0: fp8 first ----
@@ -1861,7 +1978,7 @@ static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
     knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, p.P, KP8, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                out_val, out_idx, nullptr, mode, -1, 0, w.list0, w.stats + ST_FLAG8,
-                                                               CERT_Z, KH8, 1.0f / (F8_SCALE * F8_SCALE), SD_PRIOR8, nullptr, nullptr);
+                                                               CERT_Z, KH8, 1.0f / (F8_SCALE * F8_SCALE), SD_PRIOR8, nullptr, nullptr, nullptr, 0);
     // ---- mode 1: bf16 first (every frame into list0) ----
     if (w.probe_n > 0) flag_all_kernel<<<(unsigned)((Tt + 255) / 256), 256, 0, s>>>(w.list0, w.stats + ST_FLAG8, Tt, mode, 0, 1);
     bf16_tiers_launch(w, lib_bf16, rows_f32, norms, M, Tt, idx_base, k, out_val, out_idx, s);
@@ -1883,9 +2000,10 @@ extern "C" int alive_knn_search_fp8_timed(const float* src, int N, int T, const 
 
 // device pointer (inside ws) to the counters of the last search on this workspace, int[8]:
 //   [0] frames the fp8 certificate sent to the bf16 stage (all frames when the probe chose bf16 first)
-//   [1] frames the bf16 certificate sent to the exact scan
+//   [1] frames the bf16 certificate sent on (to the collect tier; [8] of them end in the exact scan)
 //   [2] frames of the probe sample, [3] of which failed the fp8 certificate, [4] 1 = the probe chose bf16 first
 //   [7] the path taken: 1 streaming scan, 2 exact scan of every frame (k > 8), 3 bf16 first, 4 fp8 first
+//   [8] frames the collect tier could not hold (dense clusters) -> exact scan;  [1] then counts the frames sent to the collect tier
 // (the counters are the first thing in the workspace: their address depends on neither the batch nor k)
 extern "C" const int* alive_knn_search_stats(int N, int T, int64_t M, void* ws) {
     return ws_layout(ws, (int64_t)N * T, M, 4).stats;

@@ -143,7 +143,7 @@ class PackedLibrary:
         if tier == 4:
             st.update(frames_researched_on_bf16=c[0], probe_sample=c[2], probe_failed_fp8_certificate=c[3],
                       probe_chose_bf16_first=bool(c[4]))
-        st.update(frames_searched_exactly=c[1], frames=n * t)
+        st.update(frames_collected_on_bf16=c[1], frames_searched_exactly=c[8], frames=n * t)
         return st
 
     def fallback_frames(self):

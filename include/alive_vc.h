@@ -66,7 +66,9 @@ int alive_library_pack(const float* tokens_DxM, int64_t M, int D,
  *   own rescored candidates; the frame passes if its k-th exact cosine clears that.  This certificate is STATISTICAL: it is
  *   wrong for a frame only if the stage error of one of its k true neighbours lies beyond those 7 sigma (audited:
  *   tools/knn_audit.py, profiles/r03_knn_audit.json; alive_knn_search_strict is the form without any such assumption).
- *   Frames that do not pass are searched
+ *   Frames that do not pass go through the COLLECT tier: the same bf16 scoring pass with a fixed per-frame threshold (the
+ *   frame's k-th exact cosine so far minus the slack it was tested with) that keeps EVERY row at or above it for exact
+ *   rescoring -- final unless more such rows exist than its lists hold (clusters of near-copies), and only those frames are searched
  *   again by the exact tier inside the same call: a brute-force fp32 scan of the whole shard with the rescoring
  *   arithmetic (launched up front, sized on the device, no sync).  k > 8: the exact scan for every frame.
  *   out_val[Tt][k] fp32 cosine, descending; out_idx[Tt][k] = idx_base + row.
@@ -103,9 +105,11 @@ int alive_knn_search_strict(const float* src, int N, int T,
  *          the batch is skipped and every frame starts at the bf16 stage;
  *   fp8    candidates, exact rescoring, certificate (fp8 error statistics);
  *   bf16   the frames that failed, compacted, through the bf16 stage: candidates, rescoring, certificate (bf16 statistics);
- *   exact  the frames that failed again: brute-force fp32 scan.
- * alive_knn_search_stats: device pointer (inside ws) to int[8] counters of the last search on that workspace:
- *   [0] frames sent to the bf16 stage  [1] frames sent to the exact scan  [2] probe sample size  [3] probe failures
+ *   collect the frames that failed again: bf16 scoring pass with a fixed threshold, every row above it rescored exactly;
+ *   exact  the frames whose collected rows overflowed: brute-force fp32 scan.
+ * alive_knn_search_stats: device pointer (inside ws) to int[16] counters of the last search on that workspace:
+ *   [0] frames sent to the bf16 stage  [1] frames sent to the collect tier  [8] frames sent to the exact scan
+ *   [2] probe sample size  [3] probe failures
  *   [4] 1 = the probe chose bf16 first  [7] the path taken: 1 streaming scan, 2 exact scan of every frame (k > 8),
  *   3 bf16 first, 4 fp8 first.  (alive_knn_search fills [1] and [7] only.)  The counters sit at the start of ws. */
 size_t alive_library_fp8_bytes(int64_t M);

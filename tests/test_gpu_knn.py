@@ -309,7 +309,9 @@ def test_knn_exact_tier_on_a_library_of_near_duplicates(prefilter, k):
     pl = PackedLibrary(lib)
     val, idx = pl.search(src, k)
     st = pl.search_stats()
-    assert st["frames_searched_exactly"] > 0, st            # every group size of the exact tier: G = 16 (k <= 4), 8 (k <= 8)
+    # the 40 copies of a cluster are more rows above the collect tier's threshold than its half-lists hold (8 each): the
+    # frames overflow it and reach the exact scan -- every group size of the exact tier: G = 16 (k <= 4), 8 (k <= 8)
+    assert st["frames_searched_exactly"] > 0 and st["frames_collected_on_bf16"] >= st["frames_searched_exactly"], st
     flat = src.permute(0, 2, 1).reshape(-1, 768)
     bv, bi = _brute_force_topk(flat, lib, k)
     _assert_equals_brute_force(val, idx, bv, bi, k, min_safe=250)
