@@ -596,70 +596,6 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
         for (int r = 0; r < 8; ++r) m = fmaxf(m, acc[lo + r]);
         return m;
     };
-#ifdef ALIVE_KNN_FOLD_PIPELINED
-    // ---- the pipelined fold (-DALIVE_KNN_FOLD_PIPELINED, an experiment of round 2, NOT the default): every tile's best score
-    // per lane is offered to the list UNCONDITIONALLY, branch-free, in pieces placed in the shadow of the next tile's MFMAs;
-    // only a SECOND admitted row of the same lane in the same tile (308 times per wave, counted) falls back to the loop.
-    // Motive: the branch-and-loop form (fold_rare) stops the matrix pipe for ~1500 cycles per trip -- by ablation 14 of 94 ms
-    // on the bench batch and 36 of 119 ms on uncorrelated frames, where nearly every admitted row is a trip of its own
-    // (-DALIVE_KNN_ABL_NORARE: 80 / 83 ms).  Result (same exact outputs, all kNN tests green): 132 / 134 ms -- data-independent
-    // as intended, but slower: without the runner-up loop compiled in 103 / 110 ms, of which the always-on LDS write + quarter
-    // rescan (2 + 4 operations per column group and tile, waited for by the lgkmcnt(0) hipcc puts in front of the next MFMA)
-    // are ~22 ms; keeping the 32 packed scores of a tile alive for the rare loop costs the rest in register traffic.
-    // Kept for the record and the A/B; see DESIGN.md 6.2.
-    struct FoldSt {
-        float m1, m2;          // largest and second largest packed score of the lane in the tile
-        float x0, x1, x2, x3;  // rescan of the quarter that takes the new entry
-        int tpos;              // list entry that is overwritten (the list minimum)
-        bool has;              // m1 is admitted
-    };
-    auto fold_pack = [&](f32x16& acc, int lo) {                        // register index into the 4 low mantissa bits
-#pragma unroll
-        for (int r = lo; r < lo + 8; ++r) acc[r] = __uint_as_float((__float_as_uint(acc[r]) & ~15u) | (unsigned)r);
-    };
-    auto fold_top2 = [&](const f32x16& acc, int lo, int n, FoldSt& f) {
-#pragma unroll
-        for (int r = lo; r < lo + n; ++r) {
-            f.m2 = __builtin_amdgcn_fmed3f(f.m1, f.m2, acc[r]);       // m1 >= m2: the median is the new runner-up
-            f.m1 = fmaxf(f.m1, acc[r]);
-        }
-    };
-    auto fold_victim = [&](int ni, FoldSt& f) {
-        const bool b01 = qv[ni][1] < qv[ni][0], b23 = qv[ni][3] < qv[ni][2];
-        const float m01 = b01 ? qv[ni][1] : qv[ni][0], m23 = b23 ? qv[ni][3] : qv[ni][2];
-        const int p01 = b01 ? qp[ni][1] : qp[ni][0], p23 = b23 ? qp[ni][3] : qp[ni][2];
-        f.tpos = m23 < m01 ? p23 : p01;
-        f.has = f.m1 > thr[ni];                                        // false for the NaN / -inf of "no tile yet"
-    };
-    auto fold_lds = [&](int ni, int tile, FoldSt& f) {                 // entry write (admitted lanes) + rescan of its quarter
-        float* lv = Lv + lc0 + ni * 64;
-        int* li = Li + lc0 + ni * 64;
-        if (f.has) {
-            const unsigned u = __float_as_uint(f.m1);
-            lv[f.tpos * 512] = f.m1;
-            li[f.tpos * 512] = (int)((int64_t)tile * LT + ((u & 3u) + 8u * ((u >> 2) & 3u)) + 4 * lh);
-        }
-        const float* qb = lv + (f.tpos & ~3) * 512;                    // after the write: LDS operations of a wave complete in order
-        f.x0 = qb[0]; f.x1 = qb[512]; f.x2 = qb[1024]; f.x3 = qb[1536];
-    };
-    auto fold_min = [&](int ni, FoldSt& f) {                           // new minimum of that quarter -> caches, threshold
-        const int tq = f.tpos >> 2;
-        const bool c1 = f.x1 < f.x0, c3 = f.x3 < f.x2;
-        const float n01 = c1 ? f.x1 : f.x0, n23 = c3 ? f.x3 : f.x2;
-        const int e01 = c1 ? 1 : 0, e23 = c3 ? 3 : 2;
-        const bool c = n23 < n01;
-        const float nq = c ? n23 : n01;
-        const int np = tq * 4 + (c ? e23 : e01);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool hit = f.has && tq == q;
-            qv[ni][q] = hit ? nq : qv[ni][q];
-            qp[ni][q] = hit ? np : qp[ni][q];
-        }
-        thr[ni] = fminf(fminf(qv[ni][0], qv[ni][1]), fminf(qv[ni][2], qv[ni][3]));
-    };
-
-#endif
     // the loop form on accumulators that already carry their register index: admits mx, then the largest score below it, ...
     // while any lane still holds an admitted score
     auto fold_loop = [&](f32x16& acc, int ni, int tile, float mx) {
@@ -768,16 +704,6 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
         thr[ni] = fminf(fminf(qv[ni][0], qv[ni][1]), fminf(qv[ni][2], qv[ni][3]));
         fold_loop(acc, ni, tile, m2);                           // returns at once unless some lane's runner-up is admitted too
     };
-#ifdef ALIVE_KNN_FOLD_PIPELINED
-    auto fold_second = [&](f32x16& acc, int ni, int tile, FoldSt& f) {    // a lane's runner-up is admitted too: the loop form, rarely
-        if (__builtin_amdgcn_ballot_w64(f.m2 > thr[ni]) == 0) return;
-
-#ifdef ALIVE_KNN_ABL_NORARE
-        return;
-#endif
-        fold_loop(acc, ni, tile, f.m2);
-    };
-#endif
     // One tile: 24 MFMAs into (c0, c1).  The accumulators of the PREVIOUS tile (p0, p1) are folded in the shadow of this tile's
     // first MFMAs, a few VALU instructions after each (one wave per SIMD: nothing else would fill the matrix pipe between the
     // last MFMA of a tile and the end of its fold -- measured 23 ms of 107 with the fold behind the tile).  Before the first
@@ -796,9 +722,7 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
         // step's first MFMA, ~120 cycles later, behind this step's second MFMA in the matrix pipe.
         v8i a[2];
         a[0] = load_a(Ab, 0);
-#ifndef ALIVE_KNN_FOLD_PIPELINED
         float pm0 = -INFINITY, pm1 = -INFINITY;
-#endif
         // written out step by step: with the folds inside a `for` hipcc gives up unrolling it and indexes bq dynamically (scratch)
 #define K8_STEP(ks, AFTER0, AFTER1)                                                                                              \
         {                                                                                                                        \
@@ -815,36 +739,12 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
             __builtin_amdgcn_sched_barrier(0);                                                                                   \
             AFTER1;                                                                                                              \
         }
-#ifndef ALIVE_KNN_FOLD_PIPELINED      // default: running maximum in the MFMA shadow, then the branch-and-loop fold (fold_rare)
         K8_STEP(0, (mask_ragged(p0, tile - 1), pm0 = max8(p0, 0, pm0)), pm0 = max8(p0, 8, pm0))
         K8_STEP(1, (mask_ragged(p1, tile - 1), pm1 = max8(p1, 0, pm1)), pm1 = max8(p1, 8, pm1))
         K8_STEP(2, (void)0, fold_rare(p0, 0, tile - 1, pm0))
         K8_STEP(3, (void)0, fold_rare(p1, 1, tile - 1, pm1))
         K8_STEP(4, (void)0, (void)0) K8_STEP(5, (void)0, (void)0) K8_STEP(6, (void)0, (void)0) K8_STEP(7, (void)0, (void)0)
         K8_STEP(8, (void)0, (void)0) K8_STEP(9, (void)0, (void)0) K8_STEP(10, (void)0, (void)0) K8_STEP(11, (void)0, (void)0)
-#else
-        // The pipelined fold of the previous tile, <= ~14 vector instructions per slot (what fits under one MFMA).  The LDS
-        // operations of a column group go out right behind a fragment request (the wait in front of the next step's first
-        // MFMA is lgkmcnt(0) either way) and are consumed two steps later.
-        FoldSt f0, f1;
-        f0.m1 = f0.m2 = f1.m1 = f1.m2 = -INFINITY;
-#ifndef ALIVE_FOLD_STAGE             // ablation builds (timing only, results wrong below 6): how much of the fold is compiled in
-#define ALIVE_FOLD_STAGE 6
-#endif
-#define FS(n, x) (ALIVE_FOLD_STAGE >= (n) ? (void)(x) : (void)0)
-        K8_STEP(0, FS(1, fold_pack(p0, 0)), (FS(1, fold_pack(p0, 8)), FS(1, mask_ragged(p0, tile - 1))))
-        K8_STEP(1, FS(2, fold_top2(p0, 0, 6, f0)), FS(2, fold_top2(p0, 6, 6, f0)))
-        K8_STEP(2, (FS(2, fold_top2(p0, 12, 4, f0)), FS(3, fold_victim(0, f0))), FS(1, fold_pack(p1, 0)))
-        K8_STEP(3, FS(4, fold_lds(0, tile - 1, f0)), (FS(1, fold_pack(p1, 8)), FS(1, mask_ragged(p1, tile - 1))))
-        K8_STEP(4, FS(2, fold_top2(p1, 0, 6, f1)), FS(2, fold_top2(p1, 6, 6, f1)))
-        K8_STEP(5, (FS(2, fold_top2(p1, 12, 4, f1)), FS(3, fold_victim(1, f1))), FS(5, fold_min(0, f0)))
-        K8_STEP(6, FS(4, fold_lds(1, tile - 1, f1)), FS(6, fold_second(p0, 0, tile - 1, f0)))
-        K8_STEP(7, (void)0, (void)0)
-        K8_STEP(8, (void)0, FS(5, fold_min(1, f1)))
-        K8_STEP(9, (void)0, FS(6, fold_second(p1, 1, tile - 1, f1)))
-        K8_STEP(10, (void)0, (void)0) K8_STEP(11, (void)0, (void)0)
-#undef FS
-#endif
 #undef K8_STEP
         // The accumulators are next read by the fold inside the NEXT tile, and hipcc sinks the whole c1 chain down to that use:
         // eight dependent MFMAs back to back behind the barrier, their A fragments parked in AGPRs.  An opaque use pins both
@@ -1408,11 +1308,11 @@ template <int G>
 __global__ __launch_bounds__(256, 2) void knn_exact_kernel(const float* __restrict__ s_f32, const float* __restrict__ rows,
                                                         const float* __restrict__ norms, int64_t M, int64_t Tt, int k,
                                                         const int* __restrict__ frame_list, const int* __restrict__ cnt_ptr,
-                                                        float* __restrict__ part_val, int* __restrict__ part_idx) {
+                                                        float* __restrict__ part_val, int* __restrict__ part_idx, int max_count) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int64_t count = Tt;
     if (cnt_ptr != nullptr) { const int c = *cnt_ptr; count = c < Tt ? c : Tt; }
-    if (count <= 0) return;
+    if (count <= 0 || count > max_count) return;           // more frames than this launch is meant for: another tier has them
     const int64_t groups = (count + G - 1) / G;
     const int nw = exact_nw(groups);
     const int64_t items = groups * nw;
@@ -1491,12 +1391,13 @@ template <int G>
 __global__ __launch_bounds__(256) void knn_exact_merge_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx,
                                                               int64_t Tt, int k, int64_t idx_base, const int* __restrict__ frame_list,
                                                               const int* __restrict__ cnt_ptr, float* __restrict__ out_val,
-                                                              int* __restrict__ out_idx) {
+                                                              int* __restrict__ out_idx, int max_count) {
     __shared__ float sv[256];
     __shared__ int si[256], sw[256];
     const int tid = threadIdx.x;
     int64_t count = Tt;
     if (cnt_ptr != nullptr) { const int c = *cnt_ptr; count = c < Tt ? c : Tt; }
+    if (count > max_count) return;
     const int64_t groups = (count + G - 1) / G;
     const int nw = exact_nw(groups);                     // <= 1024: up to four sorted lists per thread
     constexpr int NL = EX_NW_MAX / 256;
@@ -1647,6 +1548,7 @@ constexpr int FPLAN = 4096;               // ... with the library split chosen f
 constexpr float CERT_Z = 7.0f;            // sigmas of candidate-score error the certificates allow for
 constexpr float SD_PRIOR8 = 1.5e-3f;      // typical error (cosine units) of an fp8 / a bf16 candidate score: floor of the per-frame estimate
 constexpr float SD_PRIOR16 = 8.0e-5f;
+constexpr int COLLECT_MIN = 256;          // frames failing the bf16 certificate: up to this many go straight to the exact scan
 constexpr int PROBE_N = 1024;             // frames of the adaptive probe (fp8 searches of >= PROBE_MIN_T frames)
 constexpr int64_t PROBE_MIN_T = 16384;
 constexpr int PROBE_NUM = 2, PROBE_DEN = 5;   // bf16 first when more than 40 % of the sample fail the fp8 certificate:
@@ -1743,11 +1645,12 @@ static int knn_scan_launch(const float* src, int T, int64_t Tt, const float* row
 
 // exact tier over a frame list with a device-side count (list == nullptr: all Tt frames)
 static void knn_exact_launch(const SearchWs& w, const float* rows_f32, const float* norms, int64_t M, int64_t Tt, int64_t idx_base,
-                             int k, const int* list, const int* cnt, float* out_val, int32_t* out_idx, hipStream_t s) {
+                             int k, const int* list, const int* cnt, float* out_val, int32_t* out_idx, hipStream_t s,
+                             int max_count = 0x7fffffff) {
 #define ALIVE_EXACT(G_)                                                                                                        \
     {                                                                                                                          \
-        knn_exact_kernel<G_><<<EX_BLOCKS, 256, 0, s>>>(w.s_f32, rows_f32, norms, M, Tt, k, list, cnt, w.pv, w.pi);              \
-        knn_exact_merge_kernel<G_><<<1024, 256, 0, s>>>(w.pv, w.pi, Tt, k, idx_base, list, cnt, out_val, out_idx);             \
+        knn_exact_kernel<G_><<<EX_BLOCKS, 256, 0, s>>>(w.s_f32, rows_f32, norms, M, Tt, k, list, cnt, w.pv, w.pi, max_count);   \
+        knn_exact_merge_kernel<G_><<<1024, 256, 0, s>>>(w.pv, w.pi, Tt, k, idx_base, list, cnt, out_val, out_idx, max_count);  \
     }
     switch (exact_group(k)) {
         case 16: ALIVE_EXACT(16) break;
@@ -1813,12 +1716,16 @@ static void collect_tier_launch(const SearchWs& w, const void* lib_bf16, const f
     int* cnt1 = w.stats + ST_FLAG16;
     int* cnt2 = w.stats + ST_FLAGC;
     const int fcap = w.fcap;
-    gather_frames_kernel<<<(unsigned)fcap, 128, 0, s>>>(w.s_bf16, w.list1, cnt1, 0, fcap, w.s_c);
+    // a handful of frames: the exact scan costs less than the fixed cost of one more scoring pass over the library (~8 ms at 1 M
+    // rows against ~20 us per frame of exact scan)
+    knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, w.list1, cnt1, out_val, out_idx, s, COLLECT_MIN);
+    gather_frames_kernel<<<(unsigned)fcap, 128, 0, s>>>(w.s_bf16, w.list1, cnt1, COLLECT_MIN, fcap, w.s_c);
     knn_score_kernel<true><<<dim3((unsigned)(fcap / FT), w.pt.split), 256, SCORE_LDS, s>>>(
-        w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.cv1, w.ci1, cnt1, 0, fcap, 1, w.thr1);
+        w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.cv1, w.ci1, cnt1, COLLECT_MIN, fcap, 1,
+        w.thr1);
     knn_rescore_kernel<<<(unsigned)((fcap + 3) / 4), 256, 0, s>>>(w.cv1, w.ci1, w.pt.P, KP, w.s_f32, rows_f32, norms, fcap, idx_base, k,
-                                                                 out_val, out_idx, w.list1, cnt1, 0, fcap, w.list2, cnt2, CERT_Z, KH, 1.0f,
-                                                                 SD_PRIOR16, nullptr, nullptr, nullptr, 1);
+                                                                 out_val, out_idx, w.list1, cnt1, COLLECT_MIN, fcap, w.list2, cnt2, CERT_Z,
+                                                                 KH, 1.0f, SD_PRIOR16, nullptr, nullptr, nullptr, 1);
     if (w.p16.Tt_pad > fcap) {
         gather_frames_kernel<<<(unsigned)w.p16.Tt_pad, 128, 0, s>>>(w.s_bf16, w.list1, cnt1, fcap, 0x7fffffff, w.s_c);
         knn_score_kernel<true><<<dim3((unsigned)(w.p16.Tt_pad / FT), w.p16.split), 256, SCORE_LDS, s>>>(

@@ -132,7 +132,7 @@ class PackedLibrary:
         torch.cuda.synchronize()
         st = {"prefilter": self.prefilter, "certificate": "deterministic" if self.strict else "statistical"}
         off = nat.lib().alive_knn_search_stats(n, t, self.M, nat.ptr(ws)) - ws.data_ptr()
-        c = ws[off:off + 32].view(torch.int32).tolist()
+        c = ws[off:off + 64].view(torch.int32).tolist()       # int[16]: knn.hip ST_*
         tier = c[7]                                     # written by the C side on every path (knn.hip: ST_TIER)
         if tier == 1:
             return dict(st, tier="exact scan of every row (streaming)")
@@ -143,7 +143,11 @@ class PackedLibrary:
         if tier == 4:
             st.update(frames_researched_on_bf16=c[0], probe_sample=c[2], probe_failed_fp8_certificate=c[3],
                       probe_chose_bf16_first=bool(c[4]))
-        st.update(frames_collected_on_bf16=c[1], frames_searched_exactly=c[8], frames=n * t)
+        # [1] frames that failed the bf16 certificate: up to 256 of them go straight to the exact scan (knn.hip COLLECT_MIN),
+        # more go through the collect tier and only its overflow ([8]) is scanned exactly
+        direct = c[1] <= 256
+        st.update(frames_failed_bf16_certificate=c[1], frames_collected_on_bf16=0 if direct else c[1],
+                  frames_searched_exactly=c[1] if direct else c[8], frames=n * t)
         return st
 
     def fallback_frames(self):
