@@ -48,6 +48,31 @@ def test_inference_cli_matches_oracle(workdir):
     assert err < 1e-3, err
 
 
+def test_inference_cli_baseline_config_1_default_chunk_and_1k_library(workdir):
+    """BASELINE config 1 as written: a 1 s mono 24 kHz utterance, a 1 000-vector library, every flag at its default (chunk
+    48 000 -> 3 overlapping windows of 450 frames = 1 350 computed frames for 50 useful ones; k = 4, alpha = 0)
+    -- except the device, which this build only accepts as `cuda` (the reference's config 1 says `-d cpu`: there is no CPU
+    path here by contract).  Output against the oracle's restatement of inference.py:86-142."""
+    import inference
+    d, sds, wav24 = workdir
+    lib1k = synthetic.make_library(1000, 1)
+    torch.save({"tokens": lib1k}, d / "voice_library_1k.pt")
+    inference.main(["-i", str(d / "inputs"), "-o", str(d / "out_cfg1"), "-dep", str(d / "decoder.pt"),
+                    "-cep", str(d / "content_encoder.pt"), "-f0ep", str(d / "f0_estimator.pt"),
+                    "-lib", str(d / "voice_library_1k.pt"), "-d", "cuda"])
+    out, sr = audio_io.load(str(d / "out_cfg1" / "0_utt.wav"))
+    assert sr == 24000 and out.shape == (1, 24000)
+    wf = O.resample(wav24, 24000, 16000)
+    wf = (wf / wf.abs().max()).mean(dim=0, keepdim=True)
+    windows, _ = O.make_windows(wf, 48000)
+    assert windows.shape == (3, 144000)                                   # the 1 350 frames of SURVEY F10
+    ref = O.convert_utterance(sds["content_encoder.pt"], sds["f0_estimator.pt"], sds["decoder.pt"], wf, lib1k, chunk=48000,
+                              k=4, alpha=0.0)
+    ref = O.gain(O.resample(ref, 16000, 24000), 1.0)
+    err = (out - ref).pow(2).mean().sqrt().item()
+    assert err < 1e-3, err
+
+
 def test_inference_cli_target_utterance_stereo_input_gain_and_normalize(workdir):
     """inference.py:69-84,88-93,136-142: a target utterance (-t) whose content frames join the library in front of the -lib
     tokens, a stereo 22.05 kHz input (normalised over both channels, then averaged), output gain and -norm"""
