@@ -231,6 +231,13 @@ def main():
             port = s.getsockname()[1]
         os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
 
+    # stdout of a rank carries the contract's ONE JSON line and nothing else: libraries that print to file descriptor 1
+    # themselves (RCCL's version banner at communicator init, gloo's peer announcements) are pointed at stderr, and the line
+    # goes to a private duplicate of the original descriptor
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -562,7 +569,8 @@ def main():
         line.update(extra)
         if sharded is not None:
             line["sharded_knn"] = sharded
-        print(json.dumps(line), flush=True)
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
