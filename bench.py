@@ -550,8 +550,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("fp8 (e4m3) MFMA candidate scoring, certified, + exact f32 rescoring" if library.prefilter == "fp8" else
-                      "bf16 MFMA scoring + exact f32 rescoring") + "; 3-plane split-bf16 (fp32-grade) encoder GEMMs; 2-plane split-bf16 decoder GEMMs; f32 MFMA DFT / strided / small-channel convs; f64 phase scan",
+            "dtype": ("fp8 (e4m3) MFMA candidate scoring + exact f32 rescoring, every frame certified at 7 sigma of its measured "
+                      "stage error (statistical: audited against brute force, profiles/r03_knn_audit.json; ALIVE_KNN_STRICT=1 is the "
+                      "deterministic form)" if library.prefilter == "fp8" else
+                      "bf16 MFMA scoring + exact f32 rescoring, certified per frame" + (" (deterministic bound)" if library.strict else "")) + "; 3-plane split-bf16 (fp32-grade) encoder GEMMs; 2-plane split-bf16 decoder GEMMs; f32 MFMA DFT / strided / small-channel convs; f64 phase scan",
             "data": "synthetic",
             "config": {"workload": f"{args.utterances} utterances x {args.seconds:g} s per GPU -> {n_win} windows x "
                                    f"{L // FRAME} frames per step, {M}-vector library (BASELINE config 3/4 shape)",
