@@ -41,6 +41,9 @@ def build_parser():
     parser.add_argument('-g', '--gain', default=1.0, type=float)
     parser.add_argument('-a', '--alpha', default=0.0, type=float)
     parser.add_argument('-k', default=4, type=int)
+    parser.add_argument('--knn-strict', action='store_true',
+                        help="kNN match with the deterministic certificate (bf16 candidates under a Cauchy-Schwarz error bound; "
+                             "about twice the search time; this build only; same as ALIVE_KNN_STRICT=1)")
     parser.add_argument('-c', '--chunk', default=48000, type=int)
     parser.add_argument('-lib', '--voice-library-path', default="NONE")
     parser.add_argument('-noise', '--noise-amp', default=1.0, type=float)        # parsed and unused, as in the reference
@@ -61,6 +64,8 @@ def build_parser():
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    if args.knn_strict:
+        os.environ["ALIVE_KNN_STRICT"] = "1"              # read by module/common.py when the library is packed
     device = torch.device(args.device)
     if device.type != "cuda":
         raise SystemExit("this build runs on the MI355X only: pass -d cuda (the reference's spelling for ROCm devices)")

@@ -43,6 +43,9 @@ def build_parser():
     parser.add_argument('-p', '--pitch', default=0, type=float)
     parser.add_argument('-t', '--target', default='NONE')
     parser.add_argument('-k', default=4, type=int)
+    parser.add_argument('--knn-strict', action='store_true',
+                        help="kNN match with the deterministic certificate (bf16 candidates under a Cauchy-Schwarz error bound; "
+                             "about twice the search time; this build only; same as ALIVE_KNN_STRICT=1)")
     parser.add_argument('-a', '--alpha', default=0.0, type=float)
     parser.add_argument('-fp16', default=False, type=bool)
     parser.add_argument('-lib', '--voice-library-path', default="NONE")
@@ -59,6 +62,8 @@ def build_parser():
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    if args.knn_strict:
+        os.environ["ALIVE_KNN_STRICT"] = "1"              # read by module/common.py when the library is packed
     if args.device != 'cuda' or not torch.cuda.is_available():
         raise SystemExit("Error: this build needs a ROCm device: pass -d cuda on an MI355X host.")
     if args.fp16 or args.world_pitch_estimation:

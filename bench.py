@@ -34,7 +34,7 @@ import torch.distributed as dist                           # noqa: E402
 FRAME = 320
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_FP8_TFLOPS = 5000.0           # dense fp8 MFMA peak (block-scaled 32x32x64 e4m3), same table
-ALL_LEGS = ("uncorrelated", "bf16_prefilter", "clustered_library", "overlap_shared", "context_trim", "pcie_inclusive", "e2e_24k", "config2",
+ALL_LEGS = ("uncorrelated", "bf16_prefilter", "strict_knn", "clustered_library", "overlap_shared", "context_trim", "pcie_inclusive", "e2e_24k", "config2",
             "streaming", "cpu_baseline")
 
 
@@ -361,6 +361,26 @@ def main():
             finally:
                 conv.set_library(library)
         extra["bf16_prefilter"] = guarded(leg)
+
+    # The same step with the STRICT search (ALIVE_KNN_STRICT=1): bf16 candidate stage under a deterministic Cauchy-Schwarz bound,
+    # no statistical assumption anywhere -- the price of a guarantee, and a check that it returns the very same waveforms
+    if "strict_knn" in legs:
+        def leg():
+            libs = library.with_strict()
+            ts_ = ScoreTimer(nat)
+            ts_.wrap(libs)
+            conv.set_library(libs)
+            try:
+                conv.convert_windows(windows, k=args.k, window_batch=args.window_batch)
+                ts_.clear()
+                tb, os_ = timed_steps(step, 2)
+                return {"ms_per_step": round(tb * 1e3, 2), "frames_per_s": round(frames_per_step / tb, 1),
+                        "search_ms": round(ts_.search_ms(), 2), "waveforms_equal_default_search": bool(torch.equal(os_, out)),
+                        "search_tiers": libs.search_stats(),
+                        "certificate": "deterministic: |stage - exact| <= ||q - bf16(q)|| + 1.004 max_R ||r - bf16(r)|| + 1e-4"}
+            finally:
+                conv.set_library(library)
+        extra["strict_knn"] = guarded(leg)
 
     # A dense, CE-derived 1 M-vector library (every query frame has many rows at nearly its best cosine): the case in
     # which a candidate stage on fp8 cannot be certified and the search has to fall through its tiers.

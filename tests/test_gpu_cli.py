@@ -101,6 +101,23 @@ def test_inference_cli_target_utterance_stereo_input_gain_and_normalize(workdir)
     assert err < 1e-3 / peak, (err, peak)        # -norm rescales the waveform to peak 1: the 1e-3 bar scales with it
 
 
+def test_inference_cli_strict_knn_writes_the_same_file(workdir, monkeypatch):
+    """--knn-strict (this build only): the kNN match under the deterministic certificate.  Same neighbours, same file."""
+    import inference
+    from module import common
+    monkeypatch.setenv("ALIVE_KNN_STRICT", "0")              # main() sets the variable: restored when the test ends
+    d, _, _ = workdir
+    base = ["-i", str(d / "inputs"), "-dep", str(d / "decoder.pt"), "-cep", str(d / "content_encoder.pt"), "-f0ep", str(d / "f0_estimator.pt"),
+            "-lib", str(d / "voice_library.pt"), "-d", "cuda", "-c", "6400", "-a", "0.05"]
+    inference.main(base + ["-o", str(d / "out_default")])
+    inference.main(base + ["-o", str(d / "out_strict"), "--knn-strict"])
+    assert common._strict()
+    a, _ = audio_io.load(str(d / "out_default" / "0_utt.wav"))
+    b, _ = audio_io.load(str(d / "out_strict" / "0_utt.wav"))
+    assert torch.equal(a, b)
+    common.forget_packed()
+
+
 def test_inference_cli_trim_context_writes_the_same_file(workdir):
     import inference
     d, _, _ = workdir
