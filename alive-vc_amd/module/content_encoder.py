@@ -13,6 +13,14 @@ class ContentEncoder(PackedNet):
     _schema = staticmethod(schema.content_encoder_schema)
     _pack = staticmethod(pack_content_encoder)
 
+    def __init__(self, n_fft=1280, internal_channels=512, hidden_channels=1536, output_channels=768, num_layers=4, seed=None):
+        """the reference's constructor signature (content_encoder.py:9-14); the kernels are built for its default sizes --
+        the only ones inference.py / realtime_inference.py / generate_voice_library.py ever construct"""
+        if (n_fft, internal_channels, hidden_channels, output_channels, num_layers) != (1280, 512, 1536, 768, 4):
+            raise ValueError("ContentEncoder: this build implements the reference's default architecture only "
+                             "(n_fft 1280, 512 / 1536 channels, 768 outputs, 4 layers)")
+        super().__init__(seed)
+
     def forward(self, x, out=None):
         """x [N, 641, T] -> [N, 768, T]   (out: a contiguous [N, 768, T] tensor to write into, e.g. a batch slice)"""
         x = x.contiguous().float()

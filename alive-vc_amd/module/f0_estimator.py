@@ -13,6 +13,13 @@ class F0Estimator(PackedNet):
     _schema = staticmethod(schema.f0_estimator_schema)
     _pack = staticmethod(pack_f0_estimator)
 
+    def __init__(self, n_fft=1280, internal_channels=256, hidden_channels=512, output_channels=4096, num_layers=4, seed=None):
+        """the reference's constructor signature (f0_estimator.py:9-14); the kernels are built for its default sizes"""
+        if (n_fft, internal_channels, hidden_channels, output_channels, num_layers) != (1280, 256, 512, 4096, 4):
+            raise ValueError("F0Estimator: this build implements the reference's default architecture only "
+                             "(n_fft 1280, 256 / 512 channels, 4096 classes, 4 layers)")
+        super().__init__(seed)
+
     def estimate(self, x, downsample_factor=1, out=None):
         """x [N, 641, T] -> f0 [N, 1, T]   (out: a contiguous [N, 1, T] tensor to write into)"""
         x = x.contiguous().float()

@@ -254,3 +254,16 @@ def test_filter_mid_is_built_without_the_slp_vectorizer():
     src = open(os.path.join(ROOT, "alive-vc_amd", "csrc", "filter_mid.hip")).read()
     assert "#ifndef ALIVE_FILTER_MID_NO_SLP" in src and "#error" in src
     assert "diag.hip" not in [w for ln in mk.splitlines() if ln.startswith("SRCS") for w in ln.split()]      # measurement kernels stay out of the product .so
+
+
+def test_network_constructors_keep_the_reference_signature():
+    """content_encoder.py:9-14 / f0_estimator.py:9-14: keyword arguments of the reference's constructors are accepted at their
+    default values (the only ones the three scripts construct) and refused otherwise -- the kernels are built for those sizes"""
+    from module.content_encoder import ContentEncoder
+    from module.f0_estimator import F0Estimator
+    ContentEncoder(n_fft=1280, internal_channels=512, hidden_channels=1536, output_channels=768, num_layers=4)
+    F0Estimator(n_fft=1280, internal_channels=256, hidden_channels=512, output_channels=4096, num_layers=4)
+    with pytest.raises(ValueError):
+        ContentEncoder(hidden_channels=1024)
+    with pytest.raises(ValueError):
+        F0Estimator(output_channels=2048)
