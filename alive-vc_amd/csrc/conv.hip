@@ -202,25 +202,26 @@ int alive_conv_split_launch(const AliveConv* d, float ratio, hipStream_t s);
 bool alive_conv_skinny_try(const AliveConv* d, hipStream_t s, int* rc);
 
 extern "C" int alive_conv1d(const AliveConv* d, void* stream) {
-    ALIVE_CHECK_ARG(d && d->W && d->X, "alive_conv1d: null W/X");
+    ALIVE_CHECK_ARG(d && d->W && (d->X || d->Xp), "alive_conv1d: null W/X");
     ALIVE_CHECK_ARG(d->N > 0 && d->Ci > 0 && d->Co > 0 && d->Tin > 0 && d->Tout > 0, "alive_conv1d: bad sizes");
     ALIVE_CHECK_ARG(d->KW >= 1 && (d->KW <= 16 || d->Ci == 1) && d->stride >= 1 && d->dil >= 1 && d->up >= 1, "alive_conv1d: bad geometry");
     ALIVE_CHECK_ARG(d->precision >= 1 || (d->K_pad % 16 == 0 && d->K_pad >= d->Ci * d->KW), "alive_conv1d: K_pad %d for K %d", d->K_pad, d->Ci * d->KW);
     ALIVE_CHECK_ARG(d->precision >= 0 && d->precision <= 2, "alive_conv1d: precision");
     ALIVE_CHECK_ARG(d->Ci * d->KW < 32768, "alive_conv1d: K too large");
-    ALIVE_CHECK_ARG(d->Y || d->Z, "alive_conv1d: no output");
+    ALIVE_CHECK_ARG(d->Y || d->Z || d->Zp, "alive_conv1d: no output");
     if (d->up > 1) {
-        ALIVE_CHECK_ARG(d->Co % d->up == 0 && !d->residual && !d->skip && !d->Z && d->Y, "alive_conv1d: transposed conv has a plain epilogue");
+        ALIVE_CHECK_ARG(d->Co % d->up == 0 && !d->residual && !d->skip && !d->Z && !d->Zp && d->Y, "alive_conv1d: transposed conv has a plain epilogue");
     }
     ALIVE_CHECK_ARG(d->pad_mode >= 0 && d->pad_mode <= 2, "alive_conv1d: pad_mode");
     if (d->pad_mode != 0) ALIVE_CHECK_ARG(d->pad_left < d->Tin, "alive_conv1d: reflect pad %d needs Tin > pad (Tin %d)", d->pad_left, d->Tin);
-    if (d->Z) ALIVE_CHECK_ARG(d->film && d->Lf > 0, "alive_conv1d: Z needs film");
+    if (d->Z || d->Zp) ALIVE_CHECK_ARG(d->film && d->Lf > 0, "alive_conv1d: Z needs film");
+    if (d->Xp || d->Zp) ALIVE_CHECK_ARG(d->precision == 1, "alive_conv1d: plane-packed operands need the split kernel (precision 1)");
     {
         int rc;
-        if (d->film_ld == 0 && alive_conv_skinny_try(d, (hipStream_t)stream, &rc)) return rc;      // few columns (streaming)
+        if (d->film_ld == 0 && !d->Xp && !d->Zp && alive_conv_skinny_try(d, (hipStream_t)stream, &rc)) return rc;      // few columns (streaming)
     }
     if (d->precision >= 1)
-        return alive_conv_split_launch(d, d->Z ? (float)(d->film_ld ? d->film_ld : d->Lf) / (float)d->Tout : 0.0f, (hipStream_t)stream);
+        return alive_conv_split_launch(d, (d->Z || d->Zp) ? (float)(d->film_ld ? d->film_ld : d->Lf) / (float)d->Tout : 0.0f, (hipStream_t)stream);
     ALIVE_CHECK_ARG(d->film_ld == 0, "alive_conv1d: a film frame range needs the split kernel (precision 1 / 2)");
     const unsigned magic = d->Ci == 1 ? 0u : (unsigned)(((1u << 20) + d->KW - 1) / d->KW);
     const float ratio = d->Z ? (float)d->Lf / (float)d->Tout : 0.0f;

@@ -30,12 +30,23 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p) { return *(const bf16x8*)p; }
 
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+constexpr int PROW = 64;          // PLANES = true: bytes per LDS row (32 channels bf16, no pad: 16-B chunks swizzled by the row)
+
 // NP = number of bf16 planes per operand: 2 -> 3 MFMAs per product (~2^-16), 3 -> 6 MFMAs per product (~2^-24, fp32-grade)
 // BM = 256: all 256 output channels of the filter's coarsest scale in ONE block -- a wave owns 64 rows x 128 columns (2 x 4 MFMA
 // tiles, 128 accumulator registers, one block per CU).  Against two 128-row blocks per column tile that stages the X tile
 // (global loads, split, LDS writes) once instead of twice, reads every activation fragment for two row tiles instead of one
 // (0.33 instead of 0.67 LDS fragment reads per MFMA) and halves the X traffic from L2 / HBM.
-template <int BM, int NP>
+// PLANES = true (BM = 128, NP = 2; round 3): the activation operand arrives ALREADY split, plane-packed and time-major
+// (AliveConv.Xp: P[plane][n * Tin + t][Ci_pad] bf16, the format of gemm_planes.hip), so a 32-channel block of the X tile is
+// 144 row segments of 64 B per plane that LDS-DMA copies straight into LDS -- no fp32 loads, no split, no ds_write in the
+// loop.  By ablation (tools/experiments/README.md) the fp32 staging cost 0.27 - 0.35 ms of the 1.4 - 1.8 ms of a 256-channel
+// k5 conv at 128 windows (its LDS writes alone 0.12 ms); the fragment READS per tap, 80 % of the LDS read traffic, cost nothing.
+// The LDS image of a DMA is lane-linear, so the bank swizzle sits on the SOURCE address: 16-B chunk c of row r is stored at
+// chunk position c ^ ((r >> 2) & 3), which keeps every ds_read_b128 of a fragment conflict-free at any tap shift.
+template <int BM, int NP, bool PLANES = false>
 __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(AliveConv p, float film_ratio) {
     // wave tile: (32 | 64) rows x (128 | 64) columns.  BM = 256 / 128: four waves stacked along the rows; BM = 64: 2 x 2.
     constexpr int NR = BM >= 128 ? 4 : 2;         // 32-column MFMA tiles per wave
@@ -138,6 +149,32 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
         }
     };
 
+    // ---- PLANES: DMA pieces of this wave (piece q = wid + 4 i < 18: plane q / 9, 16-row group q % 9) ----
+    unsigned dma_src[5];          // byte offset of this lane's 16 B inside Xp for channel block 0
+    [[maybe_unused]] const size_t cols_pad = PLANES ? (((size_t)p.N * p.Tin + 127) & ~(size_t)127) : 0;
+    if constexpr (PLANES) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int q = wid + 4 * i;
+            const int pl = q / 9, r = (q % 9) * 16 + (lane >> 2);
+            int tin = t0 - p.pad_left + r;
+            tin = tin < 0 ? -tin : tin;                                  // reflect-left (pad_mode 1; checked on the host)
+            tin = tin < p.Tin ? tin : p.Tin - 1;                         // rows past the signal only feed columns >= Tout
+            const int chunk = (lane & 3) ^ ((r >> 2) & 3);
+            dma_src[i] = (unsigned)((((size_t)pl * cols_pad + (size_t)n * p.Tin + tin) * p.Ci_pad + chunk * 8) * 2);
+        }
+    }
+    auto dma_X = [&](int cb, int buf) {
+        const unsigned char* base = (const unsigned char*)p.Xp + (size_t)cb * (BKC * 2);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int q = wid + 4 * i;
+            if (q < 18)
+                __builtin_amdgcn_global_load_lds((gptr_t)(base + dma_src[i]),
+                                                 (lptr_t)(smem + (buf * NP + q / 9) * XPLANE + (q % 9) * 1024), 16, 0, 0);
+        }
+    };
+
     // ---- accumulators start at the bias ----
     f32x16 acc[MR][NR];
 #pragma unroll
@@ -156,16 +193,20 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
     bf16x8 a_nx2[MR][2][NP];
     int pcb = 0, pj = 0;                                       // (block, tap) of the next fragment set to fetch
     auto advance = [&]() { if (++pj == p.KW) { pj = 0; ++pcb; } };
-    load_X(0);
+    if constexpr (PLANES) dma_X(0, 0); else load_X(0);
     load_A(0, 0, a_cur);
     advance();
     if (pcb < ncb) load_A(pcb, pj, a_nxt);
     advance();
-    store_X(0);
+    if constexpr (!PLANES) store_X(0);
     __syncthreads();
     for (int cb = 0; cb < ncb; ++cb) {
         const bool more_cb = cb + 1 < ncb;
-        if (more_cb) load_X(cb + 1);                           // in flight under this block's taps
+        if constexpr (PLANES) {
+            if (more_cb) dma_X(cb + 1, (cb + 1) & 1);          // lands under this block's taps; the barrier below waits for it
+        } else {
+            if (more_cb) load_X(cb + 1);                       // in flight under this block's taps
+        }
         const unsigned char* Xs = smem + (cb & 1) * NP * XPLANE;
         for (int j = 0; j < p.KW; ++j) {
             if (pcb < ncb) load_A(pcb, pj, a_nx2);
@@ -173,11 +214,20 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 bf16x8 bf[NP][NR];
+                if constexpr (PLANES) {
+                    const int rho = wcol + lr + j * p.dil;             // + nn * 32 does not change (row >> 2) & 3
+                    const unsigned char* b = Xs + rho * PROW + (((2 * s2 + lh) ^ ((rho >> 2) & 3)) << 4);
+#pragma unroll
+                    for (int nn = 0; nn < NR; ++nn)
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl) bf[pl][nn] = lds_frag(b + nn * 32 * PROW + pl * XPLANE);
+                } else {
 #pragma unroll
                 for (int nn = 0; nn < NR; ++nn) {
                     const unsigned char* b = Xs + (wcol + nn * 32 + lr + j * p.dil) * PITCH + s2 * 32 + lh * 16;
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl) bf[pl][nn] = lds_frag(b + pl * XPLANE);
+                }
                 }
                 // all plane products (i, j) with i + j <= NP - 1, smallest terms first
 #pragma unroll
@@ -198,8 +248,8 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl) { a_cur[mr][s2][pl] = a_nxt[mr][s2][pl]; a_nxt[mr][s2][pl] = a_nx2[mr][s2][pl]; }
         }
-        if (more_cb) store_X((cb + 1) & 1);
-        __syncthreads();          // next X tile visible; this one is free to be overwritten one block later
+        if constexpr (!PLANES) { if (more_cb) store_X((cb + 1) & 1); }
+        __syncthreads();          // next X tile visible (vmcnt(0) covers the DMA); this one is free to be overwritten one block later
     }
 
     // ---- epilogue: accumulators -> LDS -> cooperative row-wise pass ----
@@ -213,8 +263,14 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
     float* Ft = Ct + PR * CP;                        // [PR][2][FILM_NF]
     static_assert((PR * CP + PR * 2 * FILM_NF) * 4 <= (int)sizeof(smem), "epilogue staging fits");
     int f_lo = 0, nf = 0;
-    if (p.Z != nullptr) film_tile_range(p, film_ratio, t0, BN, f_lo, nf);       // fit is checked on the host
+    if (p.Z != nullptr || p.Zp != nullptr) film_tile_range(p, film_ratio, t0, BN, f_lo, nf);       // fit is checked on the host
     const bool vec = (p.up == 1) && ((p.Tout & 3) == 0);
+    // Plane-packed second output (AliveConv.Zp): the modulated tile goes back into the staged tile and leaves it TRANSPOSED, 8
+    // channels x 1 column per thread.  Column-wise reads of [row][column] floats put rows 16 apart on the same banks, so the
+    // staged tile is column-swizzled in units of 8 columns by (row >> 4) & 3 (a multiple of the 4-column vectors of the
+    // row-wise pass): zsw_on = 8 when Zp is set, 0 otherwise (the fp32 outputs keep their layout).
+    const int zsw_on = p.Zp != nullptr ? 3 : 0;
+    auto zsw = [&](int row_local) { return ((row_local >> 4) & zsw_on) << 3; };
     const bool upvec = p.up >= 4 && (p.up & (p.up - 1)) == 0 && p.up <= PR && (p.Co & (p.up - 1)) == 0;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
@@ -225,9 +281,12 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
                 for (int nn = 0; nn < NR; ++nn)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        Ct[((MR == 2 ? mr : (wrow & 1)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CP + wcol + nn * 32 + lr] = acc[mr][nn][r];
+                    {
+                        const int rl = (MR == 2 ? mr : (wrow & 1)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        Ct[rl * CP + ((wcol + nn * 32 + lr) ^ zsw(rl))] = acc[mr][nn][r];
+                    }
         }
-        if (p.Z != nullptr) {
+        if (p.Z != nullptr || p.Zp != nullptr) {
             for (int e = tid; e < PR * 2 * FILM_NF; e += 256) {
                 int f = e % FILM_NF, sel = (e / FILM_NF) & 1, pr = e / (2 * FILM_NF);
                 int row = m0 + ps * 64 + pr;
@@ -251,7 +310,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
                 const int row = m0 + ps * 64 + pr;
                 const int t = t0 + c4;
                 if (row >= p.Co || t >= p.Tout) continue;
-                f32x4 v = *(const f32x4*)&Ct[pr * CP + c4];
+                f32x4 v = *(const f32x4*)&Ct[pr * CP + (c4 ^ zsw(pr))];
                 if (p.act == 1) {                                  // two values per instruction on the packed fp32 pipe
                     const f32x2 g0 = gelu_fast2(f32x2{v[0], v[1]}), g1 = gelu_fast2(f32x2{v[2], v[3]});
                     v = f32x4{g0[0], g0[1], g1[0], g1[1]};
@@ -263,7 +322,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
                 if (p.residual != nullptr) v = v + *(const f32x4*)(p.residual + o);
                 if (p.skip != nullptr) v = v + *(const f32x4*)(p.skip + o);
                 if (p.Y != nullptr) *(f32x4*)(p.Y + o) = v;
-                if (p.Z != nullptr) {
+                if (p.Z != nullptr || p.Zp != nullptr) {
                     const float* fs = Ft + pr * 2 * FILM_NF - f_lo;
                     f32x4 z;
                     const f32x2 g0 = gelu_fast2(f32x2{v[0], v[1]}), g1 = gelu_fast2(f32x2{v[2], v[3]});
@@ -275,7 +334,34 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
                         float sh = lerp_apply(lp, fs[FILM_NF + lp.i0], fs[FILM_NF + lp.i1]);
                         z[q] = gv[q] * sc + sh;
                     }
-                    *(f32x4*)(p.Z + o) = z;
+                    if (p.Z != nullptr) *(f32x4*)(p.Z + o) = z;
+                    if (p.Zp != nullptr) *(f32x4*)&Ct[pr * CP + (c4 ^ zsw(pr))] = z;      // in place: this thread's own four values
+                }
+            }
+            if (p.Zp != nullptr) {
+                // transposed leave: thread = (column, 8 channels); 8 lanes write the 128 B of a column's 64 channels per plane
+                __syncthreads();
+                unsigned short* Zp = (unsigned short*)p.Zp;
+                const int co_pad32 = (p.Co + 31) & ~31;
+                const size_t zcols_pad = ((size_t)p.N * p.Tout + 127) & ~(size_t)127;
+#pragma unroll
+                for (int e = tid; e < BN * 8; e += 256) {
+                    const int chunk = e & 7, t_l = e >> 3;
+                    const int t = t0 + t_l, row0 = m0 + ps * 64 + chunk * 8;
+                    if (t >= p.Tout || row0 >= p.Co) continue;
+                    const float* cp = Ct + (chunk * 8) * CP + (t_l ^ (((chunk >> 1) & 3) << 3));
+                    unsigned hi[4], lo[4];
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; ++k2) {
+                        const float q0 = cp[(2 * k2) * CP], q1 = cp[(2 * k2 + 1) * CP];
+                        bf16x2_t hp = {(__bf16)q0, (__bf16)q1};
+                        hi[k2] = __builtin_bit_cast(unsigned, hp);
+                        bf16x2_t lp2 = {(__bf16)(q0 - __uint_as_float(hi[k2] << 16)), (__bf16)(q1 - __uint_as_float(hi[k2] & 0xffff0000u))};
+                        lo[k2] = __builtin_bit_cast(unsigned, lp2);
+                    }
+                    unsigned short* dst = Zp + ((size_t)n * p.Tout + t) * co_pad32 + row0;
+                    *(u32x4*)dst = u32x4{hi[0], hi[1], hi[2], hi[3]};
+                    *(u32x4*)(dst + zcols_pad * co_pad32) = u32x4{lo[0], lo[1], lo[2], lo[3]};
                 }
             }
         } else if (upvec) {
@@ -379,18 +465,31 @@ int alive_conv_split_launch(const AliveConv* d, float ratio, hipStream_t s) {
         ALIVE_CHECK_ARG(span <= FILM_NF, "alive_conv1d(split): FiLM second output needs Tout >= ~8 Lf (got Lf %d, Tout %d)", d->Lf, d->Tout);
     }
     ALIVE_CHECK_ARG(d->act >= 0 && d->act <= 2, "alive_conv1d(split): activation %d not available on the split kernel", d->act);
+    if (d->Zp) {
+        const double span = (double)(d->film_ld ? d->film_ld : d->Lf) / (double)d->Tout * BN + 3.0;
+        ALIVE_CHECK_ARG(span <= FILM_NF && d->film, "alive_conv1d(split): plane second output needs FiLM rows and Tout >= ~8 Lf");
+        ALIVE_CHECK_ARG(d->up == 1 && (d->Tout & 3) == 0 && d->Co % 64 == 0 && d->Co > 64 && d->precision == 1 &&
+                        (((uintptr_t)d->Zp) & 15) == 0,
+                        "alive_conv1d(split): plane second output needs up 1, Tout %% 4 == 0, Co a multiple of 64 above 64, 2 planes");
+    }
+    if (d->Xp) {
+        ALIVE_CHECK_ARG(d->precision == 1 && d->Co > 64 && d->Ci % BKC == 0 && d->Ci_pad == d->Ci && (d->pad_mode == 1 || d->pad_left == 0) &&
+                        (((uintptr_t)d->Xp) & 15) == 0 && d->Tout <= d->Tin,
+                        "alive_conv1d(split): plane input needs 2 planes, Co > 64, Ci a multiple of 32, reflect-left padding");
+    }
     ALIVE_CHECK_ARG(d->Tout <= d->Tin + d->pad_left, "alive_conv1d(split): Tout");
     // measured (tools/bench_conv256.py, 128 windows x 4500 columns): the 256-row tile is 12 - 37 % SLOWER than two 128-row blocks
     // (k5 + FiLM + residual 2.11 against 1.72 ms, 1x1 1.15 against 0.84): at one block per CU nothing covers the LDS / L2
     // latencies of the single wave per SIMD, and no other block's main loop runs under the four epilogue passes.  Off by
     // default; ALIVE_CONV_TILE256=1 selects it (same results bit for bit).
     static const bool tile256 = getenv("ALIVE_CONV_TILE256") != nullptr && atoi(getenv("ALIVE_CONV_TILE256")) != 0;
-    if (d->Co > 128 && d->Co % 256 == 0 && d->precision == 1 && tile256) {
+    if (d->Co > 128 && d->Co % 256 == 0 && d->precision == 1 && tile256 && !d->Xp) {
         dim3 g(cdiv(d->Tout, BN), d->Co / 256, d->N);
         conv_split_kernel<256, 2><<<g, 256, 0, s>>>(*d, ratio);
     } else if (d->Co > 64) {
         dim3 g(cdiv(d->Tout, BN), cdiv(d->Co, 128), d->N);
         if (d->precision == 2) conv_split_kernel<128, 3><<<g, 256, 0, s>>>(*d, ratio);
+        else if (d->Xp) conv_split_kernel<128, 2, true><<<g, 256, 0, s>>>(*d, ratio);
         else conv_split_kernel<128, 2><<<g, 256, 0, s>>>(*d, ratio);
     } else {
         dim3 g(cdiv(d->Tout, BN), 1, d->N);

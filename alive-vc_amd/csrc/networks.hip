@@ -406,7 +406,7 @@ DecBuffers dec_layout(void* ws, int N, int Lf) {
     b.U = a.take<float>(big + 32768);                  // + the column padding of the planes of d1 it doubles as scratch for
     b.Hh = a.take<float>(big);
     b.Zz = a.take<float>(big + 32768);                 // (planes of d2)
-    b.Z2 = a.take<float>(big);
+    b.Z2 = a.take<float>(big + 32768);                 // (+ the 128-column padding of a plane-packed image)
     b.osc_ws = a.take<char>(alive_oscillator_workspace_bytes(N, NH, Lf));
     b.bytes = a.used() + 1024;
     return b;
@@ -522,9 +522,16 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
             continue;
         }
         const float* iW = t.next(); const float* ib = t.next();
+        // The modulated tensors between the convs of this block (each written once, read once) travel plane-packed and
+        // time-major when the split kernel's batch form runs them (not the few-column streaming kernel): the consumer then
+        // stages them by LDS-DMA instead of loading, splitting and storing fp32 (conv_split.hip, PLANES).  Same values bit for bit.
+        const bool zplanes = F_SPLIT[s] && (int64_t)N * L > 96 && (L & 3) == 0 && C > 64 && C % 64 == 0 &&
+                             (double)(ranged ? Lf : Lw_frames) / (double)L * 128.0 + 3.0 <= 20.0;
+        auto set_z = [&](AliveConv& d, float* buf) { if (zplanes) d.Zp = buf; else d.Z = buf; };
+        auto set_x = [&](AliveConv& d, const float* buf) { if (zplanes) { d.Xp = buf; d.X = nullptr; } };
         {   // FilterBlock.input_conv; second output feeds blocks[0].c1 (gelu + FiLM)
             AliveConv d = pw_desc(iW, ib, b.U, N, C, L, C, b.Hh);
-            d.Z = b.Zz; d.film = b.film; d.film_rows = FILM_ROWS; d.Lf = Lw_frames;
+            set_z(d, b.Zz); d.film = b.film; d.film_rows = FILM_ROWS; d.Lf = Lw_frames;
             if (ranged) { d.film_t0 = f_begin * (L / Lf); d.film_f0 = f_begin; d.film_ld = Lf; }
             d.film_scale_row = film_off; d.film_shift_row = film_off + C;
             if (F_SPLIT[s]) d = split(d);
@@ -537,7 +544,8 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
             (void)f1;
             {   // c1: conv(Zz) -> only the modulated input of c2 is kept
                 AliveConv d = conv_desc(W1, b1, b.Zz, N, C, L, C, 5, 1, dil, 4 * dil, 1, L, nullptr);
-                d.Z = b.Z2; d.film = b.film; d.film_rows = FILM_ROWS; d.Lf = Lw_frames;
+                set_x(d, b.Zz);
+                set_z(d, b.Z2); d.film = b.film; d.film_rows = FILM_ROWS; d.Lf = Lw_frames;
             if (ranged) { d.film_t0 = f_begin * (L / Lf); d.film_f0 = f_begin; d.film_ld = Lf; }
                 d.film_scale_row = f2; d.film_shift_row = f2 + C;
                 if (F_SPLIT[s]) d = split(d);
@@ -545,11 +553,12 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
             }
             {   // c2: conv(Z2) + residual (+ U-Net skip after the last block) ; next block's c1 input
                 AliveConv d = conv_desc(W2, b2, b.Z2, N, C, L, C, 5, 1, dil, 4 * dil, 1, L, b.Hh);
+                set_x(d, b.Z2);
                 d.residual = b.Hh;
                 if (j == 2) d.skip = skips[s];
                 if (j < 2) {
                     const int fn = film_off + ((j + 1) * 2) * 2 * C;
-                    d.Z = b.Zz; d.film = b.film; d.film_rows = FILM_ROWS; d.Lf = Lw_frames;
+                    set_z(d, b.Zz); d.film = b.film; d.film_rows = FILM_ROWS; d.Lf = Lw_frames;
             if (ranged) { d.film_t0 = f_begin * (L / Lf); d.film_f0 = f_begin; d.film_ld = Lf; }
                     d.film_scale_row = fn; d.film_shift_row = fn + C;
                 }

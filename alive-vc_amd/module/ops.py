@@ -21,9 +21,11 @@ def _f(t):
 
 def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, out_len=None, act=None,
            post_add=None, ch_scale=None, residual=None, skip=None, film=None, film_scale_row=0, film_shift_row=0,
-           want_raw=True, transposed=False, precision="fp32"):
+           want_raw=True, transposed=False, precision="fp32", x_planes=None, z_planes=False):
     """Generic Conv1d / ConvTranspose1d(k == stride) through alive_conv1d.
-    Returns (Y, Z): raw output (or None) and the gelu+FiLM modulated second output (or None)."""
+    Returns (Y, Z): raw output (or None) and the gelu+FiLM modulated second output (or None).
+    x_planes: the plane-packed form of x (to_planes(x, 2)) -- the split kernel then stages its input by LDS-DMA (AliveConv.Xp);
+    z_planes: Z comes back plane-packed (AliveConv.Zp; a uint8 buffer like to_planes gives) instead of fp32."""
     x = _f(x)
     n, ci, tin = x.shape
     keep = []
@@ -67,10 +69,20 @@ def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, o
     Y = torch.empty(n, co_out, tout * up, device=x.device) if want_raw else None
     Z = None
     if film is not None:
-        Z = torch.empty(n, co_out, tout, device=x.device)
+        if z_planes:
+            Z = torch.empty(nat.lib().alive_planes_bytes(n * tout, co_out, 2), dtype=torch.uint8, device=x.device)
+        else:
+            Z = torch.empty(n, co_out, tout, device=x.device)
         d.film, d.film_rows, d.Lf = nat.ptr(film), film.shape[1], film.shape[2]
         d.film_scale_row, d.film_shift_row = film_scale_row, film_shift_row
-    d.Y, d.Z = nat.ptr(Y), nat.ptr(Z)
+    d.Y = nat.ptr(Y)
+    if z_planes:
+        d.Zp = nat.ptr(Z)
+    else:
+        d.Z = nat.ptr(Z)
+    if x_planes is not None:
+        d.Xp, d.X = nat.ptr(x_planes), None
+        keep.append(x_planes)
     nat.check(nat.lib().alive_conv1d(C.byref(d), nat.stream()), "alive_conv1d")
     return Y, Z
 

@@ -186,6 +186,13 @@ typedef struct AliveConv {
      * film_ld; Lf stays the window's frame count, so the interpolation coordinates are those of the whole window.
      * film_ld == 0: film covers the whole window (film_t0 = film_f0 = 0, pitch Lf).  Split kernel only. */
     int film_t0, film_f0, film_ld;
+    /* Plane-packed operands of the split kernel (precision 1, Co > 64; round 3).  Format = "plane-packed activations" below:
+     * P[plane][n * T + t][C_pad] bf16, 2 planes, plane stride = cols_pad * C_pad, cols_pad = N * T rounded up to 128.
+     *   Xp  input instead of X (X is ignored): Ci a multiple of 32, pad_mode 1 (or no padding); staged by LDS-DMA.
+     *   Zp  the second output (gelu + FiLM) in that format instead of / beside Z: Co a multiple of 64, Tout a multiple of 4.
+     * The decoder's 256-channel FilterBlock chains its convs through these (networks.hip). */
+    const void* Xp;
+    void* Zp;
 } AliveConv;
 int alive_conv1d(const AliveConv* desc, void* stream);
 

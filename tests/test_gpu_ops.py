@@ -706,3 +706,35 @@ def test_operators_write_only_their_outputs(monkeypatch):
     assert len(bands) >= 25
     for raw in bands:
         assert bool((raw[:4096] == 0x5A).all() and (raw[raw.numel() - 4096:] == 0x5A).all()), "an operator wrote outside its output"
+
+
+# ---- split-bf16 conv with plane-packed operands (round 3): LDS-DMA staging, plane second output ----------------
+@pytest.mark.parametrize("kw,dil,t,with_res", [(5, 1, 900, True), (5, 2, 520, False), (5, 4, 4500, True), (1, 1, 300, False)])
+def test_conv1d_split_plane_operands_equal_the_fp32_staged_kernel(kw, dil, t, with_res):
+    """AliveConv.Xp / Zp (the decoder's 256-channel FilterBlock chains its convs through them): the input arrives already
+    split into two bf16 planes, time-major, and is staged by LDS-DMA; the gelu + FiLM second output leaves in the same
+    format.  Same split (round to nearest even), same MFMA order: Y bitwise equal to the fp32-staged kernel, Zp bitwise the
+    plane image of its Z.  First tile reflects at t = 0 (causal conv), last tile is ragged."""
+    from module import ops
+    n, c, lf = 3, 256, max(5, t // 10)
+    x = g(f"px{kw}{dil}{t}", (n, c, t))
+    w = g(f"pw{kw}{dil}{t}", (c, c, kw), scale=1.0 / np.sqrt(c * kw))
+    b = g(f"pb{kw}{dil}{t}", (c,), scale=0.1)
+    film = g(f"pf{kw}{dil}{t}", (n, 2 * c, lf))
+    res = g(f"pr{kw}{dil}{t}", (n, c, t)) if with_res else None
+    kwargs = dict(dilation=dil, pad_left=(kw - 1) * dil, pad_mode=1, out_len=t, residual=None if res is None else res.to(DEV),
+                  film=film.to(DEV), film_scale_row=0, film_shift_row=c, precision="bf16x3")
+    y0, z0 = ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), **kwargs)
+    xp = ops.to_planes(x.to(DEV), 2)
+    y1, zp1 = ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), x_planes=xp, z_planes=True, **kwargs)
+    assert torch.equal(y0, y1)
+    want = ops.to_planes(z0, 2)
+    cols, cols_pad = n * t, (n * t + 127) // 128 * 128
+    a = zp1.view(torch.bfloat16).view(2, cols_pad, c)[:, :cols]
+    e = want.view(torch.bfloat16).view(2, cols_pad, c)[:, :cols]
+    assert torch.equal(a.view(torch.int16), e.view(torch.int16))
+    # plane input alone (fp32 second output) and plane output alone (fp32 input)
+    y2, z2 = ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), x_planes=xp, **kwargs)
+    assert torch.equal(y2, y0) and torch.equal(z2, z0)
+    y3, zp3 = ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), z_planes=True, **kwargs)
+    assert torch.equal(y3, y0) and torch.equal(zp3.view(torch.bfloat16).view(2, cols_pad, c)[:, :cols].view(torch.int16), e.view(torch.int16))

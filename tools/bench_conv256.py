@@ -30,4 +30,15 @@ for KW, dil, with_z, with_res, want_y in ((5, 2, 1, 1, 1), (5, 4, 1, 0, 0), (1, 
     e.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(e) / 10
     fl = 2.0 * C_ * C_ * KW * L * N
-    print(f"k{KW} d{dil} z={with_z} res={with_res} y={want_y}: {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TF-eq  ({3 * fl / ms / 1e12:.2f} PF bf16)   checksum y {float(y.double().sum()) if want_y else 0:.6e} z {float(z.double().sum()) if with_z else 0:.6e}")
+    # the same conv with plane-packed operands (AliveConv.Xp / Zp: LDS-DMA staging, plane second output)
+    xp = torch.empty(L_.alive_planes_bytes(N * L, C_, 2), dtype=torch.uint8, device=dev)
+    L_.alive_to_planes(x.data_ptr(), N, C_, L, 2, xp.data_ptr(), st)
+    zp = torch.empty(L_.alive_planes_bytes(N * L, C_, 2), dtype=torch.uint8, device=dev)
+    d.Xp, d.X = xp.data_ptr(), None
+    if with_z: d.Zp, d.Z = zp.data_ptr(), None
+    for _ in range(2): nat.check(L_.alive_conv1d(C.byref(d), st))
+    a.record()
+    for _ in range(10): L_.alive_conv1d(C.byref(d), st)
+    e.record(); torch.cuda.synchronize()
+    ms_p = a.elapsed_time(e) / 10
+    print(f"k{KW} d{dil} z={with_z} res={with_res} y={want_y}: {ms:7.3f} ms (planes in/out {ms_p:7.3f} ms)   {fl / ms / 1e9:7.1f} TF-eq  ({3 * fl / ms / 1e12:.2f} PF bf16)   checksum y {float(y.double().sum()) if want_y else 0:.6e} z {float(z.double().sum()) if with_z else 0:.6e}")
