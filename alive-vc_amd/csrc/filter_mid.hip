@@ -280,12 +280,25 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
         auto mma_tile = [&](f32x4& acc0, f32x4& acc1) {
             acc0 = b4;
             acc1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#ifdef ALIVE_FB64_3CHAINS              // DIAGNOSTIC build only (tools/repro_filter_block64.sh): the two cross terms on accumulators of
+                                       // their own.  Slower (7.58 against 7.40 ms) and -- with the per-tile fence and -fno-slp-vectorize
+                                       // in place -- NOT deterministic: 19 of 20 launches differ from the first (DESIGN.md 3.2b').
+            f32x4 acc2 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int s = 0; s < 10; ++s) {
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][1], fh[s], acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][0], fl[s], acc2, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][0], fh[s], acc0, 0, 0, 0);
+            }
+            acc1 = acc1 + acc2;
+#else
 #pragma unroll
             for (int s = 0; s < 10; ++s) {
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][1], fh[s], acc1, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][0], fl[s], acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][0], fh[s], acc0, 0, 0, 0);
             }
+#endif
         };
         // the last conv has no consumer for the modulated output: it runs the same code with the FiLM rows of conv 5 and
         // writes a tile nobody reads, which keeps the column body free of branches (one basic block per tile)
