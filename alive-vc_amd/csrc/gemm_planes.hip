@@ -40,9 +40,15 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 }
 
 // ---- epilogue, straight from the accumulators (shared by the one-tile and the persistent kernel) ----
+// stage: wave-private LDS (NP x 8 KB: [plane][64 columns][64 channels] bf16) for the plane-packed output, or nullptr.  With it
+// the planes leave as 16-byte pieces, 8 lanes covering the 128 B of a column's 64 channels (the tile is written to LDS in the
+// accumulator layout -- 8 B per lane, 16-B chunk index XOR-ed with column & 7 -- and read back transposed); without it a lane
+// stores its 8-byte pieces directly, one per column and store instruction: 64 separate 64-B lines touched per instruction.
+// By ablation (tools/experiments/README.md) the epilogue was 41 % of a 512 -> 1536 + GELU -> planes layer.
 template <int NP, int ACT>
 __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[2][2], int m0, int64_t c0, int wr, int wc, int lr,
-                                              int lh, int64_t cols, int64_t cols_pad, int co_pad32) {
+                                              int lh, int64_t cols, int64_t cols_pad, int co_pad32, unsigned char* stage = nullptr,
+                                              unsigned char* stage_small = nullptr) {
     // A lane holds, per 32 x 32 tile, one column and 16 rows in 4 groups of 4 consecutive rows (8 g + 4 lh + e).
     // Offsets are 32-bit (checked on the host) against uniform bases; per-row vectors (bias, post_add, ch_scale) come
     // as clamped loads, and all residual values of a 32-row half are requested before its first store (Y may alias the
@@ -146,7 +152,57 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
                     }
                 }
             }
-            if (p.Pout != nullptr && cok[tj]) {
+            if (p.Pout != nullptr && stage != nullptr) {
+                // plane-packed output through the wave's LDS tile (columns past the end are written too, and skipped on the way out)
+                const int cl = tj * 32 + lr;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int rowl = ti * 32 + 8 * g + 4 * lh;                 // channel inside the wave's 64
+                    float q[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) q[e] = (full_rows || rbase + 8 * g + e < p.Co) ? vv[4 * g + e] : 0.0f;
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) {
+                        const unsigned h01 = pack_bf16x2(q[0], q[1]), h23 = pack_bf16x2(q[2], q[3]);
+                        *(uint2*)(stage + pl * 8192 + cl * 128 + ((((rowl >> 3)) ^ (cl & 7)) << 4) + 8 * lh) = make_uint2(h01, h23);
+                        q[0] -= __uint_as_float(h01 << 16);
+                        q[1] -= __uint_as_float(h01 & 0xffff0000u);
+                        q[2] -= __uint_as_float(h23 << 16);
+                        q[3] -= __uint_as_float(h23 & 0xffff0000u);
+                    }
+                }
+            } else if (p.Pout != nullptr && stage_small != nullptr) {
+                // the same through a 2-KB wave-private tile, one 32 x 32 sub-tile and plane at a time (the persistent kernel: its
+                // DMA ring is busy with the next tile during the epilogue, only 16 KB of LDS are free): rows of 64 B (32 channels),
+                // chunk index XOR-ed with (column >> 2) & 3; leaves as 16-byte pieces, four lanes per column
+                unsigned short* Po = (unsigned short*)p.Pout;
+                float q[4][4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) q[g][e] = (full_rows || rbase + 8 * g + e < p.Co) ? vv[4 * g + e] : 0.0f;
+                const int lane = lr + 32 * lh;
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const unsigned h01 = pack_bf16x2(q[g][0], q[g][1]), h23 = pack_bf16x2(q[g][2], q[g][3]);
+                        *(uint2*)(stage_small + lr * 64 + ((g ^ ((lr >> 2) & 3)) << 4) + 8 * lh) = make_uint2(h01, h23);
+                        q[g][0] -= __uint_as_float(h01 << 16);
+                        q[g][1] -= __uint_as_float(h01 & 0xffff0000u);
+                        q[g][2] -= __uint_as_float(h23 << 16);
+                        q[g][3] -= __uint_as_float(h23 & 0xffff0000u);
+                    }
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int idx = it * 64 + lane, cl = idx >> 2, chunk = idx & 3;
+                        const u32x4 v = *(const u32x4*)(stage_small + cl * 64 + ((chunk ^ ((cl >> 2) & 3)) << 4));
+                        const int64_t col = c0 + wc * 64 + tj * 32 + cl;
+                        const int row0 = m0 + wr * 64 + ti * 32 + chunk * 8;
+                        if (col < cols && row0 < co_pad32) *(u32x4*)(Po + ((size_t)pl * cols_pad + col) * co_pad32 + row0) = v;
+                    }
+                }
+            } else if (p.Pout != nullptr && cok[tj]) {
                 // plane-packed output for the next GEMM: 4 consecutive channels of one column -> 8 B per plane
                 unsigned short* Po = (unsigned short*)p.Pout;
                 const int64_t col = c0 + wc * 64 + tj * 32 + lr;
@@ -167,6 +223,22 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
                         q[3] -= __uint_as_float(h23 & 0xffff0000u);
                     }
                 }
+            }
+        }
+    }
+    if (p.Pout != nullptr && stage != nullptr) {
+        unsigned short* Po = (unsigned short*)p.Pout;
+        const int lane = lr + 32 * lh;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 64 + lane, cl = idx >> 3, chunk = idx & 7;
+            const int64_t col = c0 + wc * 64 + cl;
+            const int row0 = m0 + wr * 64 + chunk * 8;
+            if (col >= cols || row0 >= co_pad32) continue;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                const u32x4 v = *(const u32x4*)(stage + pl * 8192 + cl * 128 + ((chunk ^ (cl & 7)) << 4));
+                *(u32x4*)(Po + ((size_t)pl * cols_pad + col) * co_pad32 + row0) = v;
             }
         }
     }
@@ -315,7 +387,14 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
     const long long ts3 = wall_clock64();
 #endif
 
-    gemm_epilogue<NP, ACT>(p, acc, m0, c0, wr, wc, lr, lh, cols, cols_pad, co_pad32);
+    unsigned char* stage = nullptr;
+    if constexpr (ACT != 3) {
+        if (p.Pout != nullptr) {                       // block-uniform: the DMA ring is free now; each wave takes NP x 8 KB of it
+            __syncthreads();                           // every wave has read its last fragments
+            stage = smem + w * (NP * 8192);
+        }
+    }
+    gemm_epilogue<NP, ACT>(p, acc, m0, c0, wr, wc, lr, lh, cols, cols_pad, co_pad32, stage);
 #ifdef ALIVE_STAMPS
     if (stamps != nullptr && tid == 0) {
         long long* o = stamps + (size_t)blockIdx.x * 8;
@@ -477,7 +556,8 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_persistent_kernel(AliveGem
         if (has_next) wait_vmcnt<(NS - 1) * NI>(); else wait_vmcnt<0>();
         {
             const int mt = v % n_mt;
-            gemm_epilogue<NP, ACT>(p, acc, mt * GM, (int64_t)(v / n_mt) * GN, wr, wc, lr, lh, cols, cols_pad, co_pad32);
+            gemm_epilogue<NP, ACT>(p, acc, mt * GM, (int64_t)(v / n_mt) * GN, wr, wc, lr, lh, cols, cols_pad, co_pad32, nullptr,
+                                   p.Pout != nullptr ? smem + NS * SLOT + w * 2048 : nullptr);
         }
         if (!has_next) break;
         v = vn;
@@ -559,7 +639,7 @@ int launch_gemm_act(const AliveGemm& d, hipStream_t s) {
 
 template <int NP, int NS, int ACT>
 int launch_gemm_persistent_act(const AliveGemm& d, hipStream_t s) {
-    constexpr int LDS = NS * 2 * NP * PLANE_BYTES;
+    constexpr int LDS = NS * 2 * NP * PLANE_BYTES + 4 * 2048;      // the DMA ring + a 2-KB staging tile per wave (plane output)
     {
         static LdsOptIn optin;
         hipError_t e = optin.ensure({(const void*)gemm_planes_persistent_kernel<NP, NS, ACT>}, LDS);
