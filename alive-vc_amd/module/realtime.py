@@ -19,10 +19,12 @@ from .spectrogram import spectrogram
 # carried over: the oscillator (its phase is a running sum from the ring's first sample, re-anchored every step) and with it
 # the whole Filter, i.e. the decoder always runs on the full ring.
 # One more condition makes the reuse EXACT rather than merely close: the library picks its kernels by problem size (below 96
-# frame columns the fp32-activation streaming kernels, from 96 the plane-packed split-bf16 GEMMs; the norm kernel has a
-# per-frame form for T <= 32), and the two families round differently (1e-5).  A recomputed edge block must therefore go
-# through the same kernels as the full ring would: blocks of 33 frames under a ring shorter than 96 frames, blocks of 96
-# frames under a longer one.
+# frame COLUMNS -- batch x frames -- the fp32-activation streaming kernels, from 96 the plane-packed split-bf16 GEMMs; the norm
+# kernel has a per-frame form for T <= 32), and the two families round differently (1e-5).  A recomputed edge block must
+# therefore go through the same kernels as the full ring would.  Blocks are 33 frames (more than 32: the norm kernel's batch
+# form either way); under a ring of 96 frames or more the block is run as a BATCH OF THREE identical rows (>= 99 columns: the
+# plane-packed family, whose results do not depend on the row), under a shorter ring as it is (its 33 + shift frames must stay
+# below 96).  Round 2 used 96-frame blocks for long rings and had to refuse rings of 96 .. 195 frames.
 EDGE = 14            # 12 frames of ConvNeXt context + 2 of STFT reflect padding
 SPEC_MARGIN = 2      # STFT frames spoiled by the reflect padding of a slice
 PLANES_MIN_COLS = 96  # csrc/networks.hip: use_planes()
@@ -30,14 +32,17 @@ NORM_SMALL_MAX_T = 32  # csrc/blocks.hip: alive_dwconv_norm's per-frame kernel
 
 
 def reuse_block(frames, shift):
-    """frames of a recomputed edge block (EDGE new frames + margin) under a ring of `frames`, or None where no block size keeps
-    the edge blocks on the full ring's kernels"""
-    if frames < PLANES_MIN_COLS:
-        blk = NORM_SMALL_MAX_T + 1
-        ok = blk + shift < PLANES_MIN_COLS
-    else:
-        blk, ok = PLANES_MIN_COLS, True
+    """frames of a recomputed edge block (EDGE new frames + margin) under a ring of `frames`, or None where the ring is too
+    short for two edge blocks (or, below 96 frames, where a block with the shift would reach the plane-packed family)"""
+    blk = NORM_SMALL_MAX_T + 1
+    ok = frames >= PLANES_MIN_COLS or blk + shift < PLANES_MIN_COLS
     return blk if ok and frames >= 2 * (blk + SPEC_MARGIN) + shift else None
+
+
+def reuse_rows(frames):
+    """batch rows an edge block is run with: enough identical rows to reach the kernel family of the full ring"""
+    blk = NORM_SMALL_MAX_T + 1
+    return 1 if frames < PLANES_MIN_COLS else -(-PLANES_MIN_COLS // blk)
 
 
 class RealtimeConverter:
@@ -72,9 +77,10 @@ class RealtimeConverter:
                                                         (chunk * buffersize) % 320 == 0) else None
         fits = self._blk is not None
         if reuse_interior is True and not fits:
-            raise ValueError("interior reuse needs input_sr 16000, chunk a multiple of 320 and a ring of 70 + chunk .. 95 frames "
-                             f"or of at least 196 + chunk frames (got {frames} frames): see module/realtime.py")
+            raise ValueError("interior reuse needs input_sr 16000, chunk a multiple of 320 and a ring of at least 70 + chunk / 320 "
+                             f"frames (below 96 frames: 33 + chunk / 320 < 96); got {frames} frames: see module/realtime.py")
         self.reuse = bool(fits and reuse_interior in (True, "auto"))
+        self._rows = reuse_rows(frames)
         self._cache_valid = False
         if self.reuse:
             self._c_feat = torch.zeros(1, 768, frames, device=self.device)      # matched features of the ring's frames
@@ -138,12 +144,16 @@ class RealtimeConverter:
     def _front_end_slice(self, samples, f_lo, f_hi):
         """front end on a slice of the ring: spectrogram of `samples`, frames [f_lo, f_hi) of it through the networks and the
         match (the frames outside are spoiled by the slice's own reflect padding)"""
-        spec = spectrogram(samples.contiguous())[:, :, f_lo:f_hi].contiguous()
+        samples = samples.contiguous()
+        if self._rows > 1:                                  # identical rows: same kernels as the full ring (see the header)
+            samples = samples.expand(self._rows, -1).contiguous()
+        spec = spectrogram(samples)[:, :, f_lo:f_hi].contiguous()
         content = self.ce(spec)
         f0 = self.pe.estimate(spec)
         f0 = ops.pitch_transform_(f0, 1, f0_rate=self.f0_rate, pitch_shift=self.pitch)
         val, idx = self.lib.search(content, self.k)
-        return merge_gather(val, idx, 1, self.k, self.alpha, self.lib.rows, content), f0
+        out = merge_gather(val, idx, 1, self.k, self.alpha, self.lib.rows, content)
+        return out[:1], f0[:1]
 
     def enable_graph(self):
         """Capture the whole per-step device pipeline (~150 launches) into one hipGraph: the C ABI never allocates or

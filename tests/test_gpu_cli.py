@@ -229,7 +229,7 @@ def test_realtime_cli_replays_a_hipgraph_with_the_same_samples(workdir):
     assert sra == 16000 and a.shape[1] >= 160 * 50 and torch.equal(a, b)
 
 
-@pytest.mark.parametrize("graph,bs", [(False, 26), (True, 26), (False, 70)])
+@pytest.mark.parametrize("graph,bs", [(False, 26), (True, 26), (False, 70), (False, 34), (True, 44), (False, 60)])
 def test_realtime_interior_reuse_equals_full_recomputation(graph, bs):
     """a ring of 78 frames advancing by 3 frames per step.  With interior reuse only the two edge blocks of
     the ring go through spectrogram / content encoder / f0 estimator / kNN again; the emitted samples must be bitwise those
@@ -239,7 +239,9 @@ def test_realtime_interior_reuse_equals_full_recomputation(graph, bs):
     from module.f0_estimator import F0Estimator
     from module.realtime import RealtimeConverter
     lib = synthetic.make_library(3000, 1)
-    chunk, steps = 960, 7                    # bs 26: ring of 78 frames (streaming kernels, 33-frame edge blocks); 70: 210 frames (plane GEMMs, 96-frame blocks)
+    chunk, steps = 960, 7                    # bs 26: ring of 78 frames (streaming kernels, 33-frame edge blocks); 34 / 44 / 60 / 70: rings of
+                                             # 102 / 132 / 180 / 210 frames (plane GEMMs: the 33-frame blocks run as batches of three rows) -- the
+                                             # 96 .. 195-frame rings are the ones round 2 had to refuse
     pcm = (synthetic.make_waveform(chunk * (bs + steps), 64)[0].numpy() * 20000).astype(np.int16)
     outs = {}
     for reuse in (False, True):
@@ -258,8 +260,8 @@ def test_realtime_interior_reuse_equals_full_recomputation(graph, bs):
     with pytest.raises(ValueError):                                     # the reference's default ring (24 frames) is too short for it
         RealtimeConverter(ContentEncoder(seed=2), F0Estimator(seed=2), Decoder(seed=2), lib, "cuda", chunk=960, buffersize=8,
                           reuse_interior=True)
-    with pytest.raises(ValueError):                                     # 120 frames: no block size stays on the full ring's kernels
-        RealtimeConverter(ContentEncoder(seed=2), F0Estimator(seed=2), Decoder(seed=2), lib, "cuda", chunk=960, buffersize=40,
+    with pytest.raises(ValueError):                                     # 63 frames: too short for two 35-frame edge slices
+        RealtimeConverter(ContentEncoder(seed=2), F0Estimator(seed=2), Decoder(seed=2), lib, "cuda", chunk=960, buffersize=21,
                           reuse_interior=True)
 
 
