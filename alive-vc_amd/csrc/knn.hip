@@ -501,11 +501,35 @@ constexpr int ABUF8 = NPIECE8 * PIECE;     // 27648 B per tile buffer
 constexpr int SCORE8_LDS = 2 * ABUF8 + FT * KP8 * 8;   // 120832 B
 typedef int v8i __attribute__((ext_vector_type(8)));
 
+// Seeded admission (tau != nullptr; searches of >= SEED_MIN_FB frame blocks, where a library split fills at least two rounds of
+// the chip, so that the blocks of split s start after those of split s - 1 have ended): a block leaves, per frame,
+// tau = (k-th best fp8 score it has seen, over its own and the earlier splits) - SEED_MARGIN, and the block of the NEXT split
+// of the same frames starts its lists AT tau instead of at -inf -- every entry holds tau with index -1, so rows below it
+// are never admitted and the list floor the certificate reads is tau until real rows replace it.  Without a seed a split's
+// lists warm up from nothing: 16 (1 + ln(n / 16)) admissions per half-list, and every admission in any wave stops the
+// block's matrix pipes at the next barrier (ablation -DALIVE_KNN_ABL_RARE_W=1: the rare path in ONE wave of four costs
+// what it costs in all four).  A row below tau has an fp8 score more than SEED_MARGIN under k rows already seen: it is
+// "outside" in the certificate's sense, with tau as the bound on its score, exactly like a row under a full list's floor.
+// The hand-off is one LOOK at the previous split's flag (no waiting: nothing can hang, an unfinished predecessor just means
+// an unseeded block) behind the release / acquire pair of the guide; a stale or missing tau can only cost time, never a
+// result: whatever seed a block used is IN its lists, and the certificate bounds the outside rows by it.
+constexpr float SEED_MARGIN8 = 0.02f * F8_SCALE * F8_SCALE;      // cosine 0.02: certificate slack (>= 0.0105) + 4 sigma of the fp8 error
+constexpr int SEED_MIN_FB = 512;
+static float seed_margin8() {              // ALIVE_KNN_SEED_MARGIN (cosine units): experiments only
+    static const float m = [] {
+        const char* e = getenv("ALIVE_KNN_SEED_MARGIN");
+        const float v = e ? (float)atof(e) : 0.0f;
+        return v > 0.0f ? v * F8_SCALE * F8_SCALE : SEED_MARGIN8;
+    }();
+    return m;
+}
+
 __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict__ s_f8,
                                                 const unsigned char* __restrict__ lib, int64_t M, int tiles_total,
                                                 int tiles_per_split, int P, float* __restrict__ cand_val,
                                                 int* __restrict__ cand_idx, const int* __restrict__ gate_cnt,
-                                                int gate_lo, int gate_hi) {
+                                                int gate_lo, int gate_hi, float* __restrict__ tau, int* __restrict__ tau_flag,
+                                                int kk, float seed_margin, int* __restrict__ seeded_cnt) {
     {
         int c;
         if (!gate_open(gate_cnt, gate_lo, gate_hi, c)) return;                       // block-uniform
@@ -523,7 +547,30 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
     int tile_end = tile_begin + tiles_per_split;
     if (tile_end > tiles_total) tile_end = tiles_total;
 
-    for (int e = tid; e < FT * KP8; e += 256) { Lv[e] = -INFINITY; Li[e] = -1; }
+    // seeds of this block's frames (block-uniform decision; see above)
+    bool seeded = false;
+    if (tau != nullptr && split > 0) {
+        const int f = __hip_atomic_load(tau_flag + (size_t)(split - 1) * gridDim.x + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seeded = __builtin_amdgcn_readfirstlane(f) != 0;
+        if (seeded) {
+            if (tid == 0) atomicAdd(seeded_cnt, 1);
+            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    float seed[2] = {-INFINITY, -INFINITY};
+    if (seeded) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const float t = tau[frame0 + 64 * w + 32 * ni + lr];
+            seed[ni] = t == t ? t : -INFINITY;
+        }
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < KH8; ++q) { Lv[q * 512 + w * 128 + ni * 64 + lane] = seed[ni]; Li[q * 512 + w * 128 + ni * 64 + lane] = -1; }
 
     // DMA: wave w copies rows 8 w .. 8 w + 7 of the tile, 6 pieces of 8 rows x 128 B; chunk order swizzled on the source
     const int dma_row = 8 * w + (lane >> 3);
@@ -566,8 +613,8 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { qv[ni][q] = -INFINITY; qp[ni][q] = 4 * q; }
-    float thr[2] = {-INFINITY, -INFINITY};
+        for (int q = 0; q < 4; ++q) { qv[ni][q] = seed[ni]; qp[ni][q] = 4 * q; }
+    float thr[2] = {seed[0], seed[1]};
     const int lc0 = w * 128 + lane;
     __syncthreads();
 
@@ -644,6 +691,9 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
         if (__builtin_amdgcn_ballot_w64(mx > thr[ni]) == 0) return;
 #ifdef ALIVE_KNN_ABL_NORARE            // ablation build (tools/bench_knn.py): the fold's fast path only -- results are WRONG, timing only
         return;
+#endif
+#ifdef ALIVE_KNN_ABL_RARE_W            // ablation build: only waves below this number take the rare path (WRONG results): what a trip
+        if (w >= ALIVE_KNN_ABL_RARE_W) return;      // costs the OTHER waves of the block through the per-tile barrier
 #endif
         // Rare path (wave-uniform; by ablation ~1500 cycles with the matrix pipe idle, 15 % of the kernel on the bench batch and
         // 30 % on uncorrelated frames), cut for the common case of ONE admitted row per lane:
@@ -783,19 +833,51 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
         cand_val[o] = Lv[(k % KH8) * 512 + lc];
         cand_idx[o] = Li[(k % KH8) * 512 + lc];
     }
+    if (tau != nullptr) {                  // (kernel argument: block-uniform)
+        // thread = frame: the k-th largest score among the real entries of its two half-lists, by k passes over the 32 entries
+        const int col = tid;
+        const int lcb = (col >> 6) * 128 + ((col >> 5) & 1) * 64 + (col & 31);
+        float prev = INFINITY;
+        for (int j = 0; j < kk; ++j) {
+            float m = -INFINITY;
+            for (int e = 0; e < KP8; ++e) {
+                const int o = (e % KH8) * 512 + lcb + (e / KH8) * 32;
+                const float v = Lv[o];
+                if (Li[o] >= 0 && v < prev) m = fmaxf(m, v);
+            }
+            prev = m;
+        }
+        float t = prev - seed_margin;                                  // -inf with fewer than k real entries
+        if (seeded) {
+            const float tin = tau[frame0 + col];
+            t = fmaxf(t, tin == tin ? tin : -INFINITY);
+        }
+        tau[frame0 + col] = t;
+        // release: every storing wave's stores have left, then ONE agent-scope release and the flag (MI355X_MICROARCH.md)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(tau_flag + (size_t)split * gridDim.x + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // two entry points of the same body, so that a kernel trace tells the pass over the batch from the 1 024-frame probe
 __global__ __launch_bounds__(256, 1) void knn_score8_kernel(const unsigned char* __restrict__ s_f8, const unsigned char* __restrict__ lib,
                                                             int64_t M, int tiles_total, int tiles_per_split, int P,
                                                             float* __restrict__ cand_val, int* __restrict__ cand_idx,
-                                                            const int* __restrict__ gate_cnt, int gate_lo, int gate_hi) {
-    knn_score8_body(s_f8, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, gate_cnt, gate_lo, gate_hi);
+                                                            const int* __restrict__ gate_cnt, int gate_lo, int gate_hi,
+                                                            float* __restrict__ tau, int* __restrict__ tau_flag, int k,
+                                                            float seed_margin, int* __restrict__ seeded_cnt) {
+    knn_score8_body(s_f8, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, gate_cnt, gate_lo, gate_hi, tau, tau_flag, k,
+                    seed_margin, seeded_cnt);
 }
 __global__ __launch_bounds__(256, 1) void knn_probe8_kernel(const unsigned char* __restrict__ s_f8, const unsigned char* __restrict__ lib,
                                                             int64_t M, int tiles_total, int tiles_per_split, int P,
                                                             float* __restrict__ cand_val, int* __restrict__ cand_idx) {
-    knn_score8_body(s_f8, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, nullptr, 0, 0);
+    knn_score8_body(s_f8, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, nullptr, 0, 0, nullptr, nullptr, 0, 0.0f, nullptr);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -874,8 +956,10 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
             my_idx = my_idx < 0 ? -1 : my_idx;
         }
         if (certify) {
+            // (the floor of a list counts its EMPTY entries too: -inf in an unseeded list -- not full, no floor -- and the seed in a
+            // seeded one, below which the scoring kernel admitted nothing)
+            c_cut = list_floor(lane < R ? cv[lane] : -INFINITY);
             my_pre = (lane < R && my_idx >= 0) ? cv[lane] : -INFINITY;
-            c_cut = list_floor(my_pre);
             // k-th and MIN_RESCORE-th largest prefilter score of the frame (wave-wide, by removal)
             float rest = my_pre, sk = -INFINITY, s16 = -INFINITY;
             for (int j = 0; j < MIN_RESCORE; ++j) {
@@ -906,8 +990,8 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
             v[j] = in ? cv[e] : -INFINITY;
             id[j] = in ? ci[e] : -1;
             if (collect && id[j] == -2) overflow = true;
+            if (certify) c_cut = fmaxf(c_cut, list_floor(v[j]));       // empty entries included: -inf, or the seed of a seeded list
             if (id[j] < 0) v[j] = -INFINITY;
-            if (certify) c_cut = fmaxf(c_cut, list_floor(v[j]));
         }
         float sk = -INFINITY;              // k-th best prefilter score of the frame
         for (int sel = 0; sel < 64; ++sel) {
@@ -1447,7 +1531,7 @@ __global__ __launch_bounds__(256) void knn_exact_merge_kernel(const float* __res
 
 // ---- small device-side control kernels of the tiered search (no host sync anywhere) ----
 // stats[]: see alive_knn_search_stats
-enum { ST_FLAG8 = 0, ST_FLAG16 = 1, ST_PROBE_N = 2, ST_PROBE_FAIL = 3, ST_MODE = 4, ST_FIRST = 5, ST_PROBE_CNT = 6, ST_TIER = 7, ST_FLAGC = 8,
+enum { ST_FLAG8 = 0, ST_FLAG16 = 1, ST_PROBE_N = 2, ST_PROBE_FAIL = 3, ST_MODE = 4, ST_FIRST = 5, ST_PROBE_CNT = 6, ST_TIER = 7, ST_FLAGC = 8, ST_SEEDED = 9,
        ST_WORDS = 16 };
 // ST_TIER: which path the last search on this workspace took (written by every path, so that the host never has to
 // re-derive the dispatch): 1 = streaming scan, 2 = exact scan of every frame (k > 8), 3 = bf16 first, 4 = fp8 first
@@ -1549,6 +1633,9 @@ constexpr float CERT_Z = 7.0f;            // sigmas of candidate-score error the
 constexpr float SD_PRIOR8 = 1.5e-3f;      // typical error (cosine units) of an fp8 / a bf16 candidate score: floor of the per-frame estimate
 constexpr float SD_PRIOR16 = 8.0e-5f;
 constexpr int COLLECT_MIN = 256;          // frames failing the bf16 certificate: up to this many go straight to the exact scan
+constexpr int RESEARCH_MIN = 64;          // frames failing the fp8 certificate: up to this many go straight to the exact scan (a bf16
+                                          // pass for a handful of frames still computes whole 256-frame tiles: ~9 ms at 1 M rows
+                                          // against ~20 us per frame)
 constexpr int PROBE_N = 1024;             // frames of the adaptive probe (fp8 searches of >= PROBE_MIN_T frames)
 constexpr int64_t PROBE_MIN_T = 16384;
 constexpr int PROBE_NUM = 2, PROBE_DEN = 5;   // bf16 first when more than 40 % of the sample fail the fp8 certificate:
@@ -1567,6 +1654,7 @@ struct SearchWs {
     unsigned char* s_p8; float* cvp; int* cip; int* p_list;   // probe: sample rows, lists, [frame of slot | flagged frames]
     float* thr1; int* list2;               // collect tier: thresholds of the frames in list1; frames that overflowed it
     float* dq;                             // || q^ - bf16(q^) || per frame (strict certificate)
+    float* tau; int* tau_flag;             // fp8 stage: per-frame admission seeds handed from split to split, and the hand-off flags
     const float* det_q; const float* det_lib;   // set by the strict search only: frame / library share of the deterministic bound
     size_t bytes;
 };
@@ -1605,6 +1693,8 @@ static SearchWs ws_layout(void* base, int64_t Tt, int64_t M, int k) {
     w.thr1 = a.take<float>((size_t)Tp);
     w.list2 = a.take<int>((size_t)Tp);
     w.dq = a.take<float>((size_t)Tp);
+    w.tau = a.take<float>((size_t)Tp);
+    w.tau_flag = a.take<int>((size_t)(Tp / FT) * MAX_SPLIT8);
     w.det_q = nullptr;
     w.det_lib = nullptr;
     w.bytes = a.used() + 1024;
@@ -1739,7 +1829,8 @@ static void collect_tier_launch(const SearchWs& w, const void* lib_bf16, const f
 }
 
 // The bf16 re-search of the frames in list[0 .. *cnt) (compacted), certified, behind either first stage:
-//   tier 1 (1 .. fcap frames, usually a handful): library split chosen for few frames;
+//   up to RESEARCH_MIN frames: straight to the exact scan;
+//   tier 1 (.. fcap frames): library split chosen for few frames;
 //   tier 2 (more): the split of the whole batch; blocks past the count exit at once.
 // Frames that fail the bf16 certificate land in list1 and go through the exact scan.
 static void bf16_tiers_launch(const SearchWs& w, const void* lib_bf16, const float* rows_f32, const float* norms, int64_t M,
@@ -1747,11 +1838,12 @@ static void bf16_tiers_launch(const SearchWs& w, const void* lib_bf16, const flo
     int* cnt0 = w.stats + ST_FLAG8;
     int* cnt1 = w.stats + ST_FLAG16;
     const int fcap = w.fcap;
-    gather_frames_kernel<<<(unsigned)fcap, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, 0, fcap, w.s_c);
+    knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, w.list0, cnt0, out_val, out_idx, s, RESEARCH_MIN);
+    gather_frames_kernel<<<(unsigned)fcap, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, RESEARCH_MIN, fcap, w.s_c);
     knn_score_kernel<false><<<dim3((unsigned)(fcap / FT), w.pt.split), 256, SCORE_LDS, s>>>(
-        w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.cv1, w.ci1, cnt0, 0, fcap, 1, nullptr);
+        w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.cv1, w.ci1, cnt0, RESEARCH_MIN, fcap, 1, nullptr);
     knn_rescore_kernel<<<(unsigned)((fcap + 3) / 4), 256, 0, s>>>(w.cv1, w.ci1, w.pt.P, KP, w.s_f32, rows_f32, norms, fcap, idx_base, k,
-                                                                 out_val, out_idx, w.list0, cnt0, 0, fcap, w.list1, cnt1, CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0);
+                                                                 out_val, out_idx, w.list0, cnt0, RESEARCH_MIN, fcap, w.list1, cnt1, CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0);
     if (w.p16.Tt_pad > fcap) {
         gather_frames_kernel<<<(unsigned)w.p16.Tt_pad, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, fcap, 0x7fffffff, w.s_c);
         knn_score_kernel<false><<<dim3((unsigned)(w.p16.Tt_pad / FT), w.p16.split), 256, SCORE_LDS, s>>>(
@@ -1880,8 +1972,11 @@ static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f
     }
     // ---- mode 0: fp8 first ----
     if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
+    const bool seeds = p.Tt_pad / FT >= SEED_MIN_FB && p.split > 1;
+    if (seeds) (void)hipMemsetAsync(w.tau_flag, 0, (size_t)(p.Tt_pad / FT) * p.split * sizeof(int), s);
     knn_score8_kernel<<<dim3((unsigned)(p.Tt_pad / FT), p.split), 256, SCORE8_LDS, s>>>(
-        w.s_f8, (const unsigned char*)lib_f8, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, mode, -1, 0);
+        w.s_f8, (const unsigned char*)lib_f8, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, mode, -1, 0,
+        seeds ? w.tau : nullptr, seeds ? w.tau_flag : nullptr, k, seed_margin8(), w.stats + ST_SEEDED);
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
     knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, p.P, KP8, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                out_val, out_idx, nullptr, mode, -1, 0, w.list0, w.stats + ST_FLAG8,

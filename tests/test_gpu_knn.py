@@ -317,6 +317,33 @@ def test_knn_exact_tier_on_a_library_of_near_duplicates(prefilter, k):
     _assert_equals_brute_force(val, idx, bv, bi, k, min_safe=250)
 
 
+def test_knn_a_handful_of_uncertified_frames_goes_straight_to_the_exact_scan(prefilter):
+    """fp8 search in which a FEW frames fail the fp8 certificate (twelve queries that sit on a cluster of 40 near-copies, among 1 800
+    ordinary ones): up to 64 such frames skip the bf16 re-search (a pass that would compute whole 256-frame tiles for them) and
+    go to the exact scan; the result is the brute-force one and bitwise that of the bf16-first search."""
+    if prefilter != "fp8":
+        pytest.skip("fp8 candidate stage only")
+    from module.common import PackedLibrary
+    g = torch.Generator(device=DEV).manual_seed(43)
+    centres = torch.randn(768, 12, device=DEV, generator=g)
+    lib = torch.cat([torch.randn(768, 30000, device=DEV, generator=g),
+                     centres.repeat_interleave(40, dim=1) + 0.02 * torch.randn(768, 480, device=DEV, generator=g)], dim=1).contiguous()
+    src = torch.randn(4, 768, 450, device=DEV, generator=g)
+    where = torch.arange(12, device=DEV) * 149 + 7                       # frames of the flattened batch that get a cluster query
+    flat = src.permute(0, 2, 1).reshape(-1, 768)
+    flat[where] = (centres + 0.3 * torch.randn(768, 12, device=DEV, generator=g)).t()
+    src = flat.view(4, 450, 768).permute(0, 2, 1).contiguous()
+    l8 = PackedLibrary(lib, prefilter="fp8")
+    val, idx = l8.search(src, 4)
+    st = l8.search_stats()
+    assert 12 <= st["frames_failed_fp8_certificate"] <= 64, st
+    assert st["frames_researched_on_bf16"] == 0 and st["frames_searched_exactly"] == st["frames_failed_fp8_certificate"], st
+    bv, bi = _brute_force_topk(flat, lib, 4)
+    _assert_equals_brute_force(val, idx, bv, bi, 4, min_safe=1700)
+    v16, i16 = PackedLibrary(lib, prefilter="bf16").search(src, 4)
+    assert torch.equal(idx, i16) and torch.equal(val, v16)
+
+
 @pytest.mark.parametrize("n,t,m,k", [(1, 40, 500, 9), (2, 33, 3000, 16), (1, 7, 100, 64), (1, 450, 20000, 12), (1, 5, 16, 16),
                                      (1, 1, 64, 64), (3, 2, 33, 32)])
 def test_knn_k_above_8_runs_the_exact_scan(n, t, m, k):
