@@ -103,13 +103,17 @@ int alive_knn_search_strict(const float* src, int N, int T,
  *   probe  batches of >= 16384 frames: the fp8 stage and its certificate on a sample of 1024 frames; when more than 40 %
  *          of the sample fail (a library whose best cosines lie closer together than the fp8 error) the fp8 pass over
  *          the batch is skipped and every frame starts at the bf16 stage;
- *   fp8    candidates, exact rescoring, certificate (fp8 error statistics);
- *   bf16   the frames that failed, compacted, through the bf16 stage: candidates, rescoring, certificate (bf16 statistics);
+ *   fp8    candidates, exact rescoring, certificate (fp8 error statistics).  Batches of >= 512 x 256 frames: the blocks of
+ *          library split s start their candidate lists at the seeds split s - 1 left for their frames (k-th best fp8 score seen so
+ *          far minus 0.02: rows below it are never admitted, and the certificate counts the seed as the bound on them);
+ *   bf16   the frames that failed (up to 64 of them: straight to the exact scan), compacted, through the bf16 stage:
+ *          candidates, rescoring, certificate (bf16 statistics);
  *   collect the frames that failed again: bf16 scoring pass with a fixed threshold, every row above it rescored exactly;
  *   exact  the frames whose collected rows overflowed: brute-force fp32 scan.
  * alive_knn_search_stats: device pointer (inside ws) to int[16] counters of the last search on that workspace:
- *   [0] frames sent to the bf16 stage  [1] frames sent to the collect tier  [8] frames sent to the exact scan
- *   [2] probe sample size  [3] probe failures
+ *   [0] frames that failed the fp8 certificate (<= 64: exact scan; more: the bf16 stage)
+ *   [1] frames that failed the bf16 certificate (<= 256: exact scan; more: the collect tier)  [8] frames the collect tier
+ *   sent on to the exact scan  [2] probe sample size  [3] probe failures  [9] fp8 blocks that started from seeds
  *   [4] 1 = the probe chose bf16 first  [7] the path taken: 1 streaming scan, 2 exact scan of every frame (k > 8),
  *   3 bf16 first, 4 fp8 first.  (alive_knn_search fills [1] and [7] only.)  The counters sit at the start of ws. */
 size_t alive_library_fp8_bytes(int64_t M);
