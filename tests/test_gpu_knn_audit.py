@@ -83,6 +83,20 @@ def test_adversarial_libraries_against_brute_force(env, name):
     assert res["fp8"][0]["safe_frames"] > 0.5 * frames, res["fp8"][0]
 
 
+@pytest.mark.parametrize("name", ["randn_iid", "spiky", "mixture", "norms", "self"])
+def test_seeded_admission_on_adversarial_libraries_at_batch_scale(env, name):
+    """The seeded admission of the fp8 stage (knn.hip: batches of >= 512 frame blocks) on the libraries whose fp8 errors are
+    heavy-tailed: 138 150 frames (540 blocks) against brute force and against the bf16-first search, which has no seeds."""
+    res = run_case(env, name, 138_240, ("fp8", "bf16"))
+    for mode, (r, _, _) in res.items():
+        assert r["frames"] == 138_150 and r["mismatches"] == 0, (name, mode, r)
+        assert r["max_abs_value_error"] <= 2e-6, (name, mode, r)
+    assert torch.equal(res["fp8"][2], res["bf16"][2]) and torch.equal(res["fp8"][1], res["bf16"][1])
+    t8 = res["fp8"][0]["tiers"]
+    if not t8["probe_chose_bf16_first"]:
+        assert t8["fp8_blocks_seeded"] >= 540, t8            # every block of the later splits found its predecessor's seeds
+
+
 def test_search_counters_do_not_depend_on_k(env):
     """the counters used to be looked up with the layout of k = 4; for k in 5..8 and more than 32 768 frames they
     were read from inside the partial-list area.  They now sit at the start of the workspace."""
