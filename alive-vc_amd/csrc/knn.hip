@@ -293,12 +293,69 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // keeps EVERY row whose score reaches the frame's fixed threshold thr_in[slot] (= the frame's exact k-th cosine so far minus
 // the slack of its failed certificate, knn_rescore_kernel), up to 8 per half-list; a half-list that would need more marks
 // the frame as overflowed (index -2 in its first entry).  Same tiles, same MFMA loop, same output layout.
+// Seeded admission (both scoring kernels; the rationale and the protocol are written out above knn_score8_body): the blocks of
+// library split s start their lists at the seeds the blocks of split s - 1 left for the same frames.
+struct SeedArgs {
+    float* tau;        // [frame slots] seeds, in the stage's score units; nullptr: no seeding in this launch
+    int* flag;         // [splits][frame blocks] set once a block's seeds are visible
+    int k;
+    float margin;      // a seed = k-th best stage score seen so far - margin
+    int* cnt;          // counter of the blocks that started from seeds
+};
+
+// one LOOK at the predecessor's flag (block-uniform result); true: its seeds are visible to the plain loads that follow
+__device__ __forceinline__ bool seeds_look(const SeedArgs& sa, int split) {
+    if (sa.tau == nullptr || split == 0) return false;
+    const int f = __hip_atomic_load(sa.flag + (size_t)(split - 1) * gridDim.x + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool seeded = __builtin_amdgcn_readfirstlane(f) != 0;
+    if (seeded) {
+        if (threadIdx.x == 0) atomicAdd(sa.cnt, 1);
+        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    return seeded;
+}
+
+// end of a block (after the barrier behind its last tile): thread = frame; the k-th largest score among the REAL entries of the
+// frame's two half-lists (KH_ entries each, entry-major [KH_][512 lane-columns]) -> tau, then release + flag
+template <int KH_>
+__device__ __forceinline__ void seeds_publish(const SeedArgs& sa, const float* Lv, const int* Li, int64_t frame0, int split, bool seeded) {
+    const int col = threadIdx.x;
+    const int lcb = (col >> 6) * 128 + ((col >> 5) & 1) * 64 + (col & 31);
+    float prev = INFINITY;
+    for (int j = 0; j < sa.k; ++j) {
+        float m = -INFINITY;
+        for (int e = 0; e < 2 * KH_; ++e) {
+            const int o = (e % KH_) * 512 + lcb + (e / KH_) * 32;
+            const float v = Lv[o];
+            if (Li[o] >= 0 && v < prev) m = fmaxf(m, v);
+        }
+        prev = m;
+    }
+    float t = prev - sa.margin;                                        // -inf with fewer than k real entries
+    if (seeded) {
+        const float tin = sa.tau[frame0 + col];
+        t = fmaxf(t, tin == tin ? tin : -INFINITY);
+    }
+    sa.tau[frame0 + col] = t;
+    // release: every storing wave's stores have left, then ONE agent-scope release and the flag (MI355X_MICROARCH.md)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(sa.flag + (size_t)split * gridDim.x + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <bool COLLECT>
 __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short* __restrict__ s_bf16,
                                                            const unsigned short* __restrict__ lib, int64_t M, int tiles_total,
                                                            int tiles_per_split, int P, float* __restrict__ cand_val,
                                                            int* __restrict__ cand_idx, const int* __restrict__ gate_cnt,
-                                                           int gate_lo, int gate_hi, int by_count, const float* __restrict__ thr_in) {
+                                                           int gate_lo, int gate_hi, int by_count, const float* __restrict__ thr_in,
+                                                           SeedArgs sa) {
     int n_slots = 0x7fffffff;
     {
         int c;
@@ -319,7 +376,19 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
     int tile_end = tile_begin + tiles_per_split;
     if (tile_end > tiles_total) tile_end = tiles_total;
 
-    for (int e = tid; e < FT * KP; e += 256) { Lv[e] = -INFINITY; Li[e] = -1; }
+    const bool seeded = !COLLECT && seeds_look(sa, split);
+    float seed[2] = {-INFINITY, -INFINITY};
+    if (seeded) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const float t = sa.tau[frame0 + 64 * w + 32 * ni + lr];
+            seed[ni] = t == t ? t : -INFINITY;
+        }
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < KH; ++q) { Lv[q * 512 + w * 128 + ni * 64 + lane] = seed[ni]; Li[q * 512 + w * 128 + ni * 64 + lane] = -1; }
 
     // DMA source of this lane inside a piece: row (lane>>3) of the wave's 8-row group, chunk (lane&7)^(lane>>3)
     const int dma_row = 8 * w + (lane >> 3);
@@ -349,7 +418,7 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
     for (int j = 0; j < 4; ++j) a_off[j] = (lr >> 3) * PIECE + rr * 128 + ((((j * 2 + lh) ^ rr)) << 4);
 
     // lane-column id = w*128 + ni*64 + lane; entry e of its list lives at [e*512 + id]
-    float thr[2] = {-INFINITY, -INFINITY};
+    float thr[2] = {seed[0], seed[1]};
     int cnt[2] = {0, 0};                               // COLLECT: rows kept so far by this lane's half-list
     if (COLLECT) {
 #pragma unroll
@@ -483,6 +552,7 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
         cand_val[o] = Lv[(k % KH) * 512 + lc];
         cand_idx[o] = Li[(k % KH) * 512 + lc];
     }
+    if (!COLLECT && sa.tau != nullptr) seeds_publish<KH>(sa, Lv, Li, frame0, split, seeded);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -514,6 +584,8 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 // an unseeded block) behind the release / acquire pair of the guide; a stale or missing tau can only cost time, never a
 // result: whatever seed a block used is IN its lists, and the certificate bounds the outside rows by it.
 constexpr float SEED_MARGIN8 = 0.02f * F8_SCALE * F8_SCALE;      // cosine 0.02: certificate slack (>= 0.0105) + 4 sigma of the fp8 error
+constexpr float SEED_MARGIN16 = 2.5e-3f;                         // bf16 stage: its certificate's slack is ~7e-4 (7 sigma of ~1e-4)
+constexpr float SEED_MARGIN16_STRICT = 4.5e-3f;                  // strict search: above the largest deterministic bound (2 x 2^-9 + 1e-4)
 constexpr int SEED_MIN_FB = 512;
 static float seed_margin8() {              // ALIVE_KNN_SEED_MARGIN (cosine units): experiments only
     static const float m = [] {
@@ -528,8 +600,7 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
                                                 const unsigned char* __restrict__ lib, int64_t M, int tiles_total,
                                                 int tiles_per_split, int P, float* __restrict__ cand_val,
                                                 int* __restrict__ cand_idx, const int* __restrict__ gate_cnt,
-                                                int gate_lo, int gate_hi, float* __restrict__ tau, int* __restrict__ tau_flag,
-                                                int kk, float seed_margin, int* __restrict__ seeded_cnt) {
+                                                int gate_lo, int gate_hi, SeedArgs sa) {
     {
         int c;
         if (!gate_open(gate_cnt, gate_lo, gate_hi, c)) return;                       // block-uniform
@@ -547,23 +618,12 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
     int tile_end = tile_begin + tiles_per_split;
     if (tile_end > tiles_total) tile_end = tiles_total;
 
-    // seeds of this block's frames (block-uniform decision; see above)
-    bool seeded = false;
-    if (tau != nullptr && split > 0) {
-        const int f = __hip_atomic_load(tau_flag + (size_t)(split - 1) * gridDim.x + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        seeded = __builtin_amdgcn_readfirstlane(f) != 0;
-        if (seeded) {
-            if (tid == 0) atomicAdd(seeded_cnt, 1);
-            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    }
+    const bool seeded = seeds_look(sa, split);               // block-uniform (see above)
     float seed[2] = {-INFINITY, -INFINITY};
     if (seeded) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            const float t = tau[frame0 + 64 * w + 32 * ni + lr];
+            const float t = sa.tau[frame0 + 64 * w + 32 * ni + lr];
             seed[ni] = t == t ? t : -INFINITY;
         }
     }
@@ -833,51 +893,20 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
         cand_val[o] = Lv[(k % KH8) * 512 + lc];
         cand_idx[o] = Li[(k % KH8) * 512 + lc];
     }
-    if (tau != nullptr) {                  // (kernel argument: block-uniform)
-        // thread = frame: the k-th largest score among the real entries of its two half-lists, by k passes over the 32 entries
-        const int col = tid;
-        const int lcb = (col >> 6) * 128 + ((col >> 5) & 1) * 64 + (col & 31);
-        float prev = INFINITY;
-        for (int j = 0; j < kk; ++j) {
-            float m = -INFINITY;
-            for (int e = 0; e < KP8; ++e) {
-                const int o = (e % KH8) * 512 + lcb + (e / KH8) * 32;
-                const float v = Lv[o];
-                if (Li[o] >= 0 && v < prev) m = fmaxf(m, v);
-            }
-            prev = m;
-        }
-        float t = prev - seed_margin;                                  // -inf with fewer than k real entries
-        if (seeded) {
-            const float tin = tau[frame0 + col];
-            t = fmaxf(t, tin == tin ? tin : -INFINITY);
-        }
-        tau[frame0 + col] = t;
-        // release: every storing wave's stores have left, then ONE agent-scope release and the flag (MI355X_MICROARCH.md)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(tau_flag + (size_t)split * gridDim.x + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    if (sa.tau != nullptr) seeds_publish<KH8>(sa, Lv, Li, frame0, split, seeded);
 }
 
 // two entry points of the same body, so that a kernel trace tells the pass over the batch from the 1 024-frame probe
 __global__ __launch_bounds__(256, 1) void knn_score8_kernel(const unsigned char* __restrict__ s_f8, const unsigned char* __restrict__ lib,
                                                             int64_t M, int tiles_total, int tiles_per_split, int P,
                                                             float* __restrict__ cand_val, int* __restrict__ cand_idx,
-                                                            const int* __restrict__ gate_cnt, int gate_lo, int gate_hi,
-                                                            float* __restrict__ tau, int* __restrict__ tau_flag, int k,
-                                                            float seed_margin, int* __restrict__ seeded_cnt) {
-    knn_score8_body(s_f8, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, gate_cnt, gate_lo, gate_hi, tau, tau_flag, k,
-                    seed_margin, seeded_cnt);
+                                                            const int* __restrict__ gate_cnt, int gate_lo, int gate_hi, SeedArgs sa) {
+    knn_score8_body(s_f8, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, gate_cnt, gate_lo, gate_hi, sa);
 }
 __global__ __launch_bounds__(256, 1) void knn_probe8_kernel(const unsigned char* __restrict__ s_f8, const unsigned char* __restrict__ lib,
                                                             int64_t M, int tiles_total, int tiles_per_split, int P,
                                                             float* __restrict__ cand_val, int* __restrict__ cand_idx) {
-    knn_score8_body(s_f8, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, nullptr, 0, 0, nullptr, nullptr, 0, 0.0f, nullptr);
+    knn_score8_body(s_f8, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, nullptr, 0, 0, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr});
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1531,7 +1560,7 @@ __global__ __launch_bounds__(256) void knn_exact_merge_kernel(const float* __res
 
 // ---- small device-side control kernels of the tiered search (no host sync anywhere) ----
 // stats[]: see alive_knn_search_stats
-enum { ST_FLAG8 = 0, ST_FLAG16 = 1, ST_PROBE_N = 2, ST_PROBE_FAIL = 3, ST_MODE = 4, ST_FIRST = 5, ST_PROBE_CNT = 6, ST_TIER = 7, ST_FLAGC = 8, ST_SEEDED = 9,
+enum { ST_FLAG8 = 0, ST_FLAG16 = 1, ST_PROBE_N = 2, ST_PROBE_FAIL = 3, ST_MODE = 4, ST_FIRST = 5, ST_PROBE_CNT = 6, ST_TIER = 7, ST_FLAGC = 8, ST_SEEDED = 9, ST_SEEDED16 = 10,
        ST_WORDS = 16 };
 // ST_TIER: which path the last search on this workspace took (written by every path, so that the host never has to
 // re-derive the dispatch): 1 = streaming scan, 2 = exact scan of every frame (k > 8), 3 = bf16 first, 4 = fp8 first
@@ -1641,6 +1670,9 @@ constexpr int64_t PROBE_MIN_T = 16384;
 constexpr int PROBE_NUM = 2, PROBE_DEN = 5;   // bf16 first when more than 40 % of the sample fail the fp8 certificate:
                                               // fp8 + bf16 on a fraction f costs t8 + f t16 / eff against t16 = 2.3 t8
 
+// seeds for a launch of `fb` frame blocks x `split` library splits (nullptr members: no seeding); zeroes the flags on the stream
+static SeedArgs seeds_for(const struct SearchWs& w, int64_t fb, int split, int k, float margin, int counter, hipStream_t s);
+
 // ---- workspace: ONE layout function for the size query, the searches and the stats pointer ----
 struct SearchWs {
     SearchPlan p16, p8, pt, pp;            // bf16 main / fp8 main / tier-1 re-search / probe
@@ -1694,11 +1726,17 @@ static SearchWs ws_layout(void* base, int64_t Tt, int64_t M, int k) {
     w.list2 = a.take<int>((size_t)Tp);
     w.dq = a.take<float>((size_t)Tp);
     w.tau = a.take<float>((size_t)Tp);
-    w.tau_flag = a.take<int>((size_t)(Tp / FT) * MAX_SPLIT8);
+    w.tau_flag = a.take<int>((size_t)(Tp / FT) * (MAX_SPLIT > MAX_SPLIT8 ? MAX_SPLIT : MAX_SPLIT8));
     w.det_q = nullptr;
     w.det_lib = nullptr;
     w.bytes = a.used() + 1024;
     return w;
+}
+
+static SeedArgs seeds_for(const SearchWs& w, int64_t fb, int split, int k, float margin, int counter, hipStream_t s) {
+    if (fb < SEED_MIN_FB || split < 2) return SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr};
+    (void)hipMemsetAsync(w.tau_flag, 0, (size_t)fb * split * sizeof(int), s);
+    return SeedArgs{w.tau, w.tau_flag, k, margin, w.stats + counter};
 }
 
 }  // namespace
@@ -1812,7 +1850,7 @@ static void collect_tier_launch(const SearchWs& w, const void* lib_bf16, const f
     gather_frames_kernel<<<(unsigned)fcap, 128, 0, s>>>(w.s_bf16, w.list1, cnt1, COLLECT_MIN, fcap, w.s_c);
     knn_score_kernel<true><<<dim3((unsigned)(fcap / FT), w.pt.split), 256, SCORE_LDS, s>>>(
         w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.cv1, w.ci1, cnt1, COLLECT_MIN, fcap, 1,
-        w.thr1);
+        w.thr1, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr});
     knn_rescore_kernel<<<(unsigned)((fcap + 3) / 4), 256, 0, s>>>(w.cv1, w.ci1, w.pt.P, KP, w.s_f32, rows_f32, norms, fcap, idx_base, k,
                                                                  out_val, out_idx, w.list1, cnt1, COLLECT_MIN, fcap, w.list2, cnt2, CERT_Z,
                                                                  KH, 1.0f, SD_PRIOR16, nullptr, nullptr, nullptr, 1);
@@ -1820,7 +1858,7 @@ static void collect_tier_launch(const SearchWs& w, const void* lib_bf16, const f
         gather_frames_kernel<<<(unsigned)w.p16.Tt_pad, 128, 0, s>>>(w.s_bf16, w.list1, cnt1, fcap, 0x7fffffff, w.s_c);
         knn_score_kernel<true><<<dim3((unsigned)(w.p16.Tt_pad / FT), w.p16.split), 256, SCORE_LDS, s>>>(
             w.s_c, (const unsigned short*)lib_bf16, M, w.p16.tiles_total, w.p16.tiles_per_split, w.p16.P, w.cv, w.ci, cnt1, fcap,
-            0x7fffffff, 1, w.thr1);
+            0x7fffffff, 1, w.thr1, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr});
         knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, w.p16.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                    out_val, out_idx, w.list1, cnt1, fcap, 0x7fffffff, w.list2, cnt2,
                                                                    CERT_Z, KH, 1.0f, SD_PRIOR16, nullptr, nullptr, nullptr, 1);
@@ -1841,14 +1879,17 @@ static void bf16_tiers_launch(const SearchWs& w, const void* lib_bf16, const flo
     knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, w.list0, cnt0, out_val, out_idx, s, RESEARCH_MIN);
     gather_frames_kernel<<<(unsigned)fcap, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, RESEARCH_MIN, fcap, w.s_c);
     knn_score_kernel<false><<<dim3((unsigned)(fcap / FT), w.pt.split), 256, SCORE_LDS, s>>>(
-        w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.cv1, w.ci1, cnt0, RESEARCH_MIN, fcap, 1, nullptr);
+        w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.cv1, w.ci1, cnt0, RESEARCH_MIN, fcap, 1, nullptr, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr});
     knn_rescore_kernel<<<(unsigned)((fcap + 3) / 4), 256, 0, s>>>(w.cv1, w.ci1, w.pt.P, KP, w.s_f32, rows_f32, norms, fcap, idx_base, k,
                                                                  out_val, out_idx, w.list0, cnt0, RESEARCH_MIN, fcap, w.list1, cnt1, CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0);
     if (w.p16.Tt_pad > fcap) {
         gather_frames_kernel<<<(unsigned)w.p16.Tt_pad, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, fcap, 0x7fffffff, w.s_c);
+        // (the frames are compacted: a block's 256 slots are the same in every split, so the seeds are indexed by slot)
+        const SeedArgs sa = seeds_for(w, w.p16.Tt_pad / FT, w.p16.split, k, w.det_q != nullptr ? SEED_MARGIN16_STRICT : SEED_MARGIN16,
+                                      ST_SEEDED16, s);
         knn_score_kernel<false><<<dim3((unsigned)(w.p16.Tt_pad / FT), w.p16.split), 256, SCORE_LDS, s>>>(
             w.s_c, (const unsigned short*)lib_bf16, M, w.p16.tiles_total, w.p16.tiles_per_split, w.p16.P, w.cv, w.ci, cnt0, fcap,
-            0x7fffffff, 1, nullptr);
+            0x7fffffff, 1, nullptr, sa);
         knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, w.p16.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                    out_val, out_idx, w.list0, cnt0, fcap, 0x7fffffff, w.list1, cnt1,
                                                                    CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0);
@@ -1885,8 +1926,9 @@ static int knn_search_impl(const float* src, int N, int T, const void* lib_bf16,
     }
     const SearchPlan& p = w.p16;
     if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
+    const SeedArgs sa = seeds_for(w, p.Tt_pad / FT, p.split, k, w.det_q != nullptr ? SEED_MARGIN16_STRICT : SEED_MARGIN16, ST_SEEDED16, s);
     knn_score_kernel<false><<<dim3((unsigned)(p.Tt_pad / FT), p.split), 256, SCORE_LDS, s>>>(
-        w.s_bf16, (const unsigned short*)lib_bf16, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, nullptr, 0, 0, 0, nullptr);
+        w.s_bf16, (const unsigned short*)lib_bf16, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, nullptr, 0, 0, 0, nullptr, sa);
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
     knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, p.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                out_val, out_idx, nullptr, nullptr, 0, 0, w.list1, w.stats + ST_FLAG16,
@@ -1972,11 +2014,9 @@ static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f
     }
     // ---- mode 0: fp8 first ----
     if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
-    const bool seeds = p.Tt_pad / FT >= SEED_MIN_FB && p.split > 1;
-    if (seeds) (void)hipMemsetAsync(w.tau_flag, 0, (size_t)(p.Tt_pad / FT) * p.split * sizeof(int), s);
+    const SeedArgs sa8 = seeds_for(w, p.Tt_pad / FT, p.split, k, seed_margin8(), ST_SEEDED, s);
     knn_score8_kernel<<<dim3((unsigned)(p.Tt_pad / FT), p.split), 256, SCORE8_LDS, s>>>(
-        w.s_f8, (const unsigned char*)lib_f8, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, mode, -1, 0,
-        seeds ? w.tau : nullptr, seeds ? w.tau_flag : nullptr, k, seed_margin8(), w.stats + ST_SEEDED);
+        w.s_f8, (const unsigned char*)lib_f8, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, mode, -1, 0, sa8);
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
     knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, p.P, KP8, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                out_val, out_idx, nullptr, mode, -1, 0, w.list0, w.stats + ST_FLAG8,

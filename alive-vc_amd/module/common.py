@@ -149,7 +149,7 @@ class PackedLibrary:
         # [1] frames that failed the bf16 certificate: up to 256 of them go straight to the exact scan (knn.hip COLLECT_MIN),
         # more go through the collect tier and only its overflow ([8]) is scanned exactly
         direct = c[1] <= 256
-        st.update(frames_failed_bf16_certificate=c[1], frames_collected_on_bf16=0 if direct else c[1],
+        st.update(bf16_blocks_seeded=c[10], frames_failed_bf16_certificate=c[1], frames_collected_on_bf16=0 if direct else c[1],
                   frames_searched_exactly=few + (c[1] if direct else c[8]), frames=n * t)
         return st
 

@@ -6,6 +6,9 @@ from module.common import PackedLibrary
 dev = "cuda"; N, T, M = 384, 450, 1_000_000
 g = torch.Generator(device=dev).manual_seed(1)
 lib = PackedLibrary(torch.randn(768, M, device=dev, generator=g))
+mode = os.environ.get("EXP_MODE", "fp8")                 # fp8 | bf16 | strict
+if mode == "bf16": lib = lib.with_prefilter("bf16")
+if mode == "strict": lib = lib.with_strict()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record(); b.record()          # (created on first record: the C side records them again)
 for kind in (sys.argv[1:] or ["biased", "randn"]):
@@ -15,5 +18,5 @@ for kind in (sys.argv[1:] or ["biased", "randn"]):
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0.record(); lib.search(src, 4, events=(a, b)); t1.record(); torch.cuda.synchronize()
     st = lib.search_stats()
-    print(f"margin {os.environ.get('ALIVE_KNN_SEED_MARGIN', 'default')} {kind}: kernel {a.elapsed_time(b):.2f} ms  search {t0.elapsed_time(t1):.2f} ms  "
-          f"seeded blocks {st.get('fp8_blocks_seeded')}  -> bf16 {st.get('frames_researched_on_bf16')}  fail bf16 {st.get('frames_failed_bf16_certificate')}")
+    print(f"{mode} margin {os.environ.get('ALIVE_KNN_SEED_MARGIN', 'default')} {kind}: kernel {a.elapsed_time(b):.2f} ms  search {t0.elapsed_time(t1):.2f} ms  "
+          f"seeded blocks {st.get('fp8_blocks_seeded')} / {st.get('bf16_blocks_seeded')}  -> bf16 {st.get('frames_researched_on_bf16')}  fail bf16 {st.get('frames_failed_bf16_certificate')}")
