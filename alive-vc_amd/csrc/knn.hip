@@ -1560,13 +1560,20 @@ __global__ __launch_bounds__(256) void knn_exact_merge_kernel(const float* __res
 
 // ---- small device-side control kernels of the tiered search (no host sync anywhere) ----
 // stats[]: see alive_knn_search_stats
-enum { ST_FLAG8 = 0, ST_FLAG16 = 1, ST_PROBE_N = 2, ST_PROBE_FAIL = 3, ST_MODE = 4, ST_FIRST = 5, ST_PROBE_CNT = 6, ST_TIER = 7, ST_FLAGC = 8, ST_SEEDED = 9, ST_SEEDED16 = 10,
+constexpr int COLLECT_MIN = 256;          // frames failing the bf16 certificate: up to this many go straight to the exact scan
+constexpr int RESEARCH_MIN = 64;          // frames failing the fp8 certificate: up to this many go straight to the exact scan (a bf16
+                                          // pass for a handful of frames still computes whole 256-frame tiles: ~9 ms at 1 M rows
+                                          // against ~20 us per frame)
+enum { ST_FLAG8 = 0, ST_FLAG16 = 1, ST_PROBE_N = 2, ST_PROBE_FAIL = 3, ST_MODE = 4, ST_FIRST = 5, ST_PROBE_CNT = 6, ST_TIER = 7, ST_FLAGC = 8, ST_SEEDED = 9, ST_SEEDED16 = 10, ST_RESEARCH_MIN = 11, ST_COLLECT_MIN = 12,
        ST_WORDS = 16 };
 // ST_TIER: which path the last search on this workspace took (written by every path, so that the host never has to
 // re-derive the dispatch): 1 = streaming scan, 2 = exact scan of every frame (k > 8), 3 = bf16 first, 4 = fp8 first
 enum { TIER_SCAN = 1, TIER_EXACT_ALL = 2, TIER_BF16 = 3, TIER_FP8 = 4 };
 __global__ void stats_init_kernel(int* __restrict__ stats, int tier) {
-    if (threadIdx.x < ST_WORDS) stats[threadIdx.x] = threadIdx.x == ST_TIER ? tier : 0;
+    // (the two tier limits are written out with the counters, so that a reader never repeats the constants)
+    if (threadIdx.x < ST_WORDS)
+        stats[threadIdx.x] = threadIdx.x == ST_TIER ? tier
+                           : threadIdx.x == ST_RESEARCH_MIN ? RESEARCH_MIN : threadIdx.x == ST_COLLECT_MIN ? COLLECT_MIN : 0;
 }
 
 // the sample of the probe: n frames at a fixed stride through the batch (rows of s_f8 copied, padded to a block of 256)
@@ -1661,10 +1668,6 @@ constexpr int FPLAN = 4096;               // ... with the library split chosen f
 constexpr float CERT_Z = 7.0f;            // sigmas of candidate-score error the certificates allow for
 constexpr float SD_PRIOR8 = 1.5e-3f;      // typical error (cosine units) of an fp8 / a bf16 candidate score: floor of the per-frame estimate
 constexpr float SD_PRIOR16 = 8.0e-5f;
-constexpr int COLLECT_MIN = 256;          // frames failing the bf16 certificate: up to this many go straight to the exact scan
-constexpr int RESEARCH_MIN = 64;          // frames failing the fp8 certificate: up to this many go straight to the exact scan (a bf16
-                                          // pass for a handful of frames still computes whole 256-frame tiles: ~9 ms at 1 M rows
-                                          // against ~20 us per frame)
 constexpr int PROBE_N = 1024;             // frames of the adaptive probe (fp8 searches of >= PROBE_MIN_T frames)
 constexpr int64_t PROBE_MIN_T = 16384;
 constexpr int PROBE_NUM = 2, PROBE_DEN = 5;   // bf16 first when more than 40 % of the sample fail the fp8 certificate:

@@ -142,13 +142,13 @@ class PackedLibrary:
             raise RuntimeError(f"alive_knn_search_stats: no search has run on this workspace (tier word {tier})")
         few = 0
         if tier == 4:
-            # [0] frames that failed the fp8 certificate: up to 64 of them go straight to the exact scan (knn.hip RESEARCH_MIN)
-            few = c[0] if c[0] <= 64 else 0
+            # [0] frames that failed the fp8 certificate: up to [11] of them go straight to the exact scan (knn.hip RESEARCH_MIN)
+            few = c[0] if c[0] <= c[11] else 0
             st.update(frames_failed_fp8_certificate=c[0], frames_researched_on_bf16=0 if few else c[0], probe_sample=c[2],
                       probe_failed_fp8_certificate=c[3], probe_chose_bf16_first=bool(c[4]), fp8_blocks_seeded=c[9])
-        # [1] frames that failed the bf16 certificate: up to 256 of them go straight to the exact scan (knn.hip COLLECT_MIN),
+        # [1] frames that failed the bf16 certificate: up to [12] of them go straight to the exact scan (knn.hip COLLECT_MIN),
         # more go through the collect tier and only its overflow ([8]) is scanned exactly
-        direct = c[1] <= 256
+        direct = c[1] <= c[12]
         st.update(bf16_blocks_seeded=c[10], frames_failed_bf16_certificate=c[1], frames_collected_on_bf16=0 if direct else c[1],
                   frames_searched_exactly=few + (c[1] if direct else c[8]), frames=n * t)
         return st

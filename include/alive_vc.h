@@ -114,6 +114,7 @@ int alive_knn_search_strict(const float* src, int N, int T,
  *   [0] frames that failed the fp8 certificate (<= 64: exact scan; more: the bf16 stage)
  *   [1] frames that failed the bf16 certificate (<= 256: exact scan; more: the collect tier)  [8] frames the collect tier
  *   sent on to the exact scan  [2] probe sample size  [3] probe failures  [9] / [10] fp8 / bf16 blocks that started from seeds
+ *   [11] / [12] the two limits just named (64, 256), written with the counters
  *   [4] 1 = the probe chose bf16 first  [7] the path taken: 1 streaming scan, 2 exact scan of every frame (k > 8),
  *   3 bf16 first, 4 fp8 first.  (alive_knn_search fills [1] and [7] only.)  The counters sit at the start of ws. */
 size_t alive_library_fp8_bytes(int64_t M);
