@@ -849,12 +849,40 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
             __builtin_amdgcn_sched_barrier(0);                                                                                   \
             AFTER1;                                                                                                              \
         }
+#ifndef ALIVE_KNN_FOLD_EARLY
+        // The previous tile's accumulators (p0, p1) STAY in their AGPR set until the second half of this tile and are copied out
+        // there by explicit v_accvgpr_read, eight at a time behind the MFMAs of steps 6 .. 9 (the gaps of steps 0 .. 5 carry the
+        // LDS-DMA pieces), each group pinned behind its MFMA by an empty asm that names the running accumulators.  Left to itself
+        // hipcc keeps ONE accumulator set and copies it to VGPRs at the END of the tile that produced it -- 64 v_accvgpr_read and
+        // 64 v_accvgpr_write per tile behind a drained matrix pipe (found from the listing after ablation builds had shown that
+        // the always-on part of the fold, not the admissions, was the larger half of the fold's cost: 78.8 ms with no fold at
+        // all, 86.1 with the always-on part only, 91.8 with admissions).  With the reads late and spread there are two accumulator
+        // sets in the listing (a[0:31] / a[32:63]), no copy at the tile boundary, and the kernel runs 77.8 ms instead of 90.5 on the
+        // bench batch (98.2 instead of 107.2 on uncorrelated frames): faster than the build without any fold, because the pins
+        // also stop hipcc from sinking MFMA chains.  Placement matters: all 32 reads behind ONE pin 84.0 ms, reads in the
+        // DMA-carrying gaps of steps 0 .. 1 87.3 ms.
+        f32x16 v0, v1;
+        auto acc_read = [&](const f32x16& a, int lo, int hi, f32x16& v) {
+#pragma unroll
+            for (int r = lo; r < hi; ++r) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[r]) : "a"(a[r]));
+        };
+        auto acc_pin = [&]() { asm volatile("" : "+a"(c0), "+a"(c1)); };
+        K8_STEP(0, (void)0, (void)0) K8_STEP(1, (void)0, (void)0) K8_STEP(2, (void)0, (void)0) K8_STEP(3, (void)0, (void)0)
+        K8_STEP(4, (void)0, (void)0) K8_STEP(5, (void)0, acc_pin())
+        K8_STEP(6, acc_read(p0, 0, 8, v0), (acc_pin(), acc_read(p0, 8, 16, v0), mask_ragged(v0, tile - 1)))
+        K8_STEP(7, (acc_pin(), pm0 = max8(v0, 0, pm0)), pm0 = max8(v0, 8, pm0))
+        K8_STEP(8, (acc_pin(), acc_read(p1, 0, 8, v1)), (acc_pin(), acc_read(p1, 8, 16, v1), mask_ragged(v1, tile - 1)))
+        K8_STEP(9, (acc_pin(), pm1 = max8(v1, 0, pm1)), pm1 = max8(v1, 8, pm1))
+        K8_STEP(10, (void)0, fold_rare(v0, 0, tile - 1, pm0))
+        K8_STEP(11, (void)0, fold_rare(v1, 1, tile - 1, pm1))
+#else   // -DALIVE_KNN_FOLD_EARLY: the form of rounds 2 .. 3 (A/B builds): the fold reads p0 / p1 as plain values in steps 0 .. 3
         K8_STEP(0, (mask_ragged(p0, tile - 1), pm0 = max8(p0, 0, pm0)), pm0 = max8(p0, 8, pm0))
         K8_STEP(1, (mask_ragged(p1, tile - 1), pm1 = max8(p1, 0, pm1)), pm1 = max8(p1, 8, pm1))
         K8_STEP(2, (void)0, fold_rare(p0, 0, tile - 1, pm0))
         K8_STEP(3, (void)0, fold_rare(p1, 1, tile - 1, pm1))
         K8_STEP(4, (void)0, (void)0) K8_STEP(5, (void)0, (void)0) K8_STEP(6, (void)0, (void)0) K8_STEP(7, (void)0, (void)0)
         K8_STEP(8, (void)0, (void)0) K8_STEP(9, (void)0, (void)0) K8_STEP(10, (void)0, (void)0) K8_STEP(11, (void)0, (void)0)
+#endif
 #undef K8_STEP
         // The accumulators are next read by the fold inside the NEXT tile, and hipcc sinks the whole c1 chain down to that use:
         // eight dependent MFMAs back to back behind the barrier, their A fragments parked in AGPRs.  An opaque use pins both
