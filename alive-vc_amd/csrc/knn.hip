@@ -1698,8 +1698,10 @@ constexpr float SD_PRIOR8 = 1.5e-3f;      // typical error (cosine units) of an 
 constexpr float SD_PRIOR16 = 8.0e-5f;
 constexpr int PROBE_N = 1024;             // frames of the adaptive probe (fp8 searches of >= PROBE_MIN_T frames)
 constexpr int64_t PROBE_MIN_T = 16384;
-constexpr int PROBE_NUM = 2, PROBE_DEN = 5;   // bf16 first when more than 40 % of the sample fail the fp8 certificate:
-                                              // fp8 + bf16 on a fraction f costs t8 + f t16 / eff against t16 = 2.3 t8
+constexpr int PROBE_NUM = 11, PROBE_DEN = 20; // bf16 first when more than 55 % of the sample fail the fp8 certificate: fp8 + bf16 on a
+                                              // fraction f costs t8 + f t16 / eff against t16 = 2.6 t8 (80 against 206 ms since the fp8
+                                              // kernel's late accumulator copies; it was 40 % at t16 = 2.3 t8).  Measured on the dense
+                                              // library, 49 % failing: fp8 first 216.9 ms per search, bf16 first 227.9 ms
 
 // seeds for a launch of `fb` frame blocks x `split` library splits (nullptr members: no seeding); zeroes the flags on the stream
 static SeedArgs seeds_for(const struct SearchWs& w, int64_t fb, int split, int k, float margin, int counter, hipStream_t s);

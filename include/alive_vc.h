@@ -100,7 +100,7 @@ int alive_knn_search_strict(const float* src, int N, int T,
  *   lib_f8[M_pad][D]: alive_library_fp8_bytes(M) bytes, made from lib_bf16 by alive_library_pack_fp8.
  *   Same workspace, same outputs and the same contract as alive_knn_search.
  * Tiers, all launched up front and decided on the device (no sync, graph-capturable):
- *   probe  batches of >= 16384 frames: the fp8 stage and its certificate on a sample of 1024 frames; when more than 40 %
+ *   probe  batches of >= 16384 frames: the fp8 stage and its certificate on a sample of 1024 frames; when more than 55 %
  *          of the sample fail (a library whose best cosines lie closer together than the fp8 error) the fp8 pass over
  *          the batch is skipped and every frame starts at the bf16 stage;
  *   fp8    candidates, exact rescoring, certificate (fp8 error statistics).  Batches of >= 512 x 256 frames: the blocks of
