@@ -5,9 +5,12 @@
 // Here the [T][M] matrix never exists.  A search is a chain of tiers, launched up front and gated by device-side counters:
 //   probe  (big batches) the fp8 stage + its certificate on 1 024 sample frames decides whether the batch starts on fp8 or bf16.
 //   0. knn_score8_kernel  candidate stage on the block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4): frames
-//      stationary in registers, library tiles streamed through LDS by LDS-DMA, lane-private top-16 lists per half-wave.
+//      stationary in registers, library tiles streamed through LDS by LDS-DMA, lane-private top-16 lists per half-wave;
+//      a tile's accumulators are copied out and folded under the NEXT tile's MFMAs (two AGPR sets, explicit late reads);
+//      in big batches the blocks of a library split start their lists at the seeds the previous split left (SeedArgs).
 //   1. knn_score_kernel   the same structure on the bf16 MFMA (v_mfma_f32_32x32x16_bf16), lists of 8: first stage of
-//      alive_knn_search, and the re-search of the frames whose fp8 candidate set could not be certified.
+//      alive_knn_search, and the re-search of the frames whose fp8 candidate set could not be certified (up to 64 such
+//      frames go straight to 3.); <true>: the collect form (fixed per-frame threshold) behind a failed bf16 certificate.
 //   2. knn_rescore_kernel every surviving candidate is re-scored in fp32 with the reference's arithmetic
 //      (normalise-then-dot), the exact top-k is taken, and the frame is CERTIFIED against the candidate stage's score
 //      error measured on its own candidates (the MFMA passes only have to be superset generators).
