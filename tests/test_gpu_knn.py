@@ -318,10 +318,9 @@ def test_knn_exact_tier_on_a_library_of_near_duplicates(prefilter, k):
 
 
 def test_fp8_scoring_kernel_rate_guard(prefilter):
-    """A guard, not a benchmark: the fp8 scoring kernel on the bench shape (172 800 correlated frames x 1 M rows) must sustain at
-    least 3.0 PFLOP/s.  The build of this round runs 3.2 - 3.4 (box to box); the same source with hipcc's own placement of the
-    accumulator copies (one set, copied out behind a drained matrix pipe at every tile end: DESIGN 3.1a) ran 2.8 - 2.9 -- a
-    compiler update that brings that back would change no result and no other test."""
+    """A coarse guard, not a benchmark: the fp8 scoring kernel on the bench shape (172 800 correlated frames x 1 M rows) must
+    sustain at least 2.5 PFLOP/s (this round: 3.2 - 3.4 box to box; devices differ by up to 12 %, so the floor is loose --
+    the structural guard against the return of the per-tile accumulator copy-out is tests/test_host_logic.py, on the listing)."""
     if prefilter != "fp8":
         pytest.skip("fp8 candidate stage only")
     from module.common import PackedLibrary
@@ -337,7 +336,7 @@ def test_fp8_scoring_kernel_rate_guard(prefilter):
         torch.cuda.synchronize()
         best = min(best, a.elapsed_time(b))
     pf = 2 * 768 * 1e6 * 172_800 / (best * 1e-3) / 1e15
-    assert pf >= 3.0, f"scoring kernel {best:.1f} ms = {pf:.2f} PFLOP/s"
+    assert pf >= 2.5, f"scoring kernel {best:.1f} ms = {pf:.2f} PFLOP/s"
     st = lib.search_stats()
     assert st["fp8_blocks_seeded"] == 2 * 675 and st["frames_failed_fp8_certificate"] == 0, st
 
