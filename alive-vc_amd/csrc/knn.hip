@@ -1594,7 +1594,8 @@ __global__ __launch_bounds__(256) void knn_exact_merge_kernel(const float* __res
 constexpr int COLLECT_MIN = 256;          // frames failing the bf16 certificate: up to this many go straight to the exact scan
 constexpr int RESEARCH_MIN = 64;          // frames failing the fp8 certificate: up to this many go straight to the exact scan (a bf16
                                           // pass for a handful of frames still computes whole 256-frame tiles: ~9 ms at 1 M rows
-                                          // against ~20 us per frame)
+                                          // against ~0.75 ms per group of 64 / k frames of exact scan.  256 was tried: at k = 8 the 178
+                                          // frames of the bench batch then cost 111.5 instead of 104.9 ms per search)
 enum { ST_FLAG8 = 0, ST_FLAG16 = 1, ST_PROBE_N = 2, ST_PROBE_FAIL = 3, ST_MODE = 4, ST_FIRST = 5, ST_PROBE_CNT = 6, ST_TIER = 7, ST_FLAGC = 8, ST_SEEDED = 9, ST_SEEDED16 = 10, ST_RESEARCH_MIN = 11, ST_COLLECT_MIN = 12,
        ST_WORDS = 16 };
 // ST_TIER: which path the last search on this workspace took (written by every path, so that the host never has to
