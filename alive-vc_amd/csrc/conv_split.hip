@@ -474,8 +474,10 @@ int alive_conv_split_launch(const AliveConv* d, float ratio, hipStream_t s) {
     }
     if (d->Xp) {
         ALIVE_CHECK_ARG(d->precision == 1 && d->Co > 64 && d->Ci % BKC == 0 && d->Ci_pad == d->Ci && (d->pad_mode == 1 || d->pad_left == 0) &&
-                        (((uintptr_t)d->Xp) & 15) == 0 && d->Tout <= d->Tin,
-                        "alive_conv1d(split): plane input needs 2 planes, Co > 64, Ci a multiple of 32, reflect-left padding");
+                        (((uintptr_t)d->Xp) & 15) == 0 && d->Tout <= d->Tin &&
+                        (int64_t)(d->Tout - 1) * d->stride + (int64_t)(d->KW - 1) * d->dil - d->pad_left < d->Tin,
+                        "alive_conv1d(split): plane input needs 2 planes, Co > 64, Ci a multiple of 32, reflect-left padding and no valid "
+                        "output column that reads past the signal (the kernel clamps rows >= Tin instead of zero-filling them)");
     }
     ALIVE_CHECK_ARG(d->Tout <= d->Tin + d->pad_left, "alive_conv1d(split): Tout");
     // measured (tools/bench_conv256.py, 128 windows x 4500 columns): the 256-row tile is 12 - 37 % SLOWER than two 128-row blocks

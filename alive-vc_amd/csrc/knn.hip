@@ -306,18 +306,23 @@ struct SeedArgs {
     int* cnt;          // counter of the blocks that started from seeds
 };
 
-// one LOOK at the predecessor's flag (block-uniform result); true: its seeds are visible to the plain loads that follow
+// one LOOK at the predecessor's flag; true: its seeds are visible to the plain loads that follow.  The result is BLOCK-uniform:
+// thread 0 alone loads the flag (and runs the acquire), the verdict goes through LDS behind an unconditional barrier -- four
+// waves looking for themselves could see the flag flip between their loads and fall one s_barrier out of step.
 __device__ __forceinline__ bool seeds_look(const SeedArgs& sa, int split) {
-    if (sa.tau == nullptr || split == 0) return false;
-    const int f = __hip_atomic_load(sa.flag + (size_t)(split - 1) * gridDim.x + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool seeded = __builtin_amdgcn_readfirstlane(f) != 0;
-    if (seeded) {
-        if (threadIdx.x == 0) atomicAdd(sa.cnt, 1);
-        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    __shared__ int verdict[1];
+    if (sa.tau == nullptr || split == 0) return false;                     // kernel arguments: uniform over the grid
+    if (threadIdx.x == 0) {
+        const int f = __hip_atomic_load(sa.flag + (size_t)(split - 1) * gridDim.x + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f != 0) {
+            atomicAdd(sa.cnt, 1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        verdict[0] = f;
     }
-    return seeded;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(verdict[0]) != 0;
 }
 
 // end of a block (after the barrier behind its last tile): thread = frame; the k-th largest score among the REAL entries of the
@@ -481,8 +486,9 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
             }
             if (COLLECT) {
                 // every row at or above the fixed threshold is kept (rows, not a ranking: no minimum to maintain)
-                while (__builtin_amdgcn_ballot_w64(mx >= thr[ni]) != 0) {
-                    const bool has = mx >= thr[ni];
+                // (mx > -inf: a threshold of -inf -- no finite k-th value -- must not keep the loop alive on retired entries)
+                while (__builtin_amdgcn_ballot_w64(mx >= thr[ni] && mx > -INFINITY) != 0) {
+                    const bool has = mx >= thr[ni] && mx > -INFINITY;
                     int rsel = 0;
 #pragma unroll
                     for (int r = 1; r < 16; ++r) rsel = (acc[r] == mx) ? r : rsel;
@@ -1962,8 +1968,8 @@ static int knn_search_impl(const float* src, int N, int T, const void* lib_bf16,
         return ALIVE_OK;
     }
     const SearchPlan& p = w.p16;
-    if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
     const SeedArgs sa = seeds_for(w, p.Tt_pad / FT, p.split, k, w.det_q != nullptr ? SEED_MARGIN16_STRICT : SEED_MARGIN16, ST_SEEDED16, s);
+    if (g_ev_start) (void)hipEventRecord(g_ev_start, s);             // behind the memset of the seed flags: the events bracket the kernel alone
     knn_score_kernel<false><<<dim3((unsigned)(p.Tt_pad / FT), p.split), 256, SCORE_LDS, s>>>(
         w.s_bf16, (const unsigned short*)lib_bf16, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, nullptr, 0, 0, 0, nullptr, sa);
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
@@ -2050,8 +2056,8 @@ static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f
         probe_decide_kernel<<<1, 1, 0, s>>>(w.stats, w.probe_n, PROBE_NUM, PROBE_DEN);
     }
     // ---- mode 0: fp8 first ----
-    if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
     const SeedArgs sa8 = seeds_for(w, p.Tt_pad / FT, p.split, k, seed_margin8(), ST_SEEDED, s);
+    if (g_ev_start) (void)hipEventRecord(g_ev_start, s);             // behind the memset of the seed flags: the events bracket the kernel alone
     knn_score8_kernel<<<dim3((unsigned)(p.Tt_pad / FT), p.split), 256, SCORE8_LDS, s>>>(
         w.s_f8, (const unsigned char*)lib_f8, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, mode, -1, 0, sa8);
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
@@ -2077,7 +2083,7 @@ extern "C" int alive_knn_search_fp8_timed(const float* src, int N, int T, const 
                                (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
 }
 
-// device pointer (inside ws) to the counters of the last search on this workspace, int[8]:
+// device pointer (inside ws) to the counters of the last search on this workspace, int[16] (ST_WORDS; slots used today: 0-4, 7-12):
 //   [0] frames the fp8 certificate sent to the bf16 stage (all frames when the probe chose bf16 first)
 //   [1] frames the bf16 certificate sent on (to the collect tier; [8] of them end in the exact scan)
 //   [2] frames of the probe sample, [3] of which failed the fp8 certificate, [4] 1 = the probe chose bf16 first
