@@ -88,6 +88,94 @@ __global__ __launch_bounds__(256, 1) void mfma_scale_rate_kernel(const int* __re
     if (s == 12345.678f) sink[0] = s;
 }
 
+// Round 4: what a vector instruction costs BESIDE an MFMA, one wave per SIMD (tools/mfma_filler.py).  One dependent chain of
+// v_mfma_f32_32x32x16_bf16 (KIND 0, 1) or two alternating accumulators (KIND 2), NF v_fma_f32 after every MFMA: on NCH independent
+// registers (KIND 0, 2: NCH = 8) or as ONE dependent chain (KIND 1).  All of it asm volatile, so the order is the source's.
+// Returns shader cycles (s_memtime) per loop iteration of 8 MFMAs, per wave.
+template <int NF, int KIND>
+__global__ __launch_bounds__(256, 1) void mfma_filler_kernel(const unsigned short* __restrict__ rnd, int iters, long long* cycles, float* sink) {
+    const int tid = threadIdx.x;
+    bf16x8 a = *(const bf16x8*)(rnd + (tid * 8) % 32768), b = *(const bf16x8*)(rnd + (tid * 8 + 4096) % 32768);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = (float)(tid + j) * 1e-3f;
+    const float c1 = 0.999f, c2 = 1e-4f;
+    __shared__ __attribute__((aligned(16))) unsigned char fl_lds[8192];
+    u32x4 ld[4] = {};
+    uint2 wr2 = make_uint2(tid, tid);
+    if (KIND == 6 || KIND == 9 || KIND == 11) { ((u32x4*)fl_lds)[tid] = u32x4{1u, 2u, 3u, 4u}; __syncthreads(); }
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            if (KIND == 2 && (m & 1)) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc1) : "v"(a), "v"(b));
+            else if (KIND == 10) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc0) : "a"(a), "v"(b));      // A operand in an AGPR
+            else if (KIND == 12) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc0) : "v"(a), "v"(b));      // accumulator in VGPRs
+            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc0) : "v"(a), "v"(b));
+            if (KIND == 11) asm volatile("ds_read_b128 %0, %1" : "=v"(ld[m & 3]) : "v"(tid * 16));                          // one fragment read per MFMA besides the fillers
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                float& xr = x[(m * NF + f) & 7];
+                if (KIND == 1) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[0]) : "v"(c1), "v"(c2));
+                else if (KIND == 3) asm volatile("v_fmaak_f32 %0, %0, %1, 0x3fb5f0e3" : "+v"(xr) : "v"(c1));          // 32-bit literal
+                else if (KIND == 4) asm volatile("v_exp_f32 %0, %0" : "+v"(xr));
+                else if (KIND == 5) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(xr) : "v"(c1));
+                else if (KIND == 6) asm volatile("ds_read_b128 %0, %1" : "=v"(ld[(m * NF + f) & 3]) : "v"(tid * 16));
+                else if (KIND == 7) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(xr) : "a"(acc1[(m * NF + f) & 15]));
+                else if (KIND == 8) asm volatile("v_fma_f32 %0, |%0|, %1, %2" : "+v"(xr) : "v"(c1), "v"(c2));        // VOP3 source modifier
+                else if (KIND == 9) asm volatile("ds_write_b64 %0, %1" :: "v"(tid * 8), "v"(wr2));
+                else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(xr) : "v"(c1), "v"(c2));
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    float s = (float)(ld[0][0] + ld[1][1] + ld[2][2] + ld[3][3]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += x[j];
+    s += acc0[tid & 15] + acc1[tid & 15];
+    if (s == 12345.678f) sink[0] = s;
+    if ((tid & 63) == 0) cycles[blockIdx.x * 4 + (tid >> 6)] = t1 - t0;
+}
+
+}  // namespace
+
+template <int KIND>
+static void launch_filler(int nf, const unsigned short* rnd, int blocks, int iters, long long* cycles, float* sink, hipStream_t s) {
+#define ALIVE_FILLER_CASE(N) case N: mfma_filler_kernel<N, KIND><<<blocks, 256, 0, s>>>(rnd, iters, cycles, sink); break;
+    switch (nf) {
+        ALIVE_FILLER_CASE(0) ALIVE_FILLER_CASE(1) ALIVE_FILLER_CASE(2) ALIVE_FILLER_CASE(3) ALIVE_FILLER_CASE(4) ALIVE_FILLER_CASE(5)
+        ALIVE_FILLER_CASE(6) ALIVE_FILLER_CASE(7) ALIVE_FILLER_CASE(8) ALIVE_FILLER_CASE(10) ALIVE_FILLER_CASE(12) ALIVE_FILLER_CASE(16)
+        default: break;
+    }
+#undef ALIVE_FILLER_CASE
+}
+
+// cycles[blocks * 4]: shader cycles of each wave for iters x 8 MFMAs with nf fillers behind every MFMA
+extern "C" int alive_debug_mfma_filler(const void* rnd, int blocks, int iters, int nf, int kind, long long* cycles, float* sink, void* stream) {
+    ALIVE_CHECK_ARG(rnd && sink && cycles && blocks > 0 && iters > 0, "alive_debug_mfma_filler: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (kind == 0) launch_filler<0>(nf, (const unsigned short*)rnd, blocks, iters, cycles, sink, s);
+    else if (kind == 1) launch_filler<1>(nf, (const unsigned short*)rnd, blocks, iters, cycles, sink, s);
+    else if (kind == 2) launch_filler<2>(nf, (const unsigned short*)rnd, blocks, iters, cycles, sink, s);
+    else if (kind == 3) launch_filler<3>(nf, (const unsigned short*)rnd, blocks, iters, cycles, sink, s);
+    else if (kind == 4) launch_filler<4>(nf, (const unsigned short*)rnd, blocks, iters, cycles, sink, s);
+    else if (kind == 5) launch_filler<5>(nf, (const unsigned short*)rnd, blocks, iters, cycles, sink, s);
+    else if (kind == 6) launch_filler<6>(nf, (const unsigned short*)rnd, blocks, iters, cycles, sink, s);
+    else if (kind == 7) launch_filler<7>(nf, (const unsigned short*)rnd, blocks, iters, cycles, sink, s);
+    else if (kind == 8) launch_filler<8>(nf, (const unsigned short*)rnd, blocks, iters, cycles, sink, s);
+    else if (kind == 9) launch_filler<9>(nf, (const unsigned short*)rnd, blocks, iters, cycles, sink, s);
+    else if (kind == 10) launch_filler<10>(nf, (const unsigned short*)rnd, blocks, iters, cycles, sink, s);
+    else if (kind == 11) launch_filler<11>(nf, (const unsigned short*)rnd, blocks, iters, cycles, sink, s);
+    else launch_filler<12>(nf, (const unsigned short*)rnd, blocks, iters, cycles, sink, s);
+    ALIVE_CHECK_LAUNCH("alive_debug_mfma_filler");
+    return ALIVE_OK;
+}
+
+namespace {
 }  // namespace
 
 // launches `blocks` blocks of the loop above; 8 * iters MFMAs per wave.  rnd: 64 KB of random bf16.

@@ -7,24 +7,56 @@
 // it on chip through the 1x1 input conv and the six GELU -> FiLM -> reflect-left causal k5 convs:
 //   * the modulated conv input z and the intermediate y live in two LDS buffers, ALREADY SPLIT into two bf16 planes
 //     (hi = bf16(v), lo = bf16(v - hi)) and stored [column][64 channels] so that an MFMA B fragment is one ds_read_b128;
-//     the 16-B chunk order of a 128-B row is XOR-swizzled with (row & 7): fragment reads are conflict-free at any tap
-//     shift;
-//   * a wave owns 16 output channels for all 256 columns (v_mfma_f32_16x16x32_bf16): its A fragments (10 k-steps x 2
-//     planes = 80 VGPRs) are loaded from L2 once per conv and stay in registers, the residual stream h (16 column tiles
-//     x 4) lives in registers in the MFMA C layout, so residual add, GELU, FiLM and the re-split of a tile are
-//     register-local and only the modulated planes go back to LDS;
-//   * a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, smallest terms first, fp32 accumulate (the "bf16x3" product of
-//     conv_split.hip, ~2^-16 per product).
+//   * a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate (the "bf16x3" product of conv_split.hip, ~2^-16 per product).
 // HBM traffic drops to the input, the U-Net skip and the output (3 tensor passes instead of ~18).
+//
+// Round 4: rewritten for v_mfma_f32_32x32x16_bf16 as ONE software pipeline over (conv, column tile) steps.
+// What rounds 1-3's kernel (four waves, 16x16x32, 7.3 ms per 128 windows) was bound by, measured with in-kernel stamps,
+// ablation builds and a microbenchmark of instruction costs beside MFMAs (tools/stamp_fb64.py, tools/mfma_filler.py,
+// DESIGN.md 3.2b'): nothing overlapped.  A block's time was the SUM of its MFMA time, its epilogue time, its LDS fragment
+// reads and its exposed memory latencies, and an eight-wave version (two waves per SIMD) ran the same 7.3 ms: one SIMD
+// issues ONE vector instruction stream, whichever wave it comes from, and beside an MFMA an instruction costs what it costs --
+// MFMA 8 cycles of issue, plain VALU 4.4, v_exp / v_rcp 8, v_accvgpr_read 8, dependent VALU 8 (latency), ds_read_b128 16 and
+// ds_write_b64 24 per wave with four waves on the LDS; only ~24 cycles' worth hide in the 32 cycles of a 32x32x16 MFMA, and a
+// 16x16x32 MFMA (8 of 16 cycles) hides nothing.  So:
+//   * 32x32x16: half the MFMA issue cost and half the fragment reads per FLOP.  A wave owns 32 output channels (rg = w & 1) and
+//     four column tiles of 32 -- tiles chalf, chalf + 2, chalf + 4, chalf + 6 of the block's eight (chalf = w >> 1); its
+//     A fragments (20 k-steps x 2 planes = 160 registers) stay in registers for a conv, the residual stream (4 x 16) too: one
+//     wave per SIMD, the whole 512-register file.
+//   * every step runs the 60 MFMAs of one column tile and, cut into stages of ~16 INDEPENDENT vector instructions per k-step
+//     (four elements = four dependency chains per stage, one scheduling region per k-step -- hipcc otherwise puts 14 MFMAs back
+//     to back and the whole job behind them), the epilogue of the PREVIOUS step's tile: GELU -> FiLM -> re-split -> LDS.
+//   * the interleaved tile ownership is what lets the pipeline run across conv boundaries: column tile t of conv q + 1 needs
+//     tiles t - 1 and t of conv q, i.e. the k-th tile of a wave needs k-th and (k-1)-th tiles of the others, never their last
+//     one -- so the last tile's epilogue of conv q runs under the first tile's MFMAs of conv q + 1 (one barrier per step instead
+//     of a pipeline fill and drain per conv), and a conv's weights are reloaded k-step by k-step behind its last tile's MFMAs.
+//   * LDS image [column][64 channels] bf16, hi and lo plane, 16-byte chunks XOR-swizzled by (row >> 1) & 7: a 32x32x16 B fragment
+//     is read by 32 lanes of consecutive rows and the ds_read_b128 lane groups hold eight even and eight odd rows each, which
+//     (row >> 1) & 7 spreads over all eight chunk positions at any tap shift.  FiLM rows as [conv][channel][9 frames] (scale,
+//     shift) pairs: one ds_read2_b64 per element fetches both frames.
+//   * FIRST = the first tile of a window (ReflectionPad1d at t = 0, common.py:88) is an instantiation of its own with per-lane
+//     fragment addresses; every other tile reads its fragments at lane-constant bases + immediates.  Its leftmost column tile
+//     reaches up to 16 rows left of the LDS image: a 2-KB guard in front of it makes those reads legal, and what they return
+//     only reaches halo columns (the halo IS the dependency cone of the six convs).
+// 7.3 -> see DESIGN.md for the measured time.
+//
+// A hazard found on the way (and the likely mechanism of the run-to-run defect of the 16x16x32 kernel, DESIGN.md 3.2b'): when the
+// first MFMA of a NEW accumulation chain follows the last MFMA of the previous chain within ~12 wait states and the previous
+// chain's accumulator is read (v_accvgpr_read) only later, beside the new chain's MFMAs, the LAST register of that accumulator
+// comes back wrong -- deterministically for some tiles, run to run for others.  hipcc 7.2 inserts the documented wait states for
+// the first read only.  Eight more wait states between the chains (s_nop below), or reading the accumulator at once, make every
+// launch exact (tools/stress_filter_block.py: 0 of 100 differ; -DALIVE_FB64_NO_CHAIN_GAP reproduces the failure).
 #include "conv_epilogue.h"
+#include <type_traits>
 
-// With hipcc's SLP vectorizer on, filter_block64_kernel comes out as a binary whose last column tiles differ from run to run
-// (DESIGN.md 3.2b'; a static scan of that binary, tools/mfma_hazard_scan.py, finds no MFMA operand / result distance below
-// the gfx950 tables, so the defect is not one the listed software hazards explain).  The Makefile compiles this file with
-// -fno-slp-vectorize and says so with the macro; any other recipe fails here instead of shipping that binary.
+// The Makefile compiles this file with -fno-slp-vectorize and says so with the macro: packed fp32 math beside MFMAs is an
+// anti-lever on this part (a v_pk_fma_f32 costs ~22 cycles more than two v_fma_f32 there, MI355X_MICROARCH.md), and the SLP
+// vectorizer is also what produced the non-deterministic binary of the 16x16x32 kernel.
 #ifndef ALIVE_FILTER_MID_NO_SLP
 #error "filter_mid.hip must be compiled with -fno-slp-vectorize -DALIVE_FILTER_MID_NO_SLP (see csrc/Makefile)"
 #endif
+
+static long long* g_stamps64 = nullptr;
 
 namespace {
 
@@ -33,70 +65,59 @@ constexpr int HALO = 56;
 constexpr int NCONV = 6;
 constexpr int BL = 256;                 // columns per tile incl. halo
 constexpr int TT = BL - HALO;           // 200 output columns per tile
-constexpr int NCT = BL / 16;            // 16 column tiles
-constexpr int NFP = 8;                  // FiLM frames staged per tile
-constexpr int NFS = NFP + 1;            // row pitch of the staged FiLM table: the four channel groups of a column (lanes kq = 0..3,
-                                        // 4 rows apart) land on different banks (pitch 8 put them 128 B apart: 4-way conflicts)
+constexpr int NFP = 8;                  // FiLM frames a tile may span
+constexpr int NFS = NFP + 1;            // staged frames per channel (i0 <= NFP - 1, i1 = i0 + 1)
 constexpr int ROWB = 128;               // bytes per LDS row (64 channels bf16)
 constexpr int PLANE = BL * ROWB;        // 32 KB
 constexpr int BUF = 2 * PLANE;          // hi + lo
 constexpr int W_IN = 2 * C * C;         // bf16 elements of the input conv [2][64][64]
 constexpr int W_K5 = 2 * C * 5 * C;     // bf16 elements of a k5 conv [2][64][320]
-constexpr int LDS_BYTES = 2 * BUF + NCONV * 2 * C * NFS * 4 + BL * 8;
+constexpr int NT = 4;                   // column tiles of 32 per wave
+constexpr int TROW = 32 * ROWB;         // bytes per column tile in a plane
+constexpr int TSTEP = 2 * TROW;         // a wave's consecutive tiles are two column tiles apart
+constexpr int GUARD = 16 * ROWB;        // 2 KB in front of the plane buffers
+constexpr int LDS_BYTES = GUARD + 2 * BUF + NCONV * C * NFS * 8 + BL * 8;     // 162816 B
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
     bf16x2_t h = {(__bf16)a, (__bf16)b};
     return __builtin_bit_cast(unsigned, h);
 }
+__device__ __forceinline__ int swz(int r) { return (r >> 1) & 7; }
 
+template <bool FIRST>
 __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __restrict__ U, int L,
                                                                 const unsigned short* __restrict__ W16,
                                                                 const float* __restrict__ biases,
                                                                 const float* __restrict__ film, int film_rows, int Lf,
-                                                                int film_off, float ratio, int t_off, int f_off, int film_ld, const float* __restrict__ skip,
-                                                                float* __restrict__ out, long long* stamps) {
-#ifdef ALIVE_STAMPS                 // diagnostic build only (make EXTRA=-DALIVE_STAMPS; tools/bench_filter_mid.py)
-#define STAMP(i) ts[i] = wall_clock64()
-    long long ts[4], tw = 0;
+                                                                int film_off, float ratio, int t_off, int f_off, int film_ld,
+                                                                const float* __restrict__ skip, float* __restrict__ out, long long* stamps) {
+#ifdef ALIVE_STAMPS                 // diagnostic build only (tools/ab_build.sh x.so filter_mid.hip -DALIVE_STAMPS; tools/stamp_fb64.py)
+    long long ts3[12];
+    int nts = 0;
+#define STAMP3() ts3[nts++] = wall_clock64()
 #else
-#define STAMP(i)
+#define STAMP3()
 #endif
-    STAMP(0);
+    STAMP3();
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-    unsigned char* bufZ = sm;
-    unsigned char* bufY = sm + BUF;
-    float* Fs = (float*)(sm + 2 * BUF);               // [NCONV][2][C][NFS]
-    uint2* Xc = (uint2*)(Fs + NCONV * 2 * C * NFS);   // [BL] interpolation coordinates of a column: (i0 | i1 << 16, w1)
+    unsigned char* bufZ = sm + GUARD;
+    unsigned char* bufY = bufZ + BUF;
+    f32x2* Fs = (f32x2*)(bufZ + 2 * BUF);             // [NCONV][C][NFS] (scale, shift)
+    uint2* Xc = (uint2*)(Fs + NCONV * C * NFS);       // [BL] per column: (8 * i0 relative to the staged frames, w1)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c16 = lane & 15, kq = lane >> 4;
+    const int rg = w & 1, chalf = w >> 1;
+    const int n32 = lane & 31, lh = lane >> 5;
     const int n = blockIdx.y;
-    const int t0 = blockIdx.x * TT;
+    const int t0 = FIRST ? 0 : (blockIdx.x + 1) * TT;
     const int tbase = t0 - HALO;
     const float* Un = U + (size_t)n * C * L;
 
-    // ---- FiLM rows of the tile ----
+    // ---- stage the raw input tile (split into planes; thread = column) and the FiLM rows of the tile: every global load of the
+    //      prologue is issued before the first LDS write, so one memory latency covers all of them ----
     const int f_lo = lerp_coord((tbase < 0 ? 0 : tbase) + t_off, ratio, Lf).i0;     // frames of the WINDOW (t_off: range mode)
-    for (int e = tid; e < NCONV * 2 * C * NFP; e += 256) {
-        const int f = e % NFP, c = (e / NFP) % C, sel = (e / (NFP * C)) & 1, q = e / (NFP * C * 2);
-        int fr = f_lo + f;
-        fr = fr < Lf ? fr : Lf - 1;
-        int fc = fr - f_off;                             // frame of the window -> column of the film tensor
-        fc = fc < 0 ? 0 : (fc < film_ld ? fc : film_ld - 1);
-        Fs[((q * 2 + sel) * C + c) * NFS + f] = film[((size_t)n * film_rows + film_off + q * 2 * C + sel * C + c) * film_ld + fc];
-    }
-    {   // F.interpolate coordinates of this thread's column, relative to the staged FiLM frames
-        int t = tbase + tid;
-        t = t < 0 ? 0 : (t < L ? t : L - 1);
-        const Lerp lp = lerp_coord(t + t_off, ratio, Lf);
-        int i0 = lp.i0 - f_lo, i1 = lp.i1 - f_lo;
-        i0 = i0 < NFP - 1 ? i0 : NFP - 1;
-        i1 = i1 < NFP - 1 ? i1 : NFP - 1;
-        Xc[tid] = make_uint2((unsigned)i0 | ((unsigned)i1 << 16), __float_as_uint(lp.w1));
-    }
-    // ---- stage the raw input tile, split into planes: thread = column; all 64 channel loads are in flight together ----
     {
         const int t = tbase + tid;
         const bool ok = t >= 0 && t < L;
@@ -104,6 +125,26 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
         float v[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) v[c] = uc[(size_t)c * L];
+        constexpr int NFL = NCONV * 2 * C * NFS / 256;        // 27 FiLM values per thread
+        float fv[NFL];
+#pragma unroll
+        for (int k = 0; k < NFL; ++k) {
+            const int e = tid + 256 * k;
+            const int f = e % NFS, c = (e / NFS) % C, sel = (e / (NFS * C)) & 1, q = e / (NFS * C * 2);
+            int fr = f_lo + f;
+            fr = fr < Lf ? fr : Lf - 1;
+            int fc = fr - f_off;                             // frame of the window -> column of the film tensor
+            fc = fc < 0 ? 0 : (fc < film_ld ? fc : film_ld - 1);
+            fv[k] = film[((size_t)n * film_rows + film_off + q * 2 * C + sel * C + c) * film_ld + fc];
+        }
+        {   // F.interpolate coordinates of this thread's column, relative to the staged FiLM frames (i1 = i0 + 1: the table
+            // repeats the window's last frame, which is what the clamp of upsample_linear1d reads there)
+            const int tc = t < 0 ? 0 : (t < L ? t : L - 1);
+            const Lerp lp = lerp_coord(tc + t_off, ratio, Lf);
+            int i0 = lp.i0 - f_lo;
+            i0 = i0 < NFP - 1 ? i0 : NFP - 1;
+            Xc[tid] = make_uint2((unsigned)(i0 * 8), __float_as_uint(lp.w1));
+        }
 #pragma unroll
         for (int ck = 0; ck < 8; ++ck) {
             u32x4 hi, lo;
@@ -114,237 +155,282 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
                 hi[e] = h;
                 lo[e] = pack2(x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xffff0000u));
             }
-            unsigned char* dst = bufZ + tid * ROWB + ((ck ^ (tid & 7)) << 4);
+            unsigned char* dst = bufZ + tid * ROWB + ((ck ^ swz(tid)) << 4);
             *(u32x4*)dst = hi;
             *(u32x4*)(dst + PLANE) = lo;
         }
+#pragma unroll
+        for (int k = 0; k < NFL; ++k) {
+            const int e = tid + 256 * k;
+            const int f = e % NFS, c = (e / NFS) % C, sel = (e / (NFS * C)) & 1, q = e / (NFS * C * 2);
+            // the scale rows are stored halved (exact): gelu(x) * sc + sh = (x + |x| erf|x / sqrt 2|) * (sc / 2) + sh saves the 0.5 x
+            ((float*)Fs)[((q * C + c) * NFS + f) * 2 + sel] = sel == 0 ? 0.5f * fv[k] : fv[k];
+        }
     }
     __syncthreads();
-    STAMP(1);
+    STAMP3();
 
-    // residual stream: h[ct][e] = channel 16 w + 4 kq + e of column 16 ct + c16 (MFMA C layout)
-    f32x4 h[NCT];
+    // residual stream: h[i][4 g + e] = channel 32 rg + 8 g + 4 lh + e of column 32 (2 i + chalf) + n32 (MFMA C layout)
+    f32x16 h[NT];
 
-    // FiLM operands of one column tile for this lane: interpolation weight and, per channel pair, the scale / shift
-    // values at the two frames -- fetched one tile AHEAD of their use, so the epilogue has no LDS round trip in it
-    struct Film {
-        float w1;
-        f32x2 s0[2], s1[2], h0[2], h1[2];
-    };
-    auto film_fetch = [&](int q, int col, Film& F) {
-        const uint2 xc = Xc[col];
-        const int i0 = xc.x & 0xffff, i1 = xc.x >> 16;
-        F.w1 = __uint_as_float(xc.y);
-        const float* f = Fs + ((q * 2) * C + 16 * w + 4 * kq) * NFS;
+    // lane-constant pieces of the per-tile addresses: tile i of this wave adds the immediate i * TSTEP
+    const int colw = chalf * 32 + n32;                                             // column of tile i: colw + 64 i
+    int st_off[4];                                                                 // modulated planes: channels 32 rg + 8 g + 4 lh .. +3
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float* fa = f + (2 * e) * NFS;
-            const float* fb = fa + NFS;
-            F.s0[e] = f32x2{fa[i0], fb[i0]};
-            F.s1[e] = f32x2{fa[i1], fb[i1]};
-            F.h0[e] = f32x2{fa[C * NFS + i0], fb[C * NFS + i0]};
-            F.h1[e] = f32x2{fa[C * NFS + i1], fb[C * NFS + i1]};
+    for (int g = 0; g < 4; ++g) st_off[g] = colw * ROWB + (((4 * rg + g) ^ swz(colw)) << 4) + 8 * lh;
+    const uint2* xcw = Xc + colw;
+    const unsigned char* fsw = (const unsigned char*)(Fs + (32 * rg + 4 * lh) * NFS);
+
+    // FiLM operands of one channel group (4 channels) of a column: (scale, shift) at frames i0 and i0 + 1
+    struct FilmG {
+        f32x2 a0[4], a1[4];
+    };
+    // The epilogue of one column tile (an "item"): v = chain result (+ residual, c2) -> GELU -> FiLM of the next conv's input ->
+    // re-split -> LDS planes, per channel group g in five stages of four independent chains each
+    struct Epi {
+        int off;
+        float w0, w1;
+        FilmG F[2];
+        float z[4], jt[4], je[4], jsc[4], jsh[4], jx[4];
+    };
+    auto film_fetch = [&](int qf, int off, int g, FilmG& F) {
+        const unsigned char* f = fsw + qf * (C * NFS * 8) + off;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x2* fp = (const f32x2*)(f + ((8 * g + e) * NFS) * 8);
+            F.a0[e] = fp[0];
+            F.a1[e] = fp[1];
         }
     };
-    // gelu -> FiLM of the next conv's input for the 4 channels of this lane at column `col`, re-split and stored as
-    // planes; two channels per instruction on the packed fp32 pipe
-    auto modulate_store = [&](const Film& F, unsigned char* dst, int col, const f32x4& v) {
-        const float w1 = F.w1, w0 = 1.0f - w1;
-        f32x2 z[2];
+    auto epi_begin = [&](Epi& E, int qf, int t) {
+        const uint2 xc = xcw[64 * t];
+        E.off = (int)xc.x;
+        E.w1 = __uint_as_float(xc.y);
+        E.w0 = 1.0f - E.w1;
+        film_fetch(qf, E.off, 0, E.F[0]);
+    };
+    // second: the item is a c2 result (v = chain + residual stream, which it replaces); emit: a next conv exists (FiLM rows qf)
+    // and takes the modulated planes at dstp
+    auto epi_stage = [&](Epi& E, bool second, bool emit, int qf, unsigned char* dstp, int t, const f32x16& accv, int g, int st) {
+        const FilmG& Fg = E.F[g & 1];
+        if (st == 0) {
+            if (emit && g + 1 < 4) film_fetch(qf, E.off, g + 1, E.F[(g + 1) & 1]);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const f32x2 sc = pk_fma(pk_splat(w0), F.s0[e], pk_splat(w1) * F.s1[e]);    // fma(w0, a, round(w1 * b)): ATen's linear interp
-            const f32x2 sh = pk_fma(pk_splat(w0), F.h0[e], pk_splat(w1) * F.h1[e]);
-            z[e] = gelu_fast2(f32x2{v[2 * e], v[2 * e + 1]}) * sc + sh;
+            for (int e = 0; e < 4; ++e) {
+                float x = accv[4 * g + e];                 // one v_accvgpr_read per element (8 cycles beside an MFMA): kept for stage 3
+                if (second) {
+                    x = x + h[t][4 * g + e];
+                    h[t][4 * g + e] = x;
+                }
+                E.jx[e] = x;
+                E.jt[e] = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.3275911f * 0.70710678118654752440f, 1.0f));
+                const float xs = x * 0.84932180028801904272f;         // exp(-x^2 / 2) = exp2(-(x sqrt(log2(e) / 2))^2)
+                E.je[e] = __builtin_amdgcn_exp2f(-(xs * xs));
+            }
+            // (the empty asm pins a stage's results to its own scheduling region: pure arithmetic otherwise sinks to its consumer's)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(E.jt[e]), "+v"(E.je[e]), "+v"(E.jx[e]));
+        } else if (!emit) {
+        } else if (st == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                E.jsc[e] = fmaf(E.w0, Fg.a0[e][0], E.w1 * Fg.a1[e][0]);        // fma(w0, a, round(w1 * b)): ATen's linear interp
+                E.jsh[e] = fmaf(E.w0, Fg.a0[e][1], E.w1 * Fg.a1[e][1]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(E.jsc[e]), "+v"(E.jsh[e]));
+        } else if (st == 2) {          // erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7), like gelu_fast
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float p = fmaf(1.061405429f, E.jt[e], -1.453152027f);
+                p = fmaf(p, E.jt[e], 1.421413741f);
+                p = fmaf(p, E.jt[e], -0.284496736f);
+                p = fmaf(p, E.jt[e], 0.254829592f);
+                E.jt[e] = p * E.jt[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(E.jt[e]));
+        } else if (st == 3) {          // x (1 + sign(x) erf|x / sqrt 2|) = x + |x| erf_abs = 2 gelu(x); jsc is half the FiLM scale
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float erf_abs = fmaf(-E.jt[e], E.je[e], 1.0f);
+                E.z[e] = fmaf(fmaf(fabsf(E.jx[e]), erf_abs, E.jx[e]), E.jsc[e], E.jsh[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(E.z[e]));
+        } else {
+            const float* z = E.z;
+            const unsigned h01 = pack2(z[0], z[1]), h23 = pack2(z[2], z[3]);
+            const unsigned l01 = pack2(z[0] - __uint_as_float(h01 << 16), z[1] - __uint_as_float(h01 & 0xffff0000u));
+            const unsigned l23 = pack2(z[2] - __uint_as_float(h23 << 16), z[3] - __uint_as_float(h23 & 0xffff0000u));
+            unsigned char* p = dstp + st_off[g] + t * TSTEP;
+            *(uint2*)p = make_uint2(h01, h23);
+            *(uint2*)(p + PLANE) = make_uint2(l01, l23);
         }
-        const unsigned h01 = pack2(z[0][0], z[0][1]), h23 = pack2(z[1][0], z[1][1]);
-        const f32x2 r0 = z[0] - f32x2{__uint_as_float(h01 << 16), __uint_as_float(h01 & 0xffff0000u)};
-        const f32x2 r1 = z[1] - f32x2{__uint_as_float(h23 << 16), __uint_as_float(h23 & 0xffff0000u)};
-        const unsigned l01 = pack2(r0[0], r0[1]), l23 = pack2(r1[0], r1[1]);
-        // channels 16 w + 4 kq .. +3 -> chunk 2 w + (kq >> 1), byte 8 (kq & 1) inside it
-        unsigned char* p = dst + col * ROWB + (((2 * w + (kq >> 1)) ^ (col & 7)) << 4) + 8 * (kq & 1);
-        *(uint2*)p = make_uint2(h01, h23);
-        *(uint2*)(p + PLANE) = make_uint2(l01, l23);
     };
 
-    // one conv over the whole tile: KS k-steps of 32 channels, A fragments (this wave's 16 rows) in registers
-    // B fragment of (row r, ci-block cb): 16 B at r * 128 + ((4 cb + kq) ^ (r & 7)) * 16, planes PLANE apart
-    // ---- input_conv (1x1, K = 64 = 2 k-steps): h = Win * U + b ; z0 = mod_0(h) written over the same columns ----
+    // weights of the k5 convs: k-step s = 4 j + cb (tap j, 16-channel block cb), k = j * 64 + cb * 16 + 8 lh
+    bf16x8 a[20][2];
+    auto load_weights_step = [&](int q, int s) {
+        const unsigned short* Wq = W16 + W_IN + (size_t)q * W_K5 + (size_t)(32 * rg + n32) * (5 * C) + 8 * lh;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) a[s][pl] = *(const bf16x8*)(Wq + (size_t)pl * C * 5 * C + s * 16);
+    };
+
+    // ---- input_conv (1x1, K = 64 = 4 k-steps): h = Win * U + b ----
     {
-        bf16x8 a[2][2];
+        bf16x8 ai[4][2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
-                a[s][pl] = *(const bf16x8*)(W16 + (size_t)pl * C * C + (size_t)(16 * w + c16) * C + s * 32 + 8 * kq);
-        f32x4 b4;
+                ai[s][pl] = *(const bf16x8*)(W16 + (size_t)pl * C * C + (size_t)(32 * rg + n32) * C + s * 16 + 8 * lh);
+        f32x16 b16;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) b4[e] = biases[16 * w + 4 * kq + e];
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            const int r = ct * 16 + c16;
-            f32x4 acc = b4;
+            for (int e = 0; e < 4; ++e) b16[4 * g + e] = biases[32 * rg + 8 * g + 4 * lh + e];
+        const int bw = colw * ROWB + ((lh ^ swz(colw)) << 4);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const unsigned char* bp = bufZ + r * ROWB + (((4 * s + kq) ^ (r & 7)) << 4);
+        for (int i = 0; i < NT; ++i) {
+            f32x16 acc = b16;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const unsigned char* bp = bufZ + ((bw ^ (s << 5)) + i * TSTEP);
                 const bf16x8 bh = *(const bf16x8*)bp, bl = *(const bf16x8*)(bp + PLANE);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][1], bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][0], bl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][0], bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai[s][1], bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai[s][0], bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai[s][0], bh, acc, 0, 0, 0);
             }
-            h[ct] = acc;
+            h[i] = acc;
         }
     }
     __syncthreads();                       // every wave has read the raw columns
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-        Film F;
-        film_fetch(0, ct * 16 + c16, F);
-        modulate_store(F, bufZ, ct * 16 + c16, h[ct]);
+    for (int s = 0; s < 20; ++s) load_weights_step(0, s);        // 40 loads per lane in flight under the epilogues below
+    // z0 = mod_0(h) over the raw columns: the first three tiles here, the fourth under the first MFMAs of conv 0 as a "c2 item"
+    // whose chain result is zero (v = 0 + h)
+    f32x16 acc[2];
+    {
+        f32x16 zero16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
+        acc[1] = zero16;
+#pragma unroll
+        for (int i = 0; i < NT - 1; ++i) {
+            Epi E;
+            epi_begin(E, 0, i);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int st = 0; st < 5; ++st) epi_stage(E, true, true, 0, bufZ, i, zero16, g, st);
+        }
     }
     __syncthreads();
+    STAMP3();
 
-    STAMP(2);
     // ---- three FilterResBlocks: q = 2 j (c1), 2 j + 1 (c2), dilation 2^j    (decoder.py:128-134) ----
-    const bool first_tile = tbase < 0;                       // block-uniform: ReflectionPad1d applies (common.py:88)
-#pragma unroll 1
-    for (int q = 0; q < NCONV; ++q) {
-#ifdef ALIVE_STAMPS
-        const long long tq0 = wall_clock64();
-#endif
-        const unsigned short* Wq = W16 + W_IN + (size_t)q * W_K5;
-        bf16x8 a[10][2];                   // k-step s = 2 j + cb (tap j, channel block cb): k = j * 64 + cb * 32 + 8 kq
+    // One conv = four steps; step i runs the MFMAs of the wave's tile i (-> acc[i & 1]) and the epilogue of the previous step's
+    // tile (tile i - 1 of this conv, or tile 3 of the previous one), then a barrier.  SECOND: this conv is the c2 of its block.
+    auto conv = [&](auto second_tag, const int q) {
+        constexpr bool SECOND = decltype(second_tag)::value;
+        const unsigned char* in = SECOND ? bufY : bufZ;
+        unsigned char* dst = SECOND ? bufZ : bufY;
+        const bool emit = q + 1 < NCONV;
+        f32x16 b16;
 #pragma unroll
-        for (int s = 0; s < 10; ++s)
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-                a[s][pl] = *(const bf16x8*)(Wq + (size_t)pl * C * 5 * C + (size_t)(16 * w + c16) * (5 * C) + s * 32 + 8 * kq);
-        f32x4 b4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) b4[e] = biases[(1 + q) * C + 16 * w + 4 * kq + e];
+            for (int e = 0; e < 4; ++e) b16[4 * g + e] = biases[(1 + q) * C + 32 * rg + 8 * g + 4 * lh + e];
         const int d = 1 << (q >> 1);
-        const bool second = q & 1;
-        const unsigned char* in = second ? bufY : bufZ;
-        unsigned char* dst = second ? bufZ : bufY;
-
-        // B fragment of k-step s = 2 j + cb of column tile ct: row r = 16 ct + c16 + (j - 4) d, 16 B at
-        // r * 128 + ((4 cb + kq) ^ (r & 7)) * 16.  (r & 7) does not depend on ct, so the address is
-        // base[cb][j] + 2048 ct: one register per (tap, channel block) and an immediate per column tile.
-        int base[2][5];
+        // B fragment of k-step s = 4 j + cb of tile i: row r = colw + 64 i + (j - 4) d, 16 B at r * 128 + ((2 cb + lh) ^ swz(r)) * 16
+        // = base[s] + i * TSTEP (swz does not depend on i): twenty lane-constant registers per conv, immediates per tile -- an XOR
+        // per fragment read in the loop is 0.7 vector instructions per MFMA where only five are free
+        int base[20];
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            const int r0 = c16 + (j - 4) * d;
-            base[0][j] = r0 * ROWB + ((kq ^ (r0 & 7)) << 4);
-            base[1][j] = base[0][j] ^ 64;
+            const int r0 = colw + (j - 4) * d;                 // >= -16: the guard
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) base[4 * j + cb] = (r0 * ROWB + ((lh ^ swz(r0)) << 4)) ^ (cb << 5);
         }
-        bf16x8 fh[10], fl[10];
-        auto load_frags = [&](int ct) {
-            // column tile 0 reaches left of the tile (rows that are never valid: clamp), and the first tile of a window
-            // reflects at t = 0 for the columns below 16 d + HALO: those take the per-lane form
-            if (ct == 0 || (first_tile && ct < 5)) {
-                const int col = ct * 16 + c16;
+        auto frag_off = [&](int i, int s) -> int {
+            if (FIRST) {                                        // reflect at t = 0 (column HALO of this tile), per lane
+                int ta = tbase + colw + 64 * i + ((s >> 2) - 4) * d;
+                ta = ta < 0 ? -ta : ta;
+                int r = ta - tbase;
+                r = r < BL ? r : BL - 1;
+                return (r * ROWB + ((lh ^ swz(r)) << 4)) ^ ((s & 3) << 5);
+            }
+            return base[s] + i * TSTEP;
+        };
+        constexpr int PF = 3, NSLOT = PF + 1;                   // fragments are requested PF k-steps ahead of their MFMAs
+        bf16x8 fh[NSLOT], fl[NSLOT];
+        auto frag_load = [&](int i, int s, int slot) {
+            const unsigned char* bp = in + frag_off(i, s);
+            fh[slot] = *(const bf16x8*)bp;
+            fl[slot] = *(const bf16x8*)(bp + PLANE);
+        };
 #pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    int ta = tbase + col + (j - 4) * d;
-                    ta = ta < 0 ? -ta : ta;
-                    int r = ta - tbase;
-                    r = r < 0 ? 0 : (r < BL ? r : BL - 1);
-                    const int o = r * ROWB + ((kq ^ (r & 7)) << 4);
+        for (int i = 0; i < NT; ++i) {
+            // the item of this step: tile i - 1 of this conv, or (i == 0) tile 3 of the previous conv -- whose type is the other one,
+            // which always has a next conv, whose FiLM rows are this conv's and whose planes are this conv's input
+            const bool it_second = i > 0 ? SECOND : !SECOND;
+            const bool it_emit = i > 0 ? emit : true;
+            const int it_qf = i > 0 ? q + 1 : q;
+            unsigned char* it_dst = i > 0 ? dst : (unsigned char*)in;
+            const int it_t = i > 0 ? i - 1 : NT - 1;
+            const f32x16& it_acc = acc[(i + 1) & 1];
+#ifndef ALIVE_FB64_NO_CHAIN_GAP
+            asm volatile("s_nop 15" ::: "memory");            // see the header: distance between two accumulation chains
+#endif
+            Epi E;
+            if (it_emit) epi_begin(E, it_qf, it_t);
+            acc[i & 1] = b16;
 #pragma unroll
-                    for (int cb = 0; cb < 2; ++cb) {
-                        const unsigned char* bp = in + (o ^ (cb << 6));
-                        fh[2 * j + cb] = *(const bf16x8*)bp;
-                        fl[2 * j + cb] = *(const bf16x8*)(bp + PLANE);
-                    }
+            for (int s = 0; s < PF; ++s) frag_load(i, s, s);
+#pragma unroll
+            for (int s = 0; s < 20; ++s) {
+                if (s + PF < 20) frag_load(i, s + PF, (s + PF) % NSLOT);
+                acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], fh[s % NSLOT], acc[i & 1], 0, 0, 0);
+                acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], fl[s % NSLOT], acc[i & 1], 0, 0, 0);
+                acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], fh[s % NSLOT], acc[i & 1], 0, 0, 0);
+                if (i == NT - 1 && emit) load_weights_step(q + 1, s);     // a[s] is dead: the next conv's weights travel under the rest of the step
+                epi_stage(E, it_second, it_emit, it_qf, it_dst, it_t, it_acc, s / 5, s % 5);
+#ifdef ALIVE_FB64_DUP_STAGE           // diagnostic (timing only): one stage's work a second time -- the increment prices the stage
+                if (s % 5 == ALIVE_FB64_DUP_STAGE && it_emit) {
+                    Epi E2 = E;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { asm volatile("" : "+v"(E2.jt[e]), "+v"(E2.je[e]), "+v"(E2.jx[e]), "+v"(E2.jsc[e])); asm volatile("" : "+v"(E2.jsh[e]), "+v"(E2.z[e])); }
+                    epi_stage(E2, false, true, it_qf, it_dst, it_t, it_acc, s / 5, s % 5);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { asm volatile("" :: "v"(E2.jt[e]), "v"(E2.je[e]), "v"(E2.jx[e]), "v"(E2.jsc[e])); asm volatile("" :: "v"(E2.jsh[e]), "v"(E2.z[e])); }
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 5; ++j)
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb) {
-                        const unsigned char* bp = in + base[cb][j] + ct * (16 * ROWB);
-                        fh[2 * j + cb] = *(const bf16x8*)bp;
-                        fl[2 * j + cb] = *(const bf16x8*)(bp + PLANE);
-                    }
-            }
-        };
-        load_frags(0);
-#ifdef ALIVE_STAMPS
-        __builtin_amdgcn_s_waitcnt(0);
-        tw += wall_clock64() - tq0;
 #endif
-        // The column loop is unrolled (residual registers and LDS immediates are static) and software-pipelined: the
-        // MFMAs of tile ct + 1 are issued BEFORE the epilogue of tile ct, so the epilogue's VALU / LDS work sits in the
-        // shadow of a dependent MFMA chain instead of behind it (one wave per SIMD: nothing else would fill it).
-        // One fragment buffer: the fragments of tile ct + 2 are requested right behind the MFMAs of tile ct + 1.
-        auto mma_tile = [&](f32x4& acc0, f32x4& acc1) {
-            acc0 = b4;
-            acc1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#ifdef ALIVE_FB64_3CHAINS              // DIAGNOSTIC build only (tools/repro_filter_block64.sh): the two cross terms on accumulators of
-                                       // their own.  Slower (7.58 against 7.40 ms) and -- with the per-tile fence and -fno-slp-vectorize
-                                       // in place -- NOT deterministic: 19 of 20 launches differ from the first (DESIGN.md 3.2b').
-            f32x4 acc2 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int s = 0; s < 10; ++s) {
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][1], fh[s], acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][0], fl[s], acc2, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][0], fh[s], acc0, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);           // one scheduling region per k-step
             }
-            acc1 = acc1 + acc2;
-#else
-#pragma unroll
-            for (int s = 0; s < 10; ++s) {
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][1], fh[s], acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][0], fl[s], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][0], fh[s], acc0, 0, 0, 0);
-            }
-#endif
-        };
-        // the last conv has no consumer for the modulated output: it runs the same code with the FiLM rows of conv 5 and
-        // writes a tile nobody reads, which keeps the column body free of branches (one basic block per tile)
-        const int qn = q + 1 < NCONV ? q + 1 : NCONV - 1;
-        const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-        f32x4 p0, p1, n0, n1;
-        Film Fc, Fn;
-        film_fetch(qn, c16, Fc);
-        mma_tile(p0, p1);
-        load_frags(1);
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            if (ct + 1 < NCT) {
-                film_fetch(qn, (ct + 1) * 16 + c16, Fn);
-                mma_tile(n0, n1);
-                if (ct + 2 < NCT) load_frags(ct + 2);
-            }
-            f32x4 v = (p0 + p1) + (second ? h[ct] : zero4);
-            h[ct] = second ? v : h[ct];
-            modulate_store(Fc, dst, ct * 16 + c16, v);
-            // The fence is load-bearing: with the 16 column bodies merged into one scheduling region hipcc (ROCm 7.2) produced a
-            // schedule whose results differed from run to run (1.5e-2 off); with one region per column tile they are exact.
-#if !defined(ALIVE_NO_TILE_FENCE)    // -DALIVE_NO_TILE_FENCE[=n]: diagnostic builds only (tools/diag_filter_nofence.py, DESIGN.md 3.2b')
-            __builtin_amdgcn_sched_barrier(0);
-#elif ALIVE_NO_TILE_FENCE == 1       // compiler-level memory clobber instead of the scheduling fence
-            asm volatile("" ::: "memory");
-#elif ALIVE_NO_TILE_FENCE == 2       // fence only behind the last four column tiles
-            if (ct >= 12) __builtin_amdgcn_sched_barrier(0);
-#elif ALIVE_NO_TILE_FENCE == 3       // fence only behind the first twelve
-            if (ct < 12) __builtin_amdgcn_sched_barrier(0);
-#endif
-            p0 = n0;
-            p1 = n1;
-            Fc = Fn;
+            __syncthreads();
         }
-        __syncthreads();
+    };
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) {
+        conv(std::false_type{}, 2 * j);
+        STAMP3();
+        conv(std::true_type{}, 2 * j + 1);
+        STAMP3();
     }
+    // drain: the last conv's last tile only adds into the residual stream
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h[NT - 1][r] = acc[1][r] + h[NT - 1][r];
 
-    STAMP(3);
     // ---- store the tile (+ U-Net skip, decoder.py:191): through LDS so that global accesses are 16-B vectors along t ----
-    float* Ht = (float*)sm;                           // [64][BL + 4] fp32 = 66.5 KB over bufZ / bufY
+    float* Ht = (float*)bufZ;                         // [64][BL + 4] fp32 = 66.5 KB over bufZ / bufY
     constexpr int HP = BL + 4;
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Ht[(16 * w + 4 * kq + e) * HP + ct * 16 + c16] = h[ct][e];
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Ht[(32 * rg + 8 * g + 4 * lh + e) * HP + colw + 64 * i] = h[i][4 * g + e];
     __syncthreads();
     constexpr int NV = (C * (TT / 4) + 255) / 256;          // 13 vectors of 4 columns per thread
     f32x4 sk[NV];
@@ -371,16 +457,17 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
         }
     }
 #ifdef ALIVE_STAMPS
-    if (stamps != nullptr && tid == 0) {
-        long long* o = stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
-        o[0] = ts[1] - ts[0]; o[1] = ts[2] - ts[1]; o[2] = ts[3] - ts[2]; o[3] = wall_clock64() - ts[3]; o[4] = tw;
+    // per block 32 words: wave 0 -> [0..8] phase durations (staging, input conv, six convs, store); wave 2 -> [16..]
+    if (stamps != nullptr && (tid == 0 || tid == 128)) {
+        long long* o = stamps + ((size_t)blockIdx.y * (gridDim.x + 1) + (FIRST ? 0 : blockIdx.x + 1)) * 32 + (tid ? 16 : 0);
+        for (int i = 0; i + 1 < nts; ++i) o[i] = ts3[i + 1] - ts3[i];
+        o[nts - 1] = wall_clock64() - ts3[nts - 1];
     }
 #endif
 }
 
 }  // namespace
 
-static long long* g_stamps64 = nullptr;
 extern "C" void alive_debug_set_stamps64(long long* p) { g_stamps64 = p; }
 extern "C" int64_t alive_filter_block64_weights(void) { return (int64_t)W_IN + (int64_t)NCONV * W_K5; }
 
@@ -401,16 +488,20 @@ extern "C" int alive_filter_block64_range(const float* U, int N, int L, const vo
     ALIVE_CHECK_ARG((double)BL * film_ld / L + 3.0 <= NFP, "alive_filter_block64: tile spans more than %d frames (L %d, frames %d)", NFP, L, film_ld);
     {
         static LdsOptIn optin;
-        hipError_t e = optin.ensure({(const void*)filter_block64_kernel}, LDS_BYTES);
+        hipError_t e = optin.ensure({(const void*)filter_block64_kernel<false>, (const void*)filter_block64_kernel<true>}, LDS_BYTES);
         if (e != hipSuccess) {
             alive_set_error("alive_filter_block64: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(e));
             return ALIVE_ERR_LAUNCH;
         }
     }
     const float ratio = (float)film_ld / (float)L;       // == window frames / window samples at this rate
-    dim3 g(cdiv(L, TT), N);
-    filter_block64_kernel<<<g, 256, LDS_BYTES, (hipStream_t)stream>>>(U, L, (const unsigned short*)W16, biases, film, film_rows,
-                                                                     Lf, film_off, ratio, t0, f0, film_ld, skip, out, g_stamps64);
+    const int tiles = cdiv(L, TT);
+    // the first tile of every window reflects at t = 0 (per-lane fragment addresses): an instantiation and a launch of its own
+    filter_block64_kernel<true><<<dim3(1, N), 256, LDS_BYTES, (hipStream_t)stream>>>(U, L, (const unsigned short*)W16, biases, film, film_rows,
+                                                                                   Lf, film_off, ratio, t0, f0, film_ld, skip, out, g_stamps64);
+    if (tiles > 1)
+        filter_block64_kernel<false><<<dim3(tiles - 1, N), 256, LDS_BYTES, (hipStream_t)stream>>>(
+            U, L, (const unsigned short*)W16, biases, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld, skip, out, g_stamps64);
     ALIVE_CHECK_LAUNCH("alive_filter_block64");
     return ALIVE_OK;
 }

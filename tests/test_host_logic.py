@@ -244,15 +244,20 @@ def test_overlap_sharing_geometry_against_the_oracle():
     assert near.abs().max() > 1e-3
 
 
-def test_filter_mid_is_built_without_the_slp_vectorizer():
-    """csrc/Makefile must compile filter_mid.hip with -fno-slp-vectorize (DESIGN.md 3.2b': with SLP on, the fused 64-channel
-    FilterBlock is not deterministic); the source refuses to compile without the macro that accompanies the flag"""
+def test_filter_mid_is_built_with_the_flags_its_schedule_needs():
+    """csrc/Makefile must compile filter_mid.hip with -fno-slp-vectorize (packed fp32 math beside MFMAs costs more than it saves, and
+    SLP is what made the 16x16x32 kernel of rounds 1-3 non-deterministic) and with the max-ilp scheduling strategy (the default one
+    serialises the four dependency chains of an epilogue stage); the source refuses to compile without the macro that accompanies
+    the flags (DESIGN.md 3.2b')"""
     mk = open(os.path.join(ROOT, "alive-vc_amd", "csrc", "Makefile")).read()
     line = [ln for ln in mk.splitlines() if ln.startswith("FLAGS_filter_mid")]
     assert len(line) == 1 and "-fno-slp-vectorize" in line[0] and "-DALIVE_FILTER_MID_NO_SLP" in line[0], line
+    assert "-amdgpu-sched-strategy=max-ilp" in line[0], line
     assert "$(FLAGS_$*)" in mk
     src = open(os.path.join(ROOT, "alive-vc_amd", "csrc", "filter_mid.hip")).read()
     assert "#ifndef ALIVE_FILTER_MID_NO_SLP" in src and "#error" in src
+    assert "v_mfma_f32_16x16x32" not in src and "mfma_f32_16x16x32_bf16(" not in src          # the shape that carried the defect is gone
+    assert 'asm volatile("s_nop 15"' in src and "ALIVE_FB64_NO_CHAIN_GAP" in src                # the wait states between two chains
     assert "diag.hip" not in [w for ln in mk.splitlines() if ln.startswith("SRCS") for w in ln.split()]      # measurement kernels stay out of the product .so
 
 

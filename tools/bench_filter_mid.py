@@ -17,13 +17,4 @@ e.record(); torch.cuda.synchronize()
 ms = a.elapsed_time(e) / 10
 fl = 2.0 * 64 * (64 + 6 * 320) * N * L * 3
 print(f"fused FilterBlock C=64: {ms:.3f} ms per 128 windows  ({fl / ms / 1e9:.0f} TF MFMA-equivalent, {3 * x.numel() * 4 / ms / 1e6:.0f} GB/s of tensor I/O)")
-import ctypes as C
-nb = N * ((L + 199) // 200)
-stamps = torch.zeros(nb, 8, dtype=torch.int64, device=dev)
-L_.alive_debug_set_stamps64.argtypes = [C.c_void_p]
-L_.alive_debug_set_stamps64(stamps.data_ptr()); run(); torch.cuda.synchronize(); L_.alive_debug_set_stamps64(None)
-s = stamps.cpu().double() / 100.0
-if s.abs().sum().item() == 0:
-    print("(no in-kernel stamps: build the diagnostic library with `make -C alive-vc_amd/csrc clean all EXTRA=-DALIVE_STAMPS`)")
-else:
-  print("per tile mean us: staging %.1f  input conv %.1f  six convs %.1f (of which weights+first-fragment wait %.1f)  store %.1f" % tuple(s[:, i].mean().item() for i in range(5))[:5])
+print("(phase stamps: tools/ab_build.sh tools/_ab/fb64_stamps.so filter_mid.hip -DALIVE_STAMPS; ALIVE_VC_LIB=tools/_ab/fb64_stamps.so python tools/stamp_fb64.py)")

@@ -1,6 +1,6 @@
 """Run-to-run determinism of the fused FilterBlock kernels at the bench shape (128 windows): `reps` launches on the same
 inputs, every output compared bitwise with the first.  ALIVE_VC_LIB selects the library under test (e.g. a build with
--DALIVE_NO_TILE_FENCE).   python tools/stress_filter_block.py [reps] [N]"""
+-DALIVE_FB64_NO_CHAIN_GAP).   python tools/stress_filter_block.py [reps] [N]"""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "alive-vc_amd"))
 from module import _native as nat
