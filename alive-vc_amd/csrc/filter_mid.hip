@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
     const int rg = w & 1, chalf = w >> 1;
     const int n32 = lane & 31, lh = lane >> 5;
     const int n = blockIdx.y;
-    const int t0 = FIRST ? 0 : (blockIdx.x + 1) * TT;
+    const int t0 = FIRST ? blockIdx.x * TT : (blockIdx.x + 1) * TT;      // FIRST: the host launches it for tile 0 (or for every tile of a small problem)
     const int tbase = t0 - HALO;
     const float* Un = U + (size_t)n * C * L;
 
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
 #ifdef ALIVE_STAMPS
     // per block 32 words: wave 0 -> [0..8] phase durations (staging, input conv, six convs, store); wave 2 -> [16..]
     if (stamps != nullptr && (tid == 0 || tid == 128)) {
-        long long* o = stamps + ((size_t)blockIdx.y * (gridDim.x + 1) + (FIRST ? 0 : blockIdx.x + 1)) * 32 + (tid ? 16 : 0);
+        long long* o = stamps + ((size_t)blockIdx.y * (gridDim.x + 1) + (FIRST ? blockIdx.x : blockIdx.x + 1)) * 32 + (tid ? 16 : 0);
         for (int i = 0; i + 1 < nts; ++i) o[i] = ts3[i + 1] - ts3[i];
         o[nts - 1] = wall_clock64() - ts3[nts - 1];
     }
@@ -496,10 +496,14 @@ extern "C" int alive_filter_block64_range(const float* U, int N, int L, const vo
     }
     const float ratio = (float)film_ld / (float)L;       // == window frames / window samples at this rate
     const int tiles = cdiv(L, TT);
-    // the first tile of every window reflects at t = 0 (per-lane fragment addresses): an instantiation and a launch of its own
-    filter_block64_kernel<true><<<dim3(1, N), 256, LDS_BYTES, (hipStream_t)stream>>>(U, L, (const unsigned short*)W16, biases, film, film_rows,
-                                                                                   Lf, film_off, ratio, t0, f0, film_ld, skip, out, g_stamps64);
-    if (tiles > 1)
+    // The first tile of every window reflects at t = 0 (per-lane fragment addresses): an instantiation and a launch of its own.  Its
+    // address form is valid for every tile (no reflection happens further right, rows left of the image fall into the guard), only
+    // slower -- so a problem that does not fill the chip anyway (the streaming ring: 4 tiles) runs ALL its tiles in that one launch
+    // instead of two dependent ones.
+    const bool small = (int64_t)tiles * N <= 256;
+    filter_block64_kernel<true><<<dim3(small ? tiles : 1, N), 256, LDS_BYTES, (hipStream_t)stream>>>(
+        U, L, (const unsigned short*)W16, biases, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld, skip, out, g_stamps64);
+    if (tiles > 1 && !small)
         filter_block64_kernel<false><<<dim3(tiles - 1, N), 256, LDS_BYTES, (hipStream_t)stream>>>(
             U, L, (const unsigned short*)W16, biases, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld, skip, out, g_stamps64);
     ALIVE_CHECK_LAUNCH("alive_filter_block64");

@@ -94,7 +94,7 @@ def main(argv=None):
     print(f"library holds {tgt.shape[2]} vectors")
     conv = Converter(CE, PE, Dec, device).set_library(tgt)
 
-    paths = sorted(glob.glob(os.path.join(args.inputs, "*")))
+    paths = glob.glob(os.path.join(args.inputs, "*"))        # the reference's enumeration (inference.py:86): its order decides the {i}_ prefix of the outputs
     for i, path in enumerate(paths):
         wf, sr = audio_io.load(path)
         wf = audio_io.resample(wf.to(device), sr, 16000)

@@ -213,6 +213,7 @@ def main():
     ap.add_argument("--window-batch", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-oracle leg (0 = skip)")
     ap.add_argument("--legs", default="all", help="comma list of secondary legs (N = 1): " + ",".join(ALL_LEGS) + " | all | none")
+    ap.add_argument("--no-nets-roofline", action="store_true", help="skip the separate timed passes of the networks (profiling runs: keeps the kernel trace to the steps)")
     ap.add_argument("--stream-steps", type=int, default=1000, help="steps of the streaming leg (BASELINE config 5)")
     ap.add_argument("--no-shard-library", action="store_true", help="skip the library-sharded leg (config 4) of a multi-GPU run")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -309,18 +310,63 @@ def main():
     # ---- roofline of the scoring kernel ----
     ms, flops, launches = timer.totals()
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    traffic = None
     fp8 = library.prefilter == "fp8"
     peak = PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS
-    pmc = os.path.join(ROOT, "profiles", "knn_score8_pmc.json" if fp8 else "knn_score_pmc.json")
+    # `traffic` (HBM bytes per launch from PMC counters) cannot be collected inside this run -- counters need rocprofv3 around the
+    # process -- so it is null here; what the committed profile of the same kernel on the same shape measured is reported beside it
+    # under a name of its own, with the file it comes from
+    traffic_profiled = None
+    pmc_name = "knn_score8_pmc.json" if fp8 else "knn_score_pmc.json"
+    pmc = os.path.join(ROOT, "profiles", pmc_name)
     if os.path.exists(pmc):
-        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        pj = json.load(open(pmc))
+        traffic_profiled = {"hbm_bytes_per_launch": pj.get("hbm_bytes_per_launch"), "algorithmic_bytes_per_launch": pj.get("algorithmic_bytes_per_launch"),
+                            "source": "profiles/" + pmc_name + " (rocprofv3 --pmc passes of tools/pmc_knn8.sh, not this run)"}
     roofline = {"kernel": "knn_score8_kernel" if fp8 else "knn_score_kernel", "bound": "mfma", "achieved": round(achieved, 1),
-                "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None, "traffic_profiled": traffic_profiled,
                 "mfma_dtype": "fp8 e4m3, block-scaled 32x32x64" if fp8 else "bf16 32x32x16",
                 "launches": launches, "avg_launch_ms": round(ms / max(1, launches), 3),
                 "kernel_share_of_step": round(ms * 1e-3 / dt, 3), "search_ms": round(timer.search_ms(), 2),
                 "search_tiers_last_step": stats}
+
+    # ---- roofline of the networks (the other 60 % of the step), measured live: the front end (spectrogram, f0 estimator, content
+    #      encoder) and the decoder once more over the same window batches, each family alone on the current stream between two
+    #      events.  Algorithmic FLOP per frame from SURVEY.md 8(d): DFT 3.3 + PE 4.54 + CE 14.05 MFLOP (front end, six bf16 MFMA
+    #      products per fp32-grade product: effective peak 2.5 PF / 6) and fe 18.12 + ho 0.07 + filter 78.40 MFLOP (decoder, three
+    #      products per product: 2.5 PF / 3).  The step-level fraction prices the whole step against those three peaks.
+    def nets_roofline():
+        wb = args.window_batch
+        feat = torch.empty(n_win, 768, L // FRAME, device=dev)
+        f0 = torch.empty(n_win, 1, L // FRAME, device=dev)
+        wav = torch.empty(n_win, L, device=dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        def run():
+            ev[0].record()
+            for i in range(0, n_win, wb):
+                conv.features(windows[i:i + wb], out=(feat[i:i + wb], f0[i:i + wb]))
+            ev[1].record()
+            for i in range(0, n_win, wb):
+                conv.dec(feat[i:i + wb], f0[i:i + wb], out=wav[i:i + wb])
+            ev[2].record()
+            torch.cuda.synchronize()
+            return ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+        run()
+        t = [run() for _ in range(2)]
+        ms_enc, ms_dec = min(x[0] for x in t), min(x[1] for x in t)
+        fl_enc = (3.3 + 4.54 + 14.05) * 1e6 * frames_per_step
+        fl_dec = (18.12 + 0.07 + 78.40) * 1e6 * frames_per_step
+        pk_enc, pk_dec = PEAK_BF16_TFLOPS / 6, PEAK_BF16_TFLOPS / 3
+        fl_knn = 2.0 * 768 * M * frames_per_step
+        ideal_ms = (fl_knn / (peak * 1e12) + fl_dec / (pk_dec * 1e12) + fl_enc / (pk_enc * 1e12)) * 1e3
+        fam = lambda ms_, fl, pk, what: {"what": what, "ms_per_step": round(ms_, 2), "algorithmic_tflop": round(fl / 1e12, 2),
+                                         "achieved": round(fl / (ms_ * 1e-3) / 1e12, 1), "peak": round(pk, 1), "unit": "TFLOP/s",
+                                         "frac": round(fl / (ms_ * 1e-3) / 1e12 / pk, 4)}
+        return {"bound": "mfma", "timing": "HIP events on the launching stream, each family alone, one stream (the step overlaps window batches on side streams)",
+                "front_end": fam(ms_enc, fl_enc, pk_enc, "spectrogram (DFT as a GEMM) + F0Estimator + ContentEncoder: 3-plane split bf16, 6 MFMAs per product"),
+                "decoder": fam(ms_dec, fl_dec, pk_dec, "FeatureExtractor + HarmonicOscillator + Filter: 2-plane split bf16, 3 MFMAs per product (f32 MFMA at C <= 16)"),
+                "step": {"ideal_ms": round(ideal_ms, 1), "ms_per_step": round(dt / args.steps * 1e3, 2), "frac": round(ideal_ms / (dt / args.steps * 1e3), 4),
+                         "ideal": "kNN 2*768*M*T FLOP at the candidate stage's MFMA peak + decoder at 2.5 PF / 3 + front end at 2.5 PF / 6"}}
+    roofline_nets = guarded(nets_roofline) if rank == 0 and not args.no_nets_roofline else None
 
     extra = {}
     # Data dependence of the scoring kernel: the candidate-list path is taken more often when the frames of a wave
@@ -583,6 +629,7 @@ def main():
             "useful_frames_per_s": round(world * useful_frames * args.steps / dt, 1),
             "rtf": round((dt / args.steps) / audio_s, 6),
             "roofline": roofline,
+            "roofline_nets": roofline_nets,
             "cpu_baseline": cpu,
         }
         if dist_on:

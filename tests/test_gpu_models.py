@@ -251,3 +251,45 @@ def test_network_entry_points_stay_inside_their_workspaces(nets, n, t):
     assert intact(ws, need), "decoder wrote behind its workspace"
     assert bool((wave[n * t * 320:] == 7.0).all() and (phi[n * 64:] == 7.0).all())
     assert torch.isfinite(wave[:n * t * 320]).all()
+
+
+def test_f0_estimator_forward_returns_the_reference_logits(nets):
+    """F0Estimator.forward (/root/reference/module/f0_estimator.py:22-27): class logits [N, 4096, T], layer by layer through the
+    op-level C ABI; their argmax is what the fused `estimate` returns"""
+    _, pe, _, cpu = nets
+    spec = O.spectrogram(synthetic.make_waveform(320 * 24, 50 + 24))
+    lg = pe(spec.to(DEV))
+    ref = O.f0_logits(cpu[1], spec)
+    assert lg.shape == ref.shape == (1, 4096, 24)
+    assert rms(lg, ref) < 1e-5 * max(1.0, ref.pow(2).mean().sqrt().item())
+    top2 = ref.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-4
+    assert torch.equal(lg.argmax(1).cpu()[safe], ref.argmax(1)[safe])
+    assert torch.equal(pe.estimate(spec.to(DEV))[:, 0].cpu()[safe], ref.argmax(1).float()[safe])
+
+
+@pytest.mark.parametrize("sizes", [(1280, 64, 96, 48, 2), (1280, 96, 160, 200, 3)])
+def test_encoders_with_non_default_sizes_run_the_generic_path(sizes):
+    """the reference's constructors take sizes (content_encoder.py:9-14, f0_estimator.py:9-14): anything but the defaults runs layer
+    by layer through alive_conv1d / alive_dwconv_norm / alive_channel_norm and matches the oracle on the same state_dict"""
+    from module.content_encoder import ContentEncoder
+    from module.f0_estimator import F0Estimator
+    n_fft, c, hdim, out, layers = sizes
+    spec = O.spectrogram(synthetic.make_waveform(320 * 40, 7))
+    ce = ContentEncoder(n_fft, c, hdim, out, layers, seed=5).to(DEV)
+    assert ce.generic and set(ce.state_dict()) == set(schema.content_encoder_schema(c, hdim, out, layers))
+    sd = {k: v.cpu() for k, v in ce.state_dict().items()}
+    ref = O.content_encoder(sd, spec)
+    got = ce(spec.to(DEV))
+    assert got.shape == ref.shape == (1, out, 40)
+    assert rms(got, ref) < 2e-5 * max(1.0, ref.pow(2).mean().sqrt().item()), rms(got, ref)
+    pe = F0Estimator(n_fft, c, hdim, out, layers, seed=6).to(DEV)
+    sd = {k: v.cpu() for k, v in pe.state_dict().items()}
+    ref = O.f0_logits(sd, spec)
+    lg = pe(spec.to(DEV))
+    assert rms(lg, ref) < 2e-5 * max(1.0, ref.pow(2).mean().sqrt().item())
+    top2 = ref.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-4
+    assert torch.equal(pe.estimate(spec.to(DEV))[:, 0].cpu()[safe], ref.argmax(1).float()[safe])
+    with pytest.raises(RuntimeError):
+        ContentEncoder(n_fft, c, hdim, out, layers, seed=5)(spec)          # no CPU path

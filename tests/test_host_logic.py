@@ -118,8 +118,13 @@ def test_cli_flags_match_the_reference():
     assert (d["inputs"], d["outputs"], d["decoder_path"], d["chunk"], d["k"], d["gain"], d["alpha"], d["f0_rate"],
             d["intonation"], d["pitch"], d["voice_library_path"], d["target"]) == \
         ("./inputs/", "./outputs/", "decoder.pt", 48000, 4, 1.0, 0.0, 1.0, 1.0, 0, "NONE", "NONE")
+    # -d / --device: the reference defaults to "cpu" (inference.py:31, realtime_inference.py:23-24).  This package has no CPU path by
+    # contract (a missing GPU raises instead of falling back), so its documented deviation is the default "cuda" -- the flag, its
+    # long name and its choices are the reference's
+    assert d["device"] == "cuda" and "-d" in inf._option_string_actions and "--device" in inf._option_string_actions
     rt = importlib.import_module("realtime_inference").build_parser()
     d = vars(rt.parse_args([]))
+    assert d["device"] == "cuda" and set(rt._option_string_actions["-d"].choices) == {"cpu", "cuda", "mps"}
     assert (d["buffersize"], d["chunk"], d["input_sr"], d["output_sr"], d["gain"], d["k"]) == (8, 960, 16000, 16000, 0.0, 4)
     for flag in ("-dep", "-cep", "-f0ep", "-f0", "-p", "-t", "-a", "-lib", "-wpe", "-isr", "-osr", "-lsr", "-ic", "-oc", "-lc",
                  "-ig", "-b", "-c", "-l", "-fp16"):
