@@ -70,6 +70,8 @@ class RealtimeConverter:
         self.phi = 0
         self._graph = None
         self.last_f0 = None
+        self._side = None                  # side stream of the f0 estimator (see _f0_on_side_stream)
+        self._f0_bufs = {}
         # interior reuse: only where it is exact -- no resampling in front (the ring IS the 16 kHz signal), a shift of whole
         # frames, and a ring long enough that the two recomputed edge blocks do not meet.  "auto": on when that holds.
         self.frames, self.shift = frames, chunk // 320
@@ -93,24 +95,45 @@ class RealtimeConverter:
             return self._device_step_reuse(data, phi)
         data = audio_io.resample(data, self.input_sr, 16000, post_gain_db=self.input_gain)     # resample, then gain (:146-147)
         spec = spectrogram(data)
+        f0, join = self._f0_on_side_stream(spec)
         content = self.ce(spec)
-        f0 = self.pe.estimate(spec)
-        f0 = ops.pitch_transform_(f0, 1, f0_rate=self.f0_rate, pitch_shift=self.pitch)
         val, idx = self.lib.search(content, self.k)
         content = merge_gather(val, idx, 1, self.k, self.alpha, self.lib.rows, content)
+        join()
         wave, phi_out = self.dec(content, f0=f0, phi=phi, crop=(self.begin_of_output, self.end_of_output))
         self.last_f0 = f0
         wave = audio_io.resample(wave, 16000, self.output_sr, pre_gain_db=self.gain)[0]         # gain, then resample (:173-175)
         return wave, phi_out[:, :, self.end_of_output]
 
+    def _f0_on_side_stream(self, spec):
+        """The f0 estimator (+ the pitch transform) needs nothing but the spectrogram and feeds nothing before the decoder: its ~35
+        dependent launches run on a side stream beside the content encoder and the match (a step is a chain of ~150 small kernels,
+        bound by their latencies, not by the chip).  Returns (f0, join): the f0 tensor -- a persistent buffer per shape, so that no
+        allocation happens on the side stream (hipGraph capture, caching allocator) -- and the call that makes the current stream
+        wait for it.  Same kernels, same results; captured into the step's hipGraph as a parallel branch."""
+        cur = torch.cuda.current_stream(spec.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=spec.device)
+        key = (spec.shape[0], spec.shape[2])
+        buf = self._f0_bufs.get(key)
+        if buf is None:
+            buf = self._f0_bufs[key] = torch.empty(spec.shape[0], 1, spec.shape[2], device=spec.device)
+        side = self._side
+        side.wait_stream(cur)                                   # the spectrogram is complete
+        with torch.cuda.stream(side):
+            f0 = self.pe.estimate(spec, out=buf)
+            f0 = ops.pitch_transform_(f0, 1, f0_rate=self.f0_rate, pitch_shift=self.pitch)
+        return f0, (lambda: cur.wait_stream(side))
+
     def _front_end(self, data):
         """16 kHz ring [1, n] -> (matched content [1, 768, F], transformed f0 [1, 1, F]) for every frame"""
         spec = spectrogram(data)
+        f0, join = self._f0_on_side_stream(spec)
         content = self.ce(spec)
-        f0 = self.pe.estimate(spec)
-        f0 = ops.pitch_transform_(f0, 1, f0_rate=self.f0_rate, pitch_shift=self.pitch)
         val, idx = self.lib.search(content, self.k)
-        return merge_gather(val, idx, 1, self.k, self.alpha, self.lib.rows, content), f0
+        out = merge_gather(val, idx, 1, self.k, self.alpha, self.lib.rows, content)
+        join()
+        return out, f0
 
     def _device_step_reuse(self, data, phi):
         """the same step with the front end computed for the two edge blocks only; interior frames come from the previous
@@ -148,12 +171,12 @@ class RealtimeConverter:
         if self._rows > 1:                                  # identical rows: same kernels as the full ring (see the header)
             samples = samples.expand(self._rows, -1).contiguous()
         spec = spectrogram(samples)[:, :, f_lo:f_hi].contiguous()
+        f0, join = self._f0_on_side_stream(spec)
         content = self.ce(spec)
-        f0 = self.pe.estimate(spec)
-        f0 = ops.pitch_transform_(f0, 1, f0_rate=self.f0_rate, pitch_shift=self.pitch)
         val, idx = self.lib.search(content, self.k)
         out = merge_gather(val, idx, 1, self.k, self.alpha, self.lib.rows, content)
-        return out[:1], f0[:1]
+        join()
+        return out[:1], f0[:1].clone()                   # (f0 lives in a per-shape buffer the next slice overwrites)
 
     def enable_graph(self):
         """Capture the whole per-step device pipeline (~150 launches) into one hipGraph: the C ABI never allocates or
