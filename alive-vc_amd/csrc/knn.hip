@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
                                                            int tiles_per_split, int P, float* __restrict__ cand_val,
                                                            int* __restrict__ cand_idx, const int* __restrict__ gate_cnt,
                                                            int gate_lo, int gate_hi, int by_count, const float* __restrict__ thr_in,
-                                                           SeedArgs sa) {
+                                                           SeedArgs sa, int caps) {
     int n_slots = 0x7fffffff;
     {
         int c;
@@ -393,10 +393,23 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
             seed[ni] = t == t ? t : -INFINITY;
         }
     }
+    // COLLECT (round 4): collected rows go straight to the block's own segment of the candidate arrays, cand[slot][split][caps],
+    // through one LDS counter per frame (the two half-waves of a frame column share it): `caps` (64) rows per frame and library
+    // split instead of 8 per half-list, so a cluster of a few dozen near-copies still fits and only more than that overflows
+    int* cntF = (int*)Lv;                      // [FT] (the list area is not used by the collect form)
+    if (COLLECT) {
+        cntF[tid] = 0;
+        for (int e = tid; e < FT * caps; e += 256) {
+            const size_t o = ((size_t)(frame0 + e / caps) * P + split) * caps + e % caps;
+            cand_val[o] = -INFINITY;
+            cand_idx[o] = -1;
+        }
+    } else {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int q = 0; q < KH; ++q) { Lv[q * 512 + w * 128 + ni * 64 + lane] = seed[ni]; Li[q * 512 + w * 128 + ni * 64 + lane] = -1; }
+            for (int q = 0; q < KH; ++q) { Lv[q * 512 + w * 128 + ni * 64 + lane] = seed[ni]; Li[q * 512 + w * 128 + ni * 64 + lane] = -1; }
+    }
 
     // DMA source of this lane inside a piece: row (lane>>3) of the wave's 8-row group, chunk (lane&7)^(lane>>3)
     const int dma_row = 8 * w + (lane >> 3);
@@ -427,7 +440,6 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
 
     // lane-column id = w*128 + ni*64 + lane; entry e of its list lives at [e*512 + id]
     float thr[2] = {seed[0], seed[1]};
-    int cnt[2] = {0, 0};                               // COLLECT: rows kept so far by this lane's half-list
     if (COLLECT) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
@@ -493,11 +505,13 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
 #pragma unroll
                     for (int r = 1; r < 16; ++r) rsel = (acc[r] == mx) ? r : rsel;
                     if (has) {
-                        if (cnt[ni] < KH) {
-                            Lv[(size_t)cnt[ni] * 512 + lc0 + ni * 64] = mx;
-                            Li[(size_t)cnt[ni] * 512 + lc0 + ni * 64] = (int)(row0 + (rsel & 3) + 8 * (rsel >> 2) + 4 * lh);
+                        const int fcol = 64 * w + 32 * ni + lr;
+                        const int pos = atomicAdd(&cntF[fcol], 1);
+                        if (pos < caps) {
+                            const size_t o = ((size_t)(frame0 + fcol) * P + split) * caps + pos;
+                            cand_val[o] = mx;
+                            cand_idx[o] = (int)(row0 + (rsel & 3) + 8 * (rsel >> 2) + 4 * lh);
                         }
-                        ++cnt[ni];
                     }
                     float nmx = -INFINITY;
 #pragma unroll
@@ -547,11 +561,9 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
         __syncthreads();                               // next tile landed (vmcnt(0)), this buffer free for tile+2
     }
 
-    if (COLLECT) {                                     // a half-list that met more than 8 rows above the threshold: overflow mark
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-            if (cnt[ni] > KH) Li[lc0 + ni * 64] = -2;
-        __syncthreads();
+    if (COLLECT) {                                     // more rows above a frame's threshold than its segment holds: overflow mark
+        if (cntF[tid] > caps) cand_idx[((size_t)(frame0 + tid) * P + split) * caps] = -2;
+        return;
     }
     // ---- write this block's lists: cand[frame][P][KP]; entries 0..7 from the lower half-wave, 8..15 from the upper ----
     for (int e = tid; e < FT * KP; e += 256) {
@@ -562,6 +574,205 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
         cand_idx[o] = Li[(k % KH) * 512 + lc];
     }
     if (!COLLECT && sa.tau != nullptr) seeds_publish<KH>(sa, Lv, Li, frame0, split, seeded);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Round 4: the split-bf16 collect tier of the STRICT search (alive_knn_search_strict with a lo-plane library)
+// ----------------------------------------------------------------------------------------------
+// The strict search certifies a frame with a deterministic bound on |bf16 stage score - exact cosine| (~1.8e-3: Cauchy-Schwarz
+// on two rounding-error vectors, 20 x the real error), and on a dense library that bound is wider than the neighbour gaps: 74 000
+// of 172 800 frames failed it, 70 000 of them overflowed the collect tier (more rows inside the band than its lists hold) and
+// went through the VALU exact scan -- 3.65 s per search.  This tier puts an MFMA pass with a TIGHT deterministic bound in front
+// of that scan: both operands as two bf16 planes (hi = bf16(v), lo = bf16(v - hi)), score = q_hi.r_hi + q_lo.r_hi + q_hi.r_lo,
+//   |score - q^.r^| <= ||q^ - q_hi - q_lo|| + ||r^ - r_hi - r_lo|| + ||q_lo|| ||r_lo|| + fp32 accumulation of 3 x 768 products
+//                  <= 2^-18 + 2^-18 + 2^-18 (1 + 2^-8) + 2304 * 2^-24 * 1.01                  = 1.5e-4,
+// plus the rounding of the rescoring arithmetic itself (< 1e-5): SPLIT_BOUND = 1.7e-4, a tenth of the single-plane bound.  Every
+// row whose split score reaches v_k - SPLIT_BOUND (v_k: the frame's k-th exact cosine so far, a lower bound of the true one) is
+// collected and rescored exactly together with the frame's current top-k; only frames with more such rows than the lists hold
+// (genuine near-ties: clusters of near-copies) go on to the exact scan.
+// Structure of knn_score_kernel<true>, re-cut for two planes: a wave keeps 32 frames x 2 planes stationary (the same 384
+// registers), a library tile is streamed as TWO LDS tiles -- its hi rows (two MFMAs per k-step: q_hi, q_lo) while the lo rows
+// travel into the other buffer, then its lo rows (one MFMA per k-step: q_hi) while the next tile's hi rows travel.
+constexpr int FT2 = 128;                                // frames per block
+constexpr int SPLIT_LDS = 2 * ABUF + FT2 * 4;           // two tile buffers + one counter per frame
+constexpr int SPLIT_ROWS = 256;                         // candidate entries per frame a bulk collect launch may fill (ws_layout: rows_b)
+constexpr float SPLIT_BOUND = 1.7e-4f;
+
+// lib_lo[m][d] = bf16(r^ - bf16(r^)), r^ = rows[m][d] / norms[m] exactly as lib_pack_kernel forms it; zero rows up to M_pad
+__global__ __launch_bounds__(256) void lib_lo_kernel(const unsigned short* __restrict__ lib, const float* __restrict__ rows,
+                                                     const float* __restrict__ norms, int64_t M, int64_t M_pad,
+                                                     unsigned short* __restrict__ lo) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M_pad * D) return;
+    const int64_t m = i / D;
+    unsigned short v = 0;
+    if (m < M) {
+        const float q = rows[i] / norms[m];
+        v = f32_to_bf16_rn(q - __uint_as_float((unsigned)lib[i] << 16));
+    }
+    lo[i] = v;
+}
+
+// compacts both planes of the flagged frames: hi[slot] = s_bf16[list[slot]], lo[slot] = bf16(s_f32 - hi); zero rows up to the next 128
+__global__ __launch_bounds__(128) void gather_frames_split_kernel(const unsigned short* __restrict__ s_bf16, const float* __restrict__ s_f32,
+                                                                  const int* __restrict__ list, const int* __restrict__ cnt, int gate_lo,
+                                                                  unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+    const int c = *cnt;
+    const int slot = blockIdx.x;
+    if (c <= gate_lo || slot >= (c + FT2 - 1) / FT2 * FT2) return;
+    if (threadIdx.x >= 96) return;
+    u32x4 h = {0u, 0u, 0u, 0u}, l = {0u, 0u, 0u, 0u};
+    if (slot < c) {
+        const size_t ft = (size_t)list[slot];
+        h = ((const u32x4*)(s_bf16 + ft * D))[threadIdx.x];
+        const f32x4* qp = (const f32x4*)(s_f32 + ft * D) + 2 * threadIdx.x;
+        const f32x4 q0 = qp[0], q1 = qp[1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = (e < 2 ? q0[2 * e] : q1[2 * e - 4]) - __uint_as_float(h[e] << 16);
+            const float b = (e < 2 ? q0[2 * e + 1] : q1[2 * e - 3]) - __uint_as_float(h[e] & 0xffff0000u);
+            l[e] = (unsigned)f32_to_bf16_rn(a) | ((unsigned)f32_to_bf16_rn(b) << 16);
+        }
+    }
+    ((u32x4*)(hi + (size_t)slot * D))[threadIdx.x] = h;
+    ((u32x4*)(lo + (size_t)slot * D))[threadIdx.x] = l;
+}
+
+__global__ __launch_bounds__(256, 1) void knn_collect_split_kernel(const unsigned short* __restrict__ s_hi, const unsigned short* __restrict__ s_lo,
+                                                                   const unsigned short* __restrict__ lib_hi,
+                                                                   const unsigned short* __restrict__ lib_lo, int64_t M, int tiles_total,
+                                                                   int tiles_per_split, int P, int caps, float* __restrict__ cand_val,
+                                                                   int* __restrict__ cand_idx, const int* __restrict__ cnt_ptr, int gate_lo,
+                                                                   const float* __restrict__ thr_in) {
+    const int n_slots = *cnt_ptr;
+    if (n_slots <= gate_lo || (int64_t)blockIdx.x * FT2 >= n_slots) return;           // block-uniform
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // collected rows go straight to the block's own segment of the candidate arrays, cand[slot][split][caps], through one LDS
+    // counter per frame (the two half-waves of a frame column share it): a list of `caps` (64) rows per frame and library split
+    // instead of 8 per half-list, so a cluster of a few dozen near-copies still fits and only more than that reaches the exact scan
+    int* cntF = (int*)(smem + 2 * ABUF);       // [FT2]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int64_t frame0 = (int64_t)blockIdx.x * FT2;
+    const int split = blockIdx.y;
+    const int tile_begin = split * tiles_per_split;
+    int tile_end = tile_begin + tiles_per_split;
+    if (tile_end > tiles_total) tile_end = tiles_total;
+    if (tid < FT2) cntF[tid] = 0;
+    for (int e = tid; e < FT2 * caps; e += 256) {      // empty entries of this block's segment
+        const size_t o = ((size_t)(frame0 + e / caps) * P + split) * caps + e % caps;
+        cand_val[o] = -INFINITY;
+        cand_idx[o] = -1;
+    }
+
+    const int dma_row = 8 * w + (lane >> 3);
+    const int dma_chunk = (lane & 7) ^ (lane >> 3);
+    auto dma_src = [&](const unsigned short* lib, int tile) { return lib + ((size_t)tile * LT + dma_row) * D + dma_chunk * 8; };
+    if (tile_begin < tile_end) {
+        const unsigned short* g = dma_src(lib_hi, tile_begin);
+        unsigned char* l = smem + w * PIECE;
+#pragma unroll
+        for (int sg = 0; sg < D / 64; ++sg)
+            __builtin_amdgcn_global_load_lds((gptr_t)(g + sg * 64), (lptr_t)(l + sg * 4 * PIECE), 16, 0, 0);
+    }
+    // stationary B fragments, both planes: frame = frame0 + 32 w + lr, k = 16 ks + 8 lh .. +7
+    bf16x8 bq[2][NK16];
+    {
+        const size_t fo = (size_t)(frame0 + 32 * w + lr) * D + 8 * lh;
+#pragma unroll
+        for (int ks = 0; ks < NK16; ++ks) {
+            bq[0][ks] = *(const bf16x8*)(s_hi + fo + 16 * ks);
+            bq[1][ks] = *(const bf16x8*)(s_lo + fo + 16 * ks);
+        }
+    }
+    const int rr = lr & 7;
+    int a_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_off[j] = (lr >> 3) * PIECE + rr * 128 + ((((j * 2 + lh) ^ rr)) << 4);
+    const int64_t slot = frame0 + 32 * w + lr;
+    const float thr = slot < n_slots ? thr_in[slot] : INFINITY;        // padding slots collect nothing
+    const size_t seg = ((size_t)slot * P + split) * caps;
+    __syncthreads();                                   // segment and counters initialised, the first hi tile landed (vmcnt(0) + barrier)
+
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const int next_tile = tile + 1 < tile_end ? tile + 1 : tile;       // last tile: the same rows once more into the idle buffer
+        constexpr int PD = 4;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        // ---- phase 0: the tile's hi rows (buffer 0) against both frame planes; its lo rows travel into buffer 1 ----
+        {
+            const unsigned short* gnext = dma_src(lib_lo, tile);
+            unsigned char* lnext = smem + ABUF + w * PIECE;
+            const unsigned char* Ab = smem;
+            bf16x8 a[PD + 1];
+#pragma unroll
+            for (int i = 0; i < PD; ++i) a[i] = *(const bf16x8*)(Ab + a_off[i & 3] + (i >> 2) * 4 * PIECE);
+#pragma unroll
+            for (int ks = 0; ks < NK16; ++ks) {
+                if (ks + PD < NK16) a[(ks + PD) % (PD + 1)] = *(const bf16x8*)(Ab + a_off[(ks + PD) & 3] + ((ks + PD) >> 2) * 4 * PIECE);
+                if ((ks & 3) == 1)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(gnext + (ks >> 2) * 64), (lptr_t)(lnext + (ks >> 2) * 4 * PIECE), 16, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % (PD + 1)], bq[1][ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % (PD + 1)], bq[0][ks], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();                               // lo rows landed (vmcnt(0)), buffer 0 free
+        // ---- phase 1: the tile's lo rows (buffer 1) against the frames' hi plane; the next tile's hi rows travel into buffer 0 ----
+        {
+            const unsigned short* gnext = dma_src(lib_hi, next_tile);
+            unsigned char* lnext = smem + w * PIECE;
+            const unsigned char* Ab = smem + ABUF;
+            bf16x8 a[PD + 1];
+#pragma unroll
+            for (int i = 0; i < PD; ++i) a[i] = *(const bf16x8*)(Ab + a_off[i & 3] + (i >> 2) * 4 * PIECE);
+#pragma unroll
+            for (int ks = 0; ks < NK16; ++ks) {
+                if (ks + PD < NK16) a[(ks + PD) % (PD + 1)] = *(const bf16x8*)(Ab + a_off[(ks + PD) & 3] + ((ks + PD) >> 2) * 4 * PIECE);
+                if ((ks & 3) == 1)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(gnext + (ks >> 2) * 64), (lptr_t)(lnext + (ks >> 2) * 4 * PIECE), 16, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % (PD + 1)], bq[0][ks], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- collect: acc[r] = library row row0 + (r & 3) + 8 (r >> 2) + 4 lh, frame column 32 w + lr ----
+        const int64_t row0 = (int64_t)tile * LT;
+        const bool ragged = row0 + LT > M;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (ragged && row0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= M) acc[r] = -INFINITY;
+            mx = fmaxf(mx, acc[r]);
+        }
+        while (__builtin_amdgcn_ballot_w64(mx >= thr && mx > -INFINITY) != 0) {
+            const bool has = mx >= thr && mx > -INFINITY;
+            int rsel = 0;
+#pragma unroll
+            for (int r = 1; r < 16; ++r) rsel = (acc[r] == mx) ? r : rsel;
+            if (has) {
+                const int pos = atomicAdd(&cntF[32 * w + lr], 1);
+                if (pos < caps) {
+                    cand_val[seg + pos] = mx;
+                    cand_idx[seg + pos] = (int)(row0 + (rsel & 3) + 8 * (rsel >> 2) + 4 * lh);
+                }
+            }
+            float nmx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (has && r == rsel) acc[r] = -INFINITY;
+                nmx = fmaxf(nmx, acc[r]);
+            }
+            mx = nmx;
+        }
+        __syncthreads();                               // next hi tile landed (vmcnt(0)), buffer 1 free
+    }
+    // a frame with more rows above its threshold than its segment holds: overflow mark in the first entry (-> exact scan)
+    if (tid < FT2 && cntF[tid] > caps) cand_idx[((size_t)(frame0 + tid) * P + split) * caps] = -2;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -974,7 +1185,7 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
                                                           int* __restrict__ flag_list, int* __restrict__ flag_cnt, float zsig,
                                                           int list_len, float pre_scale, float sd_prior,
                                                           const float* __restrict__ det_q, const float* __restrict__ det_lib,
-                                                          float* __restrict__ thr_list, int collect) {
+                                                          float* __restrict__ thr_list, int collect, float overflow_slack) {
     const int lane = threadIdx.x & 63;
     const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // candidate lists are indexed by slot
     int gc;
@@ -1199,10 +1410,18 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
             // belong to its top-k: its k-th exact cosine so far minus the slack it was just tested with (stage-score units)
             const int pos = atomicAdd(flag_cnt, 1);
             flag_list[pos] = (int)ft;
-            if (thr_list != nullptr) thr_list[pos] = (vk - (bound - c_cut * pre_scale)) / pre_scale;
+            // (overflow_slack > 0: the next tier is the split-bf16 collect pass of the strict search, which collects above v_k minus
+            //  ITS bound, not above v_k minus the slack this certificate was tested with)
+            if (thr_list != nullptr) thr_list[pos] = overflow_slack > 0.0f ? vk - overflow_slack : (vk - (bound - c_cut * pre_scale)) / pre_scale;
         }
     }
-    if (collect && lane == 0 && overflow) flag_list[atomicAdd(flag_cnt, 1)] = (int)ft;
+    if (collect && lane == 0 && overflow) {
+        // the frame's lists did not hold every row above its threshold: next tier.  Its k-th exact cosine so far (exact scores of real
+        // rows: a lower bound of the true k-th) minus the next tier's slack is the threshold that tier collects above.
+        const int pos = atomicAdd(flag_cnt, 1);
+        flag_list[pos] = (int)ft;
+        if (thr_list != nullptr) thr_list[pos] = vk - overflow_slack;
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1729,6 +1948,10 @@ struct SearchWs {
     unsigned char* s_p8; float* cvp; int* cip; int* p_list;   // probe: sample rows, lists, [frame of slot | flagged frames]
     float* thr1; int* list2;               // collect tier: thresholds of the frames in list1; frames that overflowed it
     float* dq;                             // || q^ - bf16(q^) || per frame (strict certificate)
+    unsigned short* s_c2h; unsigned short* s_c2l;   // split tier (strict search): both planes of the frames that failed the deterministic certificate
+    float* c2v; int* c2i;                  // candidate lists of the collect tiers: [slot][split][caps]
+    int rows_t, rows_b;                    // rows per frame they may fill: tier-1 launches (<= fcap frames) / bulk launches
+    const unsigned short* lib_lo;          // set by the strict search when the library carries its lo plane
     float* tau; int* tau_flag;             // fp8 stage: per-frame admission seeds handed from split to split, and the hand-off flags
     const float* det_q; const float* det_lib;   // set by the strict search only: frame / library share of the deterministic bound
     size_t bytes;
@@ -1768,6 +1991,16 @@ static SearchWs ws_layout(void* base, int64_t Tt, int64_t M, int k) {
     w.thr1 = a.take<float>((size_t)Tp);
     w.list2 = a.take<int>((size_t)Tp);
     w.dq = a.take<float>((size_t)Tp);
+    w.s_c2h = a.take<unsigned short>((size_t)Tp * D);
+    w.s_c2l = a.take<unsigned short>((size_t)Tp * D);
+    // rows per frame the collect tiers may fill (the rescoring kernel takes up to 1024): 1024 for up to FCAP frames (few frames: many
+    // library splits, and a cluster must still fit one split's segment), SPLIT_ROWS for the bulk launches of a big batch
+    const size_t c2n = (size_t)(Tp < FCAP ? Tp : FCAP) * 1024 > (size_t)Tp * SPLIT_ROWS ? (size_t)(Tp < FCAP ? Tp : FCAP) * 1024 : (size_t)Tp * SPLIT_ROWS;
+    w.c2v = a.take<float>(c2n);
+    w.c2i = a.take<int>(c2n);
+    w.rows_t = (int)(c2n / (size_t)w.fcap < 1024 ? c2n / (size_t)w.fcap : 1024);
+    w.rows_b = (int)(c2n / (size_t)Tp < 1024 ? c2n / (size_t)Tp : 1024);
+    w.lib_lo = nullptr;
     w.tau = a.take<float>((size_t)Tp);
     w.tau_flag = a.take<int>((size_t)(Tp / FT) * (MAX_SPLIT > MAX_SPLIT8 ? MAX_SPLIT : MAX_SPLIT8));
     w.det_q = nullptr;
@@ -1849,9 +2082,10 @@ static int check_search_args(const char* what, const void* a, const void* b, int
 }
 
 static int lds_optin(const char* what) {
-    static LdsOptIn optin8, optin16;
+    static LdsOptIn optin8, optin16, optin_split;
     hipError_t e = optin8.ensure({(const void*)knn_score8_kernel, (const void*)knn_probe8_kernel}, SCORE8_LDS);
     if (e == hipSuccess) e = optin16.ensure({(const void*)knn_score_kernel<false>, (const void*)knn_score_kernel<true>}, SCORE_LDS);
+    if (e == hipSuccess) e = optin_split.ensure({(const void*)knn_collect_split_kernel}, SPLIT_LDS);
     if (e != hipSuccess) {
         alive_set_error("%s: cannot reserve %d B of LDS: %s", what, SCORE_LDS, hipGetErrorString(e));
         return ALIVE_ERR_LAUNCH;
@@ -1887,24 +2121,43 @@ static void collect_tier_launch(const SearchWs& w, const void* lib_bf16, const f
     int* cnt1 = w.stats + ST_FLAG16;
     int* cnt2 = w.stats + ST_FLAGC;
     const int fcap = w.fcap;
+    if (w.lib_lo != nullptr) {
+        // Strict search with a lo-plane library: the frames that failed the deterministic certificate (list1, thresholds
+        // thr1 = v_k - SPLIT_BOUND) go STRAIGHT to the split-bf16 collect pass -- on a dense library 95 % of them overflow the
+        // single-plane collect tier (its band is the certificate's 1.8e-3), which would be a wasted pass over the library -- its
+        // rows are rescored exactly, and only what overflows it (clusters of near-copies) reaches the exact scan.
+        const unsigned Tp = (unsigned)w.p16.Tt_pad;
+        knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, w.list1, cnt1, out_val, out_idx, s, COLLECT_MIN);
+        gather_frames_split_kernel<<<Tp, 128, 0, s>>>(w.s_bf16, w.s_f32, w.list1, cnt1, COLLECT_MIN, w.s_c2h, w.s_c2l);
+        const int caps = w.rows_b / w.p16.P < 64 ? w.rows_b / w.p16.P : 64;              // P <= MAX_SPLIT = 64: at least 4
+        knn_collect_split_kernel<<<dim3(Tp / FT2, w.p16.split), 256, SPLIT_LDS, s>>>(
+            w.s_c2h, w.s_c2l, (const unsigned short*)lib_bf16, w.lib_lo, M, w.p16.tiles_total, w.p16.tiles_per_split, w.p16.P, caps,
+            w.c2v, w.c2i, cnt1, COLLECT_MIN, w.thr1);
+        knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.c2v, w.c2i, w.p16.P, caps, w.s_f32, rows_f32, norms, Tt, idx_base, k,
+                                                                   out_val, out_idx, w.list1, cnt1, COLLECT_MIN, 0x7fffffff, w.list2, cnt2,
+                                                                   CERT_Z, KH, 1.0f, SD_PRIOR16, nullptr, nullptr, nullptr, 1, 0.0f);
+        knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, w.list2, cnt2, out_val, out_idx, s);
+        return;
+    }
     // a handful of frames: the exact scan costs less than the fixed cost of one more scoring pass over the library (~8 ms at 1 M
     // rows against ~20 us per frame of exact scan)
+    const int caps_t = w.rows_t / w.pt.P < 64 ? w.rows_t / w.pt.P : 64, caps_b = w.rows_b / w.p16.P < 64 ? w.rows_b / w.p16.P : 64;
     knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, w.list1, cnt1, out_val, out_idx, s, COLLECT_MIN);
     gather_frames_kernel<<<(unsigned)fcap, 128, 0, s>>>(w.s_bf16, w.list1, cnt1, COLLECT_MIN, fcap, w.s_c);
     knn_score_kernel<true><<<dim3((unsigned)(fcap / FT), w.pt.split), 256, SCORE_LDS, s>>>(
-        w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.cv1, w.ci1, cnt1, COLLECT_MIN, fcap, 1,
-        w.thr1, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr});
-    knn_rescore_kernel<<<(unsigned)((fcap + 3) / 4), 256, 0, s>>>(w.cv1, w.ci1, w.pt.P, KP, w.s_f32, rows_f32, norms, fcap, idx_base, k,
+        w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.c2v, w.c2i, cnt1, COLLECT_MIN, fcap, 1,
+        w.thr1, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr}, caps_t);
+    knn_rescore_kernel<<<(unsigned)((fcap + 3) / 4), 256, 0, s>>>(w.c2v, w.c2i, w.pt.P, caps_t, w.s_f32, rows_f32, norms, fcap, idx_base, k,
                                                                  out_val, out_idx, w.list1, cnt1, COLLECT_MIN, fcap, w.list2, cnt2, CERT_Z,
-                                                                 KH, 1.0f, SD_PRIOR16, nullptr, nullptr, nullptr, 1);
+                                                                 KH, 1.0f, SD_PRIOR16, nullptr, nullptr, nullptr, 1, 0.0f);
     if (w.p16.Tt_pad > fcap) {
         gather_frames_kernel<<<(unsigned)w.p16.Tt_pad, 128, 0, s>>>(w.s_bf16, w.list1, cnt1, fcap, 0x7fffffff, w.s_c);
         knn_score_kernel<true><<<dim3((unsigned)(w.p16.Tt_pad / FT), w.p16.split), 256, SCORE_LDS, s>>>(
-            w.s_c, (const unsigned short*)lib_bf16, M, w.p16.tiles_total, w.p16.tiles_per_split, w.p16.P, w.cv, w.ci, cnt1, fcap,
-            0x7fffffff, 1, w.thr1, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr});
-        knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, w.p16.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
+            w.s_c, (const unsigned short*)lib_bf16, M, w.p16.tiles_total, w.p16.tiles_per_split, w.p16.P, w.c2v, w.c2i, cnt1, fcap,
+            0x7fffffff, 1, w.thr1, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr}, caps_b);
+        knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.c2v, w.c2i, w.p16.P, caps_b, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                    out_val, out_idx, w.list1, cnt1, fcap, 0x7fffffff, w.list2, cnt2,
-                                                                   CERT_Z, KH, 1.0f, SD_PRIOR16, nullptr, nullptr, nullptr, 1);
+                                                                   CERT_Z, KH, 1.0f, SD_PRIOR16, nullptr, nullptr, nullptr, 1, 0.0f);
     }
     knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, w.list2, cnt2, out_val, out_idx, s);
 }
@@ -1922,9 +2175,9 @@ static void bf16_tiers_launch(const SearchWs& w, const void* lib_bf16, const flo
     knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, w.list0, cnt0, out_val, out_idx, s, RESEARCH_MIN);
     gather_frames_kernel<<<(unsigned)fcap, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, RESEARCH_MIN, fcap, w.s_c);
     knn_score_kernel<false><<<dim3((unsigned)(fcap / FT), w.pt.split), 256, SCORE_LDS, s>>>(
-        w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.cv1, w.ci1, cnt0, RESEARCH_MIN, fcap, 1, nullptr, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr});
+        w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.cv1, w.ci1, cnt0, RESEARCH_MIN, fcap, 1, nullptr, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr}, 0);
     knn_rescore_kernel<<<(unsigned)((fcap + 3) / 4), 256, 0, s>>>(w.cv1, w.ci1, w.pt.P, KP, w.s_f32, rows_f32, norms, fcap, idx_base, k,
-                                                                 out_val, out_idx, w.list0, cnt0, RESEARCH_MIN, fcap, w.list1, cnt1, CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0);
+                                                                 out_val, out_idx, w.list0, cnt0, RESEARCH_MIN, fcap, w.list1, cnt1, CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0, w.lib_lo != nullptr ? SPLIT_BOUND : 0.0f);
     if (w.p16.Tt_pad > fcap) {
         gather_frames_kernel<<<(unsigned)w.p16.Tt_pad, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, fcap, 0x7fffffff, w.s_c);
         // (the frames are compacted: a block's 256 slots are the same in every split, so the seeds are indexed by slot)
@@ -1932,10 +2185,10 @@ static void bf16_tiers_launch(const SearchWs& w, const void* lib_bf16, const flo
                                       ST_SEEDED16, s);
         knn_score_kernel<false><<<dim3((unsigned)(w.p16.Tt_pad / FT), w.p16.split), 256, SCORE_LDS, s>>>(
             w.s_c, (const unsigned short*)lib_bf16, M, w.p16.tiles_total, w.p16.tiles_per_split, w.p16.P, w.cv, w.ci, cnt0, fcap,
-            0x7fffffff, 1, nullptr, sa);
+            0x7fffffff, 1, nullptr, sa, 0);
         knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, w.p16.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                    out_val, out_idx, w.list0, cnt0, fcap, 0x7fffffff, w.list1, cnt1,
-                                                                   CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0);
+                                                                   CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0, w.lib_lo != nullptr ? SPLIT_BOUND : 0.0f);
     }
     collect_tier_launch(w, lib_bf16, rows_f32, norms, M, Tt, idx_base, k, out_val, out_idx, s);
 }
@@ -1945,7 +2198,8 @@ static void bf16_tiers_launch(const SearchWs& w, const void* lib_bf16, const flo
 // half-list of the candidate stage): the exact scan for every frame.
 static int knn_search_impl(const float* src, int N, int T, const void* lib_bf16, const float* rows_f32,
                            const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
-                           void* ws, void* stream, hipEvent_t g_ev_start, hipEvent_t g_ev_stop, const float* strict_bound = nullptr) {
+                           void* ws, void* stream, hipEvent_t g_ev_start, hipEvent_t g_ev_stop, const float* strict_bound = nullptr,
+                           const void* lib_lo = nullptr) {
     ALIVE_CHECK_ARG(src && lib_bf16 && rows_f32 && norms && out_val && out_idx && ws, "alive_knn_search: null pointer");
     if (int rc = check_search_args("alive_knn_search", src, ws, N, T, k, M)) return rc;
     const int64_t Tt = (int64_t)N * T;
@@ -1953,6 +2207,7 @@ static int knn_search_impl(const float* src, int N, int T, const void* lib_bf16,
     if (strict_bound != nullptr) {         // deterministic certificate: per-frame rounding error + the library's (alive_library_rounding_bound)
         w.det_q = w.dq;
         w.det_lib = strict_bound;
+        w.lib_lo = (const unsigned short*)lib_lo;      // nullptr: no split tier, collect-tier overflow goes straight to the exact scan
     }
     hipStream_t s = (hipStream_t)stream;
     if (Tt * k <= 64 && M <= SCAN_ROWS_MAX)            // a handful of frames: exact fp32 scan of the rows, no candidate stage
@@ -1971,11 +2226,11 @@ static int knn_search_impl(const float* src, int N, int T, const void* lib_bf16,
     const SeedArgs sa = seeds_for(w, p.Tt_pad / FT, p.split, k, w.det_q != nullptr ? SEED_MARGIN16_STRICT : SEED_MARGIN16, ST_SEEDED16, s);
     if (g_ev_start) (void)hipEventRecord(g_ev_start, s);             // behind the memset of the seed flags: the events bracket the kernel alone
     knn_score_kernel<false><<<dim3((unsigned)(p.Tt_pad / FT), p.split), 256, SCORE_LDS, s>>>(
-        w.s_bf16, (const unsigned short*)lib_bf16, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, nullptr, 0, 0, 0, nullptr, sa);
+        w.s_bf16, (const unsigned short*)lib_bf16, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, nullptr, 0, 0, 0, nullptr, sa, 0);
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
     knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, p.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                out_val, out_idx, nullptr, nullptr, 0, 0, w.list1, w.stats + ST_FLAG16,
-                                                               CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0);
+                                                               CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0, w.lib_lo != nullptr ? SPLIT_BOUND : 0.0f);
     collect_tier_launch(w, lib_bf16, rows_f32, norms, M, Tt, idx_base, k, out_val, out_idx, s);
     ALIVE_CHECK_LAUNCH("alive_knn_search");
     return ALIVE_OK;
@@ -1998,12 +2253,23 @@ extern "C" int alive_knn_search(const float* src, int N, int T, const void* lib_
 // Strict search: the bf16 candidate stage with a DETERMINISTIC certificate (knn_rescore_kernel: det_bound), frames that
 // fail it through the exact fp32 scan.  No statistical assumption anywhere: the result is the exact top-k of the rescoring
 // arithmetic for every input.  bound: device float[1] from alive_library_rounding_bound.
-extern "C" int alive_knn_search_strict(const float* src, int N, int T, const void* lib_bf16, const float* rows_f32,
+extern "C" int alive_knn_search_strict(const float* src, int N, int T, const void* lib_bf16, const void* lib_lo, const float* rows_f32,
                                        const float* norms, const float* bound, int64_t M, int64_t idx_base, int k, float* out_val,
                                        int32_t* out_idx, void* ws, void* stream, void* ev_start, void* ev_stop) {
     ALIVE_CHECK_ARG(bound != nullptr, "alive_knn_search_strict: null bound (alive_library_rounding_bound)");
     return knn_search_impl(src, N, T, lib_bf16, rows_f32, norms, M, idx_base, k, out_val, out_idx, ws, stream,
-                           (hipEvent_t)ev_start, (hipEvent_t)ev_stop, bound);
+                           (hipEvent_t)ev_start, (hipEvent_t)ev_stop, bound, lib_lo);
+}
+
+// lo plane of a packed library (strict searches): lib_lo[M_pad][768] = bf16(r^ - lib_bf16), 2 * 768 * alive_library_padded_rows(M) bytes
+extern "C" int alive_library_pack_lo(const void* lib_bf16, const float* rows_f32, const float* norms, int64_t M, void* lib_lo,
+                                     void* stream) {
+    ALIVE_CHECK_ARG(lib_bf16 && rows_f32 && norms && lib_lo && M >= 1, "alive_library_pack_lo: bad args");
+    const int64_t M_pad = alive_library_padded_rows(M);
+    lib_lo_kernel<<<(unsigned)((M_pad * D + 255) / 256), 256, 0, (hipStream_t)stream>>>((const unsigned short*)lib_bf16, rows_f32, norms, M,
+                                                                                     M_pad, (unsigned short*)lib_lo);
+    ALIVE_CHECK_LAUNCH("alive_library_pack_lo");
+    return ALIVE_OK;
 }
 
 extern "C" int alive_library_rounding_bound(const void* lib_bf16, const float* rows_f32, const float* norms, int64_t M,
@@ -2052,7 +2318,7 @@ static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f
         knn_rescore_kernel<<<(unsigned)((w.probe_n + 3) / 4), 256, 0, s>>>(w.cvp, w.cip, w.pp.P, KP8, w.s_f32, rows_f32, norms, w.probe_n,
                                                                           idx_base, k, out_val, out_idx, w.p_list, nullptr, 0, 0,
                                                                           w.p_list + w.probe_pad, w.stats + ST_PROBE_CNT, CERT_Z, KH8,
-                                                                          1.0f / (F8_SCALE * F8_SCALE), SD_PRIOR8, nullptr, nullptr, nullptr, 0);
+                                                                          1.0f / (F8_SCALE * F8_SCALE), SD_PRIOR8, nullptr, nullptr, nullptr, 0, 0.0f);
         probe_decide_kernel<<<1, 1, 0, s>>>(w.stats, w.probe_n, PROBE_NUM, PROBE_DEN);
     }
     // ---- mode 0: fp8 first ----
@@ -2063,7 +2329,7 @@ static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
     knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, p.P, KP8, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                out_val, out_idx, nullptr, mode, -1, 0, w.list0, w.stats + ST_FLAG8,
-                                                               CERT_Z, KH8, 1.0f / (F8_SCALE * F8_SCALE), SD_PRIOR8, nullptr, nullptr, nullptr, 0);
+                                                               CERT_Z, KH8, 1.0f / (F8_SCALE * F8_SCALE), SD_PRIOR8, nullptr, nullptr, nullptr, 0, 0.0f);
     // ---- mode 1: bf16 first (every frame into list0) ----
     if (w.probe_n > 0) flag_all_kernel<<<(unsigned)((Tt + 255) / 256), 256, 0, s>>>(w.list0, w.stats + ST_FLAG8, Tt, mode, 0, 1);
     bf16_tiers_launch(w, lib_bf16, rows_f32, norms, M, Tt, idx_base, k, out_val, out_idx, s);
@@ -2089,6 +2355,7 @@ extern "C" int alive_knn_search_fp8_timed(const float* src, int N, int T, const 
 //   [2] frames of the probe sample, [3] of which failed the fp8 certificate, [4] 1 = the probe chose bf16 first
 //   [7] the path taken: 1 streaming scan, 2 exact scan of every frame (k > 8), 3 bf16 first, 4 fp8 first
 //   [8] frames the collect tier could not hold (dense clusters) -> exact scan;  [1] then counts the frames sent to the collect tier
+//       (strict search with a lo-plane library: the collect tier IS the split-bf16 pass)
 // (the counters are the first thing in the workspace: their address depends on neither the batch nor k)
 extern "C" const int* alive_knn_search_stats(int N, int T, int64_t M, void* ws) {
     return ws_layout(ws, (int64_t)N * T, M, 4).stats;

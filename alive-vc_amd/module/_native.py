@@ -52,7 +52,8 @@ PROTOTYPES = {
     "alive_knn_search": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP]),
     "alive_library_fp8_bytes": (_SZ, [_I64]),
     "alive_library_rounding_bound": (_I, [_VP, _VP, _VP, _I64, _VP, _VP]),
-    "alive_knn_search_strict": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "alive_library_pack_lo": (_I, [_VP, _VP, _VP, _I64, _VP, _VP]),
+    "alive_knn_search_strict": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "alive_library_pack_fp8": (_I, [_VP, _I64, _VP, _VP]),
     "alive_knn_search_fp8": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP]),
     "alive_knn_search_stats": (_VP, [_I, _I, _I64, _VP]),

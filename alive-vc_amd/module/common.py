@@ -61,15 +61,22 @@ class PackedLibrary:
             nat.check(L.alive_library_pack_fp8(nat.ptr(self.lib_bf16), self.M, nat.ptr(self.lib_f8), nat.stream()),
                       "alive_library_pack_fp8")
         self.bound = None
+        self.lib_lo = None
         if self.strict:
             self._make_bound()
         self._ws = nat.Workspace()
 
     def _make_bound(self):
-        """max_R || r^ - bf16(r^) ||: the library's share of the strict certificate's deterministic bound"""
+        """max_R || r^ - bf16(r^) ||: the library's share of the strict certificate's deterministic bound -- and the library's lo
+        plane bf16(r^ - bf16(r^)) for the split-bf16 collect tier behind it (ALIVE_KNN_STRICT_SPLIT=0: without, the round-3 form)"""
         self.bound = torch.zeros(1, dtype=torch.float32, device=self.rows.device)
         nat.check(nat.lib().alive_library_rounding_bound(nat.ptr(self.lib_bf16), nat.ptr(self.rows), nat.ptr(self.norms), self.M,
                                                          nat.ptr(self.bound), nat.stream()), "alive_library_rounding_bound")
+        self.lib_lo = None
+        if os.environ.get("ALIVE_KNN_STRICT_SPLIT", "1") not in ("0", "false", "False"):
+            self.lib_lo = torch.empty_like(self.lib_bf16)
+            nat.check(nat.lib().alive_library_pack_lo(nat.ptr(self.lib_bf16), nat.ptr(self.rows), nat.ptr(self.norms), self.M,
+                                                      nat.ptr(self.lib_lo), nat.stream()), "alive_library_pack_lo")
 
     def search(self, source, k, events=None):
         """exact top-k of this shard: (val[Tt,k] fp32 desc, idx[Tt,k] int32 global).
@@ -81,7 +88,7 @@ class PackedLibrary:
         ws = self._ws.get(L.alive_knn_workspace_bytes(n * t, self.M), source.device)
         ev = (None, None) if events is None else (events[0].cuda_event, events[1].cuda_event)
         if self.strict:
-            nat.check(L.alive_knn_search_strict(nat.ptr(source), n, t, nat.ptr(self.lib_bf16), nat.ptr(self.rows), nat.ptr(self.norms),
+            nat.check(L.alive_knn_search_strict(nat.ptr(source), n, t, nat.ptr(self.lib_bf16), nat.ptr(self.lib_lo), nat.ptr(self.rows), nat.ptr(self.norms),
                                                 nat.ptr(self.bound), self.M, self.idx_base, k, nat.ptr(val), nat.ptr(idx),
                                                 nat.ptr(ws), nat.stream(), *ev), "alive_knn_search_strict")
         elif self.lib_f8 is not None:
@@ -104,7 +111,7 @@ class PackedLibrary:
         other = copy.copy(self)
         other.__dict__.pop("search", None)             # an instrumented search (bench.py) stays with the original
         other.prefilter = prefilter
-        other.strict, other.bound = False, None
+        other.strict, other.bound, other.lib_lo = False, None, None
         other._ws = nat.Workspace()
         other._last = None
         if prefilter == "bf16":
@@ -149,8 +156,12 @@ class PackedLibrary:
         # [1] frames that failed the bf16 certificate: up to [12] of them go straight to the exact scan (knn.hip COLLECT_MIN),
         # more go through the collect tier and only its overflow ([8]) is scanned exactly
         direct = c[1] <= c[12]
-        st.update(bf16_blocks_seeded=c[10], frames_failed_bf16_certificate=c[1], frames_collected_on_bf16=0 if direct else c[1],
+        split = self.strict and getattr(self, "lib_lo", None) is not None       # the collect tier is the split-bf16 pass then
+        st.update(bf16_blocks_seeded=c[10], frames_failed_bf16_certificate=c[1],
+                  frames_collected_on_bf16=0 if direct or split else c[1],
                   frames_searched_exactly=few + (c[1] if direct else c[8]), frames=n * t)
+        if split:
+            st.update(frames_collected_on_split_bf16=0 if direct else c[1])
         return st
 
     def fallback_frames(self):

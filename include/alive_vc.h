@@ -86,11 +86,18 @@ int alive_knn_search(const float* src, int N, int T,
  * rounding of the rescoring arithmetic).  Frames that do not clear it go through the exact fp32 scan, so the returned
  * lists are the exact top-k of the rescoring arithmetic for EVERY input, adversarial ones included.
  *   bound: device float[1] = max_R || r^ - bf16(r^) ||, filled by alive_library_rounding_bound from a packed library.
- *   ev_start / ev_stop: as in the *_timed forms below (NULL: none).  Counters: alive_knn_search_stats [1], [7]. */
+ *   lib_lo: NULL, or the library's lo plane (alive_library_pack_lo: bf16(r^ - lib_bf16), 2 * 768 * alive_library_padded_rows(M)
+ *           bytes).  With it the frames that fail the certificate (more than 256 of them) go through an MFMA COLLECT pass on BOTH
+ *           planes of both operands (three bf16 products per product) whose deterministic bound is 1.7e-4 (two-plane rounding
+ *           3 x 2^-18 + the fp32 accumulation of 3 x 768 products) instead of the single-plane collect tier, whose band is the
+ *           certificate's own 1.8e-3: every row at or above v_k - 1.7e-4 is rescored exactly, and only frames with more such rows
+ *           than the lists hold reach the exact scan.
+ *   ev_start / ev_stop: as in the *_timed forms below (NULL: none).  Counters: alive_knn_search_stats [1], [7], [8]. */
 int alive_library_rounding_bound(const void* lib_bf16, const float* rows_f32, const float* norms, int64_t M,
                                  float* bound, void* stream);
+int alive_library_pack_lo(const void* lib_bf16, const float* rows_f32, const float* norms, int64_t M, void* lib_lo, void* stream);
 int alive_knn_search_strict(const float* src, int N, int T,
-                            const void* lib_bf16, const float* rows_f32, const float* norms, const float* bound,
+                            const void* lib_bf16, const void* lib_lo, const float* rows_f32, const float* norms, const float* bound,
                             int64_t M, int64_t idx_base, int k,
                             float* out_val, int32_t* out_idx, void* ws, void* stream, void* ev_start, void* ev_stop);
 

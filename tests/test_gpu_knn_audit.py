@@ -64,6 +64,14 @@ def test_every_frame_of_the_bench_batch_against_brute_force(env, name):
     assert torch.equal(res["fp8"][2], res["bf16"][2]) and torch.equal(res["fp8"][1], res["bf16"][1])
     assert torch.equal(res["strict"][2], res["bf16"][2])
     assert res["strict"][0]["tiers"]["certificate"] == "deterministic"
+    if name == "dense":              # round 4: the strict search's failed certificates (43 % of the frames: the deterministic 1.8e-3 band
+                                     # is wider than the neighbour gaps) go through the split-bf16 collect tier (bound 1.7e-4) and NONE of
+                                     # them reaches the VALU exact scan (round 3: 70 449 did, 3.65 s per search); the statistical modes'
+                                     # collect tier keeps 64 rows per frame and split instead of 8 per half-list
+        ts = res["strict"][0]["tiers"]
+        assert ts["frames_collected_on_split_bf16"] == ts["frames_failed_bf16_certificate"] > 50_000, ts
+        assert ts["frames_searched_exactly"] <= 64 and ts["frames_collected_on_bf16"] == 0, ts
+        assert res["bf16"][0]["tiers"]["frames_searched_exactly"] <= 100, res["bf16"][0]["tiers"]
     if name == "randn":              # the headline case: certified on fp8, nothing re-searched on bf16; every block of the second
                                      # and third library split started from the seeds its predecessor left (knn.hip: seeded admission)
         t8 = res["fp8"][0]["tiers"]
@@ -75,12 +83,19 @@ def test_every_frame_of_the_bench_batch_against_brute_force(env, name):
 def test_adversarial_libraries_against_brute_force(env, name):
     """rows with 1-8 dominant coordinates, norms over six decades, a dense / spiky mixture with queries that carry a matching
     spike, rank-16 rows, queries that are library rows, clusters of near-copies denser than any stage's error"""
-    frames = 450 * (8 if name == "clusters" else 48)             # clusters: every frame ends in the exact scan
+    frames = 450 * (8 if name == "clusters" else 48)             # clusters: every frame fails every certificate
     res = run_case(env, name, frames, ("fp8", "bf16", "strict"))
     for mode, (r, _, _) in res.items():
         assert r["mismatches"] == 0, (name, mode, r)
         assert r["max_abs_value_error"] <= 2e-6, (name, mode, r)
     assert res["fp8"][0]["safe_frames"] > 0.5 * frames, res["fp8"][0]
+    if name == "clusters":           # clusters of 40 near-copies: every frame fails every certificate, and since round 4 the collect tiers
+                                     # (64 rows per frame and split; the split-bf16 pass in the strict search) hold a whole cluster -- no frame
+                                     # is left for the exact scan (round 3: all of them, 955 ms per search instead of 60 - 110)
+        for mode in ("fp8", "bf16", "strict"):
+            t = res[mode][0]["tiers"]
+            assert t["frames_failed_bf16_certificate"] > 0.95 * frames and t["frames_searched_exactly"] == 0, (mode, t)
+        assert res["strict"][0]["tiers"]["frames_collected_on_split_bf16"] > 0.95 * frames
 
 
 @pytest.mark.parametrize("name", ["randn_iid", "spiky", "mixture", "norms", "self"])
