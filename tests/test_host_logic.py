@@ -295,13 +295,20 @@ def test_fp8_scoring_kernel_listing_keeps_two_accumulator_sets(tmp_path):
 
 
 def test_network_constructors_keep_the_reference_signature():
-    """content_encoder.py:9-14 / f0_estimator.py:9-14: keyword arguments of the reference's constructors are accepted at their
-    default values (the only ones the three scripts construct) and refused otherwise -- the kernels are built for those sizes"""
+    """content_encoder.py:9-14 / f0_estimator.py:9-14: the reference's constructors take sizes.  The defaults (the only ones the three
+    scripts construct) run through the fused entry points; other sizes build the reference's state_dict for those sizes and run layer
+    by layer through the op-level C ABI (module/_generic.py; numerics: tests/test_gpu_models.py)"""
+    from module import schema
     from module.content_encoder import ContentEncoder
     from module.f0_estimator import F0Estimator
-    ContentEncoder(n_fft=1280, internal_channels=512, hidden_channels=1536, output_channels=768, num_layers=4)
-    F0Estimator(n_fft=1280, internal_channels=256, hidden_channels=512, output_channels=4096, num_layers=4)
-    with pytest.raises(ValueError):
-        ContentEncoder(hidden_channels=1024)
-    with pytest.raises(ValueError):
-        F0Estimator(output_channels=2048)
+    ce = ContentEncoder(n_fft=1280, internal_channels=512, hidden_channels=1536, output_channels=768, num_layers=4)
+    pe = F0Estimator(n_fft=1280, internal_channels=256, hidden_channels=512, output_channels=4096, num_layers=4)
+    assert not ce.generic and not pe.generic
+    ce2 = ContentEncoder(hidden_channels=1024, num_layers=2)
+    assert ce2.generic and ce2.state_dict()["mid_layers.1.pw_conv1.weight"].shape == (1024, 512, 1)
+    assert "mid_layers.2.scale" not in ce2.state_dict()
+    pe2 = F0Estimator(output_channels=2048)
+    assert pe2.generic and pe2.state_dict()["output_layer.weight"].shape == (2048, 256, 1)
+    assert set(pe.state_dict()) == set(schema.f0_estimator_schema())
+    with pytest.raises(RuntimeError):
+        pe2.forward(torch.zeros(1, 641, 8))              # no CPU path
