@@ -1,268 +1,433 @@
-// FilterBlock.forward for the 16- and 8-channel scales of the decoder's U-Net
-// (/root/reference/module/decoder.py:105-150): input_conv 1x1 + 3 x FilterResBlock, i.e. six GELU -> FiLM ->
-// reflect-left causal k5 convs with dilations 1,1,2,2,4,4 and three residual adds, fused into ONE kernel.
+// FilterBlock.forward for the 16- and 8-channel scales of the decoder's U-Net (/root/reference/module/decoder.py:105-150),
+// fused into ONE kernel per scale: input conv 1x1 + three FilterResBlocks (six GELU -> FiLM -> reflect-left causal k5 convs,
+// dilations 1, 1, 2, 2, 4, 4) + the U-Net skip, per tile of 1024 (C = 16) / 2048 (C = 8) samples (56 of them the recomputed
+// causal halo).  Conv by conv these scales (72 000 / 144 000 samples per window) are HBM-bound: ~14 tensor passes each.
 //
-// At 72 000 / 144 000 samples x 16 / 8 channels these layers are HBM-bound when run conv by conv (each conv
-// reads and writes 1-2 full tensors: ~14 tensor passes per scale).  Here a block owns a time tile and keeps it on
-// chip through all seven convs: the modulated conv input z and the intermediate y live in two LDS buffers, the
-// residual stream h in registers; the 56-sample causal halo (4 x (1+1+2+2+4+4)) is recomputed instead of
-// exchanged, so HBM traffic drops to the input, the U-Net skip and the output.
-//
-// Arithmetic: exact fp32 on v_mfma_f32_16x16x4_f32 with the WEIGHTS stationary in registers: a conv has
-// K = 5*C <= 80, i.e. at most 20 MFMA k-steps, so the A fragments of all seven convs are 124 VGPRs per lane for
-// the whole kernel, and the only per-MFMA operand traffic is one ds_read_b32 of the B fragment (16 time columns x
-// 4 k).  (A first VALU version streamed the weights through SGPRs / LDS and was bound by those fetches: 4.6 ms vs
-// the ~0.6 ms of MFMA work.)  A wave owns fixed 16-column groups through all convs, so the epilogue of a group
-// (residual add, GELU, FiLM) is register-local and only the modulated result goes back to LDS.
+// Round 4: rewritten on the design of the 64-channel block (filter_mid.hip, DESIGN.md 3.2b'), i.e. on the split-bf16 product
+// (a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate, ~2^-16 per product) of v_mfma_f32_32x32x16_bf16 instead of the exact
+// f32 MFMA 16x16x4 of rounds 1-3: that kernel spent 2.5 matrix-pipe cycles and ~25 serialised vector instructions per output element
+// (16.4 ms per step for the two scales, pipe 0.35-0.41 busy, two waves per SIMD taking turns on one issue port); the three-product
+// bf16 form needs 0.6 pipe cycles per element and leaves the epilogue as the bound, which is then hidden as in filter_mid.hip:
+//   * activations live in LDS as two bf16 planes [column][C channels] (32 / 16 B rows), two buffers; output channels are padded
+//     to the MFMA's 32 rows (rows >= C have zero weights and are never read back), K = 5 C: one tap per k-step at C = 16, two taps
+//     per k-step at C = 8 (the lane halves lh = 0 / 1 read different taps; the sixth tap of the last k-step has zero weights);
+//   * a block is 4 waves, one per SIMD; wave w owns column tiles w, w + 4, w + 8, ... of 32 columns (8 / 16 tiles); its A fragments
+//     (40 / 24 registers per conv) and the residual stream of its tiles (64 registers) stay in registers;
+//   * ONE software pipeline over (conv, tile) steps: a step runs the tile's 15 / 9 MFMAs and, beside them, the epilogue of the
+//     previous step's tile in stages of four independent dependency chains (GELU -> FiLM -> re-split -> LDS); the interleaved tile
+//     ownership lets it run across conv boundaries, with ONE barrier per half conv (tile t of conv q + 1 needs tiles t - 1, t of
+//     conv q, which were written at least NT / 2 steps earlier);
+//   * C = 16: the two 16-byte halves of a row are swapped by (column >> 3) & 1, which makes the 32-lane fragment reads conflict-free.
+// Parity: the block's outputs move from "bit for bit an fp32 fmaf chain" to the split-bf16 error of the 64- and 256-channel scales
+// (unit tests: 4e-5 relative instead of 5e-6; the decoder fixtures' waveform RMS error is unchanged at 1.1e-4, bar 1e-3).
 #include "conv_epilogue.h"
+#include <type_traits>
+#include <stdlib.h>
+
+#ifndef ALIVE_FILTER_MID_NO_SLP
+#error "filter_small.hip must be compiled with the flags of filter_mid.hip: -fno-slp-vectorize -DALIVE_FILTER_MID_NO_SLP -mllvm -amdgpu-sched-strategy=max-ilp (see csrc/Makefile)"
+#endif
+
+static long long* g_stamps_small = nullptr;
+extern "C" void alive_debug_set_stamps_small(long long* p) { g_stamps_small = p; }
 
 namespace {
 
-#ifdef ALIVE_STAMPS
-__device__ long long* g_small_stamps = nullptr;
-#endif
-
 constexpr int HALO = 56;
 constexpr int NCONV = 6;
-constexpr int NFP = 10;         // FiLM frames staged per tile (tile span / 160 or / 320 + 2 taps + slack)
-constexpr int NT = 512;         // 8 waves: two per SIMD
+constexpr int NFP = 10;                 // FiLM frames a tile may span (1024 columns at 160 per frame = 6.4, + 3 of slack)
+constexpr int NFS = NFP + 1;            // staged frames per channel (i0 <= NFP - 1, i1 = i0 + 1)
+constexpr int PLANE = 32768;            // bytes per plane: BL * ROWB in both configurations
+constexpr int BUF = 2 * PLANE;          // hi + lo
 
 template <int C>
-struct SmallCfg {
-    static constexpr int BL = C == 8 ? 768 : 1024;      // columns per tile incl. halo.  At 8 channels the tile buffers are small
-                                                        // enough for the blocks per CU to matter more than the halo (64 windows
-                                                        // x 144 000 samples: 256 cols 1.83 ms, 512 1.67, 768 1.62, 1024 1.83; at 16
-                                                        // channels 1024 stays best: 1.32 against 1.42 / 1.52 ms)
+struct Cfg {
+    static constexpr int ROWB = 2 * C;                  // bytes per LDS row
+    static constexpr int BL = PLANE / ROWB;             // 1024 / 2048 columns per tile incl. halo
     static constexpr int TT = BL - HALO;                // output columns per tile
-    static constexpr int P = BL + 16;                   // LDS row pitch: the four k-rows of a B fragment land on disjoint banks
-    static constexpr int NG = BL / 16;                  // 16-column groups per tile
-    static constexpr int G = NG / 8;                    // groups per wave
-    static constexpr int KS = 5 * C / 4;                // MFMA k-steps of a k5 conv (20 / 10)
-    static constexpr int KS_IN = C / 4;                 // k-steps of the 1x1 input conv
-    static constexpr int WFLOATS = (C + NCONV * 5 * C) * 16 + (1 + NCONV) * 16;   // [k][16 co] per conv, then 7 x bias[16]
+    static constexpr int NT = BL / 128;                 // column tiles of 32 per wave (8 / 16)
+    static constexpr int TSTEP = 128 * ROWB;            // a wave's consecutive tiles are four column tiles apart
+    static constexpr int G = C / 8;                     // channel groups of 8 (rows 8 g + 4 lh + e) that hold real channels
+    static constexpr int KS = C == 16 ? 5 : 3;          // k-steps of a k5 conv (K = 5 C, padded to 48 at C = 8)
+    static constexpr int KP = 16 * KS;                  // padded K
+    static constexpr int GUARD = 16 * ROWB;             // rows left of the image the leftmost tile may read
+    static constexpr int W_IN = 2 * 32 * 16;            // bf16 elements of the input conv [2 planes][32 rows][16]
+    static constexpr int W_K5 = 2 * 32 * KP;            // of a k5 conv [2][32][KP]
+    static constexpr int WFLOATS = 7 * 32 + (W_IN + NCONV * W_K5) / 2;       // fp32 biases [7][32], then the bf16 weights
+    static constexpr int LDS = GUARD + 2 * BUF + NCONV * C * NFS * 8 + BL * 8;
 };
 
-template <int C>
-__global__ __launch_bounds__(NT, 2) void filter_block_small_kernel(const float* __restrict__ U, int L,
-                                                                   const float* __restrict__ wpack,
-                                                                   const float* __restrict__ film, int film_rows, int Lf,
-                                                                   int film_off, float ratio, int t_off, int f_off, int film_ld, const float* __restrict__ skip,
-                                                                   float* __restrict__ out) {
-    using Cfg = SmallCfg<C>;
-    constexpr int BL = Cfg::BL, TT = Cfg::TT, P = Cfg::P, G = Cfg::G, KS = Cfg::KS, KS_IN = Cfg::KS_IN;
-#ifdef ALIVE_STAMPS                 // diagnostic build only (make EXTRA=-DALIVE_STAMPS; tools/bench_filter_small.py)
-#define FS_STAMP(i) ts[i] = wall_clock64()
-    long long ts[5];
-#else
-#define FS_STAMP(i)
-#endif
-    FS_STAMP(0);
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* bufZ = sm;                       // [C][P]
-    float* bufY = bufZ + C * P;             // [C][P]
-    float* Fs = bufY + C * P;               // [NCONV][2][C][NFP]
-    uint2* Xc = (uint2*)(Fs + NCONV * 2 * C * NFP);   // [BL] interpolation coordinates of a column: (i0 | i1 << 16, w1)
+__device__ __forceinline__ unsigned pack2s(float a, float b) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t h = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ln = lane & 15, lq = lane >> 4;
+template <int C, bool FIRST>
+__global__ __launch_bounds__(256, 1) void filter_block_small_kernel(const float* __restrict__ U, int L, const float* __restrict__ wpack,
+                                                                   const float* __restrict__ film, int film_rows, int Lf, int film_off,
+                                                                   float ratio, int t_off, int f_off, int film_ld,
+                                                                   const float* __restrict__ skip, float* __restrict__ out, long long* stamps) {
+    using K = Cfg<C>;
+#ifdef ALIVE_STAMPS                 // diagnostic build only (tools/ab_build.sh x.so filter_small.hip -DALIVE_STAMPS; tools/stamp_fbs.py)
+    long long tsx[12];
+    int nts = 0;
+#define STAMPS() tsx[nts++] = wall_clock64()
+#else
+#define STAMPS()
+#endif
+    STAMPS();
+    constexpr int ROWB = K::ROWB, BL = K::BL, TT = K::TT, NT = K::NT, TSTEP = K::TSTEP, G = K::G, KS = K::KS, KP = K::KP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    unsigned char* bufZ = sm + K::GUARD;
+    unsigned char* bufY = bufZ + BUF;
+    f32x2* Fs = (f32x2*)(bufZ + 2 * BUF);             // [NCONV][C][NFS] (scale / 2, shift)
+    uint2* Xc = (uint2*)(Fs + NCONV * C * NFS);       // [BL] per column: (8 * i0 relative to the staged frames, w1)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n32 = lane & 31, lh = lane >> 5;
     const int n = blockIdx.y;
-    const int t0 = blockIdx.x * TT;
+    const int t0 = FIRST ? blockIdx.x * TT : (blockIdx.x + 1) * TT;
     const int tbase = t0 - HALO;
     const float* Un = U + (size_t)n * C * L;
+    const float* biases = wpack;                                              // [7][32]
+    const unsigned short* W16 = (const unsigned short*)(wpack + 7 * 32);
 
-    // ---- stationary A fragments: lane (co = ln, k-slot lq) of k-step s holds W[k = 4s + lq][co] ----
-    // (the input conv's here; each k5 conv reloads its 20 / 10 values from L2 at the top of its pass, which keeps the
-    //  register footprint at two waves per SIMD and the conv loop rolled)
-    float a_in[KS_IN], bias_in[4];
-#pragma unroll
-    for (int s = 0; s < KS_IN; ++s) a_in[s] = wpack[(4 * s + lq) * 16 + ln];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bias_in[r] = wpack[(C + NCONV * 5 * C) * 16 + lq * 4 + r];
+    // swap of the two 16-byte halves of a 32-byte row (C = 16): (column >> 3) & 1
+    auto hsw = [](int r) { return C == 16 ? (r >> 3) & 1 : 0; };
 
-    // ---- FiLM rows of the tile ----
+    // ---- prologue: raw input tile -> planes, FiLM rows, interpolation coordinates; every global load before the first LDS write ----
     const int f_lo = lerp_coord((tbase < 0 ? 0 : tbase) + t_off, ratio, Lf).i0;     // frames of the WINDOW (t_off: range mode)
-    for (int e = tid; e < NCONV * 2 * C * NFP; e += NT) {
-        int f = e % NFP, c = (e / NFP) % C, sel = (e / (NFP * C)) & 1, q = e / (NFP * C * 2);
-        int fr = f_lo + f;
-        fr = fr < Lf ? fr : Lf - 1;
-        int fc = fr - f_off;                             // frame of the window -> column of the film tensor
-        fc = fc < 0 ? 0 : (fc < film_ld ? fc : film_ld - 1);
-        Fs[e] = film[((size_t)n * film_rows + film_off + q * 2 * C + sel * C + c) * film_ld + fc];
-    }
-    for (int i = tid; i < BL; i += NT) {
-        int t = tbase + i;
-        t = t < 0 ? 0 : (t < L ? t : L - 1);
-        const Lerp lp = lerp_coord(t + t_off, ratio, Lf);
-        int i0 = lp.i0 - f_lo, i1 = lp.i1 - f_lo;
-        i0 = i0 < NFP - 1 ? i0 : NFP - 1;
-        i1 = i1 < NFP - 1 ? i1 : NFP - 1;
-        Xc[i] = make_uint2((unsigned)i0 | ((unsigned)i1 << 16), __float_as_uint(lp.w1));
-    }
-    // ---- stage the input tile (raw U) into bufZ: 16-B vectors, all of a thread's loads in flight together ----
-    // (tbase, L and the row pitch are multiples of 4, so a vector lies entirely inside or outside [0, L))
     {
-        constexpr int NVEC = C * (BL / 4) / NT;          // 8 (C = 16) or 4 (C = 8) vectors per thread
-        f32x4 v[NVEC];
+        constexpr int NCOL = BL / 256;                        // columns per thread: tid, tid + 256, ...
+        float v[NCOL][C];
 #pragma unroll
-        for (int k = 0; k < NVEC; ++k) {
-            const int e = tid + NT * k;
-            const int c = e / (BL / 4), i4 = (e - c * (BL / 4)) * 4;
-            const int t = tbase + i4;
-            v[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (t >= 0 && t + 3 < L) v[k] = *(const f32x4*)(Un + (size_t)c * L + t);
-            else if (t >= 0 && t < L) { for (int q = 0; q < 4 && t + q < L; ++q) v[k][q] = Un[(size_t)c * L + t + q]; }
+        for (int j = 0; j < NCOL; ++j) {
+            const int t = tbase + tid + 256 * j;
+            const bool ok = t >= 0 && t < L;
+            const float* uc = Un + (ok ? t : 0);
+#pragma unroll
+            for (int c = 0; c < C; ++c) v[j][c] = ok ? uc[(size_t)c * L] : 0.0f;
+        }
+        constexpr int NFT = NCONV * 2 * C * NFS;              // FiLM values of the tile
+        constexpr int NFL = (NFT + 255) / 256;
+        float fv[NFL];
+#pragma unroll
+        for (int k = 0; k < NFL; ++k) {
+            const int e = tid + 256 * k;
+            const int f = e % NFS, c = (e / NFS) % C, sel = (e / (NFS * C)) & 1, q = e / (NFS * C * 2);
+            int fr = f_lo + f;
+            fr = fr < Lf ? fr : Lf - 1;
+            int fc = fr - f_off;                             // frame of the window -> column of the film tensor
+            fc = fc < 0 ? 0 : (fc < film_ld ? fc : film_ld - 1);
+            fv[k] = e < NFT ? film[((size_t)n * film_rows + film_off + q * 2 * C + sel * C + c) * film_ld + fc] : 0.0f;
         }
 #pragma unroll
-        for (int k = 0; k < NVEC; ++k) {
-            const int e = tid + NT * k;
-            const int c = e / (BL / 4), i4 = (e - c * (BL / 4)) * 4;
-            *(f32x4*)&bufZ[c * P + i4] = v[k];
+        for (int j = 0; j < NCOL; ++j) {
+            const int col = tid + 256 * j;
+            int tc = tbase + col;
+            tc = tc < 0 ? 0 : (tc < L ? tc : L - 1);
+            const Lerp lp = lerp_coord(tc + t_off, ratio, Lf);
+            int i0 = lp.i0 - f_lo;
+            i0 = i0 < NFP - 1 ? i0 : NFP - 1;
+            Xc[col] = make_uint2((unsigned)(i0 * 8), __float_as_uint(lp.w1));
+#pragma unroll
+            for (int ck = 0; ck < C / 8; ++ck) {
+                u32x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = v[j][ck * 8 + 2 * e], x1 = v[j][ck * 8 + 2 * e + 1];
+                    const unsigned h = pack2s(x0, x1);
+                    hi[e] = h;
+                    lo[e] = pack2s(x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xffff0000u));
+                }
+                unsigned char* dst = bufZ + col * ROWB + ((ck ^ hsw(col)) << 4);
+                *(u32x4*)dst = hi;
+                *(u32x4*)(dst + PLANE) = lo;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NFL; ++k) {
+            const int e = tid + 256 * k;
+            const int f = e % NFS, c = (e / NFS) % C, sel = (e / (NFS * C)) & 1, q = e / (NFS * C * 2);
+            // the scale rows are stored halved (exact): gelu(x) * sc + sh = (x + |x| erf|x / sqrt 2|) * (sc / 2) + sh
+            if (e < NFT) ((float*)Fs)[((q * C + c) * NFS + f) * 2 + sel] = sel == 0 ? 0.5f * fv[k] : fv[k];
         }
     }
     __syncthreads();
+    STAMPS();
 
-    // gelu -> FiLM of conv q's input, for channel rows lq*4 + r of column `col`; two channels per instruction on the
-    // packed fp32 pipe, interpolation coordinates from the per-column table
-    auto modulate_store = [&](int q, float* dst, int col, const f32x4& v) {
-        const uint2 xc = Xc[col];
-        const int i0 = xc.x & 0xffff, i1 = xc.x >> 16;
-        const float w1 = __uint_as_float(xc.y), w0 = 1.0f - w1;
-        if (lq * 4 >= C) return;                         // C = 8: the upper half of the MFMA tile is padding
-        const float* f = Fs + ((q * 2) * C + lq * 4) * NFP;
+    // residual stream of the wave's tiles: h[i][4 g + e] = channel 8 g + 4 lh + e of column 32 (4 i + w) + n32 (MFMA C layout)
+    float h[NT][4 * G];
+    const int colw = 32 * w + n32;                                                 // column of tile i: colw + 128 i
+    int st_off[G];                                                                 // modulated planes: channels 8 g + 4 lh .. +3
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float* fa = f + (2 * e) * NFP;
-            const float* fb = fa + NFP;
-            const f32x2 s0 = {fa[i0], fb[i0]}, s1 = {fa[i1], fb[i1]};
-            const f32x2 h0 = {fa[C * NFP + i0], fb[C * NFP + i0]}, h1 = {fa[C * NFP + i1], fb[C * NFP + i1]};
-            const f32x2 sc = pk_fma(pk_splat(w0), s0, pk_splat(w1) * s1);          // fma(w0, a, round(w1 * b))
-            const f32x2 sh = pk_fma(pk_splat(w0), h0, pk_splat(w1) * h1);
-            const f32x2 z = gelu_fast2(f32x2{v[2 * e], v[2 * e + 1]}) * sc + sh;
-            dst[(lq * 4 + 2 * e) * P + col] = z[0];
-            dst[(lq * 4 + 2 * e + 1) * P + col] = z[1];
+    for (int g = 0; g < G; ++g) st_off[g] = colw * ROWB + ((g ^ hsw(colw)) << 4) + 8 * lh;
+    const uint2* xcw = Xc + colw;
+    const unsigned char* fsw = (const unsigned char*)(Fs + 4 * lh * NFS);
+
+    struct FilmG {
+        f32x2 a0[4], a1[4];
+    };
+    struct Epi {
+        int off;
+        float w0, w1;
+        FilmG F[2];
+        float z[4], jt[4], je[4], jsc[4], jsh[4], jx[4];
+    };
+    auto film_fetch = [&](int qf, int off, int g, FilmG& F) {
+        const unsigned char* f = fsw + qf * (C * NFS * 8) + off;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x2* fp = (const f32x2*)(f + ((8 * g + e) * NFS) * 8);
+            F.a0[e] = fp[0];
+            F.a1[e] = fp[1];
+        }
+    };
+    auto epi_begin = [&](Epi& E, int qf, int t) {
+        const uint2 xc = xcw[128 * t];
+        E.off = (int)xc.x;
+        E.w1 = __uint_as_float(xc.y);
+        E.w0 = 1.0f - E.w1;
+        film_fetch(qf, E.off, 0, E.F[0]);
+    };
+    // one stage (st = 0..4) of the epilogue of channel group g of a tile ("item"); see filter_mid.hip for the staging
+    auto epi_stage = [&](Epi& E, bool second, bool emit, int qf, unsigned char* dstp, int t, const f32x16& accv, int g, int st) {
+        const FilmG& Fg = E.F[g & 1];
+        if (st == 0) {
+            if (emit && g + 1 < G) film_fetch(qf, E.off, g + 1, E.F[(g + 1) & 1]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = accv[4 * g + e];
+                if (second) {
+                    x = x + h[t][4 * g + e];
+                    h[t][4 * g + e] = x;
+                }
+                E.jx[e] = x;
+                E.jt[e] = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.3275911f * 0.70710678118654752440f, 1.0f));
+                const float xs = x * 0.84932180028801904272f;
+                E.je[e] = __builtin_amdgcn_exp2f(-(xs * xs));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(E.jt[e]), "+v"(E.je[e]), "+v"(E.jx[e]));
+        } else if (!emit) {
+        } else if (st == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                E.jsc[e] = fmaf(E.w0, Fg.a0[e][0], E.w1 * Fg.a1[e][0]);        // fma(w0, a, round(w1 * b)): ATen's linear interp
+                E.jsh[e] = fmaf(E.w0, Fg.a0[e][1], E.w1 * Fg.a1[e][1]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(E.jsc[e]), "+v"(E.jsh[e]));
+        } else if (st == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float p = fmaf(1.061405429f, E.jt[e], -1.453152027f);
+                p = fmaf(p, E.jt[e], 1.421413741f);
+                p = fmaf(p, E.jt[e], -0.284496736f);
+                p = fmaf(p, E.jt[e], 0.254829592f);
+                E.jt[e] = p * E.jt[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(E.jt[e]));
+        } else if (st == 3) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float erf_abs = fmaf(-E.jt[e], E.je[e], 1.0f);
+                E.z[e] = fmaf(fmaf(fabsf(E.jx[e]), erf_abs, E.jx[e]), E.jsc[e], E.jsh[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(E.z[e]));
+        } else {
+            const float* z = E.z;
+            const unsigned h01 = pack2s(z[0], z[1]), h23 = pack2s(z[2], z[3]);
+            const unsigned l01 = pack2s(z[0] - __uint_as_float(h01 << 16), z[1] - __uint_as_float(h01 & 0xffff0000u));
+            const unsigned l23 = pack2s(z[2] - __uint_as_float(h23 << 16), z[3] - __uint_as_float(h23 & 0xffff0000u));
+            unsigned char* p = dstp + st_off[g] + t * TSTEP;
+            *(uint2*)p = make_uint2(h01, h23);
+            *(uint2*)(p + PLANE) = make_uint2(l01, l23);
         }
     };
 
-    // B-fragment row offsets: k = 4s + lq -> ci = (4s + lq) % C = 4*(s % (C/4)) + lq
-    int rowoff[C / 4];
+    // weights of the k5 convs: k-step s covers k = 16 s .. 16 s + 15 (k = tap * C + ci), lane half lh the second eight of them
+    bf16x8 a[KS][2];
+    auto load_weights = [&](int q) {
+        const unsigned short* Wq = W16 + K::W_IN + (size_t)q * K::W_K5 + (size_t)n32 * KP + 8 * lh;
 #pragma unroll
-    for (int u = 0; u < C / 4; ++u) rowoff[u] = (4 * u + lq) * P;
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) a[s][pl] = *(const bf16x8*)(Wq + (size_t)pl * 32 * KP + s * 16);
+    };
 
-    FS_STAMP(1);
-    // residual stream of this wave's column groups (group g = wv + 8*i, column = 16 g + ln), MFMA C layout
-    f32x4 h[G];
-
-    // ---- input_conv (1x1): h = Win * U + b ; z0 = mod_0(h), written back over the same columns ----
-#pragma unroll
-    for (int i = 0; i < G; ++i) {
-        const int col = (wv + 8 * i) * 16 + ln;
-        f32x4 acc = {bias_in[0], bias_in[1], bias_in[2], bias_in[3]};
-#pragma unroll
-        for (int s = 0; s < KS_IN; ++s)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_in[s], bufZ[rowoff[s] + col], acc, 0, 0, 0);
-        h[i] = acc;
-    }
-    __syncthreads();            // every wave has read its raw columns (a group's rows are read by that group only, but
-                                // the A x B product of one MFMA gathers all 16 lanes' columns: keep it simple and safe)
-#pragma unroll
-    for (int i = 0; i < G; ++i) modulate_store(0, bufZ, (wv + 8 * i) * 16 + ln, h[i]);
-    __syncthreads();
-
-    FS_STAMP(2);
-    // ---- three FilterResBlocks: q = 2j (c1), 2j+1 (c2), dilation 2^j    (decoder.py:128-134) ----
-#pragma unroll 1
-    for (int q = 0; q < NCONV; ++q) {
-        float a_q[KS], bias_q[4];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) a_q[s] = wpack[(C + q * 5 * C + 4 * s + lq) * 16 + ln];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bias_q[r] = wpack[(C + NCONV * 5 * C) * 16 + (1 + q) * 16 + lq * 4 + r];
-        const int d = 1 << (q >> 1);
-        const bool second = q & 1;
-        const float* in = second ? bufY : bufZ;
-        float* dst = second ? bufZ : bufY;
-        // B fragments of a group (KS values per lane) are read one group AHEAD of their MFMAs: with the weights in
-        // registers the ds_read latency is the only thing an MFMA could wait for.
-        auto load_group = [&](int i, float (&bv)[KS]) {
-            const int col = (wv + 8 * i) * 16 + ln;
-            int idx[5];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                int ta = tbase + col + (j - 4) * d;
-                ta = ta < 0 ? -ta : ta;                      // ReflectionPad1d on the left (common.py:88)
-                int ia = ta - tbase;
-                ia = ia < 0 ? 0 : ia;                        // only never-stored halo columns can be clamped
-                idx[j] = ia < BL ? ia : BL - 1;
-            }
-#pragma unroll
-            for (int s = 0; s < KS; ++s) bv[s] = in[rowoff[s % (C / 4)] + idx[(4 * s) / C]];
-        };
-        float bcur[KS], bnxt[KS];
-        load_group(0, bcur);
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-            if (i + 1 < G) load_group(i + 1, bnxt);
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4 acc0 = {bias_q[0], bias_q[1], bias_q[2], bias_q[3]};
-            f32x4 acc1 = {0.0f, 0.0f, 0.0f, 0.0f};           // two chains: the 16x16x4 MFMA has a 40-cycle dependent latency
-#pragma unroll
-            for (int s = 0; s < KS; s += 2) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_q[s], bcur[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_q[s + 1], bcur[s + 1], acc1, 0, 0, 0);
-            }
-            acc0 = acc0 + acc1;
-            if (second) {
-                acc0 = acc0 + h[i];
-                h[i] = acc0;
-            }
-            if (q + 1 < NCONV) modulate_store(q + 1, dst, (wv + 8 * i) * 16 + ln, acc0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < KS; ++s) bcur[s] = bnxt[s];
-        }
-        __syncthreads();
-    }
-
-    FS_STAMP(3);
-    // ---- store the tile (+ U-Net skip, decoder.py:191): through LDS, so that global accesses are 16-B vectors along t and
-    // all skip vectors of a thread are in flight together ----
-    float* Ht = bufZ;                                    // [C][P] fp32: both conv buffers are free now
-#pragma unroll
-    for (int i = 0; i < G; ++i) {
-        const int col = (wv + 8 * i) * 16 + ln;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (lq * 4 + r < C) Ht[(lq * 4 + r) * P + col] = h[i][r];
-    }
-    __syncthreads();
+    f32x16 acc[2];
+    Epi EP[2];
+    // ---- input_conv (1x1, one k-step): h = Win * U + b ----
     {
-        constexpr int NV = (C * (TT / 4) + NT - 1) / NT;     // 242 vectors per channel row
-        f32x4 sk[NV];
+        bf16x8 ai[2];
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int e = tid + NT * k;
-            const int c = e / (TT / 4), t = t0 + (e - c * (TT / 4)) * 4;
-            sk[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (skip != nullptr && e < C * (TT / 4) && t + 3 < L) sk[k] = *(const f32x4*)(skip + ((size_t)n * C + c) * L + t);
+        for (int pl = 0; pl < 2; ++pl) ai[pl] = *(const bf16x8*)(W16 + (size_t)pl * 32 * 16 + (size_t)n32 * 16 + 8 * lh);
+        f32x16 b16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) b16[r] = biases[8 * (r >> 2) + 4 * lh + (r & 3)];
+        // C = 16: channels 8 lh .. of the column; C = 8: the column's eight channels for both halves (the upper half's weights are zero)
+        const int bw = colw * ROWB + (C == 16 ? ((lh ^ hsw(colw)) << 4) : 0);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const unsigned char* bp = bufZ + bw + i * TSTEP;
+            const bf16x8 bh = *(const bf16x8*)bp, bl = *(const bf16x8*)(bp + PLANE);
+            f32x16 c = b16;
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai[1], bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai[0], bl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai[0], bh, c, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4 * G; ++r) h[i][r] = c[r];
         }
+    }
+    __syncthreads();                       // every wave has read the raw columns
+    load_weights(0);
+    // z0 = mod_0(h) over the raw columns: all tiles but the last here, the last one under the first MFMAs of conv 0 as a "c2 item"
+    // whose chain result is zero (v = 0 + h)
+    {
+        f32x16 zero16;
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int e = tid + NT * k;
-            const int c = e / (TT / 4), c4 = (e - c * (TT / 4)) * 4, t = t0 + c4;
-            if (e >= C * (TT / 4) || t >= L) continue;
-            const size_t o = ((size_t)n * C + c) * L + t;
-            const f32x4 v = *(const f32x4*)&Ht[c * P + HALO + c4];
-            if (t + 3 < L) {
-                *(f32x4*)(out + o) = v + sk[k];
-            } else {
-                for (int q = 0; q < 4 && t + q < L; ++q) out[o + q] = v[q] + (skip != nullptr ? skip[o + q] : 0.0f);
+        for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
+        acc[1] = zero16;
+#pragma unroll
+        for (int i = 0; i < NT - 1; ++i) {
+            Epi E;
+            epi_begin(E, 0, i);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int st = 0; st < 5; ++st) epi_stage(E, true, true, 0, bufZ, i, zero16, g, st);
+        }
+    }
+    __syncthreads();
+    STAMPS();
+    epi_begin(EP[0], 0, NT - 1);           // the pending item of the first step
+
+    // ---- three FilterResBlocks: q = 2 j (c1), 2 j + 1 (c2), dilation 2^j    (decoder.py:128-134) ----
+    // SECOND: the c2 of its block (adds into the residual stream); EMIT: a next conv exists and takes the modulated output -- a
+    // compile-time flag: tested at run time it puts a branch into every k-step region of the c2 bodies (+1.5 .. 2.5 us per conv)
+    auto conv = [&](auto second_tag, auto emit_tag, const int q) {
+        constexpr bool SECOND = decltype(second_tag)::value;
+        constexpr bool emit = decltype(emit_tag)::value;
+        const unsigned char* in = SECOND ? bufY : bufZ;
+        unsigned char* dst = SECOND ? bufZ : bufY;
+        f32x16 b16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) b16[r] = biases[(1 + q) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3)];
+        const int d = 1 << (q >> 1);
+        // B fragment of k-step s of tile i.  C = 16: tap s, channels 8 lh ..: row r = colw + 128 i + (s - 4) d, 16 B at
+        // r * 32 + ((lh ^ hsw(r)) << 4).  C = 8: tap 2 s + lh (the phantom sixth tap reads the fifth's row; its weights are zero): the
+        // whole 16-byte row r = colw + 128 i + (tap - 4) d.  hsw does not depend on i: base[s] + i * TSTEP.
+        auto tap_of = [&](int s) { return C == 16 ? s : (2 * s + lh < 5 ? 2 * s + lh : 4); };
+        int base[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int r0 = colw + (tap_of(s) - 4) * d;          // >= -16: the guard
+            base[s] = r0 * ROWB + (C == 16 ? ((lh ^ hsw(r0)) << 4) : 0);
+        }
+        auto frag_off = [&](int i, int s) -> int {
+            if (FIRST) {                                        // reflect at t = 0 (column HALO of this tile), per lane
+                int ta = tbase + colw + 128 * i + (tap_of(s) - 4) * d;
+                ta = ta < 0 ? -ta : ta;
+                int r = ta - tbase;
+                r = r < BL ? r : BL - 1;
+                return r * ROWB + (C == 16 ? ((lh ^ hsw(r)) << 4) : 0);
             }
+            return base[s] + i * TSTEP;
+        };
+        constexpr int NJ = 5 * G;                               // stage jobs of an item, spread over the KS k-step regions
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            // the item of this step: tile i - 1 of this conv, or (i == 0) the last tile of the previous conv -- the other type, which
+            // always has a next conv, whose FiLM rows are this conv's and whose planes are this conv's input
+            const bool it_second = i > 0 ? SECOND : !SECOND;
+            const bool it_emit = i > 0 ? emit : true;
+            const int it_qf = i > 0 ? q + 1 : q;
+            unsigned char* it_dst = i > 0 ? dst : (unsigned char*)in;
+            const int it_t = i > 0 ? i - 1 : NT - 1;
+            const f32x16& it_acc = acc[(i + 1) & 1];
+            asm volatile("s_nop 7" ::: "memory");             // distance between two accumulation chains (filter_mid.hip, DESIGN.md 3.2b')
+            // the item's coordinates and first FiLM group were requested one step ago (two dependent LDS latencies that nothing
+            // in a 9- or 15-MFMA step could cover); now the same for the next step's item, which is always tile i of this conv
+            Epi& E = EP[i & 1];
+            if (emit) epi_begin(EP[(i + 1) & 1], q + 1, i);
+            acc[i & 1] = b16;
+            bf16x8 fh[KS], fl[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const unsigned char* bp = in + frag_off(i, s);
+                fh[s] = *(const bf16x8*)bp;
+                fl[s] = *(const bf16x8*)(bp + PLANE);
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], fh[s], acc[i & 1], 0, 0, 0);
+                acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], fl[s], acc[i & 1], 0, 0, 0);
+                acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], fh[s], acc[i & 1], 0, 0, 0);
+#pragma unroll
+                for (int j = s * NJ / KS; j < (s + 1) * NJ / KS; ++j) epi_stage(E, it_second, it_emit, it_qf, it_dst, it_t, it_acc, j / 5, j % 5);
+                __builtin_amdgcn_sched_barrier(0);           // one scheduling region per k-step
+            }
+            if (i == NT - 1 && emit) load_weights(q + 1);    // the A registers are free: the next conv's weights travel under its first steps' wait
+            if (i == NT / 2 - 1 || i == NT - 1) __syncthreads();      // what the next half conv reads was written >= NT / 2 steps ago
+        }
+    };
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) {
+        conv(std::false_type{}, std::true_type{}, 2 * j);
+        STAMPS();
+        if (j < 2) conv(std::true_type{}, std::true_type{}, 2 * j + 1);
+        else conv(std::true_type{}, std::false_type{}, 2 * j + 1);
+        STAMPS();
+    }
+    // drain: the last conv's last tile only adds into the residual stream
+#pragma unroll
+    for (int r = 0; r < 4 * G; ++r) h[NT - 1][r] = acc[1][r] + h[NT - 1][r];
+
+    // ---- store the tile (+ U-Net skip, decoder.py:191): through LDS so that global accesses are 16-B vectors along t ----
+    float* Ht = (float*)bufZ;                         // [C][BL + 4] fp32 over bufZ / bufY
+    constexpr int HP = BL + 4;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Ht[(8 * g + 4 * lh + e) * HP + colw + 128 * i] = h[i][4 * g + e];
+    // (the skip loads of the whole tile are in flight together; prefetching them under the last conv spills: 64 more registers)
+    constexpr int NV = (C * (TT / 4) + 255) / 256;          // vectors of 4 output columns per thread
+    f32x4 sk[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int g = tid + 256 * u;
+        const int co = g / (TT / 4), c4 = (g - co * (TT / 4)) * 4;
+        const int t = t0 + c4;
+        sk[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (skip != nullptr && g < C * (TT / 4) && t + 3 < L) sk[u] = *(const f32x4*)(skip + ((size_t)n * C + co) * L + t);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int g = tid + 256 * u;
+        const int co = g / (TT / 4), c4 = (g - co * (TT / 4)) * 4;
+        const int t = t0 + c4;
+        if (g >= C * (TT / 4) || t >= L) continue;
+        const size_t o = ((size_t)n * C + co) * L + t;
+        const f32x4 v = *(const f32x4*)&Ht[co * HP + HALO + c4];
+        if (t + 3 < L) {
+            *(f32x4*)(out + o) = v + sk[u];
+        } else {
+            for (int e = 0; e < 4 && t + e < L; ++e) out[o + e] = v[e] + (skip != nullptr ? skip[o + e] : 0.0f);
         }
     }
 #ifdef ALIVE_STAMPS
-    if (g_small_stamps != nullptr && tid == 0) {
-        long long* o = g_small_stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
-        o[0] = ts[1] - ts[0]; o[1] = ts[2] - ts[1]; o[2] = ts[3] - ts[2]; o[3] = wall_clock64() - ts[3];
+    if (stamps != nullptr && tid == 0 && !FIRST) {
+        long long* o = stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
+        for (int i = 0; i + 1 < nts; ++i) o[i] = tsx[i + 1] - tsx[i];
+        o[nts - 1] = wall_clock64() - tsx[nts - 1];
     }
 #endif
 }
@@ -270,20 +435,27 @@ __global__ __launch_bounds__(NT, 2) void filter_block_small_kernel(const float* 
 template <int C>
 int launch_small(const float* U, int N, int L, const float* wpack, const float* film, int film_rows, int Lf, int film_off,
                  int t0, int f0, int film_ld, const float* skip, float* out, hipStream_t s) {
-    using Cfg = SmallCfg<C>;
-    const int lds = (2 * C * Cfg::P + NCONV * 2 * C * NFP) * (int)sizeof(float) + Cfg::BL * 8;
+    using K = Cfg<C>;
     {
         static LdsOptIn optin;                               // one per instantiation <C>
-        hipError_t e = optin.ensure({(const void*)filter_block_small_kernel<C>}, lds);
+        hipError_t e = optin.ensure({(const void*)filter_block_small_kernel<C, false>, (const void*)filter_block_small_kernel<C, true>}, K::LDS);
         if (e != hipSuccess) {
-            alive_set_error("alive_filter_block_small: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
+            alive_set_error("alive_filter_block_small: cannot reserve %d B of LDS: %s", K::LDS, hipGetErrorString(e));
             return ALIVE_ERR_LAUNCH;
         }
     }
     const float ratio = (float)film_ld / (float)L;       // == window frames / window samples at this rate
-    ALIVE_CHECK_ARG((double)Cfg::BL * film_ld / L + 3.0 <= NFP, "alive_filter_block_small: tile spans more than %d frames (L %d, frames %d)", NFP, L, film_ld);
-    dim3 g(cdiv(L, Cfg::TT), N);
-    filter_block_small_kernel<C><<<g, NT, lds, s>>>(U, L, wpack, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld, skip, out);
+    ALIVE_CHECK_ARG((double)K::BL * film_ld / L + 3.0 <= NFP, "alive_filter_block_small: tile spans more than %d frames (L %d, frames %d)", NFP, L, film_ld);
+    const int tiles = cdiv(L, K::TT);
+    // the first tile of a window reflects at t = 0 (per-lane fragment addresses); a problem that does not fill the chip runs all its
+    // tiles through that form in one launch (filter_mid.hip)
+    static const int force = getenv("ALIVE_FBS_FORCE") ? atoi(getenv("ALIVE_FBS_FORCE")) : 0;      // diagnostic: 1 = every tile through the FIRST form, 2 = never
+    const bool small = force == 1 || (force != 2 && (int64_t)tiles * N <= 256);
+    filter_block_small_kernel<C, true><<<dim3(small ? tiles : 1, N), 256, K::LDS, s>>>(U, L, wpack, film, film_rows, Lf, film_off, ratio, t0,
+                                                                                     f0, film_ld, skip, out, g_stamps_small);
+    if (tiles > 1 && !small)
+        filter_block_small_kernel<C, false><<<dim3(tiles - 1, N), 256, K::LDS, s>>>(U, L, wpack, film, film_rows, Lf, film_off, ratio, t0, f0,
+                                                                                  film_ld, skip, out, g_stamps_small);
     ALIVE_CHECK_LAUNCH("alive_filter_block_small");
     return ALIVE_OK;
 }
@@ -291,7 +463,7 @@ int launch_small(const float* U, int N, int L, const float* wpack, const float* 
 }  // namespace
 
 extern "C" int alive_filter_block_small_weights(int C) {
-    return C == 8 ? SmallCfg<8>::WFLOATS : (C == 16 ? SmallCfg<16>::WFLOATS : -1);
+    return C == 8 ? Cfg<8>::WFLOATS : (C == 16 ? Cfg<16>::WFLOATS : -1);
 }
 
 extern "C" int alive_filter_block_small(const float* U, int N, int C, int L, const float* wpack, const float* film,
@@ -306,13 +478,9 @@ extern "C" int alive_filter_block_small_range(const float* U, int N, int C, int 
     ALIVE_CHECK_ARG(N > 0 && L > 16 && Lf > 0, "alive_filter_block_small: bad sizes (L must exceed the largest reflect pad, 16)");
     ALIVE_CHECK_ARG(C == 8 || C == 16, "alive_filter_block_small: C must be 8 or 16, got %d", C);
     ALIVE_CHECK_ARG(U != out, "alive_filter_block_small: in-place not supported (tiles read a halo of their left neighbour)");
-    ALIVE_CHECK_ARG((L & 3) == 0 && ((((uintptr_t)U) | ((uintptr_t)out) | ((uintptr_t)skip)) & 15) == 0,
-                    "alive_filter_block_small: L must be a multiple of 4 and U / out / skip 16-byte aligned");
+    ALIVE_CHECK_ARG((L & 3) == 0 && ((((uintptr_t)U) | ((uintptr_t)out) | ((uintptr_t)skip) | ((uintptr_t)wpack)) & 15) == 0,
+                    "alive_filter_block_small: L must be a multiple of 4 and U / out / skip / wpack 16-byte aligned");
     ALIVE_CHECK_ARG(film_ld > 0 && t0 >= 0 && f0 >= 0, "alive_filter_block_small: bad frame range");
     if (C == 8) return launch_small<8>(U, N, L, wpack, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, (hipStream_t)stream);
     return launch_small<16>(U, N, L, wpack, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, (hipStream_t)stream);
 }
-
-#ifdef ALIVE_STAMPS
-extern "C" void alive_debug_set_stamps_small(long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_small_stamps), &p, sizeof(p)); }
-#endif

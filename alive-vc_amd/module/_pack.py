@@ -119,24 +119,33 @@ def pack_filter_mid(sd, prefix):
 
 
 def pack_filter_small(sd, prefix):
-    """FilterBlock weights for the fused 8/16-channel kernel (csrc/filter_small.hip): MFMA A-operand order.
-    [k = ci][16] input conv, then per conv q [k = j*C + ci][16] (output channel padded to 16), then 7 x bias[16]."""
-    def pad_co(m):                       # [K, C] -> [K, 16]
-        out = torch.zeros(m.shape[0], 16, dtype=torch.float32, device=m.device)
-        out[:, :m.shape[1]] = m
-        return out
+    """FilterBlock weights for the fused 8/16-channel kernel (csrc/filter_small.hip, round 4: split-bf16 on the 32x32x16 MFMA):
+    one fp32 buffer = biases [7][32] (input conv first; rows >= C zero), then -- bf16 pairs viewed as fp32 -- the input conv
+    [2 planes][32 rows][16] (k = ci) and per conv q = 0..5 [2 planes][32 rows][KP] with k = tap * C + ci, KP = 80 (C = 16) / 48 (C = 8);
+    output rows >= C and the padding k are zero.  Planes: hi = bf16(w), lo = bf16(w - hi)."""
     w_in = sd[prefix + ".input_conv.weight"].float()                           # [co, ci, 1]
-    mats, biases = [pad_co(w_in[:, :, 0].t())], [sd[prefix + ".input_conv.bias"].float()]
+    c = w_in.shape[0]
+    kp = 80 if c == 16 else 48
+    dev = w_in.device
+
+    def planes(m, kpad):                 # [co, K] fp32 -> bf16 [2][32][kpad]
+        full = torch.zeros(32, kpad, dtype=torch.float32, device=dev)
+        full[:m.shape[0], :m.shape[1]] = m
+        hi = full.to(torch.bfloat16)
+        lo = (full - hi.float()).to(torch.bfloat16)
+        return torch.stack([hi, lo], 0).reshape(-1)
+
+    mats, biases = [planes(w_in[:, :, 0], 16)], [sd[prefix + ".input_conv.bias"].float()]
     for j in range(3):
         for cc in ("c1", "c2"):
             w = sd[f"{prefix}.blocks.{j}.{cc}.conv.conv.weight"].float()         # [co, ci, 5]
-            c = w.shape[0]
-            mats.append(pad_co(w.permute(2, 1, 0).reshape(5 * c, c)))            # k = tap*C + ci
+            mats.append(planes(w.permute(0, 2, 1).reshape(c, 5 * c), kp))        # k = tap * C + ci
             biases.append(sd[f"{prefix}.blocks.{j}.{cc}.conv.conv.bias"].float())
-    bvec = torch.zeros(len(biases), 16, dtype=torch.float32, device=w_in.device)
+    bvec = torch.zeros(len(biases), 32, dtype=torch.float32, device=dev)
     for i, b in enumerate(biases):
         bvec[i, :b.numel()] = b
-    return torch.cat([m.reshape(-1) for m in mats] + [bvec.reshape(-1)]).contiguous()
+    wbits = torch.cat(mats).contiguous().view(torch.int16).view(torch.float32)   # two bf16 per fp32 word, bit for bit
+    return torch.cat([bvec.reshape(-1), wbits]).contiguous()
 
 
 def pack_decoder(sd):

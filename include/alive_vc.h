@@ -248,11 +248,14 @@ int alive_gemm_planes(const AliveGemm* desc, void* stream);
 /* out[col] = (float) row of the largest value over the nblk per-block candidates of column col (smallest row on ties) */
 int alive_argmax_merge(const float* arg_val, const int32_t* arg_idx, int nblk, int64_t cols, float* out, void* stream);
 
-/* FilterBlock.forward (decoder.py:137-150) for C = 8 or 16 fused into one kernel: input_conv 1x1 + three
+/* FilterBlock.forward (decoder.py:137-150) for C = 8 or 16 fused into one kernel (filter_small.hip): input_conv 1x1 + three
  * FilterResBlocks (six GELU -> FiLM -> reflect-left causal k5 convs, dilations 1,1,2,2,4,4), optional U-Net skip
  * added to the result.  U[N][C][L] -> out[N][C][L] (not in place).
- *   wpack: alive_filter_block_small_weights(C) floats = Win[ci][co], bin[co], then per conv q = 0..5
- *          W[ci][j][co], b[co]   (module/_pack.py::pack_filter_small)
+ *   wpack: alive_filter_block_small_weights(C) floats, 16-byte aligned = fp32 biases [7][32] (input conv first, rows >= C zero), then
+ *          bf16 pairs in fp32 words: input conv [2 planes][32 rows][16] (k = ci) and per conv q = 0..5 [2 planes][32 rows][KP],
+ *          k = tap * C + ci, KP = 80 (C = 16) / 48 (C = 8), zero padded; planes hi = bf16(w), lo = bf16(w - hi)
+ *          (module/_pack.py::pack_filter_small).  Since round 4 the block computes on the split-bf16 product of the 32x32x16 MFMA
+ *          (~2^-16 per product, like the 64- and 256-channel scales), not on the exact f32 MFMA
  *   film[N][film_rows][Lf]; conv q reads its scale rows at film_off + q*2C and shift rows at film_off + q*2C + C. */
 int alive_filter_block_small_weights(int C);
 int alive_filter_block_small(const float* U, int N, int C, int L, const float* wpack, const float* film,

@@ -332,7 +332,7 @@ def test_fused_filter_block_small(c, l, lf):
     fused = ops.filter_block64 if c == 64 else ops.filter_block_small
     out = fused(x.to(DEV), {k: v.to(DEV) for k, v in sd.items()}, "n", film, pad_rows, skip=skip.to(DEV))
     e = relerr(out, ref)
-    assert e < (4e-5 if c == 64 else 5e-6), e
+    assert e < 4e-5, e             # split-bf16 products (~2^-16 each) at every scale since round 4 (C = 8 / 16 were exact f32 MFMA: 5e-6)
     for _ in range(3):                                # run-to-run determinism (see DESIGN.md 3.2b': the scheduling fence)
         again = fused(x.to(DEV), {k: v.to(DEV) for k, v in sd.items()}, "n", film, pad_rows, skip=skip.to(DEV))
         assert torch.equal(again, out)
@@ -623,7 +623,9 @@ def test_fused_filter_blocks_are_deterministic_at_batch_scale(c, l):
             nat.check(L_.alive_filter_block64(x.data_ptr(), N, l, w.data_ptr(), b.data_ptr(), film.data_ptr(), 4128, lf, 3072,
                                               skip.data_ptr(), out.data_ptr(), st))
     else:
-        w = torch.randn(L_.alive_filter_block_small_weights(c), device=DEV, generator=gen) * 0.1
+        nw = L_.alive_filter_block_small_weights(c)
+        w = (torch.cat([torch.randn(224, device=DEV, generator=gen) * 0.1,        # fp32 biases [7][32], then bf16 weight pairs in fp32 words
+                       (torch.randn(2 * (nw - 224), device=DEV, generator=gen) * 0.1).to(torch.bfloat16).view(torch.int16).view(torch.float32)]).contiguous())
 
         def run():
             nat.check(L_.alive_filter_block_small(x.data_ptr(), N, c, l, w.data_ptr(), film.data_ptr(), 4128, lf, 100,

@@ -21,7 +21,9 @@ for C, L in ((64, 36000), (16, 72000), (8, 144000)):
         run = lambda: nat.check(L_.alive_filter_block64(x.data_ptr(), N, L, w.data_ptr(), b.data_ptr(), film.data_ptr(), 4128, Lf, 3072,
                                                         skip.data_ptr(), out.data_ptr(), st))
     else:
-        w = torch.randn(L_.alive_filter_block_small_weights(C), device=dev, generator=g) * 0.1
+        nw = L_.alive_filter_block_small_weights(C)
+        w = (torch.cat([torch.randn(224, device=dev, generator=g) * 0.1,        # fp32 biases [7][32], then bf16 weight pairs in fp32 words
+                       (torch.randn(2 * (nw - 224), device=dev, generator=g) * 0.1).to(torch.bfloat16).view(torch.int16).view(torch.float32)]).contiguous())
         run = lambda: nat.check(L_.alive_filter_block_small(x.data_ptr(), N, C, L, w.data_ptr(), film.data_ptr(), 4128, Lf, 100,
                                                             skip.data_ptr(), out.data_ptr(), st))
     bad = 0; worst = 0.0
