@@ -26,7 +26,9 @@ __device__ __forceinline__ float skinny_x(const AliveConv& p, const float* xn, i
 
 constexpr int SKW = 8;                  // waves per block = K-split
 
-template <int NP>
+// PW: a pointwise conv (KW == 1, stride 1, no padding: two thirds of a streaming step's launches) -- the im2col index is ci * Tin + t,
+// not the ~15 vector instructions of skinny_x per loaded value (round 4: they, not the loads or the MFMAs, were most of the kernel)
+template <int NP, bool PW>
 __global__ __launch_bounds__(64 * SKW) void conv_skinny_kernel(AliveConv p, int ncols) {
     __shared__ f32x4 red[2][SKW][64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -80,6 +82,22 @@ __global__ __launch_bounds__(64 * SKW) void conv_skinny_kernel(AliveConv p, int 
         }
         float x[2][4];
         const int jt = NP == 0 ? 0 : k0 / p.Ci_pad, cbase = NP == 0 ? 0 : k0 - jt * p.Ci_pad;
+        // plane-packed weights are tap-major: the 16 k of a step share one tap, so the padding / reflection logic of skinny_x runs
+        // once per column here instead of once per loaded value
+        int tin_h[2] = {0, 0};
+        bool ok_h[2] = {false, false};
+        if (NP != 0 && !PW) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int tin = tcol[h] * p.stride + jt * p.dil - p.pad_left;
+                bool ok = cok[h] && !(tin < 0 && p.pad_mode == 0);
+                tin = tin < 0 ? -tin : tin;
+                ok = ok && !(tin >= p.Tin && p.pad_mode != 2);
+                tin = tin >= p.Tin ? 2 * (p.Tin - 1) - tin : tin;
+                ok_h[h] = ok && tin >= 0 && tin < p.Tin;
+                tin_h[h] = tin;
+            }
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int k = k0 + 4 * lq + s;
@@ -92,7 +110,19 @@ __global__ __launch_bounds__(64 * SKW) void conv_skinny_kernel(AliveConv p, int 
                 j = jt;
             }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) x[h][s] = cok[h] ? skinny_x(p, xn[h], ci, tcol[h], j) : 0.0f;
+            for (int h = 0; h < 2; ++h) {
+                if (PW) {
+                    const bool ok = cok[h] && ci < p.Ci;
+                    const float v = xn[h][ok ? (size_t)ci * p.Tin + tcol[h] : 0];
+                    x[h][s] = ok ? v : 0.0f;
+                } else if (NP != 0) {
+                    const bool ok = ok_h[h] && ci < p.Ci;
+                    const float v = xn[h][ok ? (size_t)ci * p.Tin + tin_h[h] : 0];
+                    x[h][s] = ok ? v : 0.0f;
+                } else {
+                    x[h][s] = cok[h] ? skinny_x(p, xn[h], ci, tcol[h], j) : 0.0f;
+                }
+            }
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -136,9 +166,10 @@ bool alive_conv_skinny_try(const AliveConv* d, hipStream_t s, int* rc) {
     if (ncols > SKINNY_COLS) return false;
     if (d->precision == 0 && (d->K_pad & 15)) return false;
     dim3 g(cdiv(d->Co, 16), cdiv(ncols, 32));
-    if (d->precision == 0) conv_skinny_kernel<0><<<g, 64 * SKW, 0, s>>>(*d, ncols);
-    else if (d->precision == 1) conv_skinny_kernel<2><<<g, 64 * SKW, 0, s>>>(*d, ncols);
-    else conv_skinny_kernel<3><<<g, 64 * SKW, 0, s>>>(*d, ncols);
+    const bool pw = d->KW == 1 && d->stride == 1 && d->pad_left == 0 && d->Tout <= d->Tin;
+    if (d->precision == 0) { if (pw) conv_skinny_kernel<0, true><<<g, 64 * SKW, 0, s>>>(*d, ncols); else conv_skinny_kernel<0, false><<<g, 64 * SKW, 0, s>>>(*d, ncols); }
+    else if (d->precision == 1) { if (pw) conv_skinny_kernel<2, true><<<g, 64 * SKW, 0, s>>>(*d, ncols); else conv_skinny_kernel<2, false><<<g, 64 * SKW, 0, s>>>(*d, ncols); }
+    else { if (pw) conv_skinny_kernel<3, true><<<g, 64 * SKW, 0, s>>>(*d, ncols); else conv_skinny_kernel<3, false><<<g, 64 * SKW, 0, s>>>(*d, ncols); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         alive_set_error("alive_conv1d(skinny): %s", hipGetErrorString(e));
