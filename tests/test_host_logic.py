@@ -258,6 +258,9 @@ def test_filter_mid_is_built_with_the_flags_its_schedule_needs():
     line = [ln for ln in mk.splitlines() if ln.startswith("FLAGS_filter_mid")]
     assert len(line) == 1 and "-fno-slp-vectorize" in line[0] and "-DALIVE_FILTER_MID_NO_SLP" in line[0], line
     assert "-amdgpu-sched-strategy=max-ilp" in line[0], line
+    small = [ln for ln in mk.splitlines() if ln.startswith("FLAGS_filter_small")]           # same design since round 4, same flags
+    assert len(small) == 1 and "$(FLAGS_filter_mid)" in small[0], small
+    assert "#ifndef ALIVE_FILTER_MID_NO_SLP" in open(os.path.join(ROOT, "alive-vc_amd", "csrc", "filter_small.hip")).read()
     assert "$(FLAGS_$*)" in mk
     src = open(os.path.join(ROOT, "alive-vc_amd", "csrc", "filter_mid.hip")).read()
     assert "#ifndef ALIVE_FILTER_MID_NO_SLP" in src and "#error" in src
