@@ -6,6 +6,7 @@
 // HBM-bound kernels: lanes run along time (coalesced 256-B rows), channels are
 // split over the 4 waves of a block and reduced through LDS.
 #include "common.h"
+#include "planes_layout.h"
 
 namespace {
 
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void dwconv_norm_kernel(
 // ~1.1 TB/s), and alive_to_planes then re-reads the result to split it.  Here a block keeps its [C][64 columns] tile of
 // dw(x) in LDS (133 KB at C = 512), takes mean / sigma from it, applies the affine in place (lanes along time, so the
 // per-sample scale / shift rows of the adaptive form are read coalesced) and leaves through an LDS transpose as bf16
-// planes [col][C]: HBM sees x once and the planes once.
+// planes (k-blocked, planes_layout.h): HBM sees x once and the planes once.
 constexpr int NPT = 512;                 // 8 waves: channels are split over the waves
 // TW = columns per tile: 64 (a wave row is one channel) or 32 (a wave row is two channels; halves the LDS tile so that two
 // blocks share a CU at C = 512 -- with one block of 8 waves per CU the passes are latency-bound)
@@ -158,10 +159,11 @@ __global__ __launch_bounds__(NPT) void dwconv_norm_planes_kernel(
         tile[c * PT + tl] = ok ? v * g + o : 0.0f;
     }
     __syncthreads();
-    // pass 4: [C][col] -> planes [col][C]: thread = (column, 8-channel chunk)
+    // pass 4: [C][col] -> k-blocked planes (planes_layout.h): thread = (k-block, column, 8-channel chunk of the block); 4 TW
+    // consecutive threads write TW x 64 B = one contiguous run
     const int chunks = C / 8;
     for (int item = threadIdx.x; item < TW * chunks; item += NPT) {
-        const int ck = item % chunks, cl = item / chunks;
+        const int cl = (item >> 2) % TW, ck = (item / (4 * TW)) * 4 + (item & 3);
         if (t0 + cl >= T) continue;
         float vv[8];
 #pragma unroll
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(NPT) void dwconv_norm_planes_kernel(
                 vv[2 * e] -= __uint_as_float(h << 16);
                 vv[2 * e + 1] -= __uint_as_float(h & 0xffff0000u);
             }
-            *(u32x4*)(P + ((size_t)pl * cols_pad + col) * C + ck * 8) = o4;
+            *(u32x4*)(P + planes_at(pl, col, ck * 8, cols_pad, C)) = o4;
         }
     }
 }

@@ -7,6 +7,7 @@
 // summed through LDS and go through the common epilogue.  Weights are read in whatever format the layer was packed
 // for the tiled kernels: fp32 [Co_pad][K_pad], or 2 / 3 bf16 planes whose sum is the (16- / 24-bit mantissa) weight.
 #include "conv_epilogue.h"
+#include "planes_layout.h"
 
 namespace {
 
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(64 * SKW) void conv_skinny_kernel(AliveConv p, int 
             w = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int pl = NP - 1; pl >= 0; --pl) {      // smallest plane first: the partial sums stay exact
-                const uint2 q = *(const uint2*)(W16 + ((size_t)pl * co_pad + row) * Kp + k0 + 4 * lq);
+                const uint2 q = *(const uint2*)(W16 + planes_at(pl, row, k0 + 4 * lq, co_pad, Kp));      // k-blocked planes
                 w[0] += __uint_as_float(q.x << 16);
                 w[1] += __uint_as_float(q.x & 0xffff0000u);
                 w[2] += __uint_as_float(q.y << 16);

@@ -16,6 +16,7 @@
 // buffered per k-step.  Block = 4 waves, tile BM x 128 (BM = 128: 2x2 waves of 64x64; BM = 64: 1x4 waves
 // of 64x32), v_mfma_f32_32x32x16_bf16.
 #include "conv_epilogue.h"
+#include "planes_layout.h"
 #include <stdlib.h>
 
 namespace {
@@ -40,8 +41,8 @@ constexpr int PROW = 64;          // PLANES = true: bytes per LDS row (32 channe
 // (global loads, split, LDS writes) once instead of twice, reads every activation fragment for two row tiles instead of one
 // (0.33 instead of 0.67 LDS fragment reads per MFMA) and halves the X traffic from L2 / HBM.
 // PLANES = true (BM = 128, NP = 2; round 3): the activation operand arrives ALREADY split, plane-packed and time-major
-// (AliveConv.Xp: P[plane][n * Tin + t][Ci_pad] bf16, the format of gemm_planes.hip), so a 32-channel block of the X tile is
-// 144 row segments of 64 B per plane that LDS-DMA copies straight into LDS -- no fp32 loads, no split, no ds_write in the
+// (AliveConv.Xp: the k-blocked planes of gemm_planes.hip / planes_layout.h, rows = n * Tin + t), so a 32-channel block of the X
+// tile is ONE run of 144 consecutive 64-B row segments per plane that LDS-DMA copies straight into LDS -- no fp32 loads, no split, no ds_write in the
 // loop.  By ablation (tools/experiments/README.md) the fp32 staging cost 0.27 - 0.35 ms of the 1.4 - 1.8 ms of a 256-channel
 // k5 conv at 128 windows (its LDS writes alone 0.12 ms); the fragment READS per tap, 80 % of the LDS read traffic, cost nothing.
 // The LDS image of a DMA is lane-linear, so the bank swizzle sits on the SOURCE address: 16-B chunk c of row r is stored at
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
         int grow = m0 + wrow * 32 * MR + mr * 32 + lr;
         grow = grow < co_pad ? grow : co_pad - 1;
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) Wrow[mr][pl] = W16 + ((size_t)pl * co_pad + grow) * K2 + lh * 8;
+        for (int pl = 0; pl < NP; ++pl) Wrow[mr][pl] = W16 + planes_at(pl, grow, 0, co_pad, K2) + lh * 8;      // k-blocked (planes_layout.h)
     }
     bf16x8 a_cur[MR][2][NP], a_nxt[MR][2][NP];    // [row tile][k16 step][plane]
     auto load_A = [&](int cb, int j, bf16x8 (&a)[MR][2][NP]) {
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl) a[mr][s2][pl] = *(const bf16x8*)(Wrow[mr][pl] + kcol + s2 * 16);
+                for (int pl = 0; pl < NP; ++pl) a[mr][s2][pl] = *(const bf16x8*)(Wrow[mr][pl] + (size_t)kcol * co_pad + s2 * 16);   // kcol / 32 blocks of co_pad * 32
     };
 
     // ---- X staging: 9 (row, channel-pair) items per thread per 32-channel block.  Everything that does not depend on
@@ -161,11 +162,11 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
             tin = tin < 0 ? -tin : tin;                                  // reflect-left (pad_mode 1; checked on the host)
             tin = tin < p.Tin ? tin : p.Tin - 1;                         // rows past the signal only feed columns >= Tout
             const int chunk = (lane & 3) ^ ((r >> 2) & 3);
-            dma_src[i] = (unsigned)((((size_t)pl * cols_pad + (size_t)n * p.Tin + tin) * p.Ci_pad + chunk * 8) * 2);
+            dma_src[i] = (unsigned)((planes_at(pl, (int64_t)n * p.Tin + tin, 0, cols_pad, p.Ci_pad) + chunk * 8) * 2);
         }
     }
     auto dma_X = [&](int cb, int buf) {
-        const unsigned char* base = (const unsigned char*)p.Xp + (size_t)cb * (BKC * 2);
+        const unsigned char* base = (const unsigned char*)p.Xp + (size_t)cb * cols_pad * (BKC * 2);      // one k-block further
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int q = wid + 4 * i;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
                         bf16x2_t lp2 = {(__bf16)(q0 - __uint_as_float(hi[k2] << 16)), (__bf16)(q1 - __uint_as_float(hi[k2] & 0xffff0000u))};
                         lo[k2] = __builtin_bit_cast(unsigned, lp2);
                     }
-                    unsigned short* dst = Zp + ((size_t)n * p.Tout + t) * co_pad32 + row0;
+                    unsigned short* dst = Zp + planes_at(0, (int64_t)n * p.Tout + t, row0, zcols_pad, co_pad32);
                     *(u32x4*)dst = u32x4{hi[0], hi[1], hi[2], hi[3]};
                     *(u32x4*)(dst + zcols_pad * co_pad32) = u32x4{lo[0], lo[1], lo[2], lo[3]};
                 }

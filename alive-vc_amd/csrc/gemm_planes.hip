@@ -2,11 +2,16 @@
 //
 //   D[co][col] = bias[co] + sum_k W[co][k] * X[col][k]          co < Co, col = n*T + t < N*T, k < Ci
 //
-// Both operands are stored as NP bf16 planes (v = p0 + p1 (+ p2)) with k contiguous, so a tile of either is a set of
-// 64-byte row segments that LDS-DMA (`global_load_lds_dwordx4`) copies straight into LDS: no VGPR round trip, no
-// conversion and no ds_write in the loop, which is what bound conv_split.hip on these shapes (one 32-channel block of a
-// 1x1 conv is only 24 MFMAs per wave between two barriers, and the fp32 activations had to be loaded, split and stored
-// behind them).  The product of two split values keeps the plane pairs (i, j) with i + j <= NP - 1:
+// Both operands are stored as NP bf16 planes (v = p0 + p1 (+ p2)), K-BLOCKED (planes_layout.h): element (plane, row, k) of an
+// operand with R padded rows sits at ((plane * K/32 + k/32) * R + row) * 32 + k % 32, so the 64-byte k-segments of consecutive
+// rows are consecutive in memory and one K-step of a 128-row tile plane is ONE contiguous 8-KB run that LDS-DMA
+// (`global_load_lds_dwordx4`) copies straight into LDS in 1-KB pieces of whole cache lines: no VGPR round trip, no conversion
+// and no ds_write in the loop, which is what bound conv_split.hip on these shapes (one 32-channel block of a 1x1 conv is only
+// 24 MFMAs per wave between two barriers, and the fp32 activations had to be loaded, split and stored behind them).
+// (Until round 4 the planes were row-major with k contiguous: a piece was 16 row segments of 64 B, each HALF of a 128-B line
+// whose other half the next K-step asked for again -- twice the L2 requests for the same bytes; these kernels ran 5 - 12 %
+// slower on it, tools/experiments/README.md.)
+// The product of two split values keeps the plane pairs (i, j) with i + j <= NP - 1:
 //   NP = 2: 3 MFMAs ("bf16x3", ~2^-16 per product)    NP = 3: 6 MFMAs ("bf16x6", fp32-grade)
 //
 // Block = 4 waves (2 x 2), tile 128 (co) x 128 (col), wave tile 64 x 64 = 2 x 2 v_mfma_f32_32x32x16_bf16 tiles.
@@ -17,6 +22,7 @@
 // lane-linear, so the bank swizzle sits on the SOURCE address: 16-B chunk c of row r is stored at chunk
 // c ^ ((r >> 2) & 3), which makes every ds_read_b128 of an MFMA fragment conflict-free (16-lane groups, 256-B bank rows).
 #include "conv_epilogue.h"
+#include "planes_layout.h"
 
 namespace {
 
@@ -33,6 +39,24 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 __device__ __forceinline__ void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14)); }
 
+// Where K-step s of a tile's operands starts, relative to step 0 (elements).  W and the packed B planes are k-blocked: one block
+// further is one padded operand further (a_ks, b_blk).  Custom row placement (AliveGemm.b_row != 0) walks `ncb` k-blocks per tap
+// and then moves one row segment (32 elements) on: ncb = 1, b_blk = 0 for rows that are k-contiguous in memory (the STFT's signal).
+struct GemmWalk {
+    int64_t a_ks, b_blk, b_tap;
+    int ncb;
+};
+struct StepWalk {
+    int64_t a = 0, b = 0;
+    int blk = 0;
+    __device__ __forceinline__ void reset() { a = 0; b = 0; blk = 0; }
+    __device__ __forceinline__ void advance(const GemmWalk& g) {
+        a += g.a_ks;
+        b += g.b_blk;
+        if (++blk == g.ncb) { blk = 0; b += g.b_tap - (int64_t)g.ncb * g.b_blk; }
+    }
+};
+
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
     bf16x2_t h = {(__bf16)a, (__bf16)b};
@@ -41,7 +65,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 
 // ---- epilogue, straight from the accumulators (shared by the one-tile and the persistent kernel) ----
 // stage: wave-private LDS (NP x 8 KB: [plane][64 columns][64 channels] bf16) for the plane-packed output, or nullptr.  With it
-// the planes leave as 16-byte pieces, 8 lanes covering the 128 B of a column's 64 channels (the tile is written to LDS in the
+// the planes leave as 16-byte pieces, 64 lanes covering 16 columns x the 64 B of a k-block (the tile is written to LDS in the
 // accumulator layout -- 8 B per lane, 16-B chunk index XOR-ed with column & 7 -- and read back transposed); without it a lane
 // stores its 8-byte pieces directly, one per column and store instruction: 64 separate 64-B lines touched per instruction.
 // By ablation (tools/experiments/README.md) the epilogue was 41 % of a 512 -> 1536 + GELU -> planes layer.
@@ -199,7 +223,8 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
                         const u32x4 v = *(const u32x4*)(stage_small + cl * 64 + ((chunk ^ ((cl >> 2) & 3)) << 4));
                         const int64_t col = c0 + wc * 64 + tj * 32 + cl;
                         const int row0 = m0 + wr * 64 + ti * 32 + chunk * 8;
-                        if (col < cols && row0 < co_pad32) *(u32x4*)(Po + ((size_t)pl * cols_pad + col) * co_pad32 + row0) = v;
+                        // (64 lanes: 16 columns x the 64 B of one k-block -- one contiguous 1-KB run of the k-blocked planes)
+                        if (col < cols && row0 < co_pad32) *(u32x4*)(Po + planes_at(pl, col, row0, cols_pad, co_pad32)) = v;
                     }
                 }
             } else if (p.Pout != nullptr && cok[tj]) {
@@ -216,7 +241,7 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl) {
                         const unsigned h01 = pack_bf16x2(q[0], q[1]), h23 = pack_bf16x2(q[2], q[3]);
-                        *(uint2*)(Po + ((size_t)pl * cols_pad + col) * co_pad32 + row) = make_uint2(h01, h23);
+                        *(uint2*)(Po + planes_at(pl, col, row, cols_pad, co_pad32)) = make_uint2(h01, h23);
                         q[0] -= __uint_as_float(h01 << 16);
                         q[1] -= __uint_as_float(h01 & 0xffff0000u);
                         q[2] -= __uint_as_float(h23 << 16);
@@ -231,14 +256,15 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
         const int lane = lr + 32 * lh;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const int idx = it * 64 + lane, cl = idx >> 3, chunk = idx & 7;
+            // one store instruction = 16 columns x the 64 B of one k-block: a contiguous 1-KB run of the k-blocked planes
+            const int cl = (it & 3) * 16 + (lane >> 2), chunk = (it >> 2) * 4 + (lane & 3);
             const int64_t col = c0 + wc * 64 + cl;
             const int row0 = m0 + wr * 64 + chunk * 8;
             if (col >= cols || row0 >= co_pad32) continue;
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
                 const u32x4 v = *(const u32x4*)(stage + pl * 8192 + cl * 128 + ((chunk ^ (cl & 7)) << 4));
-                *(u32x4*)(Po + ((size_t)pl * cols_pad + col) * co_pad32 + row0) = v;
+                *(u32x4*)(Po + planes_at(pl, col, row0, cols_pad, co_pad32)) = v;
             }
         }
     }
@@ -247,7 +273,7 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
 template <int NP, int NS, int MINB, int ACT>
 __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int n_mt, int ntiles, int64_t cols,
                                                              int64_t cols_pad, int co_pad, int co_pad32, int kpad,
-                                                             long long* stamps) {
+                                                             GemmWalk gw, long long* stamps) {
 #ifdef ALIVE_STAMPS                 // diagnostic build only (make EXTRA=-DALIVE_STAMPS; tools/stamp_gemm.py)
     const long long ts0 = wall_clock64();
 #endif
@@ -285,11 +311,11 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
         if (op == 0) {
             int row = m0 + r;
             row = row < co_pad ? row : co_pad - 1;
-            src[i] = (const unsigned short*)p.W + ((size_t)pl * co_pad + row) * kpad + pchunk * 8;
+            src[i] = (const unsigned short*)p.W + planes_at(pl, row, 0, co_pad, kpad) + pchunk * 8;
         } else if (p.b_row == 0) {
             int64_t col = c0 + r;
             col = col < cols_pad ? col : cols_pad - 1;
-            src[i] = (const unsigned short*)p.P + ((size_t)pl * cols_pad + col) * kpad + pchunk * 8;
+            src[i] = (const unsigned short*)p.P + planes_at(pl, col, 0, cols_pad, kpad) + pchunk * 8;
         } else {                                         // custom row placement (overlapping rows: the STFT)
             int64_t col = c0 + r;
             col = col < cols ? col : cols - 1;
@@ -298,8 +324,10 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
         }
         ldst[i] = (op * NP + pl) * PLANE_BYTES + g * 1024;
     }
+    // the steps are issued in order: `walk` holds the offsets of the next step to issue (pieces i < 2 NP are W's, the rest B's)
+    StepWalk walk;
     auto issue = [&](int step, int i) {
-        __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + step * GK), (lptr_t)(smem + (step % NS) * SLOT + ldst[i]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (i < 2 * NP ? walk.a : walk.b)), (lptr_t)(smem + (step % NS) * SLOT + ldst[i]), 16, 0, 0);
     };
 
     // the bias joins in the epilogue: nothing but the DMA issue stands between the launch and the first MFMA
@@ -314,6 +342,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
         if (s < nsteps) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) issue(s, i);
+            walk.advance(gw);
         }
 
     // fragment byte offsets inside a plane: row * 64 + ((2 ks + lh) ^ ((row >> 2) & 3)) * 16 ; ks = 1 flips bit 5
@@ -380,6 +409,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
             for (int i = 0; i < NI; ++i)
                 if (i * NPROD / NI == n && refill) issue(s + NS, i);
         });
+        walk.advance(gw);
         __builtin_amdgcn_sched_barrier(0);
     }
     wait_vmcnt<0>();
@@ -414,7 +444,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
 // never fewer).  Needs nsteps >= NS.
 template <int NP, int NS, int ACT>
 __global__ __launch_bounds__(256, 1) void gemm_planes_persistent_kernel(AliveGemm p, int n_mt, int ntiles, int64_t cols,
-                                                                        int64_t cols_pad, int co_pad, int co_pad32, int kpad) {
+                                                                        int64_t cols_pad, int co_pad, int co_pad32, int kpad,
+                                                                        GemmWalk gw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SLOT = 2 * NP * PLANE_BYTES;
     constexpr int NI = 4 * NP;
@@ -459,11 +490,11 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_persistent_kernel(AliveGem
             if (!isB[i]) {
                 int row = mt * GM + r;
                 row = row < co_pad ? row : co_pad - 1;
-                o[i] = (unsigned)((((size_t)pl * co_pad + row) * kpad + pchunk * 8) * 2);
+                o[i] = (unsigned)((planes_at(pl, row, 0, co_pad, kpad) + pchunk * 8) * 2);
             } else if (p.b_row == 0) {
                 int64_t col = c0 + r;
                 col = col < cols_pad ? col : cols_pad - 1;
-                o[i] = (unsigned)((((size_t)pl * cols_pad + col) * kpad + pchunk * 8) * 2);
+                o[i] = (unsigned)((planes_at(pl, col, 0, cols_pad, kpad) + pchunk * 8) * 2);
             } else {                                     // custom row placement (overlapping rows: the STFT)
                 int64_t col = c0 + r;
                 col = col < cols ? col : cols - 1;
@@ -472,10 +503,13 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_persistent_kernel(AliveGem
             }
         }
     };
-    // stream element = (tile parity `which`, step); slot = running step count mod NS
-    auto issue = [&](int which, int step, int slot, int i) {
+    // stream element = (tile parity `which`, step); slot = running step count mod NS.  The elements are issued in stream order:
+    // `walk` holds the step offsets of the next one (reset at every tile seam)
+    StepWalk walk;
+    auto issue = [&](int which, int slot, int i) {
         const unsigned char* base = isB[i] ? (const unsigned char*)p.P : (const unsigned char*)p.W;
-        __builtin_amdgcn_global_load_lds((gptr_t)(base + off[which][i] + step * (GK * 2)), (lptr_t)(smem + slot * SLOT + ldst[i]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + off[which][i] + (unsigned)((isB[i] ? walk.b : walk.a) * 2)),
+                                         (lptr_t)(smem + slot * SLOT + ldst[i]), 16, 0, 0);
     };
 
     const int sw = (lr >> 2) & 3;
@@ -511,9 +545,11 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_persistent_kernel(AliveGem
     int cur = 0, qb = 0;                     // tile parity of off[], slot of the current tile's step 0
     tile_offsets(v, off[0]);
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
+    for (int s = 0; s < NS; ++s) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) issue(0, s, s, i);
+        for (int i = 0; i < NI; ++i) issue(0, s, i);
+        walk.advance(gw);
+    }
     wait_vmcnt<(NS - 1) * NI>();             // stage 0 of the first tile (this wave's pieces)
 
     while (true) {
@@ -544,12 +580,14 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_persistent_kernel(AliveGem
             const int ts = s + NS;
             const bool in_tile = ts < nsteps;
             const bool refill = in_tile || has_next;
-            const int rwhich = in_tile ? cur : (cur ^ 1), rstep = in_tile ? ts : ts - nsteps;
+            const int rwhich = in_tile ? cur : (cur ^ 1);
+            if (ts == nsteps) walk.reset();          // the stream enters the next tile
             mma(fa[1], fb[1], [&](int n) {
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
-                    if (i * NPROD / NI == n && refill) issue(rwhich, rstep, slot, i);
+                    if (i * NPROD / NI == n && refill) issue(rwhich, slot, i);
             });
+            walk.advance(gw);
             __builtin_amdgcn_sched_barrier(0);
         }
         // stage 0 of the next tile before this tile's loads / stores enter the counter
@@ -566,7 +604,7 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_persistent_kernel(AliveGem
     }
 }
 
-// fp32 [N][C][T] -> planes [NP][cols_pad][C_pad] (zero padded in both directions)
+// fp32 [N][C][T] -> k-blocked planes [NP][C_pad / 32][cols_pad][32] (zero padded in both directions)
 template <int NP>
 __global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict__ X, int C, int T, int64_t cols, int64_t cols_pad,
                                                         int c_pad, unsigned short* __restrict__ P) {
@@ -586,11 +624,12 @@ __global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict_
         }
     }
     __syncthreads();
-    // thread -> (column, 8-channel chunk): 64 columns x 8 chunks = 512 items, two per thread
+    // thread -> (k-block half of the tile, column, 8-channel chunk inside the block): 2 x 64 x 4 = 512 items, two per thread; a wave
+    // writes 16 columns x 64 B = one contiguous 1-KB run per plane
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int item = it * 256 + threadIdx.x;
-        const int ck = item & 7, cl = item >> 3;
+        const int ck = it * 4 + (item & 3), cl = (item >> 2) & 63;
         const int64_t col = col0 + cl;
         const int c = ch0 + ck * 8;
         if (col >= cols_pad || c >= c_pad) continue;
@@ -607,7 +646,7 @@ __global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict_
                 vv[2 * e] -= __uint_as_float(h << 16);
                 vv[2 * e + 1] -= __uint_as_float(h & 0xffff0000u);
             }
-            *(u32x4*)(P + ((size_t)pl * cols_pad + col) * c_pad + c) = o;
+            *(u32x4*)(P + planes_at(pl, col, c, cols_pad, c_pad)) = o;
         }
     }
 }
@@ -615,6 +654,14 @@ __global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict_
 long long* g_stamps = nullptr;
 inline int64_t pad_cols(int64_t cols) { return (cols + GN - 1) / GN * GN; }
 inline int pad32(int c) { return (c + 31) & ~31; }
+inline GemmWalk make_walk(const AliveGemm& d) {
+    GemmWalk g;
+    g.a_ks = (int64_t)((d.Co + 15) & ~15) * GK;
+    if (d.b_row == 0) { g.b_blk = pad_cols((int64_t)d.N * d.T) * GK; g.b_tap = 0; g.ncb = pad32(d.Ci) / GK; }
+    else if (d.b_cblk == 0) { g.b_blk = 0; g.b_tap = GK; g.ncb = 1; }
+    else { g.b_blk = d.b_blk; g.b_tap = GK; g.ncb = d.b_cblk; }
+    return g;
+}
 
 template <int NP, int NS, int MINB, int ACT>
 int launch_gemm_act(const AliveGemm& d, hipStream_t s) {
@@ -631,7 +678,7 @@ int launch_gemm_act(const AliveGemm& d, hipStream_t s) {
     const int n_mt = cdiv(d.Co, GM), n_ct = cdiv(cols, GN);
     const int ntiles = n_mt * n_ct;
     gemm_planes_kernel<NP, NS, MINB, ACT><<<ntiles, 256, LDS, s>>>(
-        d, n_mt, ntiles, cols, pad_cols(cols), (d.Co + 15) & ~15, pad32(d.Co), pad32(d.Ci),
+        d, n_mt, ntiles, cols, pad_cols(cols), (d.Co + 15) & ~15, pad32(d.Co), pad32(d.Ci), make_walk(d),
         g_stamps);
     ALIVE_CHECK_LAUNCH("alive_gemm_planes");
     return ALIVE_OK;
@@ -651,7 +698,7 @@ int launch_gemm_persistent_act(const AliveGemm& d, hipStream_t s) {
     const int64_t cols = (int64_t)d.N * d.T;
     const int n_mt = cdiv(d.Co, GM), n_ct = cdiv(cols, GN);
     gemm_planes_persistent_kernel<NP, NS, ACT><<<256, 256, LDS, s>>>(d, n_mt, n_mt * n_ct, cols, pad_cols(cols), (d.Co + 15) & ~15,
-                                                                   pad32(d.Co), pad32(d.Ci));
+                                                                   pad32(d.Co), pad32(d.Ci), make_walk(d));
     ALIVE_CHECK_LAUNCH("alive_gemm_planes(persistent)");
     return ALIVE_OK;
 }
@@ -728,6 +775,8 @@ extern "C" int alive_gemm_planes(const AliveGemm* d, void* stream) {
     ALIVE_CHECK_ARG(d->planes == 2 || d->planes == 3, "alive_gemm_planes: planes must be 2 or 3, got %d", d->planes);
     ALIVE_CHECK_ARG(d->b_row == 0 || ((d->b_row | d->b_win | d->b_plane) & 7) == 0, "alive_gemm_planes: custom row placement must be in multiples of 8 elements");
     ALIVE_CHECK_ARG(d->b_row == 0 || (d->Ci & 31) == 0, "alive_gemm_planes: custom row placement needs Ci %% 32 == 0");
+    ALIVE_CHECK_ARG(d->b_cblk >= 0 && (d->b_cblk == 0 || (d->b_row != 0 && (d->Ci / 32) % d->b_cblk == 0 && (d->b_blk & 7) == 0)),
+                    "alive_gemm_planes: b_cblk %d (k-blocks per tap) must divide Ci / 32 = %d, with b_row and b_blk set", d->b_cblk, d->Ci / 32);
     ALIVE_CHECK_ARG(d->act >= 0 && d->act <= 3, "alive_gemm_planes: activation %d", d->act);
     ALIVE_CHECK_ARG(((((uintptr_t)d->W) | ((uintptr_t)d->P) | ((uintptr_t)d->Pout)) & 15) == 0,
                     "alive_gemm_planes: W / P / Pout must be 16-byte aligned");

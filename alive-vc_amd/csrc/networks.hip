@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "common.h"
+#include "planes_layout.h"
 
 int alive_magnitude(const float* ri, int N, int B, int T, float* out, hipStream_t s);
 
@@ -215,7 +216,7 @@ extern "C" const char* alive_weight_name(int model, int index) {
 }
 
 // ---- spectrogram -------------------------------------------------------------------------------
-// basis buffer: fp32 [1296][1280] (streaming path: exact f32-MFMA conv), then bf16 [3 planes][1296][1280] (batch path)
+// basis buffer: fp32 [1296][1280] (streaming path: exact f32-MFMA conv), then bf16 3 planes x 1296 rows x 1280, k-blocked (batch path)
 namespace {
 constexpr size_t BASIS_F32 = (size_t)DFT_ROWS * NFFT;
 
@@ -234,7 +235,7 @@ __global__ void dft_basis_planes_kernel(unsigned short* planes) {
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
         const unsigned short h = f32_to_bf16_rn(v);
-        planes[(size_t)pl * DFT_ROWS * NFFT + i] = h;
+        planes[planes_at(pl, row, j, DFT_ROWS, NFFT)] = h;              // the GEMM's weight operand: k-blocked (planes_layout.h)
         v -= __uint_as_float((unsigned)h << 16);
     }
 }
@@ -465,9 +466,10 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
         const float* Wp = i >= 2 ? t.next() : nullptr;
         const int r = drate[i];
         if (Wp != nullptr && b.Pa != nullptr) {
-            // Conv1d(k == stride == r, no padding) on the batch path: with the input as time-major bf16 planes, the K vector of
-            // output column t is the r consecutive plane rows r t .. r t + r - 1 -- a plane GEMM whose B rows overlap nothing
-            // and start every r rows (the same custom row placement the STFT uses), 16/3 the rate of the exact-fp32 kernel
+            // Conv1d(k == stride == r, no padding) on the batch path: with the input as k-blocked bf16 planes, the K vector of
+            // output column t is the r consecutive plane rows r t .. r t + r - 1 in each of the cpad / 32 k-blocks -- a plane GEMM
+            // whose B rows overlap nothing and start every r rows (custom row placement, AliveGemm.b_cblk), 16/3 the rate of the
+            // exact-fp32 kernel
             void* Pd = i == 2 ? (void*)b.U : (void*)b.Zz;             // both idle until the up path starts
             const int cpad = (dch[i] + 31) & ~31;
             if (i == 2) RUN(alive_to_planes(dbuf[i], N, dch[i], len, 2, Pd, stream));      // i == 3: left there by downs[2]'s epilogue
@@ -477,8 +479,10 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
             g.Y = dbuf[i + 1];
             if (i == 2) g.Pout = b.Zz;                                 // d2 as planes too: the input of downs[3]
             g.b_plane = (int64_t)(alive_planes_bytes((int64_t)N * len, dch[i], 2) / 4);      // elements per plane
-            g.b_win = (int64_t)len * cpad;
-            g.b_row = (int64_t)r * cpad;
+            g.b_win = (int64_t)len * 32;
+            g.b_row = r * 32;
+            g.b_cblk = cpad / 32;
+            g.b_blk = g.b_plane / cpad * 32;                                              // padded rows of the buffer x 32
             RUN(alive_gemm_planes(&g, stream));
         } else {
             AliveConv d = conv_desc(W, bb, dbuf[i], N, dch[i], len, dch[i + 1], r, r, 1, 0, 0, len / r, dbuf[i + 1]);

@@ -35,7 +35,7 @@ class AliveGemm(C.Structure):
         ("N", C.c_int), ("T", C.c_int), ("Ci", C.c_int), ("Co", C.c_int), ("planes", C.c_int), ("act", C.c_int),
         ("post_add", C.c_void_p), ("ch_scale", C.c_void_p), ("residual", C.c_void_p),
         ("Y", C.c_void_p), ("Pout", C.c_void_p),
-        ("b_plane", C.c_int64), ("b_win", C.c_int64), ("b_row", C.c_int),
+        ("b_plane", C.c_int64), ("b_win", C.c_int64), ("b_row", C.c_int), ("b_cblk", C.c_int), ("b_blk", C.c_int64),
         ("arg_val", C.c_void_p), ("arg_idx", C.c_void_p),
     ]
 

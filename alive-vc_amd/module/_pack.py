@@ -43,14 +43,28 @@ def split_bf16(w, planes=2):
     return out
 
 
-def pack_conv_split(w, planes=2):
-    """Conv1d weight [Co, Ci, KW] -> bf16 [planes, Co_pad16, KW * Ci_pad32], tap-major k = j * Ci_pad + ci.
-    planes = 2: "bf16x3" (3 MFMAs per product, ~2^-16); planes = 3: "bf16x6" (6 MFMAs, ~2^-24, fp32-grade)."""
+def _split_rows(w, planes=2):
+    """Conv1d weight [Co, Ci, KW] -> bf16 [planes, Co_pad16, KW * Ci_pad32], row-major, tap-major k = j * Ci_pad + ci."""
     co, ci, kw = w.shape
     co_pad, ci_pad = _pad16(co), (ci + 31) // 32 * 32
     a = torch.zeros(co_pad, kw, ci_pad, dtype=torch.float32, device=w.device)
     a[:co, :, :ci] = w.float().permute(0, 2, 1)
     return torch.stack(split_bf16(a.reshape(co_pad, kw * ci_pad), planes), 0).contiguous()
+
+
+def pack_conv_split(w, planes=2):
+    """Conv1d weight [Co, Ci, KW] -> bf16 [planes, K / 32, Co_pad16, 32]: the K-BLOCKED plane format of csrc/planes_layout.h,
+    K = KW * Ci_pad32, tap-major k = j * Ci_pad + ci; element (plane, row, k) at [plane, k // 32, row, k % 32].
+    planes = 2: "bf16x3" (3 MFMAs per product, ~2^-16); planes = 3: "bf16x6" (6 MFMAs, ~2^-24, fp32-grade)."""
+    a = _split_rows(w, planes)
+    p, co_pad, k = a.shape
+    return a.view(p, co_pad, k // 32, 32).permute(0, 2, 1, 3).contiguous()
+
+
+def unpack_conv_split(W):
+    """k-blocked [planes, K / 32, Co_pad, 32] -> row-major [planes, Co_pad, K] (tests, tools)"""
+    p, kb, co_pad, _ = W.shape
+    return W.permute(0, 2, 1, 3).reshape(p, co_pad, kb * 32)
 
 
 def pack_conv_split3(w):
@@ -109,11 +123,11 @@ SPLIT_SCALE = [m != "small" for m in FILTER_MODE]      # ConvTranspose in front 
 def pack_filter_mid(sd, prefix):
     """FilterBlock weights for the fused 64-channel kernel (csrc/filter_mid.hip):
     -> (bf16 flat: input conv [2][64][64], then 6 x [2][64][k = j*64 + ci]; fp32 biases [7][64])"""
-    ws = [pack_conv_split(sd[prefix + ".input_conv.weight"]).reshape(-1)]
+    ws = [_split_rows(sd[prefix + ".input_conv.weight"]).reshape(-1)]
     bs = [sd[prefix + ".input_conv.bias"].float()]
     for j in range(3):
         for cc in ("c1", "c2"):
-            ws.append(pack_conv_split(sd[f"{prefix}.blocks.{j}.{cc}.conv.conv.weight"]).reshape(-1))
+            ws.append(_split_rows(sd[f"{prefix}.blocks.{j}.{cc}.conv.conv.weight"]).reshape(-1))
             bs.append(sd[f"{prefix}.blocks.{j}.{cc}.conv.conv.bias"].float())
     return torch.cat(ws).contiguous(), torch.stack(bs, 0).contiguous()
 

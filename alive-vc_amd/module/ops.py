@@ -59,7 +59,7 @@ def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, o
         co_out = co_rows
     d = nat.AliveConv()
     d.W, d.bias, d.X = nat.ptr(W), nat.ptr(b), nat.ptr(x)
-    d.N, d.Ci, d.Tin, d.Co, d.K_pad = n, ci, tin, co_rows, W.shape[-1]
+    d.N, d.Ci, d.Tin, d.Co, d.K_pad = n, ci, tin, co_rows, (W.shape[-1] if W.dim() == 2 else W.shape[1] * 32)
     d.precision, d.Ci_pad = (planes - 1, (ci + 31) // 32 * 32) if split else (0, 0)
     d.KW, d.stride, d.dil, d.pad_left, d.pad_mode = kw, stride_, dilation, pad_left, pad_mode
     d.Tout, d.up, d.act = tout, up, ACT[act]
@@ -100,7 +100,8 @@ def planes_to_float(P, n, c, t, planes):
     """inverse of to_planes (sum of the planes), for tests"""
     cols, cp = n * t, (c + 31) // 32 * 32
     cols_pad = (cols + 127) // 128 * 128
-    v = P.view(torch.bfloat16).view(planes, cols_pad, cp).float().sum(0)[:cols, :c]
+    v = P.view(torch.bfloat16).view(planes, cp // 32, cols_pad, 32).float().sum(0)        # k-blocked (csrc/planes_layout.h)
+    v = v.permute(1, 0, 2).reshape(cols_pad, cp)[:cols, :c]
     return v.view(n, t, c).permute(0, 2, 1).contiguous()
 
 

@@ -190,7 +190,8 @@ typedef struct AliveConv {
     int film_rows, Lf, film_scale_row, film_shift_row;
     /* arithmetic: 0 = exact fp32 (f32-input MFMA), W as above;
      *             1 = 2-term split bf16 ("bf16x3": hi*hi + hi*lo + lo*hi on the bf16 MFMA, ~2^-16 per product),
-     *                 W = bf16 [2][Co_pad][KW*Ci_pad] (plane 0 hi, plane 1 lo), tap-major k = j*Ci_pad + ci,
+     *                 W = bf16, 2 planes (hi, lo) of Co_pad rows x K = KW*Ci_pad, tap-major k = j*Ci_pad + ci, stored K-BLOCKED
+     *                 like the activation planes below: [2][K/32][Co_pad][32] (module/_pack.py::pack_conv_split);
      *                 Ci_pad a multiple of 32; stride must be 1. */
     int precision, Ci_pad;
     /* FiLM of a frame RANGE of a longer window (alive_decoder_forward_range): this conv's columns start at sample
@@ -199,7 +200,8 @@ typedef struct AliveConv {
      * film_ld == 0: film covers the whole window (film_t0 = film_f0 = 0, pitch Lf).  Split kernel only. */
     int film_t0, film_f0, film_ld;
     /* Plane-packed operands of the split kernel (precision 1, Co > 64; round 3).  Format = "plane-packed activations" below:
-     * P[plane][n * T + t][C_pad] bf16, 2 planes, plane stride = cols_pad * C_pad, cols_pad = N * T rounded up to 128.
+     * P[plane][C_pad/32][cols_pad][32] bf16 (row = n * T + t), 2 planes, plane stride = cols_pad * C_pad, cols_pad = N * T
+     * rounded up to 128.
      *   Xp  input instead of X (X is ignored): Ci a multiple of 32, pad_mode 1 (or no padding); staged by LDS-DMA.
      *   Zp  the second output (gelu + FiLM) in that format instead of / beside Z: Co a multiple of 64, Tout a multiple of 4.
      * The decoder's 256-channel FilterBlock chains its convs through these (networks.hip). */
@@ -211,18 +213,21 @@ int alive_conv1d(const AliveConv* desc, void* stream);
 /* ---- plane-packed activations: the frame-rate GEMMs of the ConvNeXt stacks --------------------------
  * The 1x1 convs of ContentEncoder / F0Estimator / FeatureExtractor (content_encoder.py:22-25,
  * f0_estimator.py:23-27, decoder.py:43-48, common.py:57-61,77-81) run as plain GEMMs whose activation operand is
- * already split into bf16 planes and stored K-contiguous, so that BOTH operands go global -> LDS by LDS-DMA and
- * the inner loop is MFMAs only:
- *   P[plane][col][C_pad] bf16, col = n*T + t, plane 0 = bf16(v), plane 1 = bf16(v - p0), plane 2 = bf16(v - p0 - p1);
+ * already split into bf16 planes and stored K-BLOCKED, so that BOTH operands go global -> LDS by LDS-DMA in contiguous
+ * runs of whole cache lines and the inner loop is MFMAs only (csrc/planes_layout.h):
+ *   P[plane][C_pad/32][cols_pad][32] bf16 -- element (plane, col, c) at ((plane * C_pad/32 + c/32) * cols_pad + col) * 32 + c % 32,
+ *   col = n*T + t, plane 0 = bf16(v), plane 1 = bf16(v - p0), plane 2 = bf16(v - p0 - p1);
  *   C_pad a multiple of 32 (zero filled), plane stride = cols_pad * C_pad with cols_pad a multiple of 128.
+ *   (Rounds 2 - 3 stored the planes row-major, [plane][col][C_pad]: a 16-row DMA piece then touched 16 half lines whose other
+ *   halves the next K-step fetched again; the k-blocked form took 5 - 12 % off every kernel that reads them.)
  * alive_to_planes converts an fp32 [N][C][T] tensor; alive_gemm_planes writes fp32 [N][Co][T] (same epilogue
  * options as alive_conv1d) and / or plane-packed output (act applied first) for the next GEMM. */
 size_t alive_planes_bytes(int64_t cols, int C, int planes);        /* bytes of a plane-packed buffer */
 int alive_to_planes(const float* X, int N, int C, int T, int planes, void* P, void* stream);
 typedef struct AliveGemm {
-    const void* W;         /* bf16 [planes][Co_pad][Ci_pad] (module/_pack.py::pack_conv_split of a k=1 conv) */
+    const void* W;         /* bf16 [planes][Ci_pad/32][Co_pad][32], k-blocked like P (module/_pack.py::pack_conv_split of a k=1 conv) */
     const float* bias;     /* [Co] or NULL */
-    const void* P;         /* input planes [planes][cols_pad][Ci_pad] */
+    const void* P;         /* input planes [planes][Ci_pad/32][cols_pad][32] */
     int N, T;              /* cols = N*T; fp32 outputs are [N][Co][T] */
     int Ci, Co;
     int planes;            /* 2: bf16x3, 3: bf16x6 (both operands) */
@@ -231,12 +236,18 @@ typedef struct AliveGemm {
     const float* ch_scale; /* [Co] or NULL */
     const float* residual; /* [N][Co][T] or NULL */
     float* Y;              /* fp32 output [N][Co][T] or NULL */
-    void* Pout;            /* plane-packed output [planes][cols_pad][Co_pad32] or NULL (Co_pad32 = Co rounded up to 32) */
+    void* Pout;            /* plane-packed output [planes][Co_pad32/32][cols_pad][32] or NULL (Co_pad32 = Co rounded up to 32) */
     /* custom placement of the input rows (all 0: the packed form above).  Row (n, t) of plane pl starts at element
      * pl*b_plane + n*b_win + t*b_row: overlapping rows (b_row < Ci) make the GEMM a strided convolution over a signal
      * stored once -- the STFT runs this way (b_row = hop 320, Ci = 1280).  Multiples of 8 elements. */
     int64_t b_plane, b_win;
     int b_row;
+    /* b_cblk = 0: such a row is k-contiguous in memory (the STFT's signal).  b_cblk > 0: the rows live in a k-blocked plane buffer
+     * (alive_to_planes / Pout) of b_cblk k-blocks, and the K vector of an output column is Ci / (32 b_cblk) consecutive rows of it:
+     * k = (tap * b_cblk + block) * 32 + i is element i of row + tap in block `block`, b_blk elements per block (the padded rows of
+     * that buffer * 32) -- the Filter's strided down convs (k == stride) run this way on the output planes of the layer before. */
+    int b_cblk;
+    int64_t b_blk;
     /* act == 3: the [Co][cols] product is never stored.  Each 64-row block of the GEMM leaves, per column, its largest
      * value (bias included) and the row it sits in -- arg_val / arg_idx [ceil(Co/64)][N*T], first row on ties, NaN wins
      * like ATen -- and alive_argmax_merge reduces the blocks: F0Estimator.estimate (f0_estimator.py:30-34) without the

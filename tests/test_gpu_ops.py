@@ -397,7 +397,8 @@ def test_to_planes_roundtrip(planes, n, c, t):
     # 2 planes carry 16 mantissa bits, 3 planes all 24
     assert (back - x).abs().max().item() <= (2.0 ** -15 if planes == 2 else 2.0 ** -22) * x.abs().max().item()
     cp, cols_pad = (c + 31) // 32 * 32, (n * t + 127) // 128 * 128
-    raw = P.view(torch.bfloat16).view(planes, cols_pad, cp).float()
+    raw = P.view(torch.bfloat16).view(planes, cp // 32, cols_pad, 32).float()              # k-blocked (csrc/planes_layout.h)
+    raw = raw.permute(0, 2, 1, 3).reshape(planes, cols_pad, cp)
     assert raw[:, n * t:, :].abs().sum().item() == 0.0 and raw[:, :, c:].abs().sum().item() == 0.0      # zero padding
 
 
@@ -714,7 +715,7 @@ def test_operators_write_only_their_outputs(monkeypatch):
 @pytest.mark.parametrize("kw,dil,t,with_res", [(5, 1, 900, True), (5, 2, 520, False), (5, 4, 4500, True), (1, 1, 300, False)])
 def test_conv1d_split_plane_operands_equal_the_fp32_staged_kernel(kw, dil, t, with_res):
     """AliveConv.Xp / Zp (the decoder's 256-channel FilterBlock chains its convs through them): the input arrives already
-    split into two bf16 planes, time-major, and is staged by LDS-DMA; the gelu + FiLM second output leaves in the same
+    split into two bf16 planes (k-blocked, rows = time) and is staged by LDS-DMA; the gelu + FiLM second output leaves in the same
     format.  Same split (round to nearest even), same MFMA order: Y bitwise equal to the fp32-staged kernel, Zp bitwise the
     plane image of its Z.  First tile reflects at t = 0 (causal conv), last tile is ragged."""
     from module import ops
@@ -732,11 +733,12 @@ def test_conv1d_split_plane_operands_equal_the_fp32_staged_kernel(kw, dil, t, wi
     assert torch.equal(y0, y1)
     want = ops.to_planes(z0, 2)
     cols, cols_pad = n * t, (n * t + 127) // 128 * 128
-    a = zp1.view(torch.bfloat16).view(2, cols_pad, c)[:, :cols]
-    e = want.view(torch.bfloat16).view(2, cols_pad, c)[:, :cols]
-    assert torch.equal(a.view(torch.int16), e.view(torch.int16))
+    a = zp1.view(torch.bfloat16).view(2, c // 32, cols_pad, 32)[:, :, :cols]           # k-blocked planes (csrc/planes_layout.h)
+    e = want.view(torch.bfloat16).view(2, c // 32, cols_pad, 32)[:, :, :cols]
+    assert torch.equal(a.contiguous().view(torch.int16), e.contiguous().view(torch.int16))
     # plane input alone (fp32 second output) and plane output alone (fp32 input)
     y2, z2 = ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), x_planes=xp, **kwargs)
     assert torch.equal(y2, y0) and torch.equal(z2, z0)
     y3, zp3 = ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), z_planes=True, **kwargs)
-    assert torch.equal(y3, y0) and torch.equal(zp3.view(torch.bfloat16).view(2, cols_pad, c)[:, :cols].view(torch.int16), e.view(torch.int16))
+    assert torch.equal(y3, y0) and torch.equal(zp3.view(torch.bfloat16).view(2, c // 32, cols_pad, 32)[:, :, :cols].contiguous().view(torch.int16),
+                                            e.contiguous().view(torch.int16))

@@ -66,14 +66,15 @@ def test_weight_tables_cover_the_schema():
             assert v.dtype in (torch.float32, torch.bfloat16) and v.is_contiguous()
             if k.endswith(".W") and v.dtype == torch.float32 and v.dim() == 2:   # exact-fp32 MFMA kernel: [Co_pad16][K_pad16]
                 assert v.shape[0] % 16 == 0 and v.shape[1] % 16 == 0
-            if k.endswith(".W") and v.dtype == torch.bfloat16:         # split kernel: [2][Co_pad16][KW * Ci_pad32]
-                assert v.shape[0] == (3 if mid < 2 else 2) and v.shape[1] % 16 == 0 and v.shape[2] % 32 == 0   # encoders: 3 planes
+            if k.endswith(".W") and v.dtype == torch.bfloat16:         # split kernel, k-blocked: [planes][KW * Ci_pad32 / 32][Co_pad16][32]
+                assert v.dim() == 4 and v.shape[0] == (3 if mid < 2 else 2) and v.shape[2] % 16 == 0 and v.shape[3] == 32   # encoders: 3 planes
     sd = synthetic.make_state_dict(schema.decoder_schema(), 2)
     p = _pack.pack_decoder(sd)
     assert p["flt.in.W"].shape == (56,) and p["flt.down0.W"].shape == (256,) and p["flt.out.W"].shape == (56,)   # streaming edge kernels
-    assert p["flt.film.W"].shape == (2, 4128, 512) and p["flt.film.post"].sum().item() == 2064
+    assert p["flt.film.W"].shape == (2, 16, 4128, 32) and p["flt.film.post"].sum().item() == 2064
     w = sd["filter.blocks.0.blocks.1.c2.conv.conv.weight"]                 # [256, 256, 5]
-    hi, lo = p["flt.blk0.1.c2.W"][0].float(), p["flt.blk0.1.c2.W"][1].float()
+    rows = _pack.unpack_conv_split(p["flt.blk0.1.c2.W"]).float()          # k-blocked -> [planes][co][k]
+    hi, lo = rows[0], rows[1]
     back = (hi + lo).view(256, 5, 256).permute(0, 2, 1)                    # tap-major -> [co, ci, j]
     assert (back - w).abs().max().item() <= 2.0 ** -16 * w.abs().max().item()
     w = torch.arange(2 * 3 * 4, dtype=torch.float32).view(2, 3, 4)            # ConvT [Ci=2, Co=3, r=4]

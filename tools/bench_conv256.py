@@ -17,7 +17,7 @@ for KW, dil, with_z, with_res, want_y in ((5, 2, 1, 1, 1), (5, 4, 1, 0, 0), (1, 
     y = torch.empty(N, C_, L, device=dev); z = torch.empty(N, C_, L, device=dev)
     d = nat.AliveConv()
     d.W, d.bias, d.X = W.data_ptr(), b.data_ptr(), x.data_ptr()
-    d.N, d.Ci, d.Tin, d.Co, d.K_pad = N, C_, L, C_, W.shape[-1]
+    d.N, d.Ci, d.Tin, d.Co, d.K_pad = N, C_, L, C_, (W.shape[-1] if W.dim() == 2 else W.shape[1] * 32)
     d.KW, d.stride, d.dil, d.pad_left, d.pad_mode, d.Tout, d.up, d.act = KW, 1, dil, (KW - 1) * dil, 1, L, 1, 0
     if want_y: d.Y = y.data_ptr()
     if with_res: d.residual = res.data_ptr()

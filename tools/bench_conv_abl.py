@@ -11,7 +11,7 @@ def run(N, Co, Ci, L, KW, with_z, with_res, Lf=450, reps=10):
     y = torch.empty(N, Co, L, device=dev); z = torch.empty(N, Co, L, device=dev); res = torch.randn(N, Co, L, device=dev)
     d = nat.AliveConv()
     d.W, d.bias, d.X = W.data_ptr(), b.data_ptr(), x.data_ptr()
-    d.N, d.Ci, d.Tin, d.Co, d.K_pad = N, Ci, L, Co, W.shape[-1]
+    d.N, d.Ci, d.Tin, d.Co, d.K_pad = N, Ci, L, Co, (W.shape[-1] if W.dim() == 2 else W.shape[1] * 32)
     d.KW, d.stride, d.dil, d.pad_left, d.pad_mode, d.Tout, d.up, d.act = KW, 1, 1, KW - 1, 1, L, 1, 0
     d.Y = y.data_ptr()
     if with_res: d.residual = res.data_ptr()
