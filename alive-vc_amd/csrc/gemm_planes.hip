@@ -45,7 +45,21 @@ __device__ __forceinline__ void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(15 
 struct GemmWalk {
     int64_t a_ks, b_blk, b_tap;
     int ncb;
+    int rg, n_ct;        // tile order (tile_of below): row tiles per group, column tiles
 };
+// Tile order: ROW GROUPS of rg row tiles, inside a group column tile by column tile.  The blocks an XCD runs together (32 CUs,
+// consecutive tiles of its contiguous chunk of this order) then share rg weight tiles -- chosen to stay resident in the XCD's 4-MB
+// L2 -- and 32 / rg activation panels that stream through it.  With all row tiles inside one column tile (rounds 2 - 3) an XCD
+// streamed the WHOLE weight matrix per column tile: 12.7 MB at 512 -> 4128 x 3 planes, nothing of it still in L2 when the next
+// column tile asked again (tools/pmc_mem.sh: 28 % of the L2 requests missed).
+__device__ __forceinline__ void tile_of(int v, int n_mt, const GemmWalk& g, int& mt, int& ct) {
+    const int gs = g.rg * g.n_ct;
+    const int grp = v / gs, rem = v - grp * gs;
+    const int left = n_mt - grp * g.rg;
+    const int rows = left < g.rg ? left : g.rg;
+    ct = rem / rows;
+    mt = grp * g.rg + (rem - ct * rows);
+}
 struct StepWalk {
     int64_t a = 0, b = 0;
     int blk = 0;
@@ -293,7 +307,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
         const int L = blockIdx.x, xcd = L & 7, j = L >> 3, q = ntiles >> 3, r = ntiles & 7;
         v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
-    const int mt = v % n_mt, ct = v / n_mt;
+    int mt, ct;
+    tile_of(v, n_mt, gw, mt, ct);
     const int m0 = mt * GM;
     const int64_t c0 = (int64_t)ct * GN;
     const int nsteps = kpad / GK;
@@ -387,6 +402,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
     load_frags(0, 0, fa[0], fb[0]);
 #ifdef ALIVE_STAMPS
     const long long ts2 = wall_clock64();
+    long long cy_vm = 0, cy_bar = 0;
+    const long long cy_l0 = __builtin_readcyclecounter();
 #endif
 
     for (int s = 0; s < nsteps; ++s) {
@@ -398,8 +415,18 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
         __builtin_amdgcn_sched_barrier(0);
         // step s + 1 must have landed for every wave; steps s + 2 .. s + NS - 1 stay in flight
         wait_lgkmcnt0();
+#ifdef ALIVE_STAMPS
+        const long long cy0 = __builtin_readcyclecounter();
+#endif
         if (s + NS - 1 < nsteps) wait_vmcnt<(NS - 2) * NI>(); else wait_vmcnt<0>();
+#ifdef ALIVE_STAMPS
+        const long long cy1 = __builtin_readcyclecounter();
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef ALIVE_STAMPS
+        const long long cy2 = __builtin_readcyclecounter();
+        cy_vm += cy1 - cy0; cy_bar += cy2 - cy1;
+#endif
         if (s + 1 < nsteps) load_frags(s + 1, 0, fa[0], fb[0]);
         __builtin_amdgcn_sched_barrier(0);
         // slot of step s is free now: refill it with step s + NS, NI pieces spread over the NPROD MFMA groups
@@ -415,6 +442,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
     wait_vmcnt<0>();
 #ifdef ALIVE_STAMPS
     const long long ts3 = wall_clock64();
+    const long long cy_l1 = __builtin_readcyclecounter();
 #endif
 
     unsigned char* stage = nullptr;
@@ -429,35 +457,37 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
     if (stamps != nullptr && tid == 0) {
         long long* o = stamps + (size_t)blockIdx.x * 8;
         o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3; o[4] = wall_clock64();
-        o[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+        o[5] = cy_l1 - cy_l0;          // core-clock cycles of the k-loop, of which waiting for the DMA stage / at the barrier:
+        o[6] = cy_vm; o[7] = cy_bar;
     }
 #endif
 }
 
-// ---- persistent form: one block per CU walks its tiles with the DMA ring running ACROSS the tile seams ----
-// In the one-tile kernel a block spends 3 us issuing its first stages and 7 us in its epilogue next to 12 - 22 us of
-// k-steps (in-kernel stamps), with nothing else resident on the CU at NP = 3.  Here the refill of step s
-// targets step s + NS of the SAME stream: once a tile's last steps are reached, the pieces come from the next tile, so
-// that tile's first NS stages land under this tile's epilogue and the next main loop starts on landed data.
-// Waits stay counted: before the epilogue the wave waits for stage 0 of the next tile (its loads / stores are not issued
-// yet), afterwards a wait is only ever conservative (older stores still in flight make it wait for more DMA stages,
-// never fewer).  Needs nsteps >= NS.
+// ---- persistent form with LOADER WAVES: one block per CU walks its tiles, the DMA ring runs ACROSS the tile seams ----
+// In the one-tile kernel a block spends 3 us issuing its first stages and 7 us in its epilogue next to 12 - 22 us of k-steps
+// (in-kernel stamps), with nothing else resident on the CU at NP = 3.  Here the refill of step s targets step
+// s + NS of the block's tile STREAM: once a tile's last steps are reached the pieces come from the next tile, so that tile's
+// first NS stages land under this tile's epilogue and the next main loop starts on landed data.  Needs nsteps >= NS.
+// Since round 4 the block has 8 waves: 0 - 3 compute, 4 - 7 only issue the LDS-DMA.  An LDS-DMA instruction holds the wave that
+// issues it for 60 - 180 cycles (MI355X_MICROARCH.md) and a wave issues in order, so in the four-wave form (rounds 2 - 3) the next
+// MFMA of the issuing wave waited too while the matrix pipe drained: cycle stamps of that k-loop showed 2.6 % of it waiting for a
+// DMA stage, 2.1 % at the barrier -- and 51 cycles per MFMA instead of 32.  A loader wave on the same SIMD stalls for free; the
+// compute waves carry fragment reads and MFMAs only (no source pointers, no vmcnt: 235 instead of 338 registers), and their epilogue
+// loads / stores no longer share a counter with the ring.  One block barrier per K-step as before: the loaders arrive after their
+// counted wait for stage s + 1, the compute waves after their last fragment read of step s; behind it slot s is refilled with
+// stream element s + NS.  Against the four-wave form, same tile order: 3 - 13 % per layer (tools/experiments/README.md).
 template <int NP, int NS, int ACT>
-__global__ __launch_bounds__(256, 1) void gemm_planes_persistent_kernel(AliveGemm p, int n_mt, int ntiles, int64_t cols,
-                                                                        int64_t cols_pad, int co_pad, int co_pad32, int kpad,
-                                                                        GemmWalk gw) {
+__global__ __launch_bounds__(512, 1) void gemm_planes_lw_kernel(AliveGemm p, int n_mt, int ntiles, int64_t cols, int64_t cols_pad,
+                                                                int co_pad, int co_pad32, int kpad, GemmWalk gw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SLOT = 2 * NP * PLANE_BYTES;
     constexpr int NI = 4 * NP;
     constexpr int NPROD = NP * (NP + 1) / 2;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w >> 1, wc = w & 1;
-    const int lr = lane & 31, lh = lane >> 5;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nsteps = kpad / GK;
 
-    // tiles of this block: the XCD's contiguous chunk of the (column tile, row tile) order, strided by the XCD's blocks
     int v, v_end;
     const int v_stride = gridDim.x >> 3;
     {
@@ -468,50 +498,92 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_persistent_kernel(AliveGem
     }
     if (v >= v_end) return;
 
-    // ---- DMA geometry: piece q = w + 4 i  ->  (operand, plane, 16-row group); byte offsets from W / P ----
-    const int prow = lane >> 2;
-    const int pchunk = (lane & 3) ^ ((prow >> 2) & 3);
-    int ldst[NI];
-    bool isB[NI];
-    unsigned off[2][NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int q = w + 4 * i;
-        isB[i] = q / (8 * NP) != 0;
-        ldst[i] = ((isB[i] ? NP : 0) + (q % (8 * NP)) / 8) * PLANE_BYTES + (q % 8) * 1024;
-    }
-    auto tile_offsets = [&](int tv, unsigned (&o)[NI]) {
-        const int mt = tv % n_mt;
-        const int64_t c0 = (int64_t)(tv / n_mt) * GN;
+    if (w8 >= 4) {
+        // ================= loader wave =================
+        const int w = w8 - 4;
+        const int prow = lane >> 2;
+        const int pchunk = (lane & 3) ^ ((prow >> 2) & 3);
+        int ldst[NI];
+        unsigned off[2][NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int q = w + 4 * i;
-            const int pl = (q % (8 * NP)) / 8, r = (q % 8) * 16 + prow;
-            if (!isB[i]) {
-                int row = mt * GM + r;
-                row = row < co_pad ? row : co_pad - 1;
-                o[i] = (unsigned)((planes_at(pl, row, 0, co_pad, kpad) + pchunk * 8) * 2);
-            } else if (p.b_row == 0) {
-                int64_t col = c0 + r;
-                col = col < cols_pad ? col : cols_pad - 1;
-                o[i] = (unsigned)((planes_at(pl, col, 0, cols_pad, kpad) + pchunk * 8) * 2);
-            } else {                                     // custom row placement (overlapping rows: the STFT)
-                int64_t col = c0 + r;
-                col = col < cols ? col : cols - 1;
-                const int64_t nn = col / p.T;
-                o[i] = (unsigned)(((size_t)pl * p.b_plane + (size_t)nn * p.b_win + (size_t)(col - nn * p.T) * p.b_row + pchunk * 8) * 2);
-            }
+            ldst[i] = ((i >= 2 * NP ? NP : 0) + (q % (8 * NP)) / 8) * PLANE_BYTES + (q % 8) * 1024;
         }
-    };
-    // stream element = (tile parity `which`, step); slot = running step count mod NS.  The elements are issued in stream order:
-    // `walk` holds the step offsets of the next one (reset at every tile seam)
-    StepWalk walk;
-    auto issue = [&](int which, int slot, int i) {
-        const unsigned char* base = isB[i] ? (const unsigned char*)p.P : (const unsigned char*)p.W;
-        __builtin_amdgcn_global_load_lds((gptr_t)(base + off[which][i] + (unsigned)((isB[i] ? walk.b : walk.a) * 2)),
-                                         (lptr_t)(smem + slot * SLOT + ldst[i]), 16, 0, 0);
-    };
+        auto tile_offsets = [&](int tv, unsigned (&o)[NI]) {
+#ifdef ALIVE_LW_ABL_SAMETILE
+            tv = (blockIdx.x & 7) + 8 * (tv & 3);          // timing only: 4 tiles per XCD, everything hits L2
+#endif
+            int mt, ct;
+            tile_of(tv, n_mt, gw, mt, ct);
+            const int64_t c0 = (int64_t)ct * GN;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int q = w + 4 * i;
+                const int pl = (q % (8 * NP)) / 8, r = (q % 8) * 16 + prow;
+                if (i < 2 * NP) {
+                    int row = mt * GM + r;
+                    row = row < co_pad ? row : co_pad - 1;
+                    o[i] = (unsigned)((planes_at(pl, row, 0, co_pad, kpad) + pchunk * 8) * 2);
+                } else if (p.b_row == 0) {
+                    int64_t col = c0 + r;
+                    col = col < cols_pad ? col : cols_pad - 1;
+                    o[i] = (unsigned)((planes_at(pl, col, 0, cols_pad, kpad) + pchunk * 8) * 2);
+                } else {
+                    int64_t col = c0 + r;
+                    col = col < cols ? col : cols - 1;
+                    const int64_t nn = col / p.T;
+                    o[i] = (unsigned)(((size_t)pl * p.b_plane + (size_t)nn * p.b_win + (size_t)(col - nn * p.T) * p.b_row + pchunk * 8) * 2);
+                }
+            }
+        };
+        StepWalk walk;
+        auto issue = [&](int which, int slot, int i) {
+            const unsigned char* base = i >= 2 * NP ? (const unsigned char*)p.P : (const unsigned char*)p.W;
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + off[which][i] + (unsigned)((i >= 2 * NP ? walk.b : walk.a) * 2)),
+                                             (lptr_t)(smem + slot * SLOT + ldst[i]), 16, 0, 0);
+        };
+        int cur = 0, qb = 0;
+        tile_offsets(v, off[0]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) issue(0, s, i);
+            walk.advance(gw);
+        }
+        wait_vmcnt<(NS - 1) * NI>();             // stage 0 of the first tile (this wave's pieces)
+        __builtin_amdgcn_s_barrier();            // ... is visible to the compute waves
+        while (true) {
+            const int vn = v + v_stride;
+            const bool has_next = vn < v_end;
+            if (has_next) tile_offsets(vn, off[cur ^ 1]);
+            for (int s = 0; s < nsteps; ++s) {
+                const int slot = (qb + s) % NS;
+                if (s + NS - 1 < nsteps || has_next) wait_vmcnt<(NS - 2) * NI>(); else wait_vmcnt<0>();      // stage s + 1 has landed
+                __builtin_amdgcn_s_barrier();    // and every compute wave has read the last fragment of step s
+                const int ts = s + NS;
+                const bool in_tile = ts < nsteps;
+                if (ts == nsteps) walk.reset();
+#ifndef ALIVE_LW_ABL_NODMA
+                if (in_tile || has_next) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) issue(in_tile ? cur : (cur ^ 1), slot, i);
+                }
+#endif
+                walk.advance(gw);
+            }
+            if (!has_next) break;
+            v = vn;
+            cur ^= 1;
+            qb = (qb + nsteps) % NS;
+        }
+        return;
+    }
 
+    // ================= compute wave =================
+    const int w = w8;
+    const int wr = w >> 1, wc = w & 1;
+    const int lr = lane & 31, lh = lane >> 5;
     const int sw = (lr >> 2) & 3;
     const int a_off = (wr * 64 + lr) * 64 + ((lh ^ sw) << 4);
     const int b_off = NP * PLANE_BYTES + (wc * 64 + lr) * 64 + ((lh ^ sw) << 4);
@@ -542,64 +614,53 @@ __global__ __launch_bounds__(256, 1) void gemm_planes_persistent_kernel(AliveGem
             }
     };
 
-    int cur = 0, qb = 0;                     // tile parity of off[], slot of the current tile's step 0
-    tile_offsets(v, off[0]);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) issue(0, s, i);
-        walk.advance(gw);
-    }
-    wait_vmcnt<(NS - 1) * NI>();             // stage 0 of the first tile (this wave's pieces)
-
+    int qb = 0;
+    __builtin_amdgcn_s_barrier();                // stage 0 of the first tile is visible
     while (true) {
         const int vn = v + v_stride;
         const bool has_next = vn < v_end;
-        if (has_next) tile_offsets(vn, off[cur ^ 1]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0.0f; acc[i][1][r] = 0.0f; }
-        __builtin_amdgcn_s_barrier();        // every wave's stage-0 pieces have landed (and its epilogue is done)
-        load_frags(qb, 0, fa[0], fb[0]);
-
+        load_frags(qb, 0, fa[0], fb[0]);         // (visible since the last barrier of the tile before)
         for (int s = 0; s < nsteps; ++s) {
             const int slot = (qb + s) % NS;
             const int slot1 = slot + 1 == NS ? 0 : slot + 1;
             mma(fa[0], fb[0], [&](int n) {
+#ifdef ALIVE_LW_ABL_NOREAD
+                if (n == 0 && s == 0) load_frags(slot, 1, fa[1], fb[1]);
+#else
                 if (n == 0) load_frags(slot, 1, fa[1], fb[1]);
+#endif
             });
             __builtin_amdgcn_sched_barrier(0);
             wait_lgkmcnt0();
-            // stage s + 1 must have landed; NS - 2 younger stages stay in flight while the stream goes on
-            if (s + NS - 1 < nsteps || has_next) wait_vmcnt<(NS - 2) * NI>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
+#ifndef ALIVE_LW_ABL_NOREAD
             if (s + 1 < nsteps) load_frags(slot1, 0, fa[0], fb[0]);
+#endif
             __builtin_amdgcn_sched_barrier(0);
-            // the slot of step s is free: refill it with stream element s + NS (this tile's, or the next tile's first steps)
-            const int ts = s + NS;
-            const bool in_tile = ts < nsteps;
-            const bool refill = in_tile || has_next;
-            const int rwhich = in_tile ? cur : (cur ^ 1);
-            if (ts == nsteps) walk.reset();          // the stream enters the next tile
-            mma(fa[1], fb[1], [&](int n) {
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-                    if (i * NPROD / NI == n && refill) issue(rwhich, slot, i);
-            });
-            walk.advance(gw);
+            mma(fa[1], fb[1], [&](int) {});
             __builtin_amdgcn_sched_barrier(0);
         }
-        // stage 0 of the next tile before this tile's loads / stores enter the counter
-        if (has_next) wait_vmcnt<(NS - 1) * NI>(); else wait_vmcnt<0>();
+#ifdef ALIVE_LW_ABL_NOEPI
+        if (nsteps < 0)
+#endif
         {
-            const int mt = v % n_mt;
-            gemm_epilogue<NP, ACT>(p, acc, mt * GM, (int64_t)(v / n_mt) * GN, wr, wc, lr, lh, cols, cols_pad, co_pad32, nullptr,
+            int mt, ct;
+            tile_of(v, n_mt, gw, mt, ct);
+            gemm_epilogue<NP, ACT>(p, acc, mt * GM, (int64_t)ct * GN, wr, wc, lr, lh, cols, cols_pad, co_pad32, nullptr,
                                    p.Pout != nullptr ? smem + NS * SLOT + w * 2048 : nullptr);
         }
+#ifdef ALIVE_LW_ABL_NOEPI
+        else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { asm volatile("" :: "v"(acc[i][0])); asm volatile("" :: "v"(acc[i][1])); }
+        }
+#endif
         if (!has_next) break;
         v = vn;
-        cur ^= 1;
         qb = (qb + nsteps) % NS;
     }
 }
@@ -660,6 +721,15 @@ inline GemmWalk make_walk(const AliveGemm& d) {
     if (d.b_row == 0) { g.b_blk = pad_cols((int64_t)d.N * d.T) * GK; g.b_tap = 0; g.ncb = pad32(d.Ci) / GK; }
     else if (d.b_cblk == 0) { g.b_blk = 0; g.b_tap = GK; g.ncb = 1; }
     else { g.b_blk = d.b_blk; g.b_tap = GK; g.ncb = d.b_cblk; }
+    // row tiles per group: their weight tiles (128 rows x K x planes) should fit in about 2.5 MB of an XCD's L2; even groups
+    static const int rg_env = getenv("ALIVE_GEMM_RG") ? atoi(getenv("ALIVE_GEMM_RG")) : 0;
+    const int n_mt = cdiv(d.Co, GM);
+    const int64_t tile_bytes = (int64_t)GM * pad32(d.Ci) * d.planes * 2;
+    int rg = rg_env > 0 ? rg_env : (int)std::max<int64_t>(1, (int64_t)(2.5 * 1048576) / tile_bytes);
+    rg = std::min(rg, n_mt);
+    const int n_rg = cdiv(n_mt, rg);
+    g.rg = cdiv(n_mt, n_rg);
+    g.n_ct = cdiv((int64_t)d.N * d.T, GN);
     return g;
 }
 
@@ -685,11 +755,11 @@ int launch_gemm_act(const AliveGemm& d, hipStream_t s) {
 }
 
 template <int NP, int NS, int ACT>
-int launch_gemm_persistent_act(const AliveGemm& d, hipStream_t s) {
-    constexpr int LDS = NS * 2 * NP * PLANE_BYTES + 4 * 2048;      // the DMA ring + a 2-KB staging tile per wave (plane output)
+int launch_gemm_lw_act(const AliveGemm& d, hipStream_t s) {
+    constexpr int LDS = NS * 2 * NP * PLANE_BYTES + 4 * 2048;
     {
         static LdsOptIn optin;
-        hipError_t e = optin.ensure({(const void*)gemm_planes_persistent_kernel<NP, NS, ACT>}, LDS);
+        hipError_t e = optin.ensure({(const void*)gemm_planes_lw_kernel<NP, NS, ACT>}, LDS);
         if (e != hipSuccess) {
             alive_set_error("alive_gemm_planes: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return ALIVE_ERR_LAUNCH;
@@ -697,18 +767,18 @@ int launch_gemm_persistent_act(const AliveGemm& d, hipStream_t s) {
     }
     const int64_t cols = (int64_t)d.N * d.T;
     const int n_mt = cdiv(d.Co, GM), n_ct = cdiv(cols, GN);
-    gemm_planes_persistent_kernel<NP, NS, ACT><<<256, 256, LDS, s>>>(d, n_mt, n_mt * n_ct, cols, pad_cols(cols), (d.Co + 15) & ~15,
-                                                                   pad32(d.Co), pad32(d.Ci), make_walk(d));
+    gemm_planes_lw_kernel<NP, NS, ACT><<<256, 512, LDS, s>>>(d, n_mt, n_mt * n_ct, cols, pad_cols(cols), (d.Co + 15) & ~15, pad32(d.Co),
+                                                            pad32(d.Ci), make_walk(d));
     ALIVE_CHECK_LAUNCH("alive_gemm_planes(persistent)");
     return ALIVE_OK;
 }
 
 template <int NP, int NS>
-int launch_gemm_persistent(const AliveGemm& d, hipStream_t s) {
-    if constexpr (NP == 3) { if (d.act == 3) return launch_gemm_persistent_act<NP, NS, 3>(d, s); }
-    if (d.act == 1) return launch_gemm_persistent_act<NP, NS, 1>(d, s);
-    if (d.act == 2) return launch_gemm_persistent_act<NP, NS, 2>(d, s);
-    return launch_gemm_persistent_act<NP, NS, 0>(d, s);
+int launch_gemm_lw(const AliveGemm& d, hipStream_t s) {
+    if constexpr (NP == 3) { if (d.act == 3) return launch_gemm_lw_act<NP, NS, 3>(d, s); }
+    if (d.act == 1) return launch_gemm_lw_act<NP, NS, 1>(d, s);
+    if (d.act == 2) return launch_gemm_lw_act<NP, NS, 2>(d, s);
+    return launch_gemm_lw_act<NP, NS, 0>(d, s);
 }
 
 template <int NP, int NS, int MINB>
@@ -790,9 +860,10 @@ extern "C" int alive_gemm_planes(const AliveGemm* d, void* stream) {
                              (d->b_row == 0 ? (int64_t)d->planes * pad_cols((int64_t)d->N * d->T) * pad32(d->Ci)
                                             : (int64_t)d->planes * d->b_plane) * 2 < (1ll << 32);          // 32-bit DMA offsets
     if (d->planes == 2) {
-        if (can_persist && variant == 2 && nsteps >= 4) return launch_gemm_persistent<2, 4>(*d, (hipStream_t)stream);
+        // two planes: the one-tile kernel with two blocks per CU (one block's epilogue under the other's MFMAs) beats one persistent block
+        if (can_persist && variant == 2 && nsteps >= 4) return launch_gemm_lw<2, 4>(*d, (hipStream_t)stream);
         return launch_gemm<2, 2, 2>(*d, (hipStream_t)stream);
     }
-    if (can_persist && nsteps >= 3) return launch_gemm_persistent<3, 3>(*d, (hipStream_t)stream);
+    if (can_persist && nsteps >= 3) return launch_gemm_lw<3, 3>(*d, (hipStream_t)stream);
     return launch_gemm<3, 3, 1>(*d, (hipStream_t)stream);
 }

@@ -29,6 +29,7 @@ def run(ci, co, planes, act, res, pout):
     d = (s[:, 1:5] - s[:, 0:4]) / 100.0      # us
     print(f"ci {ci} co {co} planes {planes} act {act} res {res} pout {pout}: blocks {nb}  total {(s[:,4].max()-t0)/100:.1f} us | "
           f"per block mean us: prologue {d[:,0].mean():.2f}  first-stage wait {d[:,1].mean():.2f}  loop {d[:,2].mean():.2f}  epilogue {d[:,3].mean():.2f} | "
-          f"block total {((s[:,4]-s[:,0])/100).mean():.2f}")
+          f"block total {((s[:,4]-s[:,0])/100).mean():.2f} | loop cycles {s[:,5].mean():.0f} ({s[:,5].mean() / d[:,2].mean() / 1e3:.2f} GHz): "
+          f"vmcnt wait {100 * s[:,6].mean() / s[:,5].mean():.1f} %  barrier wait {100 * s[:,7].mean() / s[:,5].mean():.1f} %")
 for planes in (2, 3):
     run(512, 1536, planes, 1, 0, 0); run(512, 1536, planes, 1, 0, 1); run(1536, 512, planes, 0, 1, 0); run(256, 4096, planes, 0, 0, 0)
