@@ -23,7 +23,14 @@ struct OscGeom {
     int H, Lf, seg, Lw;
     float ratio;        // (float)Lf / Lw
     float sample_rate;
+    int Q, sub;         // a frame's seg samples are walked as Q pieces of sub samples, one wave each (Q = 1: whole frames)
 };
+
+// Few frames (the streaming step: one window of 8): a wave per frame leaves 8 waves on the chip, each behind a serial chain of
+// 320 samples (fp64 add -> fp32 phase -> argument reduction in fp64 -> sin: ~500 cycles per sample).  The chain only carries the
+// running sum, so a frame is cut into Q pieces whose starting sums come from the same segment-sum / prefix pass at piece
+// granularity -- the fp64 partial sums are re-associated exactly like the per-frame sums already are.
+__host__ __device__ inline int osc_pieces(int N, int Lf, int seg) { return ((int64_t)N * Lf <= 64 && seg % 8 == 0) ? 8 : 1; }
 
 // x / 16000 correctly rounded, as one multiply and two fmas: q = x * rc, then one residual correction.  For this
 // divisor the result equals the IEEE quotient for EVERY fp32 x in [2^-24, 2^24) -- checked exhaustively on the GPU
@@ -65,18 +72,18 @@ __device__ __forceinline__ float sin_phase(float theta) {
 }
 
 __global__ __launch_bounds__(64) void osc_segsum_kernel(const float* __restrict__ f0, OscGeom g, double* __restrict__ S) {
-    const int f = blockIdx.x, n = blockIdx.y;
+    const int fq = blockIdx.x, n = blockIdx.y;               // piece fq = f * Q + q
     const int h = blockIdx.z * 64 + threadIdx.x;
     if (h >= g.H) return;
     const float* f0n = f0 + (size_t)n * g.Lf;
     const float hmul = (float)(h + 1);
     double acc = 0.0;
-    const int u0 = f * g.seg;
-    for (int i = 0; i < g.seg; ++i) {
+    const int u0 = fq * g.sub;
+    for (int i = 0; i < g.sub; ++i) {
         Lerp l = lerp_coord(u0 + i, g.ratio, g.Lf);
         acc += (double)formant_step(f0n, hmul, l, g.sample_rate);
     }
-    S[((size_t)n * g.H + h) * g.Lf + f] = acc;
+    S[((size_t)n * g.H + h) * g.Lf * g.Q + fq] = acc;
 }
 
 // exclusive scan of the segment sums (in place) and dt0 = fp32 prefix at crop0
@@ -85,11 +92,11 @@ __global__ __launch_bounds__(64) void osc_prefix_kernel(const float* __restrict_
     const int n = blockIdx.x;
     const int h = blockIdx.y * 64 + threadIdx.x;
     if (h >= g.H) return;
-    double* s = S + ((size_t)n * g.H + h) * g.Lf;
+    double* s = S + ((size_t)n * g.H + h) * g.Lf * g.Q;
     double run = 0.0;
-    const int fc = crop0 / g.seg;
+    const int fc = crop0 / g.sub;                            // the piece crop0 lies in
     double at_fc = 0.0;
-    for (int f = 0; f < g.Lf; ++f) {
+    for (int f = 0; f < g.Lf * g.Q; ++f) {
         double v = s[f];
         s[f] = run;
         if (f == fc) at_fc = run;
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(64) void osc_prefix_kernel(const float* __restrict_
     const float* f0n = f0 + (size_t)n * g.Lf;
     const float hmul = (float)(h + 1);
     double acc = at_fc;
-    for (int u = fc * g.seg; u <= crop0; ++u) {
+    for (int u = fc * g.sub; u <= crop0; ++u) {
         Lerp l = lerp_coord(u, g.ratio, g.Lf);
         acc += (double)formant_step(f0n, hmul, l, g.sample_rate);
     }
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(64) void osc_synth_kernel(const float* __restrict__
     __shared__ float tile[BT][65];
     __shared__ uint2 coord[MAX_SEG];              // per sample of the frame: (i0 | i1 << 16, w1)
     // frame f of the WINDOW; amps / wave hold the frames [f_off, f_off + amp_ld) only (range mode; else f_off = 0, amp_ld = Lf)
-    const int f = blockIdx.x + f_off, n = blockIdx.y;
+    const int f = blockIdx.x / g.Q + f_off, q = blockIdx.x % g.Q, n = blockIdx.y;      // piece q of frame f
     const int lane = threadIdx.x;
     const int h = lane;
     const bool hv = h < g.H;
@@ -127,8 +134,8 @@ __global__ __launch_bounds__(64) void osc_synth_kernel(const float* __restrict__
     const float* an = amps + ((size_t)n * g.H + (hv ? h : 0)) * amp_ld;
     const float hmul = (float)(h + 1);
     const float TWO_PI_F = 6.283185307179586f;
-    const int u0 = f * g.seg;
-    for (int i = lane; i < g.seg; i += 64) {
+    const int u0 = f * g.seg + q * g.sub;
+    for (int i = lane; i < g.sub; i += 64) {
         const Lerp l = lerp_coord(u0 + i, g.ratio, g.Lf);
         coord[i] = make_uint2((unsigned)l.i0 | ((unsigned)l.i1 << 16), __float_as_uint(l.w1));
     }
@@ -137,12 +144,12 @@ __global__ __launch_bounds__(64) void osc_synth_kernel(const float* __restrict__
     const float fo_m = f0n[fm] * hmul, fo_c = f0n[f] * hmul, fo_p = f0n[fp] * hmul;
     auto acol = [&](int fr) { int c = fr - f_off; return c < 0 ? 0 : (c < amp_ld ? c : amp_ld - 1); };
     const float am_m = an[acol(fm)], am_c = an[acol(f)], am_p = an[acol(fp)];
-    double acc = hv ? P[((size_t)n * g.H + h) * g.Lf + f] : 0.0;
+    double acc = hv ? P[((size_t)n * g.H + h) * g.Lf * g.Q + f * g.Q + q] : 0.0;
     const float d0 = hv ? dt0[(size_t)n * g.H + h] : 0.0f;
     const float ph = (hv && phi_in != nullptr) ? phi_in[(size_t)n * g.H + h] : 0.0f;
     __syncthreads();
-    for (int b0 = 0; b0 < g.seg; b0 += BT) {
-        const int nb = (g.seg - b0) < BT ? (g.seg - b0) : BT;
+    for (int b0 = 0; b0 < g.sub; b0 += BT) {
+        const int nb = (g.sub - b0) < BT ? (g.sub - b0) : BT;
         for (int i = 0; i < nb; ++i) {
             const uint2 xc = coord[b0 + i];
             const int i0 = xc.x & 0xffff, i1 = xc.x >> 16;
@@ -180,7 +187,8 @@ __global__ void div16000_check_kernel(unsigned first, unsigned count, unsigned* 
 }  // namespace
 
 extern "C" size_t alive_oscillator_workspace_bytes(int N, int H, int Lf) {
-    return align_up((size_t)N * H * Lf * sizeof(double), 256) + align_up((size_t)N * H * sizeof(float), 256);
+    const int Q = osc_pieces(N, Lf, 8);           // (the piece count the launch may pick, whatever the segment length)
+    return align_up((size_t)N * H * Lf * Q * sizeof(double), 256) + align_up((size_t)N * H * sizeof(float), 256);
 }
 
 extern "C" int alive_oscillator(const float* amps, const float* f0, const float* phi_in, int N, int H, int Lf, int seg,
@@ -200,14 +208,15 @@ extern "C" int alive_oscillator_range(const float* amps, const float* f0, const 
     const int Lw = Lf * seg;
     ALIVE_CHECK_ARG(crop0 >= 0 && crop0 < Lw, "alive_oscillator: crop0 %d outside [0,%d)", crop0, Lw);
     ALIVE_CHECK_ARG(phi_out == nullptr || (phi_col >= 0 && phi_col < Lw), "alive_oscillator: phi_col outside wave");
-    OscGeom g{H, Lf, seg, Lw, (float)Lf / (float)Lw, sample_rate};
+    const int Q = osc_pieces(N, Lf, seg);
+    OscGeom g{H, Lf, seg, Lw, (float)Lf / (float)Lw, sample_rate, Q, seg / Q};
     Arena a(ws);
-    double* S = a.take<double>((size_t)N * H * Lf);
+    double* S = a.take<double>((size_t)N * H * Lf * Q);
     float* dt0 = a.take<float>((size_t)N * H);
     hipStream_t s = (hipStream_t)stream;
-    osc_segsum_kernel<<<dim3(Lf, N, cdiv(H, 64)), 64, 0, s>>>(f0, g, S);
+    osc_segsum_kernel<<<dim3(Lf * Q, N, cdiv(H, 64)), 64, 0, s>>>(f0, g, S);
     osc_prefix_kernel<<<dim3(N, cdiv(H, 64)), 64, 0, s>>>(f0, g, crop0, S, dt0);
-    osc_synth_kernel<<<dim3(n_frames, N), 64, 0, s>>>(amps, f0, phi_in, g, S, dt0, phi_col, f_begin, n_frames, wave, phi_out);
+    osc_synth_kernel<<<dim3(n_frames * Q, N), 64, 0, s>>>(amps, f0, phi_in, g, S, dt0, phi_col, f_begin, n_frames, wave, phi_out);
     ALIVE_CHECK_LAUNCH("alive_oscillator");
     return ALIVE_OK;
 }
