@@ -8,6 +8,7 @@
 // for the tiled kernels: fp32 [Co_pad][K_pad], or 2 / 3 bf16 planes whose sum is the (16- / 24-bit mantissa) weight.
 #include "conv_epilogue.h"
 #include "planes_layout.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -25,11 +26,13 @@ __device__ __forceinline__ float skinny_x(const AliveConv& p, const float* xn, i
     return ok ? v : 0.0f;
 }
 
-constexpr int SKW = 8;                  // waves per block = K-split
+// waves per block = K-split: 8, or 16 where a wave would otherwise walk 4 or more dependent k-steps (K >= 512: the 1x1 convs
+// of the ConvNeXt layers, the k5 convs of the 256-channel FilterBlock, the strided down convs) -- these launches are latency chains of
+// load -> MFMA on 16 .. 48 CUs, and the chain is what a streaming step waits for
 
 // PW: a pointwise conv (KW == 1, stride 1, no padding: two thirds of a streaming step's launches) -- the im2col index is ci * Tin + t,
 // not the ~15 vector instructions of skinny_x per loaded value (round 4: they, not the loads or the MFMAs, were most of the kernel)
-template <int NP, bool PW>
+template <int NP, bool PW, int SKW>
 __global__ __launch_bounds__(64 * SKW) void conv_skinny_kernel(AliveConv p, int ncols) {
     __shared__ f32x4 red[2][SKW][64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -168,9 +171,15 @@ bool alive_conv_skinny_try(const AliveConv* d, hipStream_t s, int* rc) {
     if (d->precision == 0 && (d->K_pad & 15)) return false;
     dim3 g(cdiv(d->Co, 16), cdiv(ncols, 32));
     const bool pw = d->KW == 1 && d->stride == 1 && d->pad_left == 0 && d->Tout <= d->Tin;
-    if (d->precision == 0) { if (pw) conv_skinny_kernel<0, true><<<g, 64 * SKW, 0, s>>>(*d, ncols); else conv_skinny_kernel<0, false><<<g, 64 * SKW, 0, s>>>(*d, ncols); }
-    else if (d->precision == 1) { if (pw) conv_skinny_kernel<2, true><<<g, 64 * SKW, 0, s>>>(*d, ncols); else conv_skinny_kernel<2, false><<<g, 64 * SKW, 0, s>>>(*d, ncols); }
-    else { if (pw) conv_skinny_kernel<3, true><<<g, 64 * SKW, 0, s>>>(*d, ncols); else conv_skinny_kernel<3, false><<<g, 64 * SKW, 0, s>>>(*d, ncols); }
+    static const int k16 = getenv("ALIVE_SKINNY_K16") ? atoi(getenv("ALIVE_SKINNY_K16")) : 512;
+    const int Kp = d->precision == 0 ? d->K_pad : d->KW * d->Ci_pad;
+    const bool wide = Kp >= k16;
+#define SKINNY_LAUNCH(NP_, PW_) do { if (wide) conv_skinny_kernel<NP_, PW_, 16><<<g, 1024, 0, s>>>(*d, ncols); \
+                                      else conv_skinny_kernel<NP_, PW_, 8><<<g, 512, 0, s>>>(*d, ncols); } while (0)
+    if (d->precision == 0) { if (pw) SKINNY_LAUNCH(0, true); else SKINNY_LAUNCH(0, false); }
+    else if (d->precision == 1) { if (pw) SKINNY_LAUNCH(2, true); else SKINNY_LAUNCH(2, false); }
+    else { if (pw) SKINNY_LAUNCH(3, true); else SKINNY_LAUNCH(3, false); }
+#undef SKINNY_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         alive_set_error("alive_conv1d(skinny): %s", hipGetErrorString(e));
