@@ -1481,50 +1481,92 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void knn_scan_kernel(const float* 
     part_idx[(size_t)gw * 64 + lane] = li;
 }
 
-// one block per frame: merge nw partial lists of k entries -> exact top-k (descending, ties to the lower row)
+// one block per frame: merge nw partial lists of k entries -> exact top-k (descending, ties to the lower row).
+// Every thread owns the lists of waves tid, tid + 256, ... (<= 16).  K4 (k <= 4, the streaming default): the thread loads its lists
+// whole -- one 16-byte value and one 16-byte index vector per list, all in flight together -- and a round is a wave-level arg-best, one
+// LDS exchange between the four waves and one barrier: no global load after the first.  (Until round 4 every thread re-read the
+// heads of all its lists in every round and the block reduced through an LDS tree: 26 us of dependent L2 round trips for k = 4.)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <bool K4>
 __global__ __launch_bounds__(256) void knn_scan_merge_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx,
                                                              int nw, int k, int64_t idx_base, float* __restrict__ out_val,
                                                              int* __restrict__ out_idx) {
-    __shared__ float sv[256];
-    __shared__ int si[256], sw[256];
-    const int t = blockIdx.x, tid = threadIdx.x;
-    // every thread owns the lists of waves tid, tid + 256, ...: a cursor per list is not needed because each list is
-    // sorted -- the thread's best remaining candidate is found by scanning its few (<= 16) lists' heads
-    int head[SCAN_MAX_LISTS / 256];
+    constexpr int NL = SCAN_MAX_LISTS / 256;
+    __shared__ float sv[2][4];
+    __shared__ int si[2][4], sw[2][4];
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int head[NL];
+    f32x4 pv4[K4 ? NL : 1];
+    i32x4 pi4[K4 ? NL : 1];
 #pragma unroll
-    for (int i = 0; i < SCAN_MAX_LISTS / 256; ++i) head[i] = 0;
-    for (int j = 0; j < k; ++j) {
-        float bv = -INFINITY;
-        int bi = 0x7fffffff, bl = -1;
+    for (int i = 0; i < NL; ++i) head[i] = 0;
+    if constexpr (K4) {
+        // lane = frame * k + slot in a wave's 64-entry list: the k entries of frame t start at t * k; k <= 4 entries are read as
+        // scalars when k < 4 (the vector would cross into the next frame's entries, which is harmless but may be unaligned)
 #pragma unroll
-        for (int i = 0; i < SCAN_MAX_LISTS / 256; ++i) {
+        for (int i = 0; i < NL; ++i) {
+            const int w = tid + 256 * i;
+            if (k == 4) {
+                const bool in = w < nw;
+                pv4[i] = *(const f32x4*)(part_val + (size_t)(in ? w : 0) * 64 + t * 4);
+                pi4[i] = *(const i32x4*)(part_idx + (size_t)(in ? w : 0) * 64 + t * 4);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool in = w < nw && e < k;
+                    pv4[i][e] = in ? part_val[(size_t)w * 64 + t * k + e] : -INFINITY;
+                    pi4[i][e] = in ? part_idx[(size_t)w * 64 + t * k + e] : 0x7fffffff;
+                }
+            }
+        }
+    }
+    float bv;
+    int bi, bl;
+    auto rescan = [&]() {
+        bv = -INFINITY; bi = 0x7fffffff; bl = -1;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
             const int w = tid + 256 * i;
             if (w < nw && head[i] < k) {
-                const float v = part_val[(size_t)w * 64 + t * k + head[i]];
-                const int id = part_idx[(size_t)w * 64 + t * k + head[i]];
+                float v;
+                int id;
+                if constexpr (K4) {
+                    v = head[i] == 0 ? pv4[i][0] : (head[i] == 1 ? pv4[i][1] : (head[i] == 2 ? pv4[i][2] : pv4[i][3]));
+                    id = head[i] == 0 ? pi4[i][0] : (head[i] == 1 ? pi4[i][1] : (head[i] == 2 ? pi4[i][2] : pi4[i][3]));
+                } else {
+                    v = part_val[(size_t)w * 64 + t * k + head[i]];
+                    id = part_idx[(size_t)w * 64 + t * k + head[i]];
+                }
                 if (v > bv || (v == bv && id < bi)) { bv = v; bi = id; bl = i; }
             }
         }
-        sv[tid] = bv; si[tid] = bi; sw[tid] = tid;
+    };
+    rescan();
+    for (int j = 0; j < k; ++j) {
+        const int par = j & 1;
+        const int win = wave_argbest(bv, bi);           // (equal (value, row) pairs cannot meet: a row sits in exactly one list)
+        const float wvv = __shfl(bv, win);
+        const int wii = __shfl(bi, win);
+        if (lane == 0) { sv[par][wv] = wvv; si[par][wv] = wii; sw[par][wv] = wv * 64 + win; }
         __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (tid < o) {
-                const float ov = sv[tid + o];
-                const int oi = si[tid + o];
-                if (ov > sv[tid] || (ov == sv[tid] && oi < si[tid])) { sv[tid] = ov; si[tid] = oi; sw[tid] = sw[tid + o]; }
-            }
-            __syncthreads();
+        float gv = sv[par][0];
+        int gi = si[par][0], gt = sw[par][0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const float ov = sv[par][q];
+            const int oi = si[par][q];
+            if (ov > gv || (ov == gv && (unsigned)oi < (unsigned)gi)) { gv = ov; gi = oi; gt = sw[par][q]; }
         }
         if (tid == 0) {
-            out_val[(size_t)t * k + j] = sv[0];
-            out_idx[(size_t)t * k + j] = (si[0] == 0x7fffffff || !(sv[0] > -INFINITY)) ? -1 : (int)(idx_base + si[0]);
+            out_val[(size_t)t * k + j] = gv;
+            out_idx[(size_t)t * k + j] = (gi == 0x7fffffff || !(gv > -INFINITY)) ? -1 : (int)(idx_base + gi);
         }
-        if (sw[0] == tid && bl >= 0) {
+        if (gt == tid && bl >= 0) {
 #pragma unroll
-            for (int i = 0; i < SCAN_MAX_LISTS / 256; ++i)
+            for (int i = 0; i < NL; ++i)
                 if (i == bl) head[i]++;
+            rescan();
         }
-        __syncthreads();
     }
 }
 
@@ -1559,6 +1601,14 @@ __global__ __launch_bounds__(256) void knn_merge_gather_kernel(const float* __re
             size_t o = ((size_t)s * Tt + ft) * k + kk;
             id[j] = in ? cand_idx[o] : -1;
             v[j] = (in && id[j] >= 0) ? cand_val[o] : -INFINITY;
+        }
+        if (S == 1) {
+            // a single shard: its list IS the merged list (sorted, -1 behind the last valid entry)
+            if (lane < k) {
+                sel[f][lane] = id[0];
+                if (final_idx != nullptr && blockIdx.z == 0) final_idx[(size_t)ft * k + lane] = id[0];
+            }
+            continue;
         }
         for (int j = 0; j < k; ++j) {
             float bv = v[0];
@@ -2042,7 +2092,8 @@ static int knn_scan_launch(const float* src, int T, int64_t Tt, const float* row
     if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
     knn_scan_kernel<<<blocks, 64 * SCAN_WAVES, 0, s>>>(s_f32, rows_f32, norms, M, (int)Tt, k, pv, pi);
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
-    knn_scan_merge_kernel<<<(unsigned)Tt, 256, 0, s>>>(pv, pi, blocks * SCAN_WAVES, k, idx_base, out_val, out_idx);
+    if (k <= 4) knn_scan_merge_kernel<true><<<(unsigned)Tt, 256, 0, s>>>(pv, pi, blocks * SCAN_WAVES, k, idx_base, out_val, out_idx);
+    else knn_scan_merge_kernel<false><<<(unsigned)Tt, 256, 0, s>>>(pv, pi, blocks * SCAN_WAVES, k, idx_base, out_val, out_idx);
     ALIVE_CHECK_LAUNCH("alive_knn_search(scan)");
     return ALIVE_OK;
 }
