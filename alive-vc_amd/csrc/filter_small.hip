@@ -37,13 +37,18 @@ constexpr int HALO = 56;
 constexpr int NCONV = 6;
 constexpr int NFP = 10;                 // FiLM frames a tile may span (1024 columns at 160 per frame = 6.4, + 3 of slack)
 constexpr int NFS = NFP + 1;            // staged frames per channel (i0 <= NFP - 1, i1 = i0 + 1)
-constexpr int PLANE = 32768;            // bytes per plane: BL * ROWB in both configurations
-constexpr int BUF = 2 * PLANE;          // hi + lo
+constexpr int PLANE_BATCH = 32768;      // bytes per plane of the batch tiles: BL * ROWB in both configurations
 
-template <int C>
+// PL = bytes per plane.  The batch path runs 32-KB planes (1024 / 2048 columns per tile: the 56-column halo is 3 - 5 % of the work);
+// a signal of a few thousand samples (the streaming step: 1600 / 3200) would be TWO such tiles on two CUs, each walking 8 / 16
+// column tiles per wave and conv -- 50 us of a 0.9-ms step.  There the planes are 8 KB (256 / 512 columns, 2 / 4 column tiles per
+// wave): 8 blocks, a quarter of the chain each.
+template <int C, int PL = PLANE_BATCH>
 struct Cfg {
+    static constexpr int PLANE = PL;
+    static constexpr int BUF = 2 * PL;                  // hi + lo
     static constexpr int ROWB = 2 * C;                  // bytes per LDS row
-    static constexpr int BL = PLANE / ROWB;             // 1024 / 2048 columns per tile incl. halo
+    static constexpr int BL = PLANE / ROWB;             // columns per tile incl. halo (batch: 1024 / 2048)
     static constexpr int TT = BL - HALO;                // output columns per tile
     static constexpr int NT = BL / 128;                 // column tiles of 32 per wave (8 / 16)
     static constexpr int TSTEP = 128 * ROWB;            // a wave's consecutive tiles are four column tiles apart
@@ -63,12 +68,13 @@ __device__ __forceinline__ unsigned pack2s(float a, float b) {
     return __builtin_bit_cast(unsigned, h);
 }
 
-template <int C, bool FIRST>
+template <int C, bool FIRST, int PL = PLANE_BATCH>
 __global__ __launch_bounds__(256, 1) void filter_block_small_kernel(const float* __restrict__ U, int L, const float* __restrict__ wpack,
                                                                    const float* __restrict__ film, int film_rows, int Lf, int film_off,
                                                                    float ratio, int t_off, int f_off, int film_ld,
                                                                    const float* __restrict__ skip, float* __restrict__ out, long long* stamps) {
-    using K = Cfg<C>;
+    using K = Cfg<C, PL>;
+    constexpr int PLANE = K::PLANE, BUF = K::BUF;
 #ifdef ALIVE_STAMPS                 // diagnostic build only (tools/ab_build.sh x.so filter_small.hip -DALIVE_STAMPS; tools/stamp_fbs.py)
     long long tsx[12];
     int nts = 0;
@@ -432,13 +438,13 @@ __global__ __launch_bounds__(256, 1) void filter_block_small_kernel(const float*
 #endif
 }
 
-template <int C>
+template <int C, int PL>
 int launch_small(const float* U, int N, int L, const float* wpack, const float* film, int film_rows, int Lf, int film_off,
                  int t0, int f0, int film_ld, const float* skip, float* out, hipStream_t s) {
-    using K = Cfg<C>;
+    using K = Cfg<C, PL>;
     {
-        static LdsOptIn optin;                               // one per instantiation <C>
-        hipError_t e = optin.ensure({(const void*)filter_block_small_kernel<C, false>, (const void*)filter_block_small_kernel<C, true>}, K::LDS);
+        static LdsOptIn optin;                               // one per instantiation <C, PL>
+        hipError_t e = optin.ensure({(const void*)filter_block_small_kernel<C, false, PL>, (const void*)filter_block_small_kernel<C, true, PL>}, K::LDS);
         if (e != hipSuccess) {
             alive_set_error("alive_filter_block_small: cannot reserve %d B of LDS: %s", K::LDS, hipGetErrorString(e));
             return ALIVE_ERR_LAUNCH;
@@ -451,10 +457,10 @@ int launch_small(const float* U, int N, int L, const float* wpack, const float* 
     // tiles through that form in one launch (filter_mid.hip)
     static const int force = getenv("ALIVE_FBS_FORCE") ? atoi(getenv("ALIVE_FBS_FORCE")) : 0;      // diagnostic: 1 = every tile through the FIRST form, 2 = never
     const bool small = force == 1 || (force != 2 && (int64_t)tiles * N <= 256);
-    filter_block_small_kernel<C, true><<<dim3(small ? tiles : 1, N), 256, K::LDS, s>>>(U, L, wpack, film, film_rows, Lf, film_off, ratio, t0,
+    filter_block_small_kernel<C, true, PL><<<dim3(small ? tiles : 1, N), 256, K::LDS, s>>>(U, L, wpack, film, film_rows, Lf, film_off, ratio, t0,
                                                                                      f0, film_ld, skip, out, g_stamps_small);
     if (tiles > 1 && !small)
-        filter_block_small_kernel<C, false><<<dim3(tiles - 1, N), 256, K::LDS, s>>>(U, L, wpack, film, film_rows, Lf, film_off, ratio, t0, f0,
+        filter_block_small_kernel<C, false, PL><<<dim3(tiles - 1, N), 256, K::LDS, s>>>(U, L, wpack, film, film_rows, Lf, film_off, ratio, t0, f0,
                                                                                   film_ld, skip, out, g_stamps_small);
     ALIVE_CHECK_LAUNCH("alive_filter_block_small");
     return ALIVE_OK;
@@ -481,6 +487,13 @@ extern "C" int alive_filter_block_small_range(const float* U, int N, int C, int 
     ALIVE_CHECK_ARG((L & 3) == 0 && ((((uintptr_t)U) | ((uintptr_t)out) | ((uintptr_t)skip) | ((uintptr_t)wpack)) & 15) == 0,
                     "alive_filter_block_small: L must be a multiple of 4 and U / out / skip / wpack 16-byte aligned");
     ALIVE_CHECK_ARG(film_ld > 0 && t0 >= 0 && f0 >= 0, "alive_filter_block_small: bad frame range");
-    if (C == 8) return launch_small<8>(U, N, L, wpack, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, (hipStream_t)stream);
-    return launch_small<16>(U, N, L, wpack, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, (hipStream_t)stream);
+    // a signal that would be a handful of batch tiles runs on 8-KB planes (see Cfg)
+    static const int pl_env = getenv("ALIVE_FBS_PLANE") ? atoi(getenv("ALIVE_FBS_PLANE")) : 0;
+    const int big_tiles = cdiv(L, (C == 8 ? Cfg<8>::TT : Cfg<16>::TT)) * N;
+    const bool tiny = pl_env ? pl_env < PLANE_BATCH : big_tiles <= 16;
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 8) return tiny ? launch_small<8, 8192>(U, N, L, wpack, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, s)
+                            : launch_small<8, PLANE_BATCH>(U, N, L, wpack, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, s);
+    return tiny ? launch_small<16, 8192>(U, N, L, wpack, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, s)
+                : launch_small<16, PLANE_BATCH>(U, N, L, wpack, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, s);
 }
