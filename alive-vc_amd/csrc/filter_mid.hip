@@ -48,6 +48,7 @@
 // launch exact (tools/stress_filter_block.py: 0 of 100 differ; -DALIVE_FB64_NO_CHAIN_GAP reproduces the failure).
 #include "conv_epilogue.h"
 #include <type_traits>
+#include <stdlib.h>
 
 // The Makefile compiles this file with -fno-slp-vectorize and says so with the macro: packed fp32 math beside MFMAs is an
 // anti-lever on this part (a v_pk_fma_f32 costs ~22 cycles more than two v_fma_f32 there, MI355X_MICROARCH.md), and the SLP
@@ -85,7 +86,10 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 }
 __device__ __forceinline__ int swz(int r) { return (r >> 1) & 7; }
 
-template <bool FIRST>
+// NTT = column tiles of 32 per wave: 4 on the batch path (256-column tiles, 200 outputs), 2 for a signal of a few such tiles (the
+// streaming step: 800 samples = four batch tiles on four CUs, 72 us of a 0.8-ms step): 128-column tiles, 72 outputs, twelve blocks with
+// half the serial chain each.  The halo is then 44 % of a tile -- irrelevant where the chip is empty.
+template <bool FIRST, int NTT = 4>
 __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __restrict__ U, int L,
                                                                 const unsigned short* __restrict__ W16,
                                                                 const float* __restrict__ biases,
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
 #define STAMP3()
 #endif
     STAMP3();
+    constexpr int NT = NTT, BL = 64 * NT, TT = BL - HALO, PLANE = BL * ROWB, BUF = 2 * PLANE;      // (shadow the batch constants above)
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     unsigned char* bufZ = sm + GUARD;
     unsigned char* bufY = bufZ + BUF;
@@ -119,12 +124,15 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
     //      prologue is issued before the first LDS write, so one memory latency covers all of them ----
     const int f_lo = lerp_coord((tbase < 0 ? 0 : tbase) + t_off, ratio, Lf).i0;     // frames of the WINDOW (t_off: range mode)
     {
-        const int t = tbase + tid;
+        // thread = (column, part): NPT = 256 / BL threads share a column, each takes C / NPT channels (batch tiles: one thread per column)
+        constexpr int NPT = 256 / BL, CPT = C / NPT;
+        const int col = tid % BL, part = tid / BL;
+        const int t = tbase + col;
         const bool ok = t >= 0 && t < L;
-        const float* uc = Un + (ok ? t : 0);
-        float v[C];
+        const float* uc = Un + (ok ? t : 0) + (size_t)(part * CPT) * L;
+        float v[CPT];
 #pragma unroll
-        for (int c = 0; c < C; ++c) v[c] = uc[(size_t)c * L];
+        for (int c = 0; c < CPT; ++c) v[c] = uc[(size_t)c * L];
         constexpr int NFL = NCONV * 2 * C * NFS / 256;        // 27 FiLM values per thread
         float fv[NFL];
 #pragma unroll
@@ -137,16 +145,16 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
             fc = fc < 0 ? 0 : (fc < film_ld ? fc : film_ld - 1);
             fv[k] = film[((size_t)n * film_rows + film_off + q * 2 * C + sel * C + c) * film_ld + fc];
         }
-        {   // F.interpolate coordinates of this thread's column, relative to the staged FiLM frames (i1 = i0 + 1: the table
+        if (part == 0) {   // F.interpolate coordinates of this thread's column, relative to the staged FiLM frames (i1 = i0 + 1: the table
             // repeats the window's last frame, which is what the clamp of upsample_linear1d reads there)
             const int tc = t < 0 ? 0 : (t < L ? t : L - 1);
             const Lerp lp = lerp_coord(tc + t_off, ratio, Lf);
             int i0 = lp.i0 - f_lo;
             i0 = i0 < NFP - 1 ? i0 : NFP - 1;
-            Xc[tid] = make_uint2((unsigned)(i0 * 8), __float_as_uint(lp.w1));
+            Xc[col] = make_uint2((unsigned)(i0 * 8), __float_as_uint(lp.w1));
         }
 #pragma unroll
-        for (int ck = 0; ck < 8; ++ck) {
+        for (int ck = 0; ck < CPT / 8; ++ck) {
             u32x4 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
                 hi[e] = h;
                 lo[e] = pack2(x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xffff0000u));
             }
-            unsigned char* dst = bufZ + tid * ROWB + ((ck ^ swz(tid)) << 4);
+            unsigned char* dst = bufZ + col * ROWB + (((part * (CPT / 8) + ck) ^ swz(col)) << 4);
             *(u32x4*)dst = hi;
             *(u32x4*)(dst + PLANE) = lo;
         }
@@ -385,6 +393,17 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
 #endif
             Epi E;
             if (it_emit) epi_begin(E, it_qf, it_t);
+            // Two tiles per wave, window start: the reflected fragments of tile 0 (columns up to HALO + 47) lie in the columns of the
+            // pending item (tile 1 of the conv before: 64 ..), which this step would only be writing -- that block finishes the item
+            // first.  (Four tiles per wave: the pending item is columns 192 .., nothing reflects that far.)
+            const bool drain_first = NT == 2 && FIRST && tbase < 0 && i == 0;          // block-uniform
+            if (drain_first) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int st = 0; st < 5; ++st) epi_stage(E, it_second, it_emit, it_qf, it_dst, it_t, it_acc, g, st);
+                __syncthreads();
+            }
             acc[i & 1] = b16;
 #pragma unroll
             for (int s = 0; s < PF; ++s) frag_load(i, s, s);
@@ -395,7 +414,7 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
                 acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], fl[s % NSLOT], acc[i & 1], 0, 0, 0);
                 acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], fh[s % NSLOT], acc[i & 1], 0, 0, 0);
                 if (i == NT - 1 && emit) load_weights_step(q + 1, s);     // a[s] is dead: the next conv's weights travel under the rest of the step
-                epi_stage(E, it_second, it_emit, it_qf, it_dst, it_t, it_acc, s / 5, s % 5);
+                if (!drain_first) epi_stage(E, it_second, it_emit, it_qf, it_dst, it_t, it_acc, s / 5, s % 5);
 #ifdef ALIVE_FB64_DUP_STAGE           // diagnostic (timing only): one stage's work a second time -- the increment prices the stage
                 if (s % 5 == ALIVE_FB64_DUP_STAGE && it_emit) {
                     Epi E2 = E;
@@ -488,7 +507,8 @@ extern "C" int alive_filter_block64_range(const float* U, int N, int L, const vo
     ALIVE_CHECK_ARG((double)BL * film_ld / L + 3.0 <= NFP, "alive_filter_block64: tile spans more than %d frames (L %d, frames %d)", NFP, L, film_ld);
     {
         static LdsOptIn optin;
-        hipError_t e = optin.ensure({(const void*)filter_block64_kernel<false>, (const void*)filter_block64_kernel<true>}, LDS_BYTES);
+        hipError_t e = optin.ensure({(const void*)filter_block64_kernel<false>, (const void*)filter_block64_kernel<true>,
+                                     (const void*)filter_block64_kernel<true, 2>}, LDS_BYTES);
         if (e != hipSuccess) {
             alive_set_error("alive_filter_block64: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(e));
             return ALIVE_ERR_LAUNCH;
@@ -496,6 +516,15 @@ extern "C" int alive_filter_block64_range(const float* U, int N, int L, const vo
     }
     const float ratio = (float)film_ld / (float)L;       // == window frames / window samples at this rate
     const int tiles = cdiv(L, TT);
+    static const int nt_env = getenv("ALIVE_FB64_NT") ? atoi(getenv("ALIVE_FB64_NT")) : 0;
+    if (nt_env ? nt_env == 2 : (int64_t)tiles * N <= 16) {
+        // a handful of batch tiles: 128-column tiles (72 outputs) through the FIRST form, three times the blocks
+        constexpr int TT2 = 128 - HALO, LDS2 = GUARD + 2 * (2 * 128 * ROWB) + NCONV * C * NFS * 8 + 128 * 8;
+        filter_block64_kernel<true, 2><<<dim3(cdiv(L, TT2), N), 256, LDS2, (hipStream_t)stream>>>(
+            U, L, (const unsigned short*)W16, biases, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld, skip, out, g_stamps64);
+        ALIVE_CHECK_LAUNCH("alive_filter_block64");
+        return ALIVE_OK;
+    }
     // The first tile of every window reflects at t = 0 (per-lane fragment addresses): an instantiation and a launch of its own.  Its
     // address form is valid for every tile (no reflection happens further right, rows left of the image fall into the guard), only
     // slower -- so a problem that does not fill the chip anyway (the streaming ring: 4 tiles) runs ALL its tiles in that one launch
