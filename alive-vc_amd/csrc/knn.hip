@@ -1438,6 +1438,10 @@ constexpr int64_t SCAN_ROWS_MAX = 262144; // beyond this the 3-KB fp32 rows cost
 constexpr int SCAN_WAVES = 4;           // waves per block
 constexpr int SCAN_MAX_LISTS = 4096;    // total waves
 
+// PF: the next row of a wave is requested before the current one is scored (64.3 -> 59.9 us at 50 k rows x 8 frames).  Two other
+// forms were slower: the frames in registers (73.5 us: 96 more registers, fewer waves to hide the row loads behind) and the frames in
+// LDS with the prefetch (72 us).  The kernel is a mix of HBM latency, 12 IEEE divisions and 8 x 12 fmas + a wave sum per row.
+template <bool PF>
 __global__ __launch_bounds__(64 * SCAN_WAVES) void knn_scan_kernel(const float* __restrict__ s_f32, const float* __restrict__ rows,
                                                                    const float* __restrict__ norms, int64_t M, int Tt, int k,
                                                                    float* __restrict__ part_val, int* __restrict__ part_idx) {
@@ -1447,10 +1451,28 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void knn_scan_kernel(const float* 
     const bool live = lane < Tt * k;
     float lv = -INFINITY;
     int li = 0x7fffffff;
+    f32x4 n0 = {}, n1 = {}, n2 = {};
+    float nnx = 1.0f;
+    if (PF && gw < M) {
+        const f32x4* rp = (const f32x4*)(rows + (size_t)gw * D);
+        n0 = rp[lane]; n1 = rp[lane + 64]; n2 = rp[lane + 128];
+        nnx = norms[gw];
+    }
     for (int64_t r = gw; r < M; r += nw) {
-        const f32x4* rp = (const f32x4*)(rows + (size_t)r * D);
-        const float nn = norms[r];
-        f32x4 q0 = rp[lane], q1 = rp[lane + 64], q2 = rp[lane + 128];
+        f32x4 q0, q1, q2;
+        float nn;
+        if (PF) {
+            q0 = n0; q1 = n1; q2 = n2; nn = nnx;
+            if (r + nw < M) {
+                const f32x4* rp = (const f32x4*)(rows + (size_t)(r + nw) * D);
+                n0 = rp[lane]; n1 = rp[lane + 64]; n2 = rp[lane + 128];
+                nnx = norms[r + nw];
+            }
+        } else {
+            const f32x4* rp = (const f32x4*)(rows + (size_t)r * D);
+            nn = norms[r];
+            q0 = rp[lane]; q1 = rp[lane + 64]; q2 = rp[lane + 128];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) { q0[j] = q0[j] / nn; q1[j] = q1[j] / nn; q2[j] = q2[j] / nn; }
         float p = -INFINITY;                             // the score of this lane's frame (the wave sum is lane-uniform)
@@ -2090,7 +2112,7 @@ static int knn_scan_launch(const float* src, int T, int64_t Tt, const float* row
     if (blocks > SCAN_MAX_LISTS / SCAN_WAVES) blocks = SCAN_MAX_LISTS / SCAN_WAVES;
     if (blocks < 1) blocks = 1;
     if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
-    knn_scan_kernel<<<blocks, 64 * SCAN_WAVES, 0, s>>>(s_f32, rows_f32, norms, M, (int)Tt, k, pv, pi);
+    knn_scan_kernel<true><<<blocks, 64 * SCAN_WAVES, 0, s>>>(s_f32, rows_f32, norms, M, (int)Tt, k, pv, pi);
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
     if (k <= 4) knn_scan_merge_kernel<true><<<(unsigned)Tt, 256, 0, s>>>(pv, pi, blocks * SCAN_WAVES, k, idx_base, out_val, out_idx);
     else knn_scan_merge_kernel<false><<<(unsigned)Tt, 256, 0, s>>>(pv, pi, blocks * SCAN_WAVES, k, idx_base, out_val, out_idx);
