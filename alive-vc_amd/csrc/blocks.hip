@@ -5,7 +5,7 @@
 //   |re,im| -> magnitude                          module/spectrogram.py:8
 // HBM-bound kernels: lanes run along time (coalesced 256-B rows), channels are
 // split over the 4 waves of a block and reduced through LDS.
-#include "common.h"
+#include "conv_epilogue.h"
 #include "planes_layout.h"
 
 namespace {
@@ -422,6 +422,107 @@ extern "C" int alive_channel_norm(const float* X, int N, int C, int T, const flo
     dwconv_norm_kernel<false><<<g, 256, 0, (hipStream_t)stream>>>(X, C, T, nullptr, nullptr, 0, gain, offset, nullptr, 0, 0,
                                                                  0, eps, Y);
     ALIVE_CHECK_LAUNCH("alive_channel_norm");
+    return ALIVE_OK;
+}
+
+// ---- z = gelu(h) * interp(scale) + interp(shift): the input of a FilterResBlock's first modulated conv (decoder.py:112-117,130-132) ----
+// Since round 4 the Filter's coarsest up conv and the 1x1 input conv of its FilterBlock are ONE transposed conv (their weights composed
+// at checkpoint load: both are linear and nothing sits between them, decoder.py:147,192-193), so the modulated copy of its output, which
+// the input conv's epilogue used to emit, is made here -- with that epilogue's arithmetic (conv_split.hip: gelu_fast2, ATen's lerp,
+// multiply then add) and in its formats: fp32 [N][C][L] or k-blocked planes for the split kernel's plane input.
+namespace {
+template <bool PLANES>
+__global__ __launch_bounds__(256) void gelu_film_kernel(const float* __restrict__ H, int C, int L, const float* __restrict__ film,
+                                                        int film_rows, int Lf, int scale_row, int shift_row, int t_off, int f_off,
+                                                        int film_ld, float ratio, float* __restrict__ Z,
+                                                        unsigned short* __restrict__ Zp, int64_t cols_pad) {
+    __shared__ float tile[PLANES ? 64 : 1][PLANES ? 65 : 1];       // [channel][column]
+    const int tid = threadIdx.x;
+    const int n = blockIdx.z, c0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
+    const int t4 = t0 + (tid & 15) * 4;                             // this thread's four columns
+    Lerp lp[4];
+    int fc0[4], fc1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int t = t4 + q < L ? t4 + q : L - 1;
+        lp[q] = lerp_coord(t + t_off, ratio, Lf);
+        int a = lp[q].i0 - f_off, b = lp[q].i1 - f_off;             // frame of the window -> column of the film tensor
+        fc0[q] = a < 0 ? 0 : (a < film_ld ? a : film_ld - 1);
+        fc1[q] = b < 0 ? 0 : (b < film_ld ? b : film_ld - 1);
+    }
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int cl = pass * 16 + (tid >> 4), c = c0 + cl;
+        if (c >= C) continue;
+        const size_t o = ((size_t)n * C + c) * L + t4;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        const bool vec = (L & 3) == 0 && t4 + 3 < L;               // rows are 16-byte aligned only when L is a multiple of 4
+        if (vec) v = *(const f32x4*)(H + o);
+        else for (int q = 0; q < 4 && t4 + q < L; ++q) v[q] = H[o + q];
+        const f32x2 g0 = gelu_fast2(f32x2{v[0], v[1]}), g1 = gelu_fast2(f32x2{v[2], v[3]});
+        const float gv[4] = {g0[0], g0[1], g1[0], g1[1]};
+        const float* fs = film + ((size_t)n * film_rows + scale_row + c) * film_ld;
+        const float* fh = film + ((size_t)n * film_rows + shift_row + c) * film_ld;
+        f32x4 z;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float sc = lerp_apply(lp[q], fs[fc0[q]], fs[fc1[q]]);
+            const float sh = lerp_apply(lp[q], fh[fc0[q]], fh[fc1[q]]);
+            z[q] = gv[q] * sc + sh;
+        }
+        if constexpr (PLANES) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tile[cl][(tid & 15) * 4 + q] = z[q];
+        } else {
+            if (vec) *(f32x4*)(Z + o) = z;
+            else for (int q = 0; q < 4 && t4 + q < L; ++q) Z[o + q] = z[q];
+        }
+    }
+    if constexpr (PLANES) {
+        __syncthreads();
+        // thread -> (k-block half of the 64 channels, column, 8-channel chunk): a wave writes 16 columns x 64 B = 1 KB per plane
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int ck = it * 4 + (tid & 3), cl = (tid >> 2) & 63;
+            const int t = t0 + cl, c = c0 + ck * 8;
+            if (t >= L || c >= C) continue;
+            const int64_t col = (int64_t)n * L + t;
+            float vv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vv[e] = tile[ck * 8 + e][cl];
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                u32x4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bf16x2_t hp = {(__bf16)vv[2 * e], (__bf16)vv[2 * e + 1]};
+                    const unsigned h = __builtin_bit_cast(unsigned, hp);
+                    o4[e] = h;
+                    vv[2 * e] -= __uint_as_float(h << 16);
+                    vv[2 * e + 1] -= __uint_as_float(h & 0xffff0000u);
+                }
+                *(u32x4*)(Zp + planes_at(pl, col, c, cols_pad, C)) = o4;
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int alive_gelu_film(const float* H, int N, int C, int L, const float* film, int film_rows, int Lf, int scale_row,
+                               int shift_row, int t0, int f0, int film_ld, float* Z, void* Zp, void* stream) {
+    ALIVE_CHECK_ARG(H && film && (Z != nullptr) != (Zp != nullptr) && N > 0 && C > 0 && L > 0 && Lf > 0, "alive_gelu_film: bad args (one of Z / Zp)");
+    ALIVE_CHECK_ARG(film_ld > 0 && t0 >= 0 && f0 >= 0, "alive_gelu_film: bad frame range");
+    ALIVE_CHECK_ARG(((((uintptr_t)H) | ((uintptr_t)Z) | ((uintptr_t)Zp)) & 15) == 0, "alive_gelu_film: H / Z / Zp must be 16-byte aligned");
+    ALIVE_CHECK_ARG(Zp == nullptr || (C & 31) == 0, "alive_gelu_film: plane output needs C %% 32 == 0");
+    const float ratio = (float)film_ld / (float)L;           // == window frames / window samples at this rate
+    dim3 g(cdiv(L, 64), cdiv(C, 64), N);
+    const int64_t cols_pad = ((int64_t)N * L + 127) / 128 * 128;
+    if (Zp) gelu_film_kernel<true><<<g, 256, 0, (hipStream_t)stream>>>(H, C, L, film, film_rows, Lf, scale_row, shift_row, t0, f0, film_ld, ratio,
+                                                                     nullptr, (unsigned short*)Zp, cols_pad);
+    else gelu_film_kernel<false><<<g, 256, 0, (hipStream_t)stream>>>(H, C, L, film, film_rows, Lf, scale_row, shift_row, t0, f0, film_ld, ratio, Z,
+                                                                    nullptr, 0);
+    ALIVE_CHECK_LAUNCH("alive_gelu_film");
     return ALIVE_OK;
 }
 

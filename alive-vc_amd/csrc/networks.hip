@@ -72,7 +72,7 @@ const Names& names_of(int model) {
             std::string b = "flt.blk" + std::to_string(s);
             if (F_MODE[s] == 2) { dec.add(b + ".pack"); continue; }     // fused 16- / 8-channel FilterBlock
             if (F_MODE[s] == 1) { dec.add(b + ".packW"); dec.add(b + ".packB"); continue; }   // fused 64-channel FilterBlock
-            dec.add(b + ".in.W"); dec.add(b + ".in.b");
+            // (no input_conv: module/_pack.py composes it into the transposed conv in front of the block)
             for (int j = 0; j < 3; ++j)
                 for (int c = 1; c <= 2; ++c) {
                     std::string q = b + "." + std::to_string(j) + ".c" + std::to_string(c);
@@ -503,8 +503,9 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
     int cin = 256, L = Lf, film_off = 0;
     for (int s = 0; s < 4; ++s) {
         const int C = F_CH[s], r = F_UP[s];
-        {   // ConvTranspose1d(cin, C, r, r): rows = (co, j)
-            AliveConv d = conv_desc(upW[s], upb[s], cur, N, cin, L, C * r, 1, 1, 1, 0, 0, L, b.U);
+        {   // ConvTranspose1d(cin, C, r, r): rows = (co, j).  Unfused scale: the weights are ups[s] x input_conv (module/_pack.py), the
+            // output is the block's residual stream itself
+            AliveConv d = conv_desc(upW[s], upb[s], cur, N, cin, L, C * r, 1, 1, 1, 0, 0, L, F_MODE[s] == 0 ? b.Hh : b.U);
             d.up = r;
             if (F_SPLIT[s]) d = split(d);
             RUN(alive_conv1d(&d, stream));
@@ -525,7 +526,6 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
             cin = C;
             continue;
         }
-        const float* iW = t.next(); const float* ib = t.next();
         // The modulated tensors between the convs of this block (each written once, read once) travel plane-packed and
         // time-major when the split kernel's batch form runs them (not the few-column streaming kernel): the consumer then
         // stages them by LDS-DMA instead of loading, splitting and storing fp32 (conv_split.hip, PLANES).  Same values bit for bit.
@@ -533,14 +533,9 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
                              (double)(ranged ? Lf : Lw_frames) / (double)L * 128.0 + 3.0 <= 20.0;
         auto set_z = [&](AliveConv& d, float* buf) { if (zplanes) d.Zp = buf; else d.Z = buf; };
         auto set_x = [&](AliveConv& d, const float* buf) { if (zplanes) { d.Xp = buf; d.X = nullptr; } };
-        {   // FilterBlock.input_conv; second output feeds blocks[0].c1 (gelu + FiLM)
-            AliveConv d = pw_desc(iW, ib, b.U, N, C, L, C, b.Hh);
-            set_z(d, b.Zz); d.film = b.film; d.film_rows = FILM_ROWS; d.Lf = Lw_frames;
-            if (ranged) { d.film_t0 = f_begin * (L / Lf); d.film_f0 = f_begin; d.film_ld = Lf; }
-            d.film_scale_row = film_off; d.film_shift_row = film_off + C;
-            if (F_SPLIT[s]) d = split(d);
-            RUN(alive_conv1d(&d, stream));
-        }
+        // FilterBlock.input_conv is part of the transposed conv above (Hh = its output); the input of blocks[0].c1 = gelu + FiLM of it
+        RUN(alive_gelu_film(b.Hh, N, C, L, b.film, FILM_ROWS, Lw_frames, film_off, film_off + C, ranged ? f_begin * (L / Lf) : 0,
+                            ranged ? f_begin : 0, ranged ? Lf : Lw_frames, zplanes ? nullptr : b.Zz, zplanes ? (void*)b.Zz : nullptr, stream));
         for (int j = 0; j < 3; ++j) {
             const int dil = 1 << j;
             const float* W1 = t.next(); const float* b1 = t.next(); const float* W2 = t.next(); const float* b2 = t.next();

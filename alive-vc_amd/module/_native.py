@@ -62,6 +62,7 @@ PROTOTYPES = {
     "alive_dedup_pass": (_I, [_VP, _VP, _I64, _I, _D, _VP, _VP, _VP]),
     "alive_knn_merge_gather": (_I, [_VP, _VP, _I, _I, _D, _VP, _VP, _I, _I, _VP, _VP, _VP]),
     "alive_conv1d": (_I, [C.POINTER(AliveConv), _VP]),
+    "alive_gelu_film": (_I, [_VP, _I, _I, _I, _VP, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "alive_planes_bytes": (_SZ, [_I64, _I, _I]),
     "alive_to_planes": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "alive_gemm_planes": (_I, [C.POINTER(AliveGemm), _VP]),

@@ -205,7 +205,16 @@ def pack_decoder(sd):
     out["flt.mid.b"] = _vec(sd[f + ".mid_conv.conv.bias"])
     for i in range(4):
         pt = pack_convT_split if SPLIT_SCALE[i] else pack_convT
-        out[f"flt.up{i}.W"], out[f"flt.up{i}.b"] = pt(sd[f"{f}.ups.{i}.weight"], sd[f"{f}.ups.{i}.bias"])
+        wt, bt = sd[f"{f}.ups.{i}.weight"], sd[f"{f}.ups.{i}.bias"]
+        if FILTER_MODE[i] == "split":
+            # ups[i] and blocks[i].input_conv (decoder.py:147,192-193) are two linear maps with nothing in between: one transposed
+            # conv with the product of their weights, formed in float64 -- out[c'][t r + j] = sum_ci Wc[ci][c'][j] x[ci][t] + bc[c'],
+            # Wc[ci][c'][j] = sum_c Win[c'][c] Wt[ci][c][j], bc = Win bt + bin.  The 1x1 conv over the upsampled tensor is gone.
+            win = sd[f"{f}.blocks.{i}.input_conv.weight"].double()[:, :, 0]
+            bc = win @ bt.double() + sd[f"{f}.blocks.{i}.input_conv.bias"].double()
+            wt = torch.einsum("icj,dc->idj", wt.double(), win).float()
+            bt = bc.float()
+        out[f"flt.up{i}.W"], out[f"flt.up{i}.b"] = pt(wt, bt)
     for s in range(4):
         b = f"{f}.blocks.{s}"
         if FILTER_MODE[s] == "small":                # 16- / 8-channel scales: one fused kernel per FilterBlock
@@ -214,9 +223,7 @@ def pack_decoder(sd):
         if FILTER_MODE[s] == "mid":                  # 64-channel scale: fused, split-bf16
             out[f"flt.blk{s}.packW"], out[f"flt.blk{s}.packB"] = pack_filter_mid(sd, b)
             continue
-        out[f"flt.blk{s}.in.W"] = pack_conv_split(sd[b + ".input_conv.weight"])
-        out[f"flt.blk{s}.in.b"] = _vec(sd[b + ".input_conv.bias"])
-        for j in range(3):
+        for j in range(3):                           # (input_conv: composed into flt.up{s} above)
             for cc in ("c1", "c2"):
                 out[f"flt.blk{s}.{j}.{cc}.W"] = pack_conv_split(sd[f"{b}.blocks.{j}.{cc}.conv.conv.weight"])
                 out[f"flt.blk{s}.{j}.{cc}.b"] = _vec(sd[f"{b}.blocks.{j}.{cc}.conv.conv.bias"])

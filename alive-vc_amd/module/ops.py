@@ -105,6 +105,18 @@ def planes_to_float(P, n, c, t, planes):
     return v.view(n, t, c).permute(0, 2, 1).contiguous()
 
 
+def gelu_film(h, film, scale_row, shift_row, planes=False):
+    """gelu(h) * interp(film[scale rows]) + interp(film[shift rows]) (decoder.py:112-117,130-132) through alive_gelu_film:
+    fp32 [N][C][L], or the 2-plane k-blocked image (uint8 buffer like to_planes gives)."""
+    h, film = _f(h), _f(film)
+    n, c, l = h.shape
+    z = None if planes else torch.empty_like(h)
+    zp = torch.zeros(nat.lib().alive_planes_bytes(n * l, c, 2), dtype=torch.uint8, device=h.device) if planes else None
+    nat.check(nat.lib().alive_gelu_film(nat.ptr(h), n, c, l, nat.ptr(film), film.shape[1], film.shape[2], scale_row, shift_row, 0, 0,
+                                        film.shape[2], nat.ptr(z), nat.ptr(zp), nat.stream()), "alive_gelu_film")
+    return zp if planes else z
+
+
 def gemm_planes(P, n, t, weight, bias=None, planes=2, act=None, post_add=None, ch_scale=None, residual=None,
                 want_fp32=True, want_planes=False):
     """1x1 conv on a plane-packed input through alive_gemm_planes.  Returns (Y fp32 [n][co][t] or None, Pout or None)."""

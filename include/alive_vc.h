@@ -311,6 +311,12 @@ int alive_dwconv_norm_planes(const float* X, int N, int C, int T, const float* d
                              int affine_mode, const float* gain, const float* offset,
                              const float* cond, int cond_rows, int scale_row, int shift_row,
                              float eps, int planes, void* P, void* stream);
+/* z = gelu(h) * interp(film[scale_row + c]) + interp(film[shift_row + c])  (decoder.py:112-117,130-132: F.gelu, then the FiLM of a
+ * ModulatedCausalConv1d with F.interpolate(mode='linear')), the arithmetic of alive_conv1d's second output.  H [N][C][L];
+ * film [N][film_rows][film_ld] holds the frames from f0 on of a window of Lf frames, t0 = first sample of H in the window at this
+ * rate (whole window: t0 = f0 = 0, film_ld = Lf).  Exactly one of Z (fp32 [N][C][L]) and Zp (2 k-blocked bf16 planes, C % 32 == 0). */
+int alive_gelu_film(const float* H, int N, int C, int L, const float* film, int film_rows, int Lf, int scale_row,
+                    int shift_row, int t0, int f0, int film_ld, float* Z, void* Zp, void* stream);
 /* ChannelNorm alone (f0_estimator.py:25) */
 int alive_channel_norm(const float* X, int N, int C, int T, const float* gain, const float* offset,
                        float eps, float* Y, void* stream);

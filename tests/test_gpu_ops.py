@@ -451,6 +451,33 @@ def test_gemm_planes_chain_pw1_gelu_pw2(planes, tol):
     assert e < tol, e
 
 
+@pytest.mark.parametrize("n,c,l,lf", [(2, 256, 4500, 450), (1, 256, 50, 5), (3, 64, 1201, 15), (1, 96, 640, 8)])
+def test_gelu_film_equals_the_conv_second_output(n, c, l, lf):
+    """alive_gelu_film (the input of a FilterBlock's first modulated conv since its input_conv is composed into the transposed conv
+    in front, decoder.py:112-117,130-132,147,192-193) against float64, against the second output of a conv epilogue (bitwise: same
+    arithmetic) and its plane image against alive_to_planes of the fp32 form"""
+    from module import ops
+    h = g(f"gfh{c}{l}", (n, c, l))
+    film = g(f"gff{c}{l}", (n, 2 * c + 3, lf))
+    # the interpolation coordinates are fp32 in the reference (ATen's upsample_linear1d on float tensors): interpolate in fp32, the rest in float64
+    sc = F.interpolate(film[:, 3:3 + c], l, mode="linear").double()
+    sh = F.interpolate(film[:, 3 + c:3 + 2 * c], l, mode="linear").double()
+    ref = F.gelu(h.double()) * sc + sh
+    z = ops.gelu_film(h.to(DEV), film.to(DEV), 3, 3 + c)
+    assert relerr(z, ref) < 2e-6, relerr(z, ref)
+    if c % 32 == 0:
+        zp = ops.gelu_film(h.to(DEV), film.to(DEV), 3, 3 + c, planes=True)
+        want = ops.to_planes(z, 2)
+        cols, cols_pad = n * l, (n * l + 127) // 128 * 128
+        a = zp.view(torch.bfloat16).view(2, c // 32, cols_pad, 32)[:, :, :cols].contiguous()
+        e = want.view(torch.bfloat16).view(2, c // 32, cols_pad, 32)[:, :, :cols].contiguous()
+        assert torch.equal(a.view(torch.int16), e.view(torch.int16))
+    if l % 4 == 0:
+        # a 1x1 conv with the identity as weight passes h through exactly on the fp32 kernel; its second output is the same formula
+        _, z2 = ops.conv1d(h.to(DEV), torch.eye(c).unsqueeze(2).to(DEV), None, film=film.to(DEV), film_scale_row=3, film_shift_row=3 + c)
+        assert torch.equal(z2, z)
+
+
 def test_gemm_planes_argument_errors():
     from module import ops
     P = ops.to_planes(g("gex", (1, 32, 8)).to(DEV), 2)
