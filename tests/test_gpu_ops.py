@@ -12,6 +12,7 @@ from module import synthetic
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def g(name, shape, seed=7, scale=1.0):
@@ -476,6 +477,36 @@ def test_gelu_film_equals_the_conv_second_output(n, c, l, lf):
         # a 1x1 conv with the identity as weight passes h through exactly on the fp32 kernel; its second output is the same formula
         _, z2 = ops.conv1d(h.to(DEV), torch.eye(c).unsqueeze(2).to(DEV), None, film=film.to(DEV), film_scale_row=3, film_shift_row=3 + c)
         assert torch.equal(z2, z)
+
+
+def _digest_of(cmd, env):
+    import subprocess, sys as _sys
+    e = dict(os.environ); e.update(env)
+    out = subprocess.run([_sys.executable] + cmd, env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return [ln for ln in out.stdout.splitlines() if ln.startswith("digest")][-1]
+
+
+def test_gemm_results_do_not_depend_on_the_tile_order():
+    """the row-group tile order of the plane GEMMs (gemm_planes.hip::tile_of, ALIVE_GEMM_RG) decides where and when a tile runs, never
+    what it computes: every group size, the ragged last group (33 row tiles in groups of 5 / 7) and the old order give the same bits,
+    on the one-tile kernels and on the persistent kernel with loader waves (the switches are read once per process: subprocesses)"""
+    tool = os.path.join(ROOT, "tools", "run_gemm_once.py")
+    for planes, variant in ((2, "0"), (3, "0"), (3, "1")):
+        ds = {rg: _digest_of([tool, "512", "4128", str(planes), "1"], {"ALIVE_GEMM_RG": rg, "ALIVE_GEMM_VARIANT": variant})
+              for rg in ("1", "5", "7", "64")}
+        assert len(set(ds.values())) == 1, (planes, variant, ds)
+
+
+@pytest.mark.parametrize("c,l,n,switch,forms", [(64, 800, 1, "ALIVE_FB64_NT", ("4", "2")), (64, 1208, 2, "ALIVE_FB64_NT", ("4", "2")),
+                                                (16, 1600, 1, "ALIVE_FBS_PLANE", ("32768", "8192")),
+                                                (8, 3200, 1, "ALIVE_FBS_PLANE", ("32768", "8192"))])
+def test_fused_filter_blocks_short_signal_tiles_are_bitwise_the_batch_tiles(c, l, n, switch, forms):
+    """the short-signal tile forms of the fused FilterBlocks (filter_mid.hip: two column tiles per wave, with the drained first step of
+    the reflecting block; filter_small.hip: 8-KB planes) compute what the batch tiles compute, bit for bit"""
+    tool = os.path.join(ROOT, "tools", "run_fused_once.py")
+    ds = [_digest_of([tool, str(c), str(l), str(n)], {switch: f}) for f in forms]
+    assert ds[0] == ds[1], ds
 
 
 def test_gemm_planes_argument_errors():
