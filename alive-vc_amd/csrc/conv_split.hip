@@ -40,7 +40,7 @@ constexpr int PROW = 64;          // PLANES = true: bytes per LDS row (32 channe
 // tiles, 128 accumulator registers, one block per CU).  Against two 128-row blocks per column tile that stages the X tile
 // (global loads, split, LDS writes) once instead of twice, reads every activation fragment for two row tiles instead of one
 // (0.33 instead of 0.67 LDS fragment reads per MFMA) and halves the X traffic from L2 / HBM.
-// PLANES = true (BM = 128, NP = 2; round 3): the activation operand arrives ALREADY split, plane-packed and time-major
+// PLANES = true (BM = 128, NP = 2; round 3): the activation operand arrives ALREADY split, plane-packed with rows = time
 // (AliveConv.Xp: the k-blocked planes of gemm_planes.hip / planes_layout.h, rows = n * Tin + t), so a 32-channel block of the X
 // tile is ONE run of 144 consecutive 64-B row segments per plane that LDS-DMA copies straight into LDS -- no fp32 loads, no split, no ds_write in the
 // loop.  By ablation (tools/experiments/README.md) the fp32 staging cost 0.27 - 0.35 ms of the 1.4 - 1.8 ms of a 256-channel

@@ -527,7 +527,7 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
             continue;
         }
         // The modulated tensors between the convs of this block (each written once, read once) travel plane-packed and
-        // time-major when the split kernel's batch form runs them (not the few-column streaming kernel): the consumer then
+        // (k-blocked, rows = time) when the split kernel's batch form runs them (not the few-column streaming kernel): the consumer then
         // stages them by LDS-DMA instead of loading, splitting and storing fp32 (conv_split.hip, PLANES).  Same values bit for bit.
         const bool zplanes = F_SPLIT[s] && (int64_t)N * L > 96 && (L & 3) == 0 && C > 64 && C % 64 == 0 &&
                              (double)(ranged ? Lf : Lw_frames) / (double)L * 128.0 + 3.0 <= 20.0;
