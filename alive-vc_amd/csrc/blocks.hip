@@ -107,6 +107,20 @@ __global__ __launch_bounds__(NPT) void dwconv_norm_planes_kernel(
     const float* Xn = X + (size_t)n * C * T;
     // pass 1: depthwise conv (zero pad 3) -> LDS, running sum
     float s = 0.0f;
+    if (dw && t0 >= 3 && t0 + TW + 3 <= T) {
+        // interior tile (block-uniform): no tap leaves the window -- the same loads and fmas without the seven bounds tests per element
+        // (the kernel is bound by its instruction count, not by memory: tools/experiments/README.md)
+        const float* xt = Xn + t - 3;
+        for (int c = crow; c < C; c += NR) {
+            const float* xc = xt + (size_t)c * T;
+            const float* wc = dw_w + c * 7;
+            float y = dw_b[c];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) y = fmaf(wc[j], xc[j], y);
+            tile[c * PT + tl] = y;
+            s += y;
+        }
+    } else
     for (int c = crow; c < C; c += NR) {
         float y = 0.0f;
         if (ok) {
