@@ -856,7 +856,10 @@ extern "C" int alive_gemm_planes(const AliveGemm* d, void* stream) {
     static const int variant = getenv("ALIVE_GEMM_VARIANT") ? atoi(getenv("ALIVE_GEMM_VARIANT")) : 0;
     const int64_t ntiles = (int64_t)cdiv(d->Co, GM) * cdiv((int64_t)d->N * d->T, GN);
     const int nsteps = pad32(d->Ci) / GK;
-    const bool can_persist = ntiles >= 1024 && variant != 1 &&      // >= 4 tiles per CU, else the seams buy nothing
+    // from 2 tiles per CU on (512; 1024 until the loader waves: with them the form pays below four tiles per CU too -- 512 -> 256 x 3
+    // planes, 900 tiles: 0.125 -> 0.116 ms)
+    static const int persist_min = getenv("ALIVE_GEMM_PERSIST_MIN") ? atoi(getenv("ALIVE_GEMM_PERSIST_MIN")) : 512;
+    const bool can_persist = ntiles >= persist_min && variant != 1 &&
                              (d->b_row == 0 ? (int64_t)d->planes * pad_cols((int64_t)d->N * d->T) * pad32(d->Ci)
                                             : (int64_t)d->planes * d->b_plane) * 2 < (1ll << 32);          // 32-bit DMA offsets
     if (d->planes == 2) {
