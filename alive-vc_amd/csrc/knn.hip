@@ -176,7 +176,9 @@ __global__ __launch_bounds__(256) void src_prep_kernel(const float* __restrict__
             const int r = wv + 4 * i;
             const int64_t ff = f0 + r;
             if (ff < Tt_pad) {
-                float q = (ff < Tt) ? tile[lane][r] / nrm[r] : 0.0f;
+                // a zero-norm frame (the reference divides 0 / 0 -> NaN cosines, whose top-k is unspecified: common.py:102-105) has
+                // cosine 0 against every row here: the search returns val = 0 and, by the tie rule, the k lowest row indices
+                float q = (ff < Tt && nrm[r] > 0.0f) ? tile[lane][r] / nrm[r] : 0.0f;
                 if (ff < Tt) s_f32[(size_t)ff * D + d0 + lane] = q;
                 const unsigned short b = f32_to_bf16_rn(q);
                 s_bf16[(size_t)ff * D + d0 + lane] = b;
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void src_prep_small_kernel(const float* __rest
     float e2 = 0.0f;
 #pragma unroll
     for (int i = 0; i < D / 256; ++i) {
-        const float q = v[i] / nrm;
+        const float q = nrm > 0.0f ? v[i] / nrm : 0.0f;          // zero-norm frame: see src_prep_kernel
         s_f32[(size_t)ft * D + tid + 256 * i] = q;
         const unsigned short b = f32_to_bf16_rn(q);
         s_bf16[(size_t)ft * D + tid + 256 * i] = b;

@@ -53,7 +53,11 @@ def build_parser():
     parser.add_argument('-norm', '--normalize', default=False, type=bool)
     parser.add_argument('--window-batch', default=64, type=int, help="windows per device batch (this build only)")
     parser.add_argument('--trim-context', action='store_true',
-                        help="match only the frames that can reach the kept centre third of each window (same samples, ~44 %% of the kNN work)")
+                        help="(default since round 5, kept for compatibility) match and decode only the frames that can reach the kept "
+                             "centre third of each window: same samples, ~44 %% of the kNN and decoder work")
+    parser.add_argument('--no-trim-context', action='store_true',
+                        help="run the kNN match and the decoder over all three chunks of every window as the reference does (same "
+                             "samples in the kept centre third either way; this build only)")
     parser.add_argument('--no-share-overlap', action='store_true',
                         help="always run spectrogram / f0 estimator / content encoder / kNN match per window as the reference does; by "
                              "default long utterances run them once per utterance with the windows assembled from it (same samples "
@@ -103,8 +107,8 @@ def main(argv=None):
         print(f"-> {path}")
         out = conv.convert(wf, chunk=args.chunk, k=args.k, alpha=args.alpha, pitch_shift=args.pitch,
                            intonation=args.intonation, f0_rate=args.f0_rate, window_batch=args.window_batch,
-                           trim_context=args.trim_context,
-                           share_overlap=None if (args.no_share_overlap or args.trim_context) else "auto")
+                           trim_context=not args.no_trim_context,
+                           share_overlap=None if args.no_share_overlap else "auto")
         out = audio_io.resample(out, 16000, sr, post_gain_db=args.gain).cpu()      # resample, then gain (:136-137)
         if args.normalize:
             out = out / out.abs().max()

@@ -55,6 +55,14 @@ class PackedLibrary:
         self.norms = torch.empty(self.M, dtype=torch.float32, device=dev)
         nat.check(L.alive_library_pack(nat.ptr(t), self.M, DIM, nat.ptr(self.lib_bf16), nat.ptr(self.rows),
                                        nat.ptr(self.norms), nat.stream()), "alive_library_pack")
+        # A zero-norm (or non-finite) row: the reference divides it by its norm (common.py:103) and the NaN cosines that
+        # follow rank first in every frame's top-k, i.e. the row silently joins every match.  Here it is an error of the
+        # library (one reduction + sync per pack, which happens once per bank).
+        bad = ~(torch.isfinite(self.norms) & (self.norms > 0))
+        if bool(bad.any()):
+            first = int(torch.nonzero(bad)[0])
+            raise ValueError(f"voice library row {first + self.idx_base} has zero or non-finite norm ({int(bad.sum())} such rows): "
+                             f"remove them (the reference would match every frame to them through NaN cosines)")
         self.lib_f8 = None
         if self.prefilter == "fp8":
             self.lib_f8 = torch.empty(L.alive_library_fp8_bytes(self.M), dtype=torch.uint8, device=dev)

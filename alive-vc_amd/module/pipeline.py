@@ -82,15 +82,21 @@ class Converter:
         feat[:, :, a:b] = self.ce(spec[:, :, a:b].contiguous())
         return feat, f0
 
-    def features_shared(self, windows, group, k=4, alpha=0.0, utt_batch=32):
+    def features_shared(self, windows, group, k=4, alpha=0.0, utt_batch=32, frames=None):
         """(matched content features [n, 768, lf], raw f0 [n, 1, lf]) of n = m * group windows, every `group` consecutive ones
-        being the windows of one signal at hop = a third of the window (make_windows): the front end runs once per signal."""
+        being the windows of one signal at hop = a third of the window (make_windows): the front end runs once per signal.
+        frames = (r0, r1) with EDGE <= r0 < r1 <= lf - EDGE (context trimming on top of sharing): only the matched features of
+        frames [r0, r1) of every window are needed -> [n, 768, r1 - r0].  They are all interior frames of the signal, so the
+        edge blocks carry the f0 estimator alone (f0 still covers the whole window) and the match runs on the union of the
+        windows' ranges, frames [r0, (group - 1) cf + r1) of each signal."""
         n, L = windows.shape
         c = L // 3
         lf, cf = L // 320, c // 320
         if n % group or c % 320 or lf < 2 * (EDGE + NET_MARGIN + SPEC_MARGIN):
             raise ValueError(f"share_overlap needs groups of {group} windows of 3 chunks, chunk a multiple of 320 and >= "
                              f"{2 * (EDGE + NET_MARGIN + SPEC_MARGIN)} frames per window")
+        if frames is not None:
+            return self._features_shared_range(windows, group, k, alpha, utt_batch, frames)
         m = n // group
         w3 = windows.view(m, group, L)
         # the padded signal of every group: first chunk of each window, then the last two chunks of the last one
@@ -131,6 +137,45 @@ class Converter:
         self.last_front_end_frames = m * (group + 2) * cf + n * 2 * EDGE           # frames that went through the match
         return feat, f0
 
+    def _features_shared_range(self, windows, group, k, alpha, utt_batch, frames):
+        n, L = windows.shape
+        c = L // 3
+        lf, cf = L // 320, c // 320
+        r0, r1 = frames
+        if not (EDGE <= r0 < r1 <= lf - EDGE):
+            raise ValueError(f"shared front end with a frame range needs {EDGE} <= r0 < r1 <= {lf - EDGE}, got {frames}")
+        m = n // group
+        nr = r1 - r0
+        w3 = windows.view(m, group, L)
+        sig = torch.cat([w3[:, :, :c].reshape(m, group * c), w3[:, -1, c:]], dim=1).contiguous()      # [m, (group + 2) c]
+        dev = windows.device
+        tu = (group + 2) * cf
+        u0, u1 = r0, (group - 1) * cf + r1                      # frames of a signal that some window's range holds
+        a, b = max(0, u0 - CE_MARGIN), min(tu, u1 + CE_MARGIN)  # ... plus the content encoder's own receptive field
+        pu = torch.empty(m, 1, tu, device=dev)
+        fu = torch.empty(m, 768, u1 - u0, device=dev)
+        for i in range(0, m, utt_batch):
+            spec = spectrogram(sig[i:i + utt_batch])
+            pu[i:i + utt_batch] = self.pe.estimate(spec)
+            fu[i:i + utt_batch] = self.ce(spec[:, :, a:b].contiguous())[:, :, u0 - a:u1 - a]
+        nl = EDGE + NET_MARGIN
+        f0 = torch.empty(n, 1, lf, device=dev)
+        for i in range(0, n, 8 * utt_batch):                    # f0 of the edge frames of every window
+            w = windows[i:i + 8 * utt_batch]
+            sl = spectrogram(w[:, :(nl + SPEC_MARGIN) * 320].contiguous())[:, :, :nl].contiguous()
+            sr = spectrogram(w[:, L - (nl + SPEC_MARGIN) * 320:].contiguous())[:, :, SPEC_MARGIN:].contiguous()
+            f0[i:i + 8 * utt_batch, :, :EDGE] = self.pe.estimate(sl)[:, :, :EDGE]
+            f0[i:i + 8 * utt_batch, :, lf - EDGE:] = self.pe.estimate(sr)[:, :, NET_MARGIN:]
+        nu = u1 - u0
+        matched = self.match(fu.permute(1, 0, 2).reshape(1, 768, m * nu).contiguous(), k, alpha)[0].view(768, m, nu).permute(1, 0, 2)
+        feat = torch.empty(n, 768, nr, device=dev)
+        f4, p4 = feat.view(m, group, 768, nr), f0.view(m, group, 1, lf)
+        for g in range(group):                                 # window g of a signal = frames [g cf, g cf + lf) of it
+            f4[:, g] = matched[:, :, g * cf:g * cf + nr]
+            p4[:, g, :, EDGE:lf - EDGE] = pu[:, :, g * cf + EDGE:g * cf + lf - EDGE]
+        self.last_front_end_frames = m * nu                     # frames that went through the match
+        return feat, f0
+
     def match(self, feat, k=4, alpha=0.0):
         val, idx = self.library.search(feat, k)
         return merge_gather(val, idx, 1, k, alpha, self.library.rows, feat)
@@ -148,27 +193,37 @@ class Converter:
         # (the edge blocks of all windows form one launch of n x 30 frame columns: below 96 columns the library would switch
         # to its streaming kernels, which round differently from the plane GEMMs the windows themselves run on -- then the
         # per-window front end is used, so that the result never depends on the flag)
-        if share_overlap and keep_frames is None and n * (EDGE + NET_MARGIN) >= 96:
+        rng = None if keep_frames is None else (max(0, keep_frames[0] - TRIM_LEFT), min(lf, keep_frames[1] + TRIM_RIGHT))
+        # sharing and trimming together need the trimmed range to consist of interior frames of the signal (it does for the
+        # centre third of a 3-chunk window from 46 frames per chunk on); otherwise trimming alone is used -- same samples
+        share_ok = bool(share_overlap) and n * (EDGE + NET_MARGIN) >= 96
+        if share_ok and (rng is None or (EDGE <= rng[0] and rng[1] <= lf - EDGE and rng[1] - rng[0] >= 5)):
             # share_overlap = windows per signal (make_windows order): front end once per signal, decoder per window
-            feat, f0 = self.features_shared(windows, int(share_overlap), k, alpha)
+            feat, f0 = self.features_shared(windows, int(share_overlap), k, alpha, frames=rng)
             f0 = ops.pitch_transform_(f0, 0, f0_rate=f0_rate, pitch_shift=pitch_shift, intonation=intonation)
-            out = torch.empty_like(windows)
+            out = torch.empty_like(windows) if rng is None else torch.zeros_like(windows)
             cur = torch.cuda.current_stream()
             side = self._side_streams(windows.device)
+
+            def dec_shared(i):
+                if rng is None:
+                    self.dec(feat[i:i + window_batch], f0[i:i + window_batch], out=out[i:i + window_batch])
+                else:       # feat holds frames [rng[0], rng[1]) only; samples outside the range are not kept by the caller
+                    out[i:i + window_batch, rng[0] * 320:rng[1] * 320] = self.dec.forward_range(
+                        feat[i:i + window_batch], f0[i:i + window_batch], rng[0])
             for j, i in enumerate(range(0, n, window_batch)):
                 st = side[j % len(side)] if side else None
                 if st is None:
-                    self.dec(feat[i:i + window_batch], f0[i:i + window_batch], out=out[i:i + window_batch])
+                    dec_shared(i)
                     continue
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
-                    self.dec(feat[i:i + window_batch], f0[i:i + window_batch], out=out[i:i + window_batch])
+                    dec_shared(i)
             for st in side:
                 cur.wait_stream(st)
             return out
         feat = torch.empty(n, 768, lf, device=windows.device)
         f0 = torch.empty(n, 1, lf, device=windows.device)
-        rng = None if keep_frames is None else (max(0, keep_frames[0] - TRIM_LEFT), min(lf, keep_frames[1] + TRIM_RIGHT))
 
         # Window batches are independent before and after the match: they go round-robin onto side streams (scratch is per
         # stream, module/_native.py::Workspace), so that the tail of one batch's kernels overlaps the next batch's -- the
@@ -228,13 +283,15 @@ class Converter:
 
     def convert(self, wf, chunk=48000, trim_context=False, **kw):
         """one utterance: wf [1, L] at 16 kHz (already normalised / mono) -> [1, L].
-        trim_context: match only the frames that can reach the kept centre third (same samples, ~44 % of the kNN work)"""
+        trim_context: match and decode only the frames that can reach the kept centre third (same samples, ~44 % of the kNN
+        and decoder work); share_overlap=True / "auto": the front end once per utterance.  The two combine (the CLI's default):
+        the stitched output is bitwise that of the plain per-window path."""
         windows, total = make_windows(wf.to(self.device), chunk)
         keep = (chunk // 320, 2 * chunk // 320) if trim_context else None
         share = kw.get("share_overlap")
         if share is True or share == "auto":                      # one utterance: all of its windows form one group
             n = windows.shape[0]
-            ok = chunk % 320 == 0 and 3 * chunk // 320 >= 2 * (EDGE + NET_MARGIN + SPEC_MARGIN) and keep is None
+            ok = chunk % 320 == 0 and 3 * chunk // 320 >= 2 * (EDGE + NET_MARGIN + SPEC_MARGIN)
             # "auto": sharing adds ~2.5 ms of small launches (one more encoder pass, edge blocks, copies) and saves about half
             # of the front end, most of it in the kNN match -- measured break-even: 43 windows at a 50 k-vector library, 18 at 1 M
             if share == "auto" and self.library is not None:

@@ -34,7 +34,7 @@ import torch.distributed as dist                           # noqa: E402
 FRAME = 320
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_FP8_TFLOPS = 5000.0           # dense fp8 MFMA peak (block-scaled 32x32x64 e4m3), same table
-ALL_LEGS = ("uncorrelated", "bf16_prefilter", "strict_knn", "clustered_library", "overlap_shared", "context_trim", "pcie_inclusive", "e2e_24k", "config2",
+ALL_LEGS = ("uncorrelated", "bf16_prefilter", "strict_knn", "clustered_library", "overlap_shared", "context_trim", "cli_default", "pcie_inclusive", "e2e_24k", "config2",
             "streaming", "cpu_baseline")
 
 
@@ -490,6 +490,27 @@ def main():
                     "useful_frames_per_s": round(useful_frames / tt0, 1), "kept_samples_bitwise_equal": same,
                     "note": "kNN match and decoder on frames [cf-32, 2cf+16) of each window (oscillator phase over the whole window), content encoder on that range +-16; spectrogram and f0 estimator on the whole window"}
         extra["context_trim"] = guarded(leg)
+
+    # What inference.py does by default since round 5 (never `value`): overlap sharing AND context trimming together -- the front
+    # end once per utterance, the kNN match on the union of the windows' trimmed ranges, the decoder on frames [cf-32, 2cf+16)
+    # of every window.  The kept centre thirds (all the CLI writes) are bitwise those of the headline step.
+    if "cli_default" in legs:
+        def leg():
+            cf = (L // FRAME) // 3
+            per = n_win // args.utterances
+            ref_out = out[:, cf * FRAME:2 * cf * FRAME].clone()
+            cli_step = lambda: conv.convert_windows(windows, k=args.k, window_batch=args.window_batch, share_overlap=per,  # noqa: E731
+                                                    keep_frames=(cf, 2 * cf))
+            cli_step()
+            tc, out_c = timed_steps(cli_step, 2)
+            return {"ms_per_step": round(tc * 1e3, 2), "useful_frames_per_s": round(useful_frames / tc, 1),
+                    "rtf": round(tc / (args.utterances * args.seconds), 6),
+                    "kept_samples_bitwise_equal_headline": bool(torch.equal(out_c[:, cf * FRAME:2 * cf * FRAME], ref_out)),
+                    "frames_through_match": conv.last_front_end_frames, "of": frames_per_step,
+                    "note": "Converter.convert(share_overlap='auto', trim_context=True), the CLI's default: spectrogram + f0 estimator + content "
+                            "encoder once per utterance (+ the f0 estimator on the two 14-frame edge blocks of every window), kNN match on "
+                            "frames [cf-32, (per-1) cf + 2cf+16) of every utterance, decoder on frames [cf-32, 2cf+16) of every window"}
+        extra["cli_default"] = guarded(leg)
 
     # PCIe-inclusive rate (never `value`): the same step with the windows arriving from pinned host memory and the
     # waveforms returned to it, as the CLI edge does (inference.py:88-94,134)

@@ -118,3 +118,38 @@ def test_overlap_sharing_of_one_utterance(rig):
     long = (0.3 * synthetic.make_waveform(16000 * 60, 42)).to(DEV)
     out = conv.convert(long, chunk=16000, k=4, share_overlap="auto")
     assert conv.last_front_end_frames is not None and torch.equal(out, conv.convert(long, chunk=16000, k=4))
+
+
+@pytest.mark.parametrize("n_utt,window_batch", [(8, 64), (64, 128)])
+def test_overlap_sharing_with_context_trimming_keeps_the_same_samples(rig, monkeypatch, n_utt, window_batch):
+    """sharing and trimming together (the CLI's default since round 5): front end once per utterance, kNN match on the
+    union of the windows' trimmed ranges only, decoder on frames [cf - 32, 2 cf + 16) of every window -- the kept centre
+    third is bitwise that of the plain path (inference.py:96-101,132-135)"""
+    conv, _, windows = rig
+    monkeypatch.setenv("ALIVE_STREAMS", "3")
+    w = windows[:n_utt * 6]
+    kw = dict(k=4, alpha=0.1, pitch_shift=1.0, intonation=1.2, window_batch=window_batch)
+    ref = conv.convert_windows(w, **kw)
+    got = conv.convert_windows(w, share_overlap=6, keep_frames=(150, 300), **kw)
+    assert torch.equal(got[:, 48000:96000], ref[:, 48000:96000])
+    # per signal: frames [118, 5 * 150 + 316) go through the match -- 35 % of the per-window path's frames
+    assert conv.last_front_end_frames == n_utt * (5 * 150 + 316 - 118)
+    trim_only = conv.convert_windows(w, keep_frames=(150, 300), **kw)
+    assert torch.equal(got[:, 48000:96000], trim_only[:, 48000:96000])
+
+
+def test_shared_and_trimmed_conversion_of_one_utterance(rig):
+    """Converter.convert(share_overlap=..., trim_context=True) == the plain path, bitwise, over chunk sizes (a chunk of 15
+    frames cannot be trimmed onto interior frames: the code falls back to trimming / sharing alone) and an odd length"""
+    conv, _, _ = rig
+    wf = (0.3 * synthetic.make_waveform(16000 * 7 + 123, 41)).to(DEV)
+    for chunk in (48000, 16000, 4800):
+        ref = conv.convert(wf, chunk=chunk, k=4)
+        assert torch.equal(conv.convert(wf, chunk=chunk, k=4, share_overlap=True, trim_context=True), ref)
+        assert torch.equal(conv.convert(wf, chunk=chunk, k=4, trim_context=True), ref)
+    long = (0.3 * synthetic.make_waveform(16000 * 60, 42)).to(DEV)
+    conv.last_front_end_frames = None
+    out = conv.convert(long, chunk=16000, k=4, share_overlap="auto", trim_context=True)
+    assert conv.last_front_end_frames is not None                   # shared (62 windows against 200 k vectors) ...
+    assert conv.last_front_end_frames < 0.4 * 62 * 150              # ... and trimmed: about a third of the per-window frames
+    assert torch.equal(out, conv.convert(long, chunk=16000, k=4))

@@ -123,11 +123,13 @@ def test_inference_cli_trim_context_writes_the_same_file(workdir):
     d, _, _ = workdir
     base = ["-i", str(d / "inputs"), "-dep", str(d / "decoder.pt"), "-cep", str(d / "content_encoder.pt"), "-f0ep", str(d / "f0_estimator.pt"),
             "-lib", str(d / "voice_library.pt"), "-d", "cuda", "-c", "6400", "-p", "-1", "-a", "0.05"]      # 20 frames per chunk
-    inference.main(base + ["-o", str(d / "out_full")])
+    inference.main(base + ["-o", str(d / "out_full"), "--no-trim-context", "--no-share-overlap"])     # the reference's order of work
     inference.main(base + ["-o", str(d / "out_trim"), "--trim-context"])
+    inference.main(base + ["-o", str(d / "out_default")])                                             # trimmed (+ shared when it pays)
     a, _ = audio_io.load(str(d / "out_full" / "0_utt.wav"))
     b, _ = audio_io.load(str(d / "out_trim" / "0_utt.wav"))
-    assert torch.equal(a, b)
+    c, _ = audio_io.load(str(d / "out_default" / "0_utt.wav"))
+    assert torch.equal(a, b) and torch.equal(a, c)
 
 
 def test_inference_cli_overlap_sharing_writes_the_same_file(workdir):
@@ -139,10 +141,12 @@ def test_inference_cli_overlap_sharing_writes_the_same_file(workdir):
     base = ["-i", str(d / "inputs"), "-dep", str(d / "decoder.pt"), "-cep", str(d / "content_encoder.pt"), "-f0ep", str(d / "f0_estimator.pt"),
             "-lib", str(d / "voice_library.pt"), "-d", "cuda", "-c", "16000", "-p", "1.5", "-a", "0.05"]      # 50 frames per chunk
     inference.main(base + ["-o", str(d / "out_shared")])
-    inference.main(base + ["-o", str(d / "out_per_window"), "--no-share-overlap"])
+    inference.main(base + ["-o", str(d / "out_per_window"), "--no-share-overlap", "--no-trim-context"])
+    inference.main(base + ["-o", str(d / "out_shared_untrimmed"), "--no-trim-context"])
     a, _ = audio_io.load(str(d / "out_shared" / "0_utt.wav"))
     b, _ = audio_io.load(str(d / "out_per_window" / "0_utt.wav"))
-    assert torch.equal(a, b)
+    c, _ = audio_io.load(str(d / "out_shared_untrimmed" / "0_utt.wav"))
+    assert torch.equal(a, b) and torch.equal(a, c)
 
 
 def test_realtime_converter_matches_oracle(workdir):

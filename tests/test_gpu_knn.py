@@ -467,3 +467,40 @@ def test_knn_search_stays_inside_its_workspace_and_outputs(prefilter, n, t, m, k
     assert bool((outi[:1024] == 54321).all() and (outi[1024 + tt * k:] == 54321).all())
     rv, ri = lib.search(src, k)
     assert torch.equal(v.view(tt, k), rv) and torch.equal(i.view(tt, k), ri)
+
+
+@pytest.mark.parametrize("n,T,M", [(1, 8, 2000), (2, 300, 5000), (4, 450, 60_000)])
+def test_zero_norm_frames_and_rows_have_defined_semantics(n, T, M):
+    """/root/reference/module/common.py:102-104 divides by the norms, so a zero frame yields NaN cosines (its top-k is
+    whatever topk makes of a NaN row: unspecified) and a zero library row joins EVERY frame's top-k (NaN ranks first).
+    Here: a zero-norm frame has cosine 0 against every row (val = 0, the k lowest row indices by the tie rule, output =
+    their mean), every other frame of the batch is untouched; a zero-norm or non-finite library row is a ValueError."""
+    from module.common import PackedLibrary, match_features
+    lib = synthetic.make_library(M, 21).to(DEV)
+    src = synthetic.gaussian("zn.src", 22, (n, 768, T)).to(DEV)
+    ref, ridx = match_features(src, lib, k=4, alpha=0.25, return_indices=True)
+    z = src.clone()
+    zero_at = [(0, 0), (n - 1, T - 1), (n // 2, T // 2)]
+    for a, b in zero_at:
+        z[a, :, b] = 0.0
+    out, idx = match_features(z, lib, k=4, alpha=0.25, return_indices=True)
+    assert torch.isfinite(out).all()
+    idx3, ridx3 = idx.view(n, T, 4), ridx.view(n, T, 4)
+    keep = torch.ones(n, T, dtype=torch.bool, device=DEV)
+    for a, b in zero_at:
+        keep[a, b] = False
+        assert sorted(idx3[a, b].tolist()) == [0, 1, 2, 3]
+        want = lib[0, :, :4].mean(dim=1) * 0.75                      # + 0.25 * the zero frame
+        torch.testing.assert_close(out[a, :, b], want, rtol=1e-6, atol=1e-7)
+    assert torch.equal(idx3[keep], ridx3[keep])
+    assert torch.equal(out.permute(0, 2, 1)[keep], ref.permute(0, 2, 1)[keep])
+    val, _ = PackedLibrary(lib[0]).search(z, 4)
+    for a, b in zero_at:
+        assert val.view(n, T, 4)[a, b].abs().max().item() == 0.0
+    bad = lib.clone()
+    bad[0, :, 17] = 0.0
+    with pytest.raises(ValueError, match="row 17"):
+        PackedLibrary(bad[0])
+    bad[0, 5, 17] = float("nan")
+    with pytest.raises(ValueError, match="row 17"):
+        match_features(src, bad, k=4)

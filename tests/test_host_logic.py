@@ -123,6 +123,11 @@ def test_cli_flags_match_the_reference():
     # contract (a missing GPU raises instead of falling back), so its documented deviation is the default "cuda" -- the flag, its
     # long name and its choices are the reference's
     assert d["device"] == "cuda" and "-d" in inf._option_string_actions and "--device" in inf._option_string_actions
+    # this build's own switches: by default the CLI trims each window's work to what reaches the kept centre third and shares the
+    # front end between overlapping windows (bitwise the same file); each has an off switch, --trim-context stays accepted
+    assert not d["no_trim_context"] and not d["no_share_overlap"]
+    for flag in ("--trim-context", "--no-trim-context", "--no-share-overlap", "--knn-strict", "--window-batch", "--pcm16"):
+        assert flag in inf._option_string_actions, flag
     rt = importlib.import_module("realtime_inference").build_parser()
     d = vars(rt.parse_args([]))
     assert d["device"] == "cuda" and set(rt._option_string_actions["-d"].choices) == {"cpu", "cuda", "mps"}
@@ -168,8 +173,9 @@ def _cpu_merge_factory(lib_DxM):
     return merge
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n5=5, t5=9):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         lib = synthetic.make_library(777, 31)[0]
@@ -185,36 +191,50 @@ def _worker(rank, world, port, q):
         whole = torch.cat(parts, 0)
         # BASELINE config 4 end to end: frames are data-parallel too (uneven window counts: 3 + 2), so the protocol
         # all-gathers the features first, every rank searches ALL frames in its slab, and merges only its own
-        src5 = synthetic.gaussian("sh.src5", 33, (5, 768, 9))
-        counts = [e_ - b_ for b_, e_ in shard_bounds(5, world)]
-        own = src5[partition_windows(5, world, rank)]
+        src5 = synthetic.gaussian("sh.src5", 33, (n5, 768, t5))
+        counts = [e_ - b_ for b_, e_ in shard_bounds(n5, world)]
+        own = src5[partition_windows(n5, world, rank)]
         got, gidx = sl.match_distributed(own, k=3, alpha=0.1, counts=counts, return_indices=True)
-        ref5, ridx5, _ = O.match_features(src5, lib.unsqueeze(0).expand(5, -1, -1), 3, 0.1, return_indices=True)
-        want = ref5[partition_windows(5, world, rank)]
-        widx = ridx5[partition_windows(5, world, rank)].reshape(-1, 3)
+        ref5, ridx5, _ = O.match_features(src5, lib.unsqueeze(0).expand(n5, -1, -1), 3, 0.1, return_indices=True)
+        want = ref5[partition_windows(n5, world, rank)]
+        widx = ridx5[partition_windows(n5, world, rank)].reshape(-1, 3)
         e3 = float((got - want).abs().max())
         same_idx = bool((torch.sort(gidx, 1).values == torch.sort(widx, 1).values).all())
         xb = sl.last_exchange_bytes
-        ok_bytes = xb["frames_allgather_received"] == (world - 1) * 3 * 768 * 9 * 4 and \
-            xb["lists_alltoall_received"] == (world - 1) * 3 * 9 * 3 * 8        # routed: only this rank's frames arrive
+        n_max = max(counts)
+        ok_bytes = xb["frames_allgather_received"] == (world - 1) * n_max * 768 * t5 * 4 and \
+            xb["lists_alltoall_received"] == (world - 1) * n_max * t5 * 3 * 8   # routed: only this rank's frames arrive
         q.put((rank, float((out - ref).abs().max()), float((whole - ref).abs().max()), e3, same_idx and ok_bytes))
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_knn_protocol_world2_gloo():
+def _run_world(world, port_base, *extra):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = port_base + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q) + extra) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in procs]
+    res = [q.get(timeout=400) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
     for rank, e1, e2, e3, ok in res:
         assert e1 < 1e-5 and e2 < 1e-5 and e3 < 1e-5 and ok, res
+
+
+def test_sharded_knn_protocol_world2_gloo():
+    _run_world(2, 29500)
+
+
+def test_sharded_knn_protocol_world8_gloo_uneven():
+    """BASELINE config 4's shape: 8 ranks, a 777-row library (slabs of 98 and 97 rows), 50 windows (counts 7, 7, 6, ...: the
+    short ranks pad their all-gather contribution, the routed lists carry only the owner's frames)"""
+    assert [e - b for b, e in shard_bounds(777, 8)] == [98] + [97] * 7
+    assert [e - b for b, e in shard_bounds(50, 8)] == [7, 7, 6, 6, 6, 6, 6, 6]
+    _run_world(8, 33500, 50, 3)
 
 
 def test_overlap_sharing_geometry_against_the_oracle():
