@@ -301,6 +301,9 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
         const int bw = colw * ROWB + ((lh ^ swz(colw)) << 4);
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
+#ifndef ALIVE_FB64_NO_CHAIN_GAP
+            if (i > 0) ALIVE_CHAIN_GAP(7);                    // h[i - 1] stays in its accumulator registers and is read by the epilogues below
+#endif
             f32x16 acc = b16;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
             const int it_t = i > 0 ? i - 1 : NT - 1;
             const f32x16& it_acc = acc[(i + 1) & 1];
 #ifndef ALIVE_FB64_NO_CHAIN_GAP
-            asm volatile("s_nop 15" ::: "memory");            // see the header: distance between two accumulation chains
+            ALIVE_CHAIN_GAP(15);                              // see the header: distance between two accumulation chains
 #endif
             Epi E;
             if (it_emit) epi_begin(E, it_qf, it_t);

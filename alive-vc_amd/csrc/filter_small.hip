@@ -282,6 +282,9 @@ __global__ __launch_bounds__(256, 1) void filter_block_small_kernel(const float*
         for (int i = 0; i < NT; ++i) {
             const unsigned char* bp = bufZ + bw + i * TSTEP;
             const bf16x8 bh = *(const bf16x8*)bp, bl = *(const bf16x8*)(bp + PLANE);
+#ifndef ALIVE_FBS_NO_CHAIN_GAP
+            if (i > 0) ALIVE_CHAIN_GAP(7);                    // (hipcc may read the previous tile's result behind this tile's MFMAs)
+#endif
             f32x16 c = b16;
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai[1], bh, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ai[0], bl, c, 0, 0, 0);
@@ -356,7 +359,9 @@ __global__ __launch_bounds__(256, 1) void filter_block_small_kernel(const float*
             unsigned char* it_dst = i > 0 ? dst : (unsigned char*)in;
             const int it_t = i > 0 ? i - 1 : NT - 1;
             const f32x16& it_acc = acc[(i + 1) & 1];
-            asm volatile("s_nop 7" ::: "memory");             // distance between two accumulation chains (filter_mid.hip, DESIGN.md 3.2b')
+#ifndef ALIVE_FBS_NO_CHAIN_GAP
+            ALIVE_CHAIN_GAP(7);                               // distance between two accumulation chains (filter_mid.hip, DESIGN.md 3.2b')
+#endif
             // the item's coordinates and first FiLM group were requested one step ago (two dependent LDS latencies that nothing
             // in a 9- or 15-MFMA step could cover); now the same for the next step's item, which is always tile i of this conv
             Epi& E = EP[i & 1];

@@ -1055,6 +1055,12 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
         v8i a[2];
         a[0] = load_a(Ab, 0);
         float pm0 = -INFINITY, pm1 = -INFINITY;
+#ifndef ALIVE_KNN8_NO_CHAIN_GAP
+        // (p0, p1) are read in steps 6 .. 9, beside this tile's chains: the shape of the accumulation-chain hazard of the fused
+        // FilterBlocks (common.h ALIVE_CHAIN_GAP).  No wrong score has been seen here (brute-force audits of every bench frame),
+        // the eight idle wait states per 24-MFMA tile are the precaution the listing scan asks of every such chain switch.
+        ALIVE_CHAIN_GAP(7);
+#endif
         // written out step by step: with the folds inside a `for` hipcc gives up unrolling it and indexes bq dynamically (scratch)
 #define K8_STEP(ks, AFTER0, AFTER1)                                                                                              \
         {                                                                                                                        \

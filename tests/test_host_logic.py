@@ -286,8 +286,50 @@ def test_filter_mid_is_built_with_the_flags_its_schedule_needs():
     src = open(os.path.join(ROOT, "alive-vc_amd", "csrc", "filter_mid.hip")).read()
     assert "#ifndef ALIVE_FILTER_MID_NO_SLP" in src and "#error" in src
     assert "v_mfma_f32_16x16x32" not in src and "mfma_f32_16x16x32_bf16(" not in src          # the shape that carried the defect is gone
-    assert 'asm volatile("s_nop 15"' in src and "ALIVE_FB64_NO_CHAIN_GAP" in src                # the wait states between two chains
+    assert "ALIVE_CHAIN_GAP(15);" in src and "ALIVE_FB64_NO_CHAIN_GAP" in src                   # the wait states between two chains
     assert "diag.hip" not in [w for ln in mk.splitlines() if ln.startswith("SRCS") for w in ln.split()]      # measurement kernels stay out of the product .so
+
+
+def test_no_listing_starts_an_mfma_chain_beside_an_unread_accumulator_without_the_gap(tmp_path):
+    """DESIGN.md 3.2b' (the accumulation-chain hazard): every shipped MFMA kernel's gfx950 listing is scanned for the shape that
+    produced wrong last accumulator registers in the fused 64-channel FilterBlock -- the first MFMA of a new chain issued while
+    a finished chain's accumulator is still unread -- and each such chain switch must carry >= 8 idle wait states (common.h
+    ALIVE_CHAIN_GAP) between the two chains.  The scan must flag the reproducer build (-DALIVE_FB64_NO_CHAIN_GAP) and the
+    un-pinned filter_small build, so that the test cannot pass by the scanner going blind."""
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import mfma_hazard_scan as hz
+    csrc = os.path.join(ROOT, "alive-vc_amd", "csrc")
+    base = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-function",
+            "--cuda-device-only", "-S"]
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    mid = [ln for ln in mk.splitlines() if ln.startswith("FLAGS_filter_mid")][0].split(":=")[1].split()
+    jobs = {"knn": ("knn.hip", []), "gemm_planes": ("gemm_planes.hip", []), "conv_split": ("conv_split.hip", []), "conv": ("conv.hip", []),
+            "filter_mid": ("filter_mid.hip", mid), "filter_small": ("filter_small.hip", mid),
+            "filter_mid_nogap": ("filter_mid.hip", mid + ["-DALIVE_FB64_NO_CHAIN_GAP"]),
+            "filter_small_nogap": ("filter_small.hip", mid + ["-DALIVE_FBS_NO_CHAIN_GAP"])}
+
+    def build(item):
+        tag, (src, extra) = item
+        out = str(tmp_path / f"{tag}.s")
+        subprocess.run([hipcc] + base + extra + [os.path.join(csrc, src), "-o", out], check=True, capture_output=True, timeout=900)
+        return tag, out
+    with ThreadPoolExecutor(4) as ex:
+        lst = dict(ex.map(build, jobs.items()))
+    seen = {}
+    for tag, path in lst.items():
+        r = hz.chain_gap_scan(path)
+        seen[tag] = (r["mfma"], len(r["switches"]), sum(1 for s_ in r["switches"] if s_[4] < hz.CHAIN_GAP_MIN))
+    for tag in ("knn", "gemm_planes", "conv_split", "conv", "filter_mid", "filter_small"):
+        assert seen[tag][0] > 100 and seen[tag][2] == 0, (tag, seen)
+    # the pattern exists where DESIGN says it does (fused FilterBlocks, fp8 scoring kernel) and only there
+    assert seen["filter_mid"][1] >= 20 and seen["filter_small"][1] >= 40 and seen["knn"][1] >= 4, seen
+    assert seen["gemm_planes"][1] == seen["conv_split"][1] == seen["conv"][1] == 0, seen
+    assert seen["filter_mid_nogap"][2] >= 20 and seen["filter_small_nogap"][2] >= 40, seen
 
 
 def test_fp8_scoring_kernel_listing_keeps_two_accumulator_sets(tmp_path):

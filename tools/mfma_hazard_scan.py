@@ -103,3 +103,107 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The accumulation-chain rule (DESIGN.md 3.2b', measured on gfx950 with hipcc 7.2; tools/repro_filter_block64.sh):
+#   when the first MFMA of a NEW accumulation chain B is issued after the last MFMA of a finished chain A whose accumulator
+#   registers are read (v_accvgpr_read / VALU / store) only LATER, beside B's MFMAs, A's last-written register can come back
+#   wrong unless the wave idles >= 8 wait states (s_nop) between the two chains -- or reads A completely before B starts.
+# chain_gap_scan() finds every such (A_last, B_first, late read) triple in a listing and reports the explicit idle wait states
+# (sum of s_nop n + 1) between A_last and B_first; tests/test_host_logic.py fails on any triple below CHAIN_GAP_MIN.
+CHAIN_GAP_MIN = 8
+
+
+def _kernels(path):
+    """[(name, [(opcode, [operands], line_no)])] per global function of the listing, instructions in program order"""
+    out, cur, name = [], None, None
+    for no, ln in enumerate(open(path), 1):
+        s = ln.split(";")[0].rstrip()
+        m = re.match(r"^([A-Za-z_$][\w.$]*):", s)
+        if m and not m.group(1).startswith((".L", "BB", "$")):
+            name, cur = m.group(1), []
+            out.append((name, cur))
+            continue
+        if cur is None or not s.strip() or s.strip().startswith(".") or re.match(r"^\S+:", s.strip()):
+            continue
+        t = s.strip().split(None, 1)
+        cur.append((t[0], [o.strip() for o in t[1].split(",")] if len(t) > 1 else [], no))
+    return [(n, c) for n, c in out if any(i[0].startswith("v_mfma") for i in c)]
+
+
+_STORES = ("ds_write", "ds_store", "global_store", "buffer_store", "flat_store", "scratch_store", "global_atomic", "ds_add", "ds_max", "ds_min")
+
+
+def chain_gap_scan(path, want=""):
+    """-> {"kernels": n, "mfma": n, "switches": [(kernel, line A_last, line B_first, line first late read, idle wait states)]}"""
+    res = {"kernels": 0, "mfma": 0, "switches": []}
+    for name, ins in _kernels(path):
+        if want not in name:
+            continue
+        res["kernels"] += 1
+        n = len(ins)
+        # per instruction: registers written / read (MFMA: dst, srcC separately)
+        wr, rd, mf = [set()] * n, [set()] * n, [None] * n
+        for i, (op, ops, _) in enumerate(ins):
+            if op.startswith("v_mfma"):
+                res["mfma"] += 1
+                dst = frozenset(regs(ops[0]))
+                srcc = frozenset(regs(ops[3])) if len(ops) > 3 else frozenset()
+                mf[i] = (dst, srcc)
+                wr[i], rd[i] = dst, set().union(*[regs(x) for x in ops[1:]])
+            elif op.startswith(_STORES):
+                rd[i] = set().union(*[regs(x) for x in ops]) if ops else set()
+            elif op.startswith(("s_", "buffer_wbl2", "buffer_inv")):
+                pass
+            elif ops:
+                wr[i] = regs(ops[0])
+                rd[i] = set().union(*[regs(x) for x in ops[1:]]) if len(ops) > 1 else set()
+        last = {}            # dst tuple -> index of the last MFMA that wrote it (the open end of its chain)
+        fresh = set()        # tuples (of `last`) written by a non-MFMA instruction since: their next MFMA starts a new chain
+        for p in range(n):
+            if mf[p] is None:
+                if wr[p]:
+                    for t in list(last):
+                        if t & wr[p]:
+                            fresh.add(t)
+                continue
+            dst, srcc = mf[p]
+            start = dst not in last or dst in fresh or srcc != dst
+            if start:
+                for a, e in list(last.items()):
+                    if a == dst or a & dst or a in fresh:
+                        continue
+                    # is A read after p before any of its registers is written again?
+                    late, pending = None, set(a)
+                    for r in range(p + 1, min(n, p + 1500)):
+                        if mf[r] is not None and mf[r][0] == a:
+                            break                               # A's chain goes on (interleaved chains): not finished at p
+                        hit = rd[r] & pending if mf[r] is None else (rd[r] & pending) - set()
+                        if hit and not (mf[r] is not None and mf[r][1] == a and mf[r][0] == a):
+                            late = r
+                            break
+                        pending -= wr[r]
+                        if not pending:
+                            break
+                    if late is None:
+                        continue
+                    idle = sum(int(ins[j][1][0], 0) + 1 for j in range(e + 1, p) if ins[j][0] == "s_nop")
+                    res["switches"].append((name, ins[e][2], ins[p][2], ins[late][2], idle))
+            last[dst] = p
+            fresh.discard(dst)
+            for t in list(last):                                # a tuple overwritten (partly) by this MFMA under another shape
+                if t != dst and t & dst:
+                    del last[t]
+                    fresh.discard(t)
+    return res
+
+
+def chain_gap_report(path, want=""):
+    r = chain_gap_scan(path, want)
+    bad = [s for s in r["switches"] if s[4] < CHAIN_GAP_MIN]
+    print(f"{path}: {r['kernels']} kernels, {r['mfma']} MFMAs, {len(r['switches'])} chain switches with late reads of the finished "
+          f"accumulator, {len(bad)} of them with fewer than {CHAIN_GAP_MIN} idle wait states")
+    for k, a, b, c, idle in bad[:12]:
+        print(f"   {k[:60]}: last MFMA of the finished chain at line {a}, first MFMA of the new chain at line {b}, late read at line {c}, idle {idle}")
+    return r, bad
