@@ -587,8 +587,12 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
 // went through the VALU exact scan -- 3.65 s per search.  This tier puts an MFMA pass with a TIGHT deterministic bound in front
 // of that scan: both operands as two bf16 planes (hi = bf16(v), lo = bf16(v - hi)), score = q_hi.r_hi + q_lo.r_hi + q_hi.r_lo,
 //   |score - q^.r^| <= ||q^ - q_hi - q_lo|| + ||r^ - r_hi - r_lo|| + ||q_lo|| ||r_lo|| + fp32 accumulation of 3 x 768 products
-//                  <= 2^-18 + 2^-18 + 2^-18 (1 + 2^-8) + 2304 * 2^-24 * 1.01                  = 1.5e-4,
-// plus the rounding of the rescoring arithmetic itself (< 1e-5): SPLIT_BOUND = 1.7e-4, a tenth of the single-plane bound.  Every
+//                  <= 2^-18 + 2^-18 + 2^-18 (1 + 2^-8) + 2304 * u * 1.01,
+// plus the rounding of the rescoring arithmetic itself (< 1e-5).  u is the unit roundoff of the additions INSIDE
+// v_mfma_f32_32x32x16_bf16, which the ISA guide does not state: round-to-nearest (u = 2^-24) gives 1.5e-4 + 1e-5; the bound is
+// sized for a TRUNCATING accumulate instead (u = 2^-23: 2.9e-4 + 1e-5), the worst an fp32 adder can do, so that the deterministic
+// guarantee does not rest on an undocumented property of the matrix pipe: SPLIT_BOUND = 3.0e-4, a sixth of the single-plane bound
+// (round 4 shipped 1.7e-4 on the round-to-nearest assumption; the wider band collects a few more rows per frame).  Every
 // row whose split score reaches v_k - SPLIT_BOUND (v_k: the frame's k-th exact cosine so far, a lower bound of the true one) is
 // collected and rescored exactly together with the frame's current top-k; only frames with more such rows than the lists hold
 // (genuine near-ties: clusters of near-copies) go on to the exact scan.
@@ -598,7 +602,7 @@ __global__ __launch_bounds__(256, 1) void knn_score_kernel(const unsigned short*
 constexpr int FT2 = 128;                                // frames per block
 constexpr int SPLIT_LDS = 2 * ABUF + FT2 * 4;           // two tile buffers + one counter per frame
 constexpr int SPLIT_ROWS = 256;                         // candidate entries per frame a bulk collect launch may fill (ws_layout: rows_b)
-constexpr float SPLIT_BOUND = 1.7e-4f;
+constexpr float SPLIT_BOUND = 3.0e-4f;
 
 // lib_lo[m][d] = bf16(r^ - bf16(r^)), r^ = rows[m][d] / norms[m] exactly as lib_pack_kernel forms it; zero rows up to M_pad
 __global__ __launch_bounds__(256) void lib_lo_kernel(const unsigned short* __restrict__ lib, const float* __restrict__ rows,
@@ -2037,7 +2041,7 @@ struct SearchWs {
     size_t bytes;
 };
 
-static SearchWs ws_layout(void* base, int64_t Tt, int64_t M, int k) {
+static SearchWs ws_layout(void* base, int64_t Tt, int64_t M, int k, bool split = false) {
     SearchWs w;
     w.p16 = make_plan(Tt, M);
     w.p8 = make_plan(Tt, M, MAX_SPLIT8);
@@ -2071,8 +2075,6 @@ static SearchWs ws_layout(void* base, int64_t Tt, int64_t M, int k) {
     w.thr1 = a.take<float>((size_t)Tp);
     w.list2 = a.take<int>((size_t)Tp);
     w.dq = a.take<float>((size_t)Tp);
-    w.s_c2h = a.take<unsigned short>((size_t)Tp * D);
-    w.s_c2l = a.take<unsigned short>((size_t)Tp * D);
     // rows per frame the collect tiers may fill (the rescoring kernel takes up to 1024): 1024 for up to FCAP frames (few frames: many
     // library splits, and a cluster must still fit one split's segment), SPLIT_ROWS for the bulk launches of a big batch
     const size_t c2n = (size_t)(Tp < FCAP ? Tp : FCAP) * 1024 > (size_t)Tp * SPLIT_ROWS ? (size_t)(Tp < FCAP ? Tp : FCAP) * 1024 : (size_t)Tp * SPLIT_ROWS;
@@ -2085,6 +2087,10 @@ static SearchWs ws_layout(void* base, int64_t Tt, int64_t M, int k) {
     w.tau_flag = a.take<int>((size_t)(Tp / FT) * (MAX_SPLIT > MAX_SPLIT8 ? MAX_SPLIT : MAX_SPLIT8));
     w.det_q = nullptr;
     w.det_lib = nullptr;
+    // the two frame planes of the split tier (1.5 KB per frame each) exist only in the strict search's workspace
+    // (alive_knn_workspace_bytes_strict); they come last, so every other address is the same in both layouts
+    w.s_c2h = split ? a.take<unsigned short>((size_t)Tp * D) : nullptr;
+    w.s_c2l = split ? a.take<unsigned short>((size_t)Tp * D) : nullptr;
     w.bytes = a.used() + 1024;
     return w;
 }
@@ -2190,6 +2196,12 @@ extern "C" size_t alive_knn_workspace_bytes(int64_t Tt, int64_t M) {
     return a > b ? a : b;
 }
 
+// alive_knn_search_strict with a lo-plane library (lib_lo != NULL) additionally needs both bf16 planes of the frames
+extern "C" size_t alive_knn_workspace_bytes_strict(int64_t Tt, int64_t M) {
+    const size_t a = ws_layout(nullptr, Tt, M, 4, true).bytes, b = ws_layout(nullptr, Tt, M, ALIVE_MAX_K, true).bytes;
+    return a > b ? a : b;
+}
+
 // The collect tier: the frames whose bf16 certificate failed (list1, with the thresholds thr1 the rescoring kernel recorded
 // for them) go through the bf16 scoring kernel once more, in its COLLECT form -- every row whose stage score reaches the
 // frame's threshold is kept and rescored exactly, together with the frame's current top-k.  A row below the threshold
@@ -2284,7 +2296,7 @@ static int knn_search_impl(const float* src, int N, int T, const void* lib_bf16,
     ALIVE_CHECK_ARG(src && lib_bf16 && rows_f32 && norms && out_val && out_idx && ws, "alive_knn_search: null pointer");
     if (int rc = check_search_args("alive_knn_search", src, ws, N, T, k, M)) return rc;
     const int64_t Tt = (int64_t)N * T;
-    SearchWs w = ws_layout(ws, Tt, M, k);
+    SearchWs w = ws_layout(ws, Tt, M, k, strict_bound != nullptr && lib_lo != nullptr);
     if (strict_bound != nullptr) {         // deterministic certificate: per-frame rounding error + the library's (alive_library_rounding_bound)
         w.det_q = w.dq;
         w.det_lib = strict_bound;

@@ -49,6 +49,7 @@ PROTOTYPES = {
     "alive_library_padded_rows": (_I64, [_I64]),
     "alive_library_pack": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _VP]),
     "alive_knn_workspace_bytes": (_SZ, [_I64, _I64]),
+    "alive_knn_workspace_bytes_strict": (_SZ, [_I64, _I64]),
     "alive_knn_search": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP]),
     "alive_library_fp8_bytes": (_SZ, [_I64]),
     "alive_library_rounding_bound": (_I, [_VP, _VP, _VP, _I64, _VP, _VP]),

@@ -101,22 +101,27 @@ class RealtimeConverter:
         content = merge_gather(val, idx, 1, self.k, self.alpha, self.lib.rows, content)
         join()
         wave, phi_out = self.dec(content, f0=f0, phi=phi, crop=(self.begin_of_output, self.end_of_output))
-        self.last_f0 = f0
+        self.last_f0 = f0                  # (a view of the per-shape side-stream buffer: valid until the next step)
         wave = audio_io.resample(wave, 16000, self.output_sr, pre_gain_db=self.gain)[0]         # gain, then resample (:173-175)
         return wave, phi_out[:, :, self.end_of_output]
 
     def _f0_on_side_stream(self, spec):
         """The f0 estimator (+ the pitch transform) needs nothing but the spectrogram and feeds nothing before the decoder: its ~35
         dependent launches run on a side stream beside the content encoder and the match (a step is a chain of ~150 small kernels,
-        bound by their latencies, not by the chip).  Returns (f0, join): the f0 tensor -- a persistent buffer per shape, so that no
-        allocation happens on the side stream (hipGraph capture, caching allocator) -- and the call that makes the current stream
-        wait for it.  Same kernels, same results; captured into the step's hipGraph as a parallel branch."""
+        bound by their latencies, not by the chip).  Returns (f0, join): the f0 tensor -- a persistent buffer per shape (at most
+        four shapes are kept: a converter has one ring geometry and two slice geometries), so that the steady-state step allocates
+        nothing on the side stream (the estimator's scratch is sized by the eager warm-up steps that precede hipGraph capture:
+        enable_graph) -- and the call that makes the current stream wait for it.  The buffer is overwritten by the next call with
+        the same shape: `last_f0` of the non-reuse step aliases it and is valid until the next step.  Same kernels, same results;
+        captured into the step's hipGraph as a parallel branch."""
         cur = torch.cuda.current_stream(spec.device)
         if self._side is None:
             self._side = torch.cuda.Stream(device=spec.device)
         key = (spec.shape[0], spec.shape[2])
         buf = self._f0_bufs.get(key)
         if buf is None:
+            if len(self._f0_bufs) >= 4:
+                self._f0_bufs.pop(next(iter(self._f0_bufs)))
             buf = self._f0_bufs[key] = torch.empty(spec.shape[0], 1, spec.shape[2], device=spec.device)
         side = self._side
         side.wait_stream(cur)                                   # the spectrogram is complete

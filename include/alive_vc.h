@@ -75,6 +75,9 @@ int alive_library_pack(const float* tokens_DxM, int64_t M, int D,
  *   ws: alive_knn_workspace_bytes(Tt, M) bytes.
  */
 size_t alive_knn_workspace_bytes(int64_t Tt, int64_t M);
+/* workspace of alive_knn_search_strict when it is given a lo-plane library (lib_lo != NULL): the size above plus both bf16 planes of
+ * the frames (2 x 1.5 KB per frame), which only the split-bf16 collect tier of that search uses */
+size_t alive_knn_workspace_bytes_strict(int64_t Tt, int64_t M);
 int alive_knn_search(const float* src, int N, int T,
                      const void* lib_bf16, const float* rows_f32, const float* norms,
                      int64_t M, int64_t idx_base, int k,
@@ -88,10 +91,10 @@ int alive_knn_search(const float* src, int N, int T,
  *   bound: device float[1] = max_R || r^ - bf16(r^) ||, filled by alive_library_rounding_bound from a packed library.
  *   lib_lo: NULL, or the library's lo plane (alive_library_pack_lo: bf16(r^ - lib_bf16), 2 * 768 * alive_library_padded_rows(M)
  *           bytes).  With it the frames that fail the certificate (more than 256 of them) go through an MFMA COLLECT pass on BOTH
- *           planes of both operands (three bf16 products per product) whose deterministic bound is 1.7e-4 (two-plane rounding
- *           3 x 2^-18 + the fp32 accumulation of 3 x 768 products) instead of the single-plane collect tier, whose band is the
- *           certificate's own 1.8e-3: every row at or above v_k - 1.7e-4 is rescored exactly, and only frames with more such rows
- *           than the lists hold reach the exact scan.
+ *           planes of both operands (three bf16 products per product) whose deterministic bound is 3.0e-4 (two-plane rounding
+ *           3 x 2^-18 + the fp32 accumulation of 3 x 768 products, priced for a truncating adder) instead of the single-plane collect tier, whose band is the
+ *           certificate's own 1.8e-3: every row at or above v_k - 3.0e-4 is rescored exactly, and only frames with more such rows
+ *           than the lists hold reach the exact scan.  ws must then hold alive_knn_workspace_bytes_strict(Tt, M) bytes.
  *   ev_start / ev_stop: as in the *_timed forms below (NULL: none).  Counters: alive_knn_search_stats [1], [7], [8]. */
 int alive_library_rounding_bound(const void* lib_bf16, const float* rows_f32, const float* norms, int64_t M,
                                  float* bound, void* stream);

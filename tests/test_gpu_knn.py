@@ -339,8 +339,9 @@ def test_fp8_scoring_kernel_rate_guard(prefilter):
     assert pf >= 2.5, f"scoring kernel {best:.1f} ms = {pf:.2f} PFLOP/s"
     st = lib.search_stats()
     # seeding is one non-blocking look at the predecessor's flag: how many blocks find it depends on block scheduling, so only
-    # "it happened" is asserted (typically all 2 x 675); exactness is the brute-force tests' business
-    assert 0 < st["fp8_blocks_seeded"] <= 2 * 675 and st["frames_failed_fp8_certificate"] <= 16, st
+    # a floor is asserted, not the count (typically all 2 x 675: a block has ~80 ms to find a flag its predecessor raised within the
+    # first); a handful of frames may fail the certificate when a seed arrives late.  Exactness is the brute-force tests' business
+    assert 675 <= st["fp8_blocks_seeded"] <= 2 * 675 and st["frames_failed_fp8_certificate"] <= 16, st
 
 
 def test_knn_a_handful_of_uncertified_frames_goes_straight_to_the_exact_scan(prefilter):
