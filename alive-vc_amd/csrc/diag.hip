@@ -88,6 +88,76 @@ __global__ __launch_bounds__(256, 1) void mfma_scale_rate_kernel(const int* __re
     if (s == 12345.678f) sink[0] = s;
 }
 
+// Round 5: operand-feed forms that were priced before any kernel was rewritten (tools/mfma_rate.py modes 7 .. 10).
+//   mfma_mixed_rate_kernel<BFMT, NB>: the fp8 scoring kernel's loop shape -- an fp8 A fragment (32 B per lane) from LDS feeds NB
+//   MFMAs whose B operands sit in registers as fp8 (BFMT 0: 8 registers each) or fp6 e2m3 (BFMT 2: 6 registers); NB chains.
+//   12 MFMAs per loop iteration.  NB = 2, fp8: what knn_score8_kernel does today (64 stationary frames per wave); NB = 3, fp6:
+//   96 stationary frames per wave in 216 registers.
+template <int BFMT, int NB>
+__global__ __launch_bounds__(256, 1) void mfma_mixed_rate_kernel(const int* __restrict__ rnd, int iters, float* sink) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[64 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 64 * 1024 / 16; i += 256) ((u32x4*)lds)[i] = ((const u32x4*)rnd)[i] & 0xf7f7f7f7u;     // no e4m3 NaN
+    __syncthreads();
+    constexpr int NF = 12 / NB;                       // A fragments per iteration
+    v8i fb[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fb[i][e] = (e < (BFMT == 0 ? 8 : 6)) ? (rnd[((tid * 12 + i + 2048) * 8 + e) % 16384] & 0xf7f7f7f7) : 0;
+    f32x16 acc[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    const unsigned char* base = lds + lane * 32;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const unsigned char* q = base + (((it * NF + f) * 2048) & 0xf800);
+            const u32x4 lo = *(const u32x4*)q, hi = *(const u32x4*)(q + 16);
+            v8i fa;
+            fa[0] = lo[0]; fa[1] = lo[1]; fa[2] = lo[2]; fa[3] = lo[3]; fa[4] = hi[0]; fa[5] = hi[1]; fa[6] = hi[2]; fa[7] = hi[3];
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb[f * NB + j], acc[j], 0, BFMT, 0, 127, 0, 127);
+        }
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) s += acc[i][lane & 15];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+//   mfma_bf16_feed_kernel<NB>: the bf16 scoring kernel's loop shape with NB MFMAs per ds_read_b128 A fragment (NB = 2: 64 stationary
+//   frames per wave, today; NB = 1: the 32-frames-per-wave form that would leave room for a second accumulator set).  8 MFMAs per iteration.
+template <int NB>
+__global__ __launch_bounds__(256, 1) void mfma_bf16_feed_kernel(const unsigned short* __restrict__ rnd, int iters, float* sink) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[64 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 64 * 1024 / 16; i += 256) ((u32x4*)lds)[i] = ((const u32x4*)rnd)[i];
+    __syncthreads();
+    bf16x8 b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = *(const bf16x8*)(rnd + ((tid * 8 + i + 4096) * 8) % 32768);
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    const unsigned char* base = lds + lane * 16;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int f = 0; f < 8 / NB; ++f) {
+            const bf16x8 af = *(const bf16x8*)(base + (((it * (8 / NB) + f) * 1024) & 0xfc00));
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[(f * NB + j) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b[f * NB + j], acc[(f * NB + j) & 1], 0, 0, 0);
+        }
+    }
+    float s = acc[0][lane & 15] + acc[1][lane & 15];
+    if (s == 12345.678f) sink[0] = s;
+}
+
 // Round 4: what a vector instruction costs BESIDE an MFMA, one wave per SIMD (tools/mfma_filler.py).  One dependent chain of
 // v_mfma_f32_32x32x16_bf16 (KIND 0, 1) or two alternating accumulators (KIND 2), NF v_fma_f32 after every MFMA: on NCH independent
 // registers (KIND 0, 2: NCH = 8) or as ONE dependent chain (KIND 1).  All of it asm volatile, so the order is the source's.
@@ -188,6 +258,11 @@ extern "C" int alive_debug_mfma_rate(const void* rnd, int blocks, int iters, int
     else if (mode == 4) mfma_scale_rate_kernel<4, false><<<blocks, 256, 0, s>>>(ri, iters, sink);
     else if (mode == 5) mfma_scale_rate_kernel<0, true><<<blocks, 256, 0, s>>>(ri, iters, sink);
     else if (mode == 6) mfma_scale_rate_kernel<2, true><<<blocks, 256, 0, s>>>(ri, iters, sink);
+    else if (mode == 7) mfma_mixed_rate_kernel<0, 2><<<blocks, 256, 0, s>>>(ri, iters, sink);
+    else if (mode == 8) mfma_mixed_rate_kernel<2, 3><<<blocks, 256, 0, s>>>(ri, iters, sink);
+    else if (mode == 9) mfma_mixed_rate_kernel<0, 3><<<blocks, 256, 0, s>>>(ri, iters, sink);
+    else if (mode == 10) mfma_bf16_feed_kernel<2><<<blocks, 256, 0, s>>>((const unsigned short*)rnd, iters, sink);
+    else if (mode == 11) mfma_bf16_feed_kernel<1><<<blocks, 256, 0, s>>>((const unsigned short*)rnd, iters, sink);
     else mfma_rate_kernel<<<blocks, 256, 0, s>>>((const unsigned short*)rnd, iters, mode, sink);
     ALIVE_CHECK_LAUNCH("alive_debug_mfma_rate");
     return ALIVE_OK;

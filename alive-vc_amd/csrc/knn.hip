@@ -101,9 +101,51 @@ __global__ __launch_bounds__(256) void lib_rounding_bound_kernel(const unsigned 
     if (lane == 0) atomicMax(bound, __float_as_uint(sqrtf(ss) * 1.0001f));
 }
 
+// Operand format of the candidate-stage MFMA (v_mfma_scale_f32_32x32x64_f8f6f4): 0 = fp8 e4m3 (shipped).  2 = fp6 e2m3, an
+// EXPERIMENT build (tools/ab_build.sh x.so knn.hip -DALIVE_KNN8_FMT=2; DESIGN.md 3.1a "fp6"): same tile image -- every group of 32
+// features keeps its 32-byte slot, of which the 32 six-bit codes fill the first 24 bytes -- so nothing but the two conversion
+// kernels, the scale and the MFMA's format flags change.
+#ifndef ALIVE_KNN8_FMT
+#define ALIVE_KNN8_FMT 0
+#endif
 // ---- fp8 (OCP e4m3) form of the scoring operands: value * 2^8, so that the elements of unit vectors (|x| ~ 0.04)
 // sit in e4m3's normal range (2^-6 .. 448); scores come out scaled by 2^16, which a ranking does not see
-constexpr float F8_SCALE = 256.0f;
+// (fp6 e2m3: value * 2^5 -- sigma of an element ~ 1.15 on a grid of 1/8 up to 2, 1/4 up to 4, 1/2 up to the largest value 7.5)
+constexpr float F8_SCALE = ALIVE_KNN8_FMT == 2 ? 32.0f : 256.0f;
+#if ALIVE_KNN8_FMT == 2
+// OCP fp6 e2m3 code of y (round to nearest even, saturating at 7.5): sign | exponent (2) | mantissa (3), bias 1
+__device__ __forceinline__ unsigned fp6_e2m3(float y) {
+    const unsigned sgn = (__float_as_uint(y) >> 31) << 5;
+    const float a = fminf(fabsf(y), 7.5f);
+    unsigned code;
+    if (a < 1.0f) {
+        code = (unsigned)__builtin_rintf(a * 8.0f);                    // subnormals m / 8; 8 = the code of 1.0
+    } else {
+        unsigned b = __float_as_uint(a);
+        b += 0x7FFFFu + ((b >> 20) & 1u);
+        code = (b >> 20) - (126u << 3);
+        code = code < 31u ? code : 31u;
+    }
+    return sgn | code;
+}
+// bf16[n32][32] -> [n32][32 bytes]: 32 codes as a little-endian bit stream in the first 24 bytes, 8 bytes of zeros
+__global__ __launch_bounds__(256) void to_fp6_kernel(const unsigned short* __restrict__ in, int64_t n32, u32x4* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n32) return;
+    unsigned long long acc = 0;
+    int nb = 0, wi = 0;
+    unsigned wd[6];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const float v = __uint_as_float((unsigned)in[i * 32 + j] << 16) * F8_SCALE;
+        acc |= (unsigned long long)fp6_e2m3(v) << nb;
+        nb += 6;
+        if (nb >= 32) { wd[wi++] = (unsigned)acc; acc >>= 32; nb -= 32; }
+    }
+    out[2 * i] = u32x4{wd[0], wd[1], wd[2], wd[3]};
+    out[2 * i + 1] = u32x4{wd[4], wd[5], 0u, 0u};
+}
+#endif
 __device__ __forceinline__ unsigned char to_fp8(float v) {
     return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v * F8_SCALE, 0.0f, 0, false) & 0xff);
 }
@@ -809,7 +851,7 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 // The hand-off is one LOOK at the previous split's flag (no waiting: nothing can hang, an unfinished predecessor just means
 // an unseeded block) behind the release / acquire pair of the guide; a stale or missing tau can only cost time, never a
 // result: whatever seed a block used is IN its lists, and the certificate bounds the outside rows by it.
-constexpr float SEED_MARGIN8 = 0.02f * F8_SCALE * F8_SCALE;      // cosine 0.02: certificate slack (>= 0.0105) + 4 sigma of the fp8 error
+constexpr float SEED_MARGIN8 = (ALIVE_KNN8_FMT == 2 ? 0.024f : 0.02f) * F8_SCALE * F8_SCALE;      // cosine 0.02: certificate slack (>= 0.0105) + 4 sigma of the fp8 error
 constexpr float SEED_MARGIN16 = 2.5e-3f;                         // bf16 stage: its certificate's slack is ~7e-4 (7 sigma of ~1e-4)
 constexpr float SEED_MARGIN16_STRICT = 4.5e-3f;                  // strict search: above the largest deterministic bound (2 x 2^-9 + 1e-4)
 constexpr int SEED_MIN_FB = 512;
@@ -1069,7 +1111,7 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
 #define K8_STEP(ks, AFTER0, AFTER1)                                                                                              \
         {                                                                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                                                   \
-            c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(ks) & 1], bq[0][ks], c0, 0, 0, 0, 127, 0, 127);              \
+            c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(ks) & 1], bq[0][ks], c0, ALIVE_KNN8_FMT, ALIVE_KNN8_FMT, 0, 127, 0, 127);              \
             __builtin_amdgcn_sched_barrier(0);                                                                                   \
             if ((ks) + 1 < NK64) a[((ks) + 1) & 1] = load_a(Ab, (ks) + 1);                                                       \
             if ((ks) < D / 128) /* the 6 DMA pieces of the next tile go out in the FIRST half of this one: the barrier at its */  \
@@ -1077,7 +1119,7 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
                 __builtin_amdgcn_global_load_lds((gptr_t)(gnext + (ks) * 128), (lptr_t)(lnext + (ks) * 4 * PIECE), 16, 0, 0);    \
             AFTER0;                                                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                                                   \
-            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(ks) & 1], bq[1][ks], c1, 0, 0, 0, 127, 0, 127);              \
+            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(ks) & 1], bq[1][ks], c1, ALIVE_KNN8_FMT, ALIVE_KNN8_FMT, 0, 127, 0, 127);              \
             __builtin_amdgcn_sched_barrier(0);                                                                                   \
             AFTER1;                                                                                                              \
         }
@@ -2007,7 +2049,7 @@ constexpr int MAX_SPLIT8 = 1024 / KP8;    // the rescoring kernel takes up to 10
 constexpr int FCAP = 16384;               // tier 1 of the bf16 re-search: up to this many flagged frames ...
 constexpr int FPLAN = 4096;               // ... with the library split chosen for this many (blocks past the count exit at once)
 constexpr float CERT_Z = 7.0f;            // sigmas of candidate-score error the certificates allow for
-constexpr float SD_PRIOR8 = 1.5e-3f;      // typical error (cosine units) of an fp8 / a bf16 candidate score: floor of the per-frame estimate
+constexpr float SD_PRIOR8 = ALIVE_KNN8_FMT == 2 ? 1.9e-3f : 1.5e-3f;      // typical error (cosine units) of an fp8 / a bf16 candidate score: floor of the per-frame estimate
 constexpr float SD_PRIOR16 = 8.0e-5f;
 constexpr int PROBE_N = 1024;             // frames of the adaptive probe (fp8 searches of >= PROBE_MIN_T frames)
 constexpr int64_t PROBE_MIN_T = 16384;
@@ -2185,7 +2227,11 @@ extern "C" size_t alive_library_fp8_bytes(int64_t M) { return (size_t)alive_libr
 extern "C" int alive_library_pack_fp8(const void* lib_bf16, int64_t M, void* lib_f8, void* stream) {
     ALIVE_CHECK_ARG(lib_bf16 && lib_f8 && M >= 1, "alive_library_pack_fp8: bad args");
     const int64_t n8 = alive_library_padded_rows(M) * D / 8;
+#if ALIVE_KNN8_FMT == 2
+    to_fp6_kernel<<<(unsigned)((n8 / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>((const unsigned short*)lib_bf16, n8 / 4, (u32x4*)lib_f8);
+#else
     lib_to_fp8_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, (hipStream_t)stream>>>((const unsigned short*)lib_bf16, n8, (uint2*)lib_f8);
+#endif
     ALIVE_CHECK_LAUNCH("alive_library_pack_fp8");
     return ALIVE_OK;
 }
@@ -2399,7 +2445,11 @@ static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f
     stats_init_kernel<<<1, 64, 0, s>>>(w.stats, TIER_FP8);
     src_prep_launch(w, src, T, Tt, s);
     const int64_t n8 = p.Tt_pad * D / 8;
+#if ALIVE_KNN8_FMT == 2
+    to_fp6_kernel<<<(unsigned)((n8 / 4 + 255) / 256), 256, 0, s>>>(w.s_bf16, n8 / 4, (u32x4*)w.s_f8);
+#else
     src_to_fp8_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>(w.s_bf16, n8, (uint2*)w.s_f8);
+#endif
     int* mode = w.stats + ST_MODE;
     if (w.probe_n > 0) {
         probe_gather_kernel<<<(unsigned)w.probe_pad, 64, 0, s>>>(w.s_f8, Tt, w.probe_n, w.probe_pad, w.s_p8, w.p_list);

@@ -20,8 +20,14 @@ for f in sorted(glob.glob(os.path.join(root, "pass*", "run_counter_collection.cs
         cnt[name] = sum(big) / len(big)
 M, Tt = 1_000_000, 172800
 fetch_kb, write_kb = cnt.get("FETCH_SIZE", 0.0), cnt.get("WRITE_SIZE", 0.0)
+import subprocess
+try:
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
+except Exception:
+    commit = ""
 out = {
     "kernel": "knn_score8_kernel",
+    "source_commit": commit,
     "workload": "one launch: 172800 frames (384 windows x 450) x 1,000,000-vector library, split 3 (tools/bench_knn.py 384 450 1000000 1 biased; tools/pmc_knn8.sh, one counter group per pass)",
     "launch_ms_profiled": round(sum(ms) / max(1, len(ms)), 1),
     "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,

@@ -42,13 +42,32 @@ for k, a in agg.items():
         e["hbm_GBps"] = round(b / (a["_ms"] * 1e-3) / 1e9, 1)
     if a.get("SQ_LDS_IDX_ACTIVE"):
         e["lds_bank_conflict_share"] = round(a.get("SQ_LDS_BANK_CONFLICT", 0.0) / a["SQ_LDS_IDX_ACTIVE"], 4)
+    if a.get("SQ_VALU_MFMA_BUSY_CYCLES") and "SQ_VALU_MFMA_COEXEC_CYCLES" in a:
+        e["mfma_cycles_with_valu_coexecuting"] = round(a["SQ_VALU_MFMA_COEXEC_CYCLES"] / a["SQ_VALU_MFMA_BUSY_CYCLES"], 3)
+    if a.get("SQ_WAVE_CYCLES"):
+        if "SQ_ACTIVE_INST_VALU" in a:
+            e["valu_issue_share_of_wave_cycles"] = round(a["SQ_ACTIVE_INST_VALU"] / a["SQ_WAVE_CYCLES"], 3)
+        if "SQ_ACTIVE_INST_LDS" in a:
+            e["lds_issue_share_of_wave_cycles"] = round(a["SQ_ACTIVE_INST_LDS"] / a["SQ_WAVE_CYCLES"], 3)
+        if "SQ_WAIT_INST_ANY" in a:
+            e["wave_cycles_waiting_for_an_instruction"] = round(a["SQ_WAIT_INST_ANY"] / a["SQ_WAVE_CYCLES"], 3)
     out[k] = e
+import subprocess
+try:
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
+except Exception:
+    commit = ""
 res = {
+    "source_commit": commit + " (the tree the counters were collected from; set by tools/pmc_nets_agg.py at aggregation time)",
     "workload": "tools/run_nets_once.py 2: two passes of spectrogram + f0 estimator + content encoder + decoder over 128 windows x 450 frames (no kNN); tools/pmc_nets.sh: rocprofv3 --kernel-trace --pmc, one counter group per pass (MFMA busy + GRBM_GUI_ACTIVE; FETCH_SIZE; WRITE_SIZE; LDS conflicts)",
     "formulas": {"mfma_pipe_utilisation": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)",
                  "hbm_bytes": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); Infinity-Cache hits are included",
                  "hbm_GBps": "hbm_bytes / kernel time of the MFMA pass (times differ a little between passes)",
-                 "lds_bank_conflict_share": "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE"},
+                 "lds_bank_conflict_share": "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE",
+                 "mfma_cycles_with_valu_coexecuting": "SQ_VALU_MFMA_COEXEC_CYCLES / SQ_VALU_MFMA_BUSY_CYCLES",
+                 "valu_issue_share_of_wave_cycles": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (both in quad-cycles; counters of different passes)",
+                 "lds_issue_share_of_wave_cycles": "SQ_ACTIVE_INST_LDS / SQ_WAVE_CYCLES",
+                 "wave_cycles_waiting_for_an_instruction": "SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES"},
     "kernels": dict(sorted(out.items(), key=lambda kv: -kv[1]["ms_total"])),
 }
 print(json.dumps(res, indent=1))
