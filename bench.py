@@ -321,7 +321,9 @@ def main():
     if os.path.exists(pmc):
         pj = json.load(open(pmc))
         traffic_profiled = {"hbm_bytes_per_launch": pj.get("hbm_bytes_per_launch"), "algorithmic_bytes_per_launch": pj.get("algorithmic_bytes_per_launch"),
-                            "source": "profiles/" + pmc_name + " (rocprofv3 --pmc passes of tools/pmc_knn8.sh, not this run)"}
+                            "mfma_pipe_utilisation": pj.get("mfma_pipe_utilisation"), "l2_hit_rate": pj.get("l2_hit_rate"),
+                            "source_commit": pj.get("source_commit"),
+                            "source": "profiles/" + pmc_name + " (rocprofv3 --pmc passes of tools/pmc_knn8.sh over the same kernel and shape, not this run)"}
     roofline = {"kernel": "knn_score8_kernel" if fp8 else "knn_score_kernel", "bound": "mfma", "achieved": round(achieved, 1),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None, "traffic_profiled": traffic_profiled,
                 "mfma_dtype": "fp8 e4m3, block-scaled 32x32x64" if fp8 else "bf16 32x32x16",
@@ -362,8 +364,9 @@ def main():
                                          "achieved": round(fl / (ms_ * 1e-3) / 1e12, 1), "peak": round(pk, 1), "unit": "TFLOP/s",
                                          "frac": round(fl / (ms_ * 1e-3) / 1e12 / pk, 4)}
         return {"bound": "mfma", "timing": "HIP events on the launching stream, each family alone, one stream (the step overlaps window batches on side streams)",
+                "counters": "profiles/nets_pmc.json (per kernel: MFMA-pipe utilisation, bytes beyond L2, LDS conflicts, VALU co-execution; tools/pmc_nets.sh)",
                 "front_end": fam(ms_enc, fl_enc, pk_enc, "spectrogram (DFT as a GEMM) + F0Estimator + ContentEncoder: 3-plane split bf16, 6 MFMAs per product"),
-                "decoder": fam(ms_dec, fl_dec, pk_dec, "FeatureExtractor + HarmonicOscillator + Filter: 2-plane split bf16, 3 MFMAs per product (f32 MFMA at C <= 16)"),
+                "decoder": fam(ms_dec, fl_dec, pk_dec, "FeatureExtractor + HarmonicOscillator + Filter: 2-plane split bf16, 3 MFMAs per product (fused FilterBlocks at 64 / 16 / 8 channels on the same MFMA; exact f32 MFMA only for the strided / transposed convs of the two finest scales)"),
                 "step": {"ideal_ms": round(ideal_ms, 1), "ms_per_step": round(dt / args.steps * 1e3, 2), "frac": round(ideal_ms / (dt / args.steps * 1e3), 4),
                          "ideal": "kNN 2*768*M*T FLOP at the candidate stage's MFMA peak + decoder at 2.5 PF / 3 + front end at 2.5 PF / 6"}}
     roofline_nets = guarded(nets_roofline) if rank == 0 and not args.no_nets_roofline else None
