@@ -101,18 +101,15 @@ __global__ __launch_bounds__(256) void lib_rounding_bound_kernel(const unsigned 
     if (lane == 0) atomicMax(bound, __float_as_uint(sqrtf(ss) * 1.0001f));
 }
 
-// Operand format of the candidate-stage MFMA (v_mfma_scale_f32_32x32x64_f8f6f4): 0 = fp8 e4m3 (shipped).  2 = fp6 e2m3, an
-// EXPERIMENT build (tools/ab_build.sh x.so knn.hip -DALIVE_KNN8_FMT=2; DESIGN.md 3.1a "fp6"): same tile image -- every group of 32
-// features keeps its 32-byte slot, of which the 32 six-bit codes fill the first 24 bytes -- so nothing but the two conversion
-// kernels, the scale and the MFMA's format flags change.
-#ifndef ALIVE_KNN8_FMT
-#define ALIVE_KNN8_FMT 0
-#endif
 // ---- fp8 (OCP e4m3) form of the scoring operands: value * 2^8, so that the elements of unit vectors (|x| ~ 0.04)
 // sit in e4m3's normal range (2^-6 .. 448); scores come out scaled by 2^16, which a ranking does not see
-// (fp6 e2m3: value * 2^5 -- sigma of an element ~ 1.15 on a grid of 1/8 up to 2, 1/4 up to 4, 1/2 up to the largest value 7.5)
-constexpr float F8_SCALE = ALIVE_KNN8_FMT == 2 ? 32.0f : 256.0f;
-#if ALIVE_KNN8_FMT == 2
+constexpr float F8_SCALE = 256.0f;
+// ---- fp6 (OCP e2m3) form, round 5: value * 2^5 -- sigma of an element ~ 1.15 on a grid of 1/8 up to 2, 1/4 up to 4, 1/2 up to the
+// largest value 7.5.  For unit vectors of Gaussian-like elements that grid is as good as e4m3's three mantissa bits (what e4m3
+// adds is dynamic range, which normalised rows do not need): the stage's score error is 1.8e-3 in cosine against 1.35e-3
+// (simulated on CPU, measured by the certificate on the device), and the MFMA runs at twice the fp8 rate.  Same tile image: every
+// group of 32 features keeps its 32-byte slot, the 32 six-bit codes fill its first 24 bytes as a little-endian bit stream.
+constexpr float F6_SCALE = 32.0f;
 // OCP fp6 e2m3 code of y (round to nearest even, saturating at 7.5): sign | exponent (2) | mantissa (3), bias 1
 __device__ __forceinline__ unsigned fp6_e2m3(float y) {
     const unsigned sgn = (__float_as_uint(y) >> 31) << 5;
@@ -128,24 +125,34 @@ __device__ __forceinline__ unsigned fp6_e2m3(float y) {
     }
     return sgn | code;
 }
-// bf16[n32][32] -> [n32][32 bytes]: 32 codes as a little-endian bit stream in the first 24 bytes, 8 bytes of zeros
-__global__ __launch_bounds__(256) void to_fp6_kernel(const unsigned short* __restrict__ in, int64_t n32, u32x4* __restrict__ out) {
+// bf16[n32][32] -> [n32][32 bytes]: 32 codes in the first 24 bytes, 8 bytes of zeros.  Groups at or beyond n_valid (frame rows
+// past the bf16 image's padded end) are written as zeros without reading.
+// clip (optional, [rows]): set to 1 for every row (24 groups) with an element beyond e2m3's largest value.
+__global__ __launch_bounds__(256) void to_fp6_kernel(const unsigned short* __restrict__ in, int64_t n32, int64_t n_valid, u32x4* __restrict__ out,
+                                                     unsigned char* __restrict__ clip = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n32) return;
+    if (i >= n_valid) {
+        out[2 * i] = u32x4{0u, 0u, 0u, 0u};
+        out[2 * i + 1] = u32x4{0u, 0u, 0u, 0u};
+        return;
+    }
     unsigned long long acc = 0;
     int nb = 0, wi = 0;
     unsigned wd[6];
+    bool clipped = false;
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
-        const float v = __uint_as_float((unsigned)in[i * 32 + j] << 16) * F8_SCALE;
+        const float v = __uint_as_float((unsigned)in[i * 32 + j] << 16) * F6_SCALE;
+        clipped = clipped || fabsf(v) > 7.75f;                         // (7.5 .. 7.75 rounds to 7.5: not a clip)
         acc |= (unsigned long long)fp6_e2m3(v) << nb;
         nb += 6;
         if (nb >= 32) { wd[wi++] = (unsigned)acc; acc >>= 32; nb -= 32; }
     }
     out[2 * i] = u32x4{wd[0], wd[1], wd[2], wd[3]};
     out[2 * i + 1] = u32x4{wd[4], wd[5], 0u, 0u};
+    if (clip != nullptr && clipped) clip[i / (D / 32)] = 1;
 }
-#endif
 __device__ __forceinline__ unsigned char to_fp8(float v) {
     return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v * F8_SCALE, 0.0f, 0, false) & 0xff);
 }
@@ -371,26 +378,29 @@ __device__ __forceinline__ bool seeds_look(const SeedArgs& sa, int split) {
 
 // end of a block (after the barrier behind its last tile): thread = frame; the k-th largest score among the REAL entries of the
 // frame's two half-lists (KH_ entries each, entry-major [KH_][512 lane-columns]) -> tau, then release + flag
-template <int KH_>
+// (WF_ frames per wave, FRAMES_ = 4 WF_ per block: 64 / 256 in the bf16 and the shipped fp8 kernel)
+template <int KH_, int WF_ = 64, int FRAMES_ = 256>
 __device__ __forceinline__ void seeds_publish(const SeedArgs& sa, const float* Lv, const int* Li, int64_t frame0, int split, bool seeded) {
-    const int col = threadIdx.x;
-    const int lcb = (col >> 6) * 128 + ((col >> 5) & 1) * 64 + (col & 31);
-    float prev = INFINITY;
-    for (int j = 0; j < sa.k; ++j) {
-        float m = -INFINITY;
-        for (int e = 0; e < 2 * KH_; ++e) {
-            const int o = (e % KH_) * 512 + lcb + (e / KH_) * 32;
-            const float v = Lv[o];
-            if (Li[o] >= 0 && v < prev) m = fmaxf(m, v);
+    constexpr int LW_ = 4 * 2 * WF_;
+    for (int col = threadIdx.x; col < FRAMES_; col += 256) {
+        const int lcb = (col / WF_) * (2 * WF_) + ((col % WF_) >> 5) * 64 + (col & 31);
+        float prev = INFINITY;
+        for (int j = 0; j < sa.k; ++j) {
+            float m = -INFINITY;
+            for (int e = 0; e < 2 * KH_; ++e) {
+                const int o = (e % KH_) * LW_ + lcb + (e / KH_) * 32;
+                const float v = Lv[o];
+                if (Li[o] >= 0 && v < prev) m = fmaxf(m, v);
+            }
+            prev = m;
         }
-        prev = m;
+        float t = prev - sa.margin;                                    // -inf with fewer than k real entries
+        if (seeded) {
+            const float tin = sa.tau[frame0 + col];
+            t = fmaxf(t, tin == tin ? tin : -INFINITY);
+        }
+        sa.tau[frame0 + col] = t;
     }
-    float t = prev - sa.margin;                                        // -inf with fewer than k real entries
-    if (seeded) {
-        const float tin = sa.tau[frame0 + col];
-        t = fmaxf(t, tin == tin ? tin : -INFINITY);
-    }
-    sa.tau[frame0 + col] = t;
     // release: every storing wave's stores have left, then ONE agent-scope release and the flag (MI355X_MICROARCH.md)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -836,7 +846,11 @@ constexpr int KP8 = 2 * KH8;               // candidates per frame and split
 constexpr int NK64 = D / 64;               // 12 MFMA k-steps
 constexpr int NPIECE8 = 4 * (D / 128);     // 4 row groups x 6 segments of 128 B
 constexpr int ABUF8 = NPIECE8 * PIECE;     // 27648 B per tile buffer
-constexpr int SCORE8_LDS = 2 * ABUF8 + FT * KP8 * 8;   // 120832 B
+// Column tiles (32 frames each) per wave: 2 in the fp8 kernel (64 stationary frames per wave, 192 registers); 3 in the fp6 kernel
+// (round 5: 96 frames per wave in 216 registers, one A fragment feeding three MFMAs, 384 frames per block)
+constexpr int FT6 = 4 * 32 * 3;            // frames per block of the fp6 kernel
+constexpr int SCORE8_LDS = 2 * ABUF8 + FT * KP8 * 8;    // 120832 B
+constexpr int SCORE6_LDS = 2 * ABUF8 + FT6 * KP8 * 8;   // 153600 B
 typedef int v8i __attribute__((ext_vector_type(8)));
 
 // Seeded admission (tau != nullptr; searches of >= SEED_MIN_FB frame blocks, where a library split fills at least two rounds of
@@ -851,10 +865,13 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 // The hand-off is one LOOK at the previous split's flag (no waiting: nothing can hang, an unfinished predecessor just means
 // an unseeded block) behind the release / acquire pair of the guide; a stale or missing tau can only cost time, never a
 // result: whatever seed a block used is IN its lists, and the certificate bounds the outside rows by it.
-constexpr float SEED_MARGIN8 = (ALIVE_KNN8_FMT == 2 ? 0.024f : 0.02f) * F8_SCALE * F8_SCALE;      // cosine 0.02: certificate slack (>= 0.0105) + 4 sigma of the fp8 error
+constexpr float SEED_MARGIN8 = 0.02f * F8_SCALE * F8_SCALE;      // cosine 0.02: certificate slack (>= 0.0105) + 4 sigma of the fp8 error
+constexpr float SEED_MARGIN6 = 0.024f * F6_SCALE * F6_SCALE;     // fp6: slack >= 0.014 (7 x 2.0e-3) + 4 sigma of 1.8e-3, rounded up
 constexpr float SEED_MARGIN16 = 2.5e-3f;                         // bf16 stage: its certificate's slack is ~7e-4 (7 sigma of ~1e-4)
 constexpr float SEED_MARGIN16_STRICT = 4.5e-3f;                  // strict search: above the largest deterministic bound (2 x 2^-9 + 1e-4)
 constexpr int SEED_MIN_FB = 512;
+constexpr int SEED_MIN_FB6 = 300;                                // fp6 kernel, 384-frame blocks: a little over one round of the chip is enough --
+                                                                 // the look at the predecessor's flag never waits, an unfinished one means an unseeded block
 static float seed_margin8() {              // ALIVE_KNN_SEED_MARGIN (cosine units): experiments only
     static const float m = [] {
         const char* e = getenv("ALIVE_KNN_SEED_MARGIN");
@@ -863,7 +880,16 @@ static float seed_margin8() {              // ALIVE_KNN_SEED_MARGIN (cosine unit
     }();
     return m;
 }
+static float seed_margin6() {
+    static const float m = [] {
+        const char* e = getenv("ALIVE_KNN_SEED_MARGIN");
+        const float v = e ? (float)atof(e) : 0.0f;
+        return v > 0.0f ? v * F6_SCALE * F6_SCALE : SEED_MARGIN6;
+    }();
+    return m;
+}
 
+template <int FMT, int NCT8>
 __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict__ s_f8,
                                                 const unsigned char* __restrict__ lib, int64_t M, int tiles_total,
                                                 int tiles_per_split, int P, float* __restrict__ cand_val,
@@ -873,32 +899,38 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
         int c;
         if (!gate_open(gate_cnt, gate_lo, gate_hi, c)) return;                       // block-uniform
     }
+    // FMT: operand format of both MFMA operands (0 = fp8 e4m3, 2 = fp6 e2m3); NCT8 column tiles of 32 frames per wave
+    constexpr int WF8 = 32 * NCT8;             // frames per wave
+    constexpr int FT8 = 4 * WF8;               // frames per block (256 / 384)
+    constexpr int LW8 = 4 * 2 * WF8;           // lane-columns per list entry row (two half-waves per frame column)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Lv = (float*)(smem + 2 * ABUF8);
-    int* Li = (int*)(Lv + FT * KP8);           // both entry-major: [KH8][512 lane-columns]
+    int* Li = (int*)(Lv + FT8 * KP8);          // both entry-major: [KH8][LW8 lane-columns]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
-    const int64_t frame0 = (int64_t)blockIdx.x * FT;
+    const int64_t frame0 = (int64_t)blockIdx.x * FT8;
     const int split = blockIdx.y;
     const int tile_begin = split * tiles_per_split;
     int tile_end = tile_begin + tiles_per_split;
     if (tile_end > tiles_total) tile_end = tiles_total;
 
     const bool seeded = seeds_look(sa, split);               // block-uniform (see above)
-    float seed[2] = {-INFINITY, -INFINITY};
+    float seed[NCT8];
+#pragma unroll
+    for (int ni = 0; ni < NCT8; ++ni) seed[ni] = -INFINITY;
     if (seeded) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const float t = sa.tau[frame0 + 64 * w + 32 * ni + lr];
+        for (int ni = 0; ni < NCT8; ++ni) {
+            const float t = sa.tau[frame0 + WF8 * w + 32 * ni + lr];
             seed[ni] = t == t ? t : -INFINITY;
         }
     }
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NCT8; ++ni)
 #pragma unroll
-        for (int q = 0; q < KH8; ++q) { Lv[q * 512 + w * 128 + ni * 64 + lane] = seed[ni]; Li[q * 512 + w * 128 + ni * 64 + lane] = -1; }
+        for (int q = 0; q < KH8; ++q) { Lv[q * LW8 + w * (2 * WF8) + ni * 64 + lane] = seed[ni]; Li[q * LW8 + w * (2 * WF8) + ni * 64 + lane] = -1; }
 
     // DMA: wave w copies rows 8 w .. 8 w + 7 of the tile, 6 pieces of 8 rows x 128 B; chunk order swizzled on the source
     const int dma_row = 8 * w + (lane >> 3);
@@ -913,14 +945,20 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
     if (tile_begin < tile_end) issue_tile(tile_begin, 0);
 
     // stationary B fragments: frame = frame0 + 64 w + 32 ni + lr, features 64 ks + 32 lh .. + 31 (32 bytes)
-    v8i bq[2][NK64];
+    v8i bq[NCT8][NK64];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const unsigned char* fp = s_f8 + (size_t)(frame0 + 64 * w + 32 * ni + lr) * D + 32 * lh;
+    for (int ni = 0; ni < NCT8; ++ni) {
+        const unsigned char* fp = s_f8 + (size_t)(frame0 + WF8 * w + 32 * ni + lr) * D + 32 * lh;
 #pragma unroll
         for (int ks = 0; ks < NK64; ++ks) {
-            const u32x4 lo = *(const u32x4*)(fp + 64 * ks), hi = *(const u32x4*)(fp + 64 * ks + 16);
-            bq[ni][ks] = v8i{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+            if constexpr (FMT == 2) {           // 24 of the 32 bytes carry the 32 six-bit codes: no 8-register temporaries
+                const u32x4 lo = *(const u32x4*)(fp + 64 * ks);
+                const uint2 hi = *(const uint2*)(fp + 64 * ks + 16);
+                bq[ni][ks] = v8i{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi.x, (int)hi.y, 0, 0};
+            } else {
+                const u32x4 lo = *(const u32x4*)(fp + 64 * ks), hi = *(const u32x4*)(fp + 64 * ks + 16);
+                bq[ni][ks] = v8i{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+            }
         }
     }
 
@@ -936,14 +974,16 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
     // Candidate lists: 16 entries per lane and column group in LDS, cached in registers as four quarters of four -- the
     // smallest value of each quarter (qv) and where it sits (qp).  The list minimum (the admission threshold) is min(qv); an
     // insertion overwrites that entry and rescans ONE quarter (4 LDS reads) instead of the list.
-    float qv[2][4];
-    int qp[2][4];
+    float qv[NCT8][4];
+    int qp[NCT8][4];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NCT8; ++ni)
 #pragma unroll
         for (int q = 0; q < 4; ++q) { qv[ni][q] = seed[ni]; qp[ni][q] = 4 * q; }
-    float thr[2] = {seed[0], seed[1]};
-    const int lc0 = w * 128 + lane;
+    float thr[NCT8];
+#pragma unroll
+    for (int ni = 0; ni < NCT8; ++ni) thr[ni] = seed[ni];
+    const int lc0 = w * (2 * WF8) + lane;
     __syncthreads();
 
     auto load_a = [&](const unsigned char* Ab, int ks) {
@@ -987,12 +1027,12 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
             const int tpos = bq ? p23 : p01;                     // entry to overwrite
             const int tq = tpos >> 2;                            // its quarter
             if (has) {
-                lv[tpos * 512] = mx;
-                li[tpos * 512] = (int)(row0 + ((__float_as_uint(mx) & 3u) + 8u * ((__float_as_uint(mx) >> 2) & 3u)) + 4 * lh);
+                lv[tpos * LW8] = mx;
+                li[tpos * LW8] = (int)(row0 + ((__float_as_uint(mx) & 3u) + 8u * ((__float_as_uint(mx) >> 2) & 3u)) + 4 * lh);
             }
             // rescan that quarter (after the write: LDS operations of a wave complete in order)
-            const float* qb = lv + (tq * 4) * 512;
-            const float x0 = qb[0], x1 = qb[512], x2 = qb[1024], x3 = qb[1536];
+            const float* qb = lv + (tq * 4) * LW8;
+            const float x0 = qb[0], x1 = qb[LW8], x2 = qb[2 * LW8], x3 = qb[3 * LW8];
             const bool c1 = x1 < x0, c3 = x3 < x2;
             const float n01 = c1 ? x1 : x0, n23 = c3 ? x3 : x2;
             const int e01 = c1 ? 1 : 0, e23 = c3 ? 3 : 2;
@@ -1039,8 +1079,8 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
         const int p01 = b01 ? qp[ni][1] : qp[ni][0], p23 = b23 ? qp[ni][3] : qp[ni][2];
         const int tpos = m23 < m01 ? p23 : p01;                 // entry to overwrite: the list minimum
         const int tq = tpos >> 2, te = tpos & 3;
-        const float* qb = lv + (tq * 4) * 512;
-        float x0 = qb[0], x1 = qb[512], x2 = qb[1024], x3 = qb[1536];
+        const float* qb = lv + (tq * 4) * LW8;
+        float x0 = qb[0], x1 = qb[LW8], x2 = qb[2 * LW8], x3 = qb[3 * LW8];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = __uint_as_float((__float_as_uint(acc[r]) & ~15u) | (unsigned)r);
         if (row0 + LT > M) {                            // -inf with index bits is a NaN: put the rows beyond M back to -inf
@@ -1059,8 +1099,8 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
         const bool has = m1 > thr[ni];
         if (has) {
             const unsigned u = __float_as_uint(m1);
-            lv[tpos * 512] = m1;
-            li[tpos * 512] = (int)(row0 + ((u & 3u) + 8u * ((u >> 2) & 3u)) + 4 * lh);
+            lv[tpos * LW8] = m1;
+            li[tpos * LW8] = (int)(row0 + ((u & 3u) + 8u * ((u >> 2) & 3u)) + 4 * lh);
         }
         // the quarter as it stands after the write: the new entry in place of the old minimum
         x0 = (has && te == 0) ? m1 : x0;
@@ -1086,6 +1126,83 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
     // first MFMAs, a few VALU instructions after each (one wave per SIMD: nothing else would fill the matrix pipe between the
     // last MFMA of a tile and the end of its fold -- measured 23 ms of 107 with the fold behind the tile).  Before the first
     // tile p0 / p1 hold -inf: its fold finds nothing.
+    if constexpr (NCT8 == 3) {
+    // Three column tiles per wave (the fp6 kernel): 36 MFMAs per tile into (c0, c1, c2); the previous tile's accumulators
+    // (p0, p1, p2) are copied out and folded in steps 6 .. 10.  Same pieces as the two-tile form below, one more of each.
+    auto do_tile3 = [&](int tile, f32x16& c0, f32x16& c1, f32x16& c2, f32x16& p0, f32x16& p1, f32x16& p2) {
+        const int buf = (tile - tile_begin) & 1;
+        const int next_tile = tile + 1 < tile_end ? tile + 1 : tile;
+        const unsigned char* gnext = lib + ((size_t)next_tile * LT + dma_row) * D + dma_chunk * 16;
+        unsigned char* lnext = smem + (buf ^ 1) * ABUF8 + w * PIECE;
+        const unsigned char* Ab = smem + buf * ABUF8;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { c0[r] = 0.0f; c1[r] = 0.0f; c2[r] = 0.0f; }
+        v8i a[2];
+        a[0] = load_a(Ab, 0);
+        float pm0 = -INFINITY, pm1 = -INFINITY, pm2 = -INFINITY;
+        ALIVE_CHAIN_GAP(7);
+#define K8_STEP3(ks, AFTER0, AFTER1, AFTER2)                                                                                     \
+        {                                                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                                   \
+            c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(ks) & 1], bq[0][ks], c0, FMT, FMT, 0, 127, 0, 127); \
+            __builtin_amdgcn_sched_barrier(0);                                                                                   \
+            if ((ks) + 1 < NK64) a[((ks) + 1) & 1] = load_a(Ab, (ks) + 1);                                                       \
+            if ((ks) < D / 128)                                                                                                  \
+                __builtin_amdgcn_global_load_lds((gptr_t)(gnext + (ks) * 128), (lptr_t)(lnext + (ks) * 4 * PIECE), 16, 0, 0);    \
+            AFTER0;                                                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                                   \
+            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(ks) & 1], bq[1][ks], c1, FMT, FMT, 0, 127, 0, 127); \
+            __builtin_amdgcn_sched_barrier(0);                                                                                   \
+            AFTER1;                                                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                                   \
+            c2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(ks) & 1], bq[2][ks], c2, FMT, FMT, 0, 127, 0, 127); \
+            __builtin_amdgcn_sched_barrier(0);                                                                                   \
+            AFTER2;                                                                                                              \
+        }
+        f32x16 v0, v1, v2;
+        auto acc_read = [&](const f32x16& a_, int lo, int hi, f32x16& v) {
+#pragma unroll
+            for (int r = lo; r < hi; ++r) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[r]) : "a"(a_[r]));
+        };
+        auto acc_pin = [&]() { asm volatile("" : "+a"(c0), "+a"(c1), "+a"(c2)); };
+        K8_STEP3(0, (void)0, (void)0, (void)0) K8_STEP3(1, (void)0, (void)0, (void)0) K8_STEP3(2, (void)0, (void)0, (void)0)
+        K8_STEP3(3, (void)0, (void)0, (void)0) K8_STEP3(4, (void)0, (void)0, (void)0) K8_STEP3(5, (void)0, (void)0, acc_pin())
+        // (each column tile's copy is folded before the next one is read: one 16-register copy live at a time)
+        K8_STEP3(6, acc_read(p0, 0, 8, v0), (acc_pin(), acc_read(p0, 8, 16, v0), mask_ragged(v0, tile - 1)), (acc_pin(), pm0 = max8(v0, 0, pm0)))
+        K8_STEP3(7, pm0 = max8(v0, 8, pm0), fold_rare(v0, 0, tile - 1, pm0), (acc_pin(), acc_read(p1, 0, 8, v1)))
+        K8_STEP3(8, (acc_pin(), acc_read(p1, 8, 16, v1), mask_ragged(v1, tile - 1)), (acc_pin(), pm1 = max8(v1, 0, pm1)), pm1 = max8(v1, 8, pm1))
+        K8_STEP3(9, fold_rare(v1, 1, tile - 1, pm1), (acc_pin(), acc_read(p2, 0, 8, v2)), (acc_pin(), acc_read(p2, 8, 16, v2), mask_ragged(v2, tile - 1)))
+        K8_STEP3(10, (acc_pin(), pm2 = max8(v2, 0, pm2)), pm2 = max8(v2, 8, pm2), fold_rare(v2, 2, tile - 1, pm2))
+        K8_STEP3(11, (void)0, (void)0, (void)0)
+#undef K8_STEP3
+        asm volatile("" : "+a"(c0), "+a"(c1), "+a"(c2));
+        __syncthreads();
+    };
+    auto fold_now3 = [&](f32x16& p0, f32x16& p1, f32x16& p2, int tile) {
+        mask_ragged(p0, tile);
+        mask_ragged(p1, tile);
+        mask_ragged(p2, tile);
+        fold_rare(p0, 0, tile, max8(p0, 8, max8(p0, 0, -INFINITY)));
+        fold_rare(p1, 1, tile, max8(p1, 8, max8(p1, 0, -INFINITY)));
+        fold_rare(p2, 2, tile, max8(p2, 8, max8(p2, 0, -INFINITY)));
+    };
+    {
+        f32x16 A0, A1, A2, B0, B1, B2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { B0[r] = -INFINITY; B1[r] = -INFINITY; B2[r] = -INFINITY; }
+        int tile = tile_begin;
+        for (; tile + 1 < tile_end; tile += 2) {
+            do_tile3(tile, A0, A1, A2, B0, B1, B2);
+            do_tile3(tile + 1, B0, B1, B2, A0, A1, A2);
+        }
+        if (tile < tile_end) {
+            do_tile3(tile, A0, A1, A2, B0, B1, B2);
+            fold_now3(A0, A1, A2, tile);
+        } else if (tile_begin < tile_end) {
+            fold_now3(B0, B1, B2, tile_end - 1);
+        }
+    }
+    } else {
     auto do_tile = [&](int tile, f32x16& c0, f32x16& c1, f32x16& p0, f32x16& p1) {
         const int buf = (tile - tile_begin) & 1;
         const int next_tile = tile + 1 < tile_end ? tile + 1 : tile;
@@ -1111,7 +1228,7 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
 #define K8_STEP(ks, AFTER0, AFTER1)                                                                                              \
         {                                                                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                                                   \
-            c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(ks) & 1], bq[0][ks], c0, ALIVE_KNN8_FMT, ALIVE_KNN8_FMT, 0, 127, 0, 127);              \
+            c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(ks) & 1], bq[0][ks], c0, FMT, FMT, 0, 127, 0, 127);              \
             __builtin_amdgcn_sched_barrier(0);                                                                                   \
             if ((ks) + 1 < NK64) a[((ks) + 1) & 1] = load_a(Ab, (ks) + 1);                                                       \
             if ((ks) < D / 128) /* the 6 DMA pieces of the next tile go out in the FIRST half of this one: the barrier at its */  \
@@ -1119,7 +1236,7 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
                 __builtin_amdgcn_global_load_lds((gptr_t)(gnext + (ks) * 128), (lptr_t)(lnext + (ks) * 4 * PIECE), 16, 0, 0);    \
             AFTER0;                                                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                                                   \
-            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(ks) & 1], bq[1][ks], c1, ALIVE_KNN8_FMT, ALIVE_KNN8_FMT, 0, 127, 0, 127);              \
+            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(ks) & 1], bq[1][ks], c1, FMT, FMT, 0, 127, 0, 127);              \
             __builtin_amdgcn_sched_barrier(0);                                                                                   \
             AFTER1;                                                                                                              \
         }
@@ -1185,17 +1302,18 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
     } else if (tile_begin < tile_end) {    // even count: the last tile's accumulators are in B
         fold_now(B0, B1, tile_end - 1);
     }
+    }
     __syncthreads();
 
     // ---- cand[frame][P][KP8]: entries 0 .. 15 from the lower half-wave, 16 .. 31 from the upper ----
-    for (int e = tid; e < FT * KP8; e += 256) {
+    for (int e = tid; e < FT8 * KP8; e += 256) {
         const int k = e % KP8, col = e / KP8;
-        const int lc = (col >> 6) * 128 + ((col >> 5) & 1) * 64 + (k / KH8) * 32 + (col & 31);
+        const int lc = (col / WF8) * (2 * WF8) + ((col % WF8) >> 5) * 64 + (k / KH8) * 32 + (col & 31);
         const size_t o = (((size_t)(frame0 + col)) * P + split) * KP8 + k;
-        cand_val[o] = Lv[(k % KH8) * 512 + lc];
-        cand_idx[o] = Li[(k % KH8) * 512 + lc];
+        cand_val[o] = Lv[(k % KH8) * LW8 + lc];
+        cand_idx[o] = Li[(k % KH8) * LW8 + lc];
     }
-    if (sa.tau != nullptr) seeds_publish<KH8>(sa, Lv, Li, frame0, split, seeded);
+    if (sa.tau != nullptr) seeds_publish<KH8, WF8, FT8>(sa, Lv, Li, frame0, split, seeded);
 }
 
 // two entry points of the same body, so that a kernel trace tells the pass over the batch from the 1 024-frame probe
@@ -1203,12 +1321,24 @@ __global__ __launch_bounds__(256, 1) void knn_score8_kernel(const unsigned char*
                                                             int64_t M, int tiles_total, int tiles_per_split, int P,
                                                             float* __restrict__ cand_val, int* __restrict__ cand_idx,
                                                             const int* __restrict__ gate_cnt, int gate_lo, int gate_hi, SeedArgs sa) {
-    knn_score8_body(s_f8, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, gate_cnt, gate_lo, gate_hi, sa);
+    knn_score8_body<0, 2>(s_f8, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, gate_cnt, gate_lo, gate_hi, sa);
 }
 __global__ __launch_bounds__(256, 1) void knn_probe8_kernel(const unsigned char* __restrict__ s_f8, const unsigned char* __restrict__ lib,
                                                             int64_t M, int tiles_total, int tiles_per_split, int P,
                                                             float* __restrict__ cand_val, int* __restrict__ cand_idx) {
-    knn_score8_body(s_f8, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, nullptr, 0, 0, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr});
+    knn_score8_body<0, 2>(s_f8, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, nullptr, 0, 0, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr});
+}
+// the fp6 stage (round 5): e2m3 operands on both sides, three column tiles per wave
+__global__ __launch_bounds__(256, 1) void knn_score6_kernel(const unsigned char* __restrict__ s_f6, const unsigned char* __restrict__ lib,
+                                                            int64_t M, int tiles_total, int tiles_per_split, int P,
+                                                            float* __restrict__ cand_val, int* __restrict__ cand_idx,
+                                                            const int* __restrict__ gate_cnt, int gate_lo, int gate_hi, SeedArgs sa) {
+    knn_score8_body<2, 3>(s_f6, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, gate_cnt, gate_lo, gate_hi, sa);
+}
+__global__ __launch_bounds__(256, 1) void knn_probe6_kernel(const unsigned char* __restrict__ s_f6, const unsigned char* __restrict__ lib,
+                                                            int64_t M, int tiles_total, int tiles_per_split, int P,
+                                                            float* __restrict__ cand_val, int* __restrict__ cand_idx) {
+    knn_score8_body<2, 3>(s_f6, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, nullptr, 0, 0, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr});
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1239,7 +1369,10 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
                                                           int* __restrict__ flag_list, int* __restrict__ flag_cnt, float zsig,
                                                           int list_len, float pre_scale, float sd_prior,
                                                           const float* __restrict__ det_q, const float* __restrict__ det_lib,
-                                                          float* __restrict__ thr_list, int collect, float overflow_slack) {
+                                                          float* __restrict__ thr_list, int collect, float overflow_slack,
+                                                          const unsigned char* __restrict__ force_fail = nullptr) {
+    // force_fail (fp6 stage): frames whose fp6 image clipped an element (|x| 2^5 > 7.5) -- their stage scores are off by more than
+    // any error statistic of their candidates can show, so they go to the next tier whatever the certificate says
     const int lane = threadIdx.x & 63;
     const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // candidate lists are indexed by slot
     int gc;
@@ -1456,10 +1589,11 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
     // measured on this frame's own candidates) an exact score below c_cut - mu + z sd except in the z-sigma tail.  If the
     // k-th exact score does not clear that, the frame goes to the next tier: the bf16 candidate stage behind the fp8 one,
     // the exact scan behind the bf16 one (alive_knn_search_fp8 / alive_knn_search).
-    if (certify && lane == 0 && c_cut > -INFINITY) {
+    const bool forced = force_fail != nullptr && force_fail[ft] != 0;
+    if (certify && lane == 0 && (c_cut > -INFINITY || forced)) {
         const float bound = det_q != nullptr ? c_cut * pre_scale + det_bound
                                              : c_cut * pre_scale - err_mu + fmaxf(zsig * err_sd, 2.0f * err_max);
-        if (!(vk > bound)) {
+        if (!(vk > bound) || forced) {
             // the frame goes to the next tier; for the collect tier it takes along the threshold below which no row can
             // belong to its top-k: its k-th exact cosine so far minus the slack it was just tested with (stage-score units)
             const int pos = atomicAdd(flag_cnt, 1);
@@ -1951,7 +2085,7 @@ enum { ST_FLAG8 = 0, ST_FLAG16 = 1, ST_PROBE_N = 2, ST_PROBE_FAIL = 3, ST_MODE =
        ST_WORDS = 16 };
 // ST_TIER: which path the last search on this workspace took (written by every path, so that the host never has to
 // re-derive the dispatch): 1 = streaming scan, 2 = exact scan of every frame (k > 8), 3 = bf16 first, 4 = fp8 first
-enum { TIER_SCAN = 1, TIER_EXACT_ALL = 2, TIER_BF16 = 3, TIER_FP8 = 4 };
+enum { TIER_SCAN = 1, TIER_EXACT_ALL = 2, TIER_BF16 = 3, TIER_FP8 = 4, TIER_FP6 = 5 };
 __global__ void stats_init_kernel(int* __restrict__ stats, int tier) {
     // (the two tier limits are written out with the counters, so that a reader never repeats the constants)
     if (threadIdx.x < ST_WORDS)
@@ -2022,22 +2156,33 @@ struct SearchPlan {
 
 // Grid = (Tt_pad / 256 frame blocks) x (split library ranges), one block per CU at a time (1 wave / SIMD).
 // The split is chosen so that the last round of blocks over the 256 CUs is as full as possible.
-static SearchPlan make_plan(int64_t Tt, int64_t M, int split_cap = MAX_SPLIT) {
+static SearchPlan make_plan(int64_t Tt, int64_t M, int split_cap = MAX_SPLIT, int ft = FT) {
     SearchPlan p;
     p.Tt = Tt;
-    p.Tt_pad = (Tt + FT - 1) / FT * FT;
+    p.Tt_pad = (Tt + ft - 1) / ft * ft;
     p.tiles_total = (int)(((M + TILE - 1) / TILE * TILE) / LT);
-    const int64_t fb = p.Tt_pad / FT;
+    const int64_t fb = p.Tt_pad / ft;
     int max_split = p.tiles_total / 8;                 // at least 8 tiles (256 rows) per block
     if (max_split > split_cap) max_split = split_cap;
     if (max_split < 1) max_split = 1;
     int best = 1;
     double best_eff = -1.0;
+    auto eff_of = [&](int sp) {
+        const int64_t blocks = fb * sp, rounds = (blocks + 255) / 256;
+        return (double)blocks / (double)(rounds * 256);
+    };
     for (int sp = 1; sp <= max_split; ++sp) {
-        int64_t blocks = fb * sp;
-        int64_t rounds = (blocks + 255) / 256;
-        double eff = (double)blocks / (double)(rounds * 256);
+        const double eff = eff_of(sp);
         if (eff > best_eff + 0.02) { best_eff = eff; best = sp; }
+    }
+    if (ft != FT) {
+        // 384-frame blocks (the fp6 stage): the greedy rule above climbs to 25 splits for 450 frame blocks (0.9988 against 0.9766 at
+        // 5) -- 800 candidates per frame for the rescoring and 24 cold list starts per frame block.  Here: the FEWEST splits within
+        // 3 % of the best fill.
+        double top = 0.0;
+        for (int sp = 1; sp <= max_split; ++sp) top = eff_of(sp) > top ? eff_of(sp) : top;
+        for (int sp = 1; sp <= max_split; ++sp)
+            if (eff_of(sp) >= top - 0.03) { best = sp; break; }
     }
     p.split = best;
     p.tiles_per_split = (p.tiles_total + best - 1) / best;
@@ -2047,9 +2192,11 @@ static SearchPlan make_plan(int64_t Tt, int64_t M, int split_cap = MAX_SPLIT) {
 
 constexpr int MAX_SPLIT8 = 1024 / KP8;    // the rescoring kernel takes up to 1024 candidates per frame
 constexpr int FCAP = 16384;               // tier 1 of the bf16 re-search: up to this many flagged frames ...
+constexpr int TIER1A = 256;               // tier 1a: up to one frame block of flagged frames, library cut MAX_SPLIT ways
 constexpr int FPLAN = 4096;               // ... with the library split chosen for this many (blocks past the count exit at once)
 constexpr float CERT_Z = 7.0f;            // sigmas of candidate-score error the certificates allow for
-constexpr float SD_PRIOR8 = ALIVE_KNN8_FMT == 2 ? 1.9e-3f : 1.5e-3f;      // typical error (cosine units) of an fp8 / a bf16 candidate score: floor of the per-frame estimate
+constexpr float SD_PRIOR6 = 2.0e-3f;      // fp6 stage: 1.8e-3 simulated / measured on unit vectors of Gaussian elements
+constexpr float SD_PRIOR8 = 1.5e-3f;      // typical error (cosine units) of an fp8 / a bf16 candidate score: floor of the per-frame estimate
 constexpr float SD_PRIOR16 = 8.0e-5f;
 constexpr int PROBE_N = 1024;             // frames of the adaptive probe (fp8 searches of >= PROBE_MIN_T frames)
 constexpr int64_t PROBE_MIN_T = 16384;
@@ -2059,12 +2206,14 @@ constexpr int PROBE_NUM = 11, PROBE_DEN = 20; // bf16 first when more than 55 % 
                                               // library, 49 % failing: fp8 first 216.9 ms per search, bf16 first 227.9 ms
 
 // seeds for a launch of `fb` frame blocks x `split` library splits (nullptr members: no seeding); zeroes the flags on the stream
-static SeedArgs seeds_for(const struct SearchWs& w, int64_t fb, int split, int k, float margin, int counter, hipStream_t s);
+static SeedArgs seeds_for(const struct SearchWs& w, int64_t fb, int split, int k, float margin, int counter, hipStream_t s, int min_fb = SEED_MIN_FB);
 
 // ---- workspace: ONE layout function for the size query, the searches and the stats pointer ----
 struct SearchWs {
     SearchPlan p16, p8, pt, pp;            // bf16 main / fp8 main / tier-1 re-search / probe
-    int fcap, probe_n, probe_pad;
+    SearchPlan p6, pp6;                    // fp6 main / probe (384-frame blocks)
+    SearchPlan pa;                         // tier 1a of the bf16 re-search: ONE frame block, as many library splits as the rescoring takes
+    int fcap, probe_n, probe_pad, probe_pad6;
     float* s_f32; unsigned short* s_bf16; unsigned char* s_f8;
     float* cv; int* ci;                    // candidate lists of the main pass (and of tier 2 of the re-search)
     float* pv; int* pi;                    // partial lists: streaming scan / exact tier
@@ -2074,6 +2223,7 @@ struct SearchWs {
     unsigned char* s_p8; float* cvp; int* cip; int* p_list;   // probe: sample rows, lists, [frame of slot | flagged frames]
     float* thr1; int* list2;               // collect tier: thresholds of the frames in list1; frames that overflowed it
     float* dq;                             // || q^ - bf16(q^) || per frame (strict certificate)
+    unsigned char* clip6;                  // fp6 stage: 1 = the frame's fp6 image clipped an element (-> it fails the certificate)
     unsigned short* s_c2h; unsigned short* s_c2l;   // split tier (strict search): both planes of the frames that failed the deterministic certificate
     float* c2v; int* c2i;                  // candidate lists of the collect tiers: [slot][split][caps]
     int rows_t, rows_b;                    // rows per frame they may fill: tier-1 launches (<= fcap frames) / bulk launches
@@ -2087,18 +2237,24 @@ static SearchWs ws_layout(void* base, int64_t Tt, int64_t M, int k, bool split =
     SearchWs w;
     w.p16 = make_plan(Tt, M);
     w.p8 = make_plan(Tt, M, MAX_SPLIT8);
+    w.p6 = make_plan(Tt, M, MAX_SPLIT8, FT6);
     const int64_t Tp = w.p16.Tt_pad;
+    const int64_t Tp8 = w.p6.Tt_pad > Tp ? w.p6.Tt_pad : Tp;      // (the fp6 stage pads the frames to blocks of 384)
     w.fcap = Tp < FCAP ? (int)Tp : FCAP;
     w.pt = make_plan(w.fcap < FPLAN ? w.fcap : FPLAN, M);
+    w.pa = make_plan(FT, M);
     w.probe_n = Tt >= PROBE_MIN_T ? PROBE_N : 0;
     w.probe_pad = (w.probe_n + FT - 1) / FT * FT;
+    w.probe_pad6 = (w.probe_n + FT6 - 1) / FT6 * FT6;
     w.pp = make_plan(w.probe_n > 0 ? w.probe_n : 1, M, MAX_SPLIT8);
+    w.pp6 = make_plan(w.probe_n > 0 ? w.probe_n : 1, M, MAX_SPLIT8, FT6);
     Arena a(base);
     w.stats = a.take<int>(ST_WORDS);       // first: its address must not depend on k (alive_knn_search_stats has no k)
     w.s_f32 = a.take<float>((size_t)Tt * D);
     w.s_bf16 = a.take<unsigned short>((size_t)Tp * D);
-    w.s_f8 = a.take<unsigned char>((size_t)Tp * D);
-    const size_t c16 = (size_t)Tp * w.p16.P * KP, c8 = (size_t)Tp * w.p8.P * KP8;
+    w.s_f8 = a.take<unsigned char>((size_t)Tp8 * D);
+    const size_t c8a = (size_t)Tp * w.p8.P * KP8, c8b = (size_t)w.p6.Tt_pad * w.p6.P * KP8;
+    const size_t c16 = (size_t)Tp * w.p16.P * KP, c8 = c8a > c8b ? c8a : c8b;
     w.cv = a.take<float>(c16 > c8 ? c16 : c8);
     w.ci = a.take<int>(c16 > c8 ? c16 : c8);
     size_t lists = exact_lists(Tt, k <= ALIVE_MAX_K && k >= 1 ? k : 4);
@@ -2108,15 +2264,19 @@ static SearchWs ws_layout(void* base, int64_t Tt, int64_t M, int k, bool split =
     w.list0 = a.take<int>((size_t)Tp);
     w.list1 = a.take<int>((size_t)Tp);
     w.s_c = a.take<unsigned short>((size_t)Tp * D);
-    w.cv1 = a.take<float>((size_t)w.fcap * w.pt.P * KP);
-    w.ci1 = a.take<int>((size_t)w.fcap * w.pt.P * KP);
-    w.s_p8 = a.take<unsigned char>((size_t)w.probe_pad * D + 16);
-    w.cvp = a.take<float>((size_t)w.probe_pad * w.pp.P * KP8 + 4);
-    w.cip = a.take<int>((size_t)w.probe_pad * w.pp.P * KP8 + 4);
-    w.p_list = a.take<int>((size_t)2 * w.probe_pad + 8);
+    const size_t n1a = (size_t)(w.fcap < TIER1A ? w.fcap : TIER1A) * w.pa.P * KP, n1 = (size_t)w.fcap * w.pt.P * KP;
+    w.cv1 = a.take<float>(n1 > n1a ? n1 : n1a);
+    w.ci1 = a.take<int>(n1 > n1a ? n1 : n1a);
+    const size_t ppad = w.probe_pad6 > w.probe_pad ? w.probe_pad6 : w.probe_pad;
+    const size_t pcand = ppad * (size_t)(w.pp6.P > w.pp.P ? w.pp6.P : w.pp.P) * KP8;
+    w.s_p8 = a.take<unsigned char>(ppad * D + 16);
+    w.cvp = a.take<float>(pcand + 4);
+    w.cip = a.take<int>(pcand + 4);
+    w.p_list = a.take<int>(2 * ppad + 8);
     w.thr1 = a.take<float>((size_t)Tp);
     w.list2 = a.take<int>((size_t)Tp);
     w.dq = a.take<float>((size_t)Tp);
+    w.clip6 = a.take<unsigned char>((size_t)Tp8);
     // rows per frame the collect tiers may fill (the rescoring kernel takes up to 1024): 1024 for up to FCAP frames (few frames: many
     // library splits, and a cluster must still fit one split's segment), SPLIT_ROWS for the bulk launches of a big batch
     const size_t c2n = (size_t)(Tp < FCAP ? Tp : FCAP) * 1024 > (size_t)Tp * SPLIT_ROWS ? (size_t)(Tp < FCAP ? Tp : FCAP) * 1024 : (size_t)Tp * SPLIT_ROWS;
@@ -2125,7 +2285,7 @@ static SearchWs ws_layout(void* base, int64_t Tt, int64_t M, int k, bool split =
     w.rows_t = (int)(c2n / (size_t)w.fcap < 1024 ? c2n / (size_t)w.fcap : 1024);
     w.rows_b = (int)(c2n / (size_t)Tp < 1024 ? c2n / (size_t)Tp : 1024);
     w.lib_lo = nullptr;
-    w.tau = a.take<float>((size_t)Tp);
+    w.tau = a.take<float>((size_t)Tp8);
     w.tau_flag = a.take<int>((size_t)(Tp / FT) * (MAX_SPLIT > MAX_SPLIT8 ? MAX_SPLIT : MAX_SPLIT8));
     w.det_q = nullptr;
     w.det_lib = nullptr;
@@ -2137,8 +2297,8 @@ static SearchWs ws_layout(void* base, int64_t Tt, int64_t M, int k, bool split =
     return w;
 }
 
-static SeedArgs seeds_for(const SearchWs& w, int64_t fb, int split, int k, float margin, int counter, hipStream_t s) {
-    if (fb < SEED_MIN_FB || split < 2) return SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr};
+static SeedArgs seeds_for(const SearchWs& w, int64_t fb, int split, int k, float margin, int counter, hipStream_t s, int min_fb) {
+    if (fb < min_fb || split < 2) return SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr};
     (void)hipMemsetAsync(w.tau_flag, 0, (size_t)fb * split * sizeof(int), s);
     return SeedArgs{w.tau, w.tau_flag, k, margin, w.stats + counter};
 }
@@ -2206,13 +2366,14 @@ static int check_search_args(const char* what, const void* a, const void* b, int
     ALIVE_CHECK_ARG(N > 0 && T > 0, "%s: empty source", what);
     ALIVE_CHECK_ARG(k >= 1 && k <= ALIVE_MAX_K, "%s: k=%d outside [1,%d]", what, k, ALIVE_MAX_K);
     ALIVE_CHECK_ARG(M >= k, "%s: library shard has %lld vectors, fewer than k=%d", what, (long long)M, k);
-    ALIVE_CHECK_ARG((int64_t)N * T < ((int64_t)1 << 31) - FT, "%s: %lld frames in one call", what, (long long)N * T);
+    ALIVE_CHECK_ARG((int64_t)N * T < ((int64_t)1 << 31) - FT6, "%s: %lld frames in one call", what, (long long)N * T);
     return ALIVE_OK;
 }
 
 static int lds_optin(const char* what) {
-    static LdsOptIn optin8, optin16, optin_split;
+    static LdsOptIn optin8, optin6, optin16, optin_split;
     hipError_t e = optin8.ensure({(const void*)knn_score8_kernel, (const void*)knn_probe8_kernel}, SCORE8_LDS);
+    if (e == hipSuccess) e = optin6.ensure({(const void*)knn_score6_kernel, (const void*)knn_probe6_kernel}, SCORE6_LDS);
     if (e == hipSuccess) e = optin16.ensure({(const void*)knn_score_kernel<false>, (const void*)knn_score_kernel<true>}, SCORE_LDS);
     if (e == hipSuccess) e = optin_split.ensure({(const void*)knn_collect_split_kernel}, SPLIT_LDS);
     if (e != hipSuccess) {
@@ -2227,12 +2388,18 @@ extern "C" size_t alive_library_fp8_bytes(int64_t M) { return (size_t)alive_libr
 extern "C" int alive_library_pack_fp8(const void* lib_bf16, int64_t M, void* lib_f8, void* stream) {
     ALIVE_CHECK_ARG(lib_bf16 && lib_f8 && M >= 1, "alive_library_pack_fp8: bad args");
     const int64_t n8 = alive_library_padded_rows(M) * D / 8;
-#if ALIVE_KNN8_FMT == 2
-    to_fp6_kernel<<<(unsigned)((n8 / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>((const unsigned short*)lib_bf16, n8 / 4, (u32x4*)lib_f8);
-#else
     lib_to_fp8_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, (hipStream_t)stream>>>((const unsigned short*)lib_bf16, n8, (uint2*)lib_f8);
-#endif
     ALIVE_CHECK_LAUNCH("alive_library_pack_fp8");
+    return ALIVE_OK;
+}
+
+// fp6 e2m3 form of the normalised rows (x 2^5), alive_library_fp8_bytes(M) bytes like the fp8 form: every group of 32 features keeps
+// a 32-byte slot (24 bytes of codes + 8 of zeros), so that the tile image, the LDS-DMA pieces and the fragment reads are the fp8 kernel's
+extern "C" int alive_library_pack_fp6(const void* lib_bf16, int64_t M, void* lib_f6, void* stream) {
+    ALIVE_CHECK_ARG(lib_bf16 && lib_f6 && M >= 1, "alive_library_pack_fp6: bad args");
+    const int64_t n32 = alive_library_padded_rows(M) * D / 32;
+    to_fp6_kernel<<<(unsigned)((n32 + 255) / 256), 256, 0, (hipStream_t)stream>>>((const unsigned short*)lib_bf16, n32, n32, (u32x4*)lib_f6);
+    ALIVE_CHECK_LAUNCH("alive_library_pack_fp6");
     return ALIVE_OK;
 }
 
@@ -2312,11 +2479,24 @@ static void bf16_tiers_launch(const SearchWs& w, const void* lib_bf16, const flo
     int* cnt1 = w.stats + ST_FLAG16;
     const int fcap = w.fcap;
     knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, w.list0, cnt0, out_val, out_idx, s, RESEARCH_MIN);
-    gather_frames_kernel<<<(unsigned)fcap, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, RESEARCH_MIN, fcap, w.s_c);
+    // tier 1a (round 5): RESEARCH_MIN < count <= one frame block.  Tier 1's split is chosen for 4096 frames (16 frame blocks x 16
+    // splits): a hundred flagged frames keep ONE of its frame blocks busy, i.e. 16 CUs walk the whole library -- 9 ms at 1 M rows,
+    // which is what the 73 frames the fp6 stage leaves uncertified on the bench batch cost.  Here the one block's library is cut
+    // MAX_SPLIT ways (64 CUs, 1024 candidates per frame = what the rescoring kernel takes).  Same buffers as tier 1: the gates
+    // (RESEARCH_MIN, TIER1A] / (TIER1A, fcap] exclude each other.
+    const int t1a = fcap < TIER1A ? fcap : TIER1A;
+    gather_frames_kernel<<<(unsigned)t1a, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, RESEARCH_MIN, t1a, w.s_c);
+    knn_score_kernel<false><<<dim3(1, w.pa.split), 256, SCORE_LDS, s>>>(
+        w.s_c, (const unsigned short*)lib_bf16, M, w.pa.tiles_total, w.pa.tiles_per_split, w.pa.P, w.cv1, w.ci1, cnt0, RESEARCH_MIN, t1a, 1, nullptr, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr}, 0);
+    knn_rescore_kernel<<<(unsigned)((t1a + 3) / 4), 256, 0, s>>>(w.cv1, w.ci1, w.pa.P, KP, w.s_f32, rows_f32, norms, t1a, idx_base, k,
+                                                                out_val, out_idx, w.list0, cnt0, RESEARCH_MIN, t1a, w.list1, cnt1, CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0, w.lib_lo != nullptr ? SPLIT_BOUND : 0.0f);
+    if (fcap > t1a) {
+    gather_frames_kernel<<<(unsigned)fcap, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, t1a, fcap, w.s_c);
     knn_score_kernel<false><<<dim3((unsigned)(fcap / FT), w.pt.split), 256, SCORE_LDS, s>>>(
-        w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.cv1, w.ci1, cnt0, RESEARCH_MIN, fcap, 1, nullptr, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr}, 0);
+        w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.cv1, w.ci1, cnt0, t1a, fcap, 1, nullptr, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr}, 0);
     knn_rescore_kernel<<<(unsigned)((fcap + 3) / 4), 256, 0, s>>>(w.cv1, w.ci1, w.pt.P, KP, w.s_f32, rows_f32, norms, fcap, idx_base, k,
-                                                                 out_val, out_idx, w.list0, cnt0, RESEARCH_MIN, fcap, w.list1, cnt1, CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0, w.lib_lo != nullptr ? SPLIT_BOUND : 0.0f);
+                                                                 out_val, out_idx, w.list0, cnt0, t1a, fcap, w.list1, cnt1, CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0, w.lib_lo != nullptr ? SPLIT_BOUND : 0.0f);
+    }
     if (w.p16.Tt_pad > fcap) {
         gather_frames_kernel<<<(unsigned)w.p16.Tt_pad, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, fcap, 0x7fffffff, w.s_c);
         // (the frames are compacted: a block's 256 slots are the same in every split, so the seeds are indexed by slot)
@@ -2430,49 +2610,63 @@ extern "C" int alive_knn_search_timed(const float* src, int N, int T, const void
 
 static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f8, const void* lib_bf16, const float* rows_f32,
                                const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
-                               void* ws, void* stream, hipEvent_t g_ev_start, hipEvent_t g_ev_stop) {
+                               void* ws, void* stream, hipEvent_t g_ev_start, hipEvent_t g_ev_stop, int fmt = 0) {
     ALIVE_CHECK_ARG(src && lib_f8 && lib_bf16 && rows_f32 && norms && out_val && out_idx && ws, "alive_knn_search_fp8: null pointer");
     if (int rc = check_search_args("alive_knn_search_fp8", src, ws, N, T, k, M)) return rc;
     const int64_t Tt = (int64_t)N * T;
     if (k > KH)
         return knn_search_impl(src, N, T, lib_bf16, rows_f32, norms, M, idx_base, k, out_val, out_idx, ws, stream, g_ev_start, g_ev_stop);
     const SearchWs w = ws_layout(ws, Tt, M, k);
-    const SearchPlan& p = w.p8;
+    const bool f6 = fmt == 2;
+    const SearchPlan& p = f6 ? w.p6 : w.p8;
+    const SearchPlan& pp = f6 ? w.pp6 : w.pp;
+    const int ft = f6 ? FT6 : FT, probe_pad = f6 ? w.probe_pad6 : w.probe_pad, lds = f6 ? SCORE6_LDS : SCORE8_LDS;
+    const float pre = f6 ? 1.0f / (F6_SCALE * F6_SCALE) : 1.0f / (F8_SCALE * F8_SCALE), prior = f6 ? SD_PRIOR6 : SD_PRIOR8;
     hipStream_t s = (hipStream_t)stream;
     if (Tt * k <= 64 && M <= SCAN_ROWS_MAX)            // streaming ring: the exact scan, no candidate stage at all
         return knn_scan_launch(src, T, Tt, rows_f32, norms, M, idx_base, k, w.s_f32, w.s_bf16, w.pv, w.pi, out_val, out_idx, w.stats, s, g_ev_start, g_ev_stop);
     if (int rc = lds_optin("alive_knn_search_fp8")) return rc;
-    stats_init_kernel<<<1, 64, 0, s>>>(w.stats, TIER_FP8);
+    stats_init_kernel<<<1, 64, 0, s>>>(w.stats, f6 ? TIER_FP6 : TIER_FP8);
     src_prep_launch(w, src, T, Tt, s);
-    const int64_t n8 = p.Tt_pad * D / 8;
-#if ALIVE_KNN8_FMT == 2
-    to_fp6_kernel<<<(unsigned)((n8 / 4 + 255) / 256), 256, 0, s>>>(w.s_bf16, n8 / 4, (u32x4*)w.s_f8);
-#else
-    src_to_fp8_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>(w.s_bf16, n8, (uint2*)w.s_f8);
-#endif
+    if (f6) {
+        const int64_t n32 = p.Tt_pad * D / 32;
+        (void)hipMemsetAsync(w.clip6, 0, (size_t)p.Tt_pad, s);
+        to_fp6_kernel<<<(unsigned)((n32 + 255) / 256), 256, 0, s>>>(w.s_bf16, n32, w.p16.Tt_pad * D / 32, (u32x4*)w.s_f8, w.clip6);
+    } else {
+        const int64_t n8 = p.Tt_pad * D / 8;
+        src_to_fp8_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>(w.s_bf16, n8, (uint2*)w.s_f8);
+    }
     int* mode = w.stats + ST_MODE;
     if (w.probe_n > 0) {
-        probe_gather_kernel<<<(unsigned)w.probe_pad, 64, 0, s>>>(w.s_f8, Tt, w.probe_n, w.probe_pad, w.s_p8, w.p_list);
-        knn_probe8_kernel<<<dim3((unsigned)(w.probe_pad / FT), w.pp.split), 256, SCORE8_LDS, s>>>(
-            w.s_p8, (const unsigned char*)lib_f8, M, w.pp.tiles_total, w.pp.tiles_per_split, w.pp.P, w.cvp, w.cip);
+        probe_gather_kernel<<<(unsigned)probe_pad, 64, 0, s>>>(w.s_f8, Tt, w.probe_n, probe_pad, w.s_p8, w.p_list);
+        if (f6)
+            knn_probe6_kernel<<<dim3((unsigned)(probe_pad / ft), pp.split), 256, lds, s>>>(
+                w.s_p8, (const unsigned char*)lib_f8, M, pp.tiles_total, pp.tiles_per_split, pp.P, w.cvp, w.cip);
+        else
+            knn_probe8_kernel<<<dim3((unsigned)(probe_pad / ft), pp.split), 256, lds, s>>>(
+                w.s_p8, (const unsigned char*)lib_f8, M, pp.tiles_total, pp.tiles_per_split, pp.P, w.cvp, w.cip);
         // the sample's own rescoring.  The kernel writes a frame's result to the frame's own output rows (out[frame]), so
         // the sample's exact lists land in the caller's outputs and are overwritten by the pass over the batch; its flagged
         // frames (second half of p_list) are only counted
-        knn_rescore_kernel<<<(unsigned)((w.probe_n + 3) / 4), 256, 0, s>>>(w.cvp, w.cip, w.pp.P, KP8, w.s_f32, rows_f32, norms, w.probe_n,
+        knn_rescore_kernel<<<(unsigned)((w.probe_n + 3) / 4), 256, 0, s>>>(w.cvp, w.cip, pp.P, KP8, w.s_f32, rows_f32, norms, w.probe_n,
                                                                           idx_base, k, out_val, out_idx, w.p_list, nullptr, 0, 0,
-                                                                          w.p_list + w.probe_pad, w.stats + ST_PROBE_CNT, CERT_Z, KH8,
-                                                                          1.0f / (F8_SCALE * F8_SCALE), SD_PRIOR8, nullptr, nullptr, nullptr, 0, 0.0f);
+                                                                          w.p_list + probe_pad, w.stats + ST_PROBE_CNT, CERT_Z, KH8,
+                                                                          pre, prior, nullptr, nullptr, nullptr, 0, 0.0f, f6 ? w.clip6 : nullptr);
         probe_decide_kernel<<<1, 1, 0, s>>>(w.stats, w.probe_n, PROBE_NUM, PROBE_DEN);
     }
-    // ---- mode 0: fp8 first ----
-    const SeedArgs sa8 = seeds_for(w, p.Tt_pad / FT, p.split, k, seed_margin8(), ST_SEEDED, s);
+    // ---- mode 0: the fp8 / fp6 stage first ----
+    const SeedArgs sa8 = seeds_for(w, p.Tt_pad / ft, p.split, k, f6 ? seed_margin6() : seed_margin8(), ST_SEEDED, s, f6 ? SEED_MIN_FB6 : SEED_MIN_FB);
     if (g_ev_start) (void)hipEventRecord(g_ev_start, s);             // behind the memset of the seed flags: the events bracket the kernel alone
-    knn_score8_kernel<<<dim3((unsigned)(p.Tt_pad / FT), p.split), 256, SCORE8_LDS, s>>>(
-        w.s_f8, (const unsigned char*)lib_f8, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, mode, -1, 0, sa8);
+    if (f6)
+        knn_score6_kernel<<<dim3((unsigned)(p.Tt_pad / ft), p.split), 256, lds, s>>>(
+            w.s_f8, (const unsigned char*)lib_f8, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, mode, -1, 0, sa8);
+    else
+        knn_score8_kernel<<<dim3((unsigned)(p.Tt_pad / ft), p.split), 256, lds, s>>>(
+            w.s_f8, (const unsigned char*)lib_f8, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, mode, -1, 0, sa8);
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
     knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, p.P, KP8, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                out_val, out_idx, nullptr, mode, -1, 0, w.list0, w.stats + ST_FLAG8,
-                                                               CERT_Z, KH8, 1.0f / (F8_SCALE * F8_SCALE), SD_PRIOR8, nullptr, nullptr, nullptr, 0, 0.0f);
+                                                               CERT_Z, KH8, pre, prior, nullptr, nullptr, nullptr, 0, 0.0f, f6 ? w.clip6 : nullptr);
     // ---- mode 1: bf16 first (every frame into list0) ----
     if (w.probe_n > 0) flag_all_kernel<<<(unsigned)((Tt + 255) / 256), 256, 0, s>>>(w.list0, w.stats + ST_FLAG8, Tt, mode, 0, 1);
     bf16_tiers_launch(w, lib_bf16, rows_f32, norms, M, Tt, idx_base, k, out_val, out_idx, s);
@@ -2490,6 +2684,19 @@ extern "C" int alive_knn_search_fp8_timed(const float* src, int N, int T, const 
                                           void* ws, void* stream, void* ev_start, void* ev_stop) {
     return knn_search_fp8_impl(src, N, T, lib_f8, lib_bf16, rows_f32, norms, M, idx_base, k, out_val, out_idx, ws, stream,
                                (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
+}
+
+// The same search with the candidate stage on the fp6 MFMA (knn_score6_kernel); lib_f6 from alive_library_pack_fp6.
+extern "C" int alive_knn_search_fp6(const float* src, int N, int T, const void* lib_f6, const void* lib_bf16, const float* rows_f32,
+                                    const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
+                                    void* ws, void* stream) {
+    return knn_search_fp8_impl(src, N, T, lib_f6, lib_bf16, rows_f32, norms, M, idx_base, k, out_val, out_idx, ws, stream, nullptr, nullptr, 2);
+}
+extern "C" int alive_knn_search_fp6_timed(const float* src, int N, int T, const void* lib_f6, const void* lib_bf16, const float* rows_f32,
+                                          const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
+                                          void* ws, void* stream, void* ev_start, void* ev_stop) {
+    return knn_search_fp8_impl(src, N, T, lib_f6, lib_bf16, rows_f32, norms, M, idx_base, k, out_val, out_idx, ws, stream,
+                               (hipEvent_t)ev_start, (hipEvent_t)ev_stop, 2);
 }
 
 // device pointer (inside ws) to the counters of the last search on this workspace, int[16] (ST_WORDS; slots used today: 0-4, 7-12):

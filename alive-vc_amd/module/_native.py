@@ -60,6 +60,9 @@ PROTOTYPES = {
     "alive_knn_search_stats": (_VP, [_I, _I, _I64, _VP]),
     "alive_knn_search_timed": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "alive_knn_search_fp8_timed": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "alive_library_pack_fp6": (_I, [_VP, _I64, _VP, _VP]),
+    "alive_knn_search_fp6": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP]),
+    "alive_knn_search_fp6_timed": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "alive_dedup_pass": (_I, [_VP, _VP, _I64, _I, _D, _VP, _VP, _VP]),
     "alive_knn_merge_gather": (_I, [_VP, _VP, _I, _I, _D, _VP, _VP, _I, _I, _VP, _VP, _VP]),
     "alive_conv1d": (_I, [C.POINTER(AliveConv), _VP]),

@@ -2,9 +2,9 @@
 
   match_features(source, reference, k=4, alpha=0.0)   <- /root/reference/module/common.py:96-109
 
-runs on the MI355X through libalive_vc.so: fp8- (or bf16-) MFMA candidate scoring with
+runs on the MI355X through libalive_vc.so: fp6- (or fp8- / bf16-) MFMA candidate scoring with
 LDS-staged top-k' lists, exact fp32 rescoring, gather-mean-blend.  The library
-is packed (normalised fp8 / bf16 rows + fp32 rows + norms) once per reference tensor
+is packed (normalised fp6 / fp8 / bf16 rows + fp32 rows + norms) once per reference tensor
 and cached, so the per-window calls of inference.py:129 only pay for the search.
 """
 import os
@@ -15,9 +15,11 @@ import torch
 from . import _native as nat
 
 DIM = 768
-# Candidate stage of the search: "fp8" (block-scaled e4m3 MFMA, 32 candidates per frame and library split) or "bf16"
-# (16 candidates); both feed the same exact fp32 rescoring.  env ALIVE_KNN_PREFILTER overrides.
-DEFAULT_PREFILTER = "fp8"
+# Candidate stage of the search: "fp6" (block-scaled e2m3 MFMA at twice the fp8 rate, 96 stationary frames per wave; round 5),
+# "fp8" (block-scaled e4m3 MFMA) -- both 32 candidates per frame and library split -- or "bf16" (16 candidates); all of them
+# feed the same exact fp32 rescoring and the same per-frame certificate.  env ALIVE_KNN_PREFILTER overrides.
+DEFAULT_PREFILTER = "fp6"
+_STAGES = ("bf16", "fp8", "fp6")
 
 
 def _prefilter():
@@ -40,8 +42,8 @@ class PackedLibrary:
     def __init__(self, tokens_DxM: torch.Tensor, idx_base: int = 0, prefilter: str = None, strict: bool = None):
         self.strict = _strict() if strict is None else bool(strict)
         self.prefilter = "bf16" if self.strict else (prefilter or _prefilter())
-        if self.prefilter not in ("bf16", "fp8"):
-            raise ValueError(f"prefilter must be 'bf16' or 'fp8', got {self.prefilter!r}")
+        if self.prefilter not in _STAGES:
+            raise ValueError(f"prefilter must be one of {_STAGES}, got {self.prefilter!r}")
         if tokens_DxM.dim() != 2 or tokens_DxM.shape[0] != DIM:
             raise ValueError(f"library must be [768, M], got {tuple(tokens_DxM.shape)}")
         t = tokens_DxM.contiguous().float()
@@ -63,16 +65,32 @@ class PackedLibrary:
             first = int(torch.nonzero(bad)[0])
             raise ValueError(f"voice library row {first + self.idx_base} has zero or non-finite norm ({int(bad.sum())} such rows): "
                              f"remove them (the reference would match every frame to them through NaN cosines)")
-        self.lib_f8 = None
-        if self.prefilter == "fp8":
-            self.lib_f8 = torch.empty(L.alive_library_fp8_bytes(self.M), dtype=torch.uint8, device=dev)
-            nat.check(L.alive_library_pack_fp8(nat.ptr(self.lib_bf16), self.M, nat.ptr(self.lib_f8), nat.stream()),
-                      "alive_library_pack_fp8")
+        self.lib_f8 = None                 # the fp8 OR the fp6 image of the rows (same size and tile layout), per self.prefilter
+        self.fp6_declined = False
+        if self.prefilter == "fp6" and self.M > 0:
+            # e2m3 x 2^5 ends at 7.5 / 32 = 0.234: a row of a unit-norm library with a larger element (a few dominant coordinates:
+            # "spiky" banks, never a dense content-encoder bank, whose elements are ~0.036 +- a few sigma) would be CLIPPED, and a clipped
+            # row's score is low by more than any per-frame error statistic shows -- such a library is searched through the fp8 stage
+            # (e4m3 x 2^8 reaches 1.75).  One reduction + sync per pack.  (A frame that clips is caught per search: knn.hip force_fail.)
+            if self._fp6_would_clip():
+                self.prefilter, self.fp6_declined = "fp8", True
+        if self.prefilter in ("fp8", "fp6"):
+            self.lib_f8 = self._pack_stage(self.prefilter)
         self.bound = None
         self.lib_lo = None
         if self.strict:
             self._make_bound()
         self._ws = nat.Workspace()
+
+    def _fp6_would_clip(self):
+        return self.M > 0 and float(self.lib_bf16[:self.M].abs().max()) > 7.75 / 32.0
+
+    def _pack_stage(self, prefilter):
+        L = nat.lib()
+        buf = torch.empty(L.alive_library_fp8_bytes(self.M), dtype=torch.uint8, device=self.rows.device)
+        fn = L.alive_library_pack_fp6 if prefilter == "fp6" else L.alive_library_pack_fp8
+        nat.check(fn(nat.ptr(self.lib_bf16), self.M, nat.ptr(buf), nat.stream()), "alive_library_pack_" + prefilter)
+        return buf
 
     def _make_bound(self):
         """max_R || r^ - bf16(r^) ||: the library's share of the strict certificate's deterministic bound -- and the library's lo
@@ -101,9 +119,10 @@ class PackedLibrary:
                                                 nat.ptr(self.bound), self.M, self.idx_base, k, nat.ptr(val), nat.ptr(idx),
                                                 nat.ptr(ws), nat.stream(), *ev), "alive_knn_search_strict")
         elif self.lib_f8 is not None:
-            nat.check(L.alive_knn_search_fp8_timed(nat.ptr(source), n, t, nat.ptr(self.lib_f8), nat.ptr(self.lib_bf16),
-                                                   nat.ptr(self.rows), nat.ptr(self.norms), self.M, self.idx_base, k,
-                                                   nat.ptr(val), nat.ptr(idx), nat.ptr(ws), nat.stream(), *ev), "alive_knn_search_fp8")
+            fn = L.alive_knn_search_fp6_timed if self.prefilter == "fp6" else L.alive_knn_search_fp8_timed
+            nat.check(fn(nat.ptr(source), n, t, nat.ptr(self.lib_f8), nat.ptr(self.lib_bf16),
+                         nat.ptr(self.rows), nat.ptr(self.norms), self.M, self.idx_base, k,
+                         nat.ptr(val), nat.ptr(idx), nat.ptr(ws), nat.stream(), *ev), "alive_knn_search_" + self.prefilter)
         else:
             nat.check(L.alive_knn_search_timed(nat.ptr(source), n, t, nat.ptr(self.lib_bf16), nat.ptr(self.rows),
                                                nat.ptr(self.norms), self.M, self.idx_base, k, nat.ptr(val), nat.ptr(idx),
@@ -115,21 +134,21 @@ class PackedLibrary:
     def with_prefilter(self, prefilter):
         """the same resident library searched through the other candidate stage (shares every tensor)"""
         import copy
-        if prefilter not in ("bf16", "fp8"):
+        if prefilter not in _STAGES:
             raise ValueError(prefilter)
         other = copy.copy(self)
         other.__dict__.pop("search", None)             # an instrumented search (bench.py) stays with the original
+        other.fp6_declined = prefilter == "fp6" and self._fp6_would_clip()
+        if other.fp6_declined:
+            prefilter = "fp8"
         other.prefilter = prefilter
         other.strict, other.bound, other.lib_lo = False, None, None
         other._ws = nat.Workspace()
         other._last = None
         if prefilter == "bf16":
             other.lib_f8 = None
-        elif self.lib_f8 is None:
-            L = nat.lib()
-            other.lib_f8 = torch.empty(L.alive_library_fp8_bytes(self.M), dtype=torch.uint8, device=self.rows.device)
-            nat.check(L.alive_library_pack_fp8(nat.ptr(self.lib_bf16), self.M, nat.ptr(other.lib_f8), nat.stream()),
-                      "alive_library_pack_fp8")
+        elif self.lib_f8 is None or self.prefilter != prefilter:
+            other.lib_f8 = self._pack_stage(prefilter)
         return other
 
     def with_strict(self):
@@ -154,10 +173,10 @@ class PackedLibrary:
             return dict(st, tier="exact scan of every row (streaming)")
         if tier == 2:
             return dict(st, tier="exact scan of every row (k > 8)")
-        if tier not in (3, 4):
+        if tier not in (3, 4, 5):
             raise RuntimeError(f"alive_knn_search_stats: no search has run on this workspace (tier word {tier})")
         few = 0
-        if tier == 4:
+        if tier in (4, 5):              # fp8 / fp6 stage first (the counters keep their fp8 names: "the first, low-precision stage")
             # [0] frames that failed the fp8 certificate: up to [11] of them go straight to the exact scan (knn.hip RESEARCH_MIN)
             few = c[0] if c[0] <= c[11] else 0
             st.update(frames_failed_fp8_certificate=c[0], frames_researched_on_bf16=0 if few else c[0], probe_sample=c[2],

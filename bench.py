@@ -34,7 +34,8 @@ import torch.distributed as dist                           # noqa: E402
 FRAME = 320
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_FP8_TFLOPS = 5000.0           # dense fp8 MFMA peak (block-scaled 32x32x64 e4m3), same table
-ALL_LEGS = ("uncorrelated", "bf16_prefilter", "strict_knn", "clustered_library", "overlap_shared", "context_trim", "cli_default", "pcie_inclusive", "e2e_24k", "config2",
+PEAK_FP6_TFLOPS = 10000.0          # dense fp6 / fp4 MFMA peak (block-scaled 32x32x64 e2m3: "FP6 at FP4 rate"), same table
+ALL_LEGS = ("uncorrelated", "fp8_prefilter", "bf16_prefilter", "strict_knn", "clustered_library", "overlap_shared", "context_trim", "cli_default", "pcie_inclusive", "e2e_24k", "config2",
             "streaming", "cpu_baseline")
 
 
@@ -310,13 +311,14 @@ def main():
     # ---- roofline of the scoring kernel ----
     ms, flops, launches = timer.totals()
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    fp8 = library.prefilter == "fp8"
-    peak = PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS
+    stage = library.prefilter                                 # "fp6" (default since round 5), "fp8" or "bf16"
+    fp8 = stage in ("fp8", "fp6")
+    peak = {"fp6": PEAK_FP6_TFLOPS, "fp8": PEAK_FP8_TFLOPS}.get(stage, PEAK_BF16_TFLOPS)
     # `traffic` (HBM bytes per launch from PMC counters) cannot be collected inside this run -- counters need rocprofv3 around the
     # process -- so it is null here; what the committed profile of the same kernel on the same shape measured is reported beside it
     # under a name of its own, with the file it comes from
     traffic_profiled = None
-    pmc_name = "knn_score8_pmc.json" if fp8 else "knn_score_pmc.json"
+    pmc_name = {"fp6": "knn_score6_pmc.json", "fp8": "knn_score8_pmc.json"}.get(stage, "knn_score_pmc.json")
     pmc = os.path.join(ROOT, "profiles", pmc_name)
     if os.path.exists(pmc):
         pj = json.load(open(pmc))
@@ -324,9 +326,11 @@ def main():
                             "mfma_pipe_utilisation": pj.get("mfma_pipe_utilisation"), "l2_hit_rate": pj.get("l2_hit_rate"),
                             "source_commit": pj.get("source_commit"),
                             "source": "profiles/" + pmc_name + " (rocprofv3 --pmc passes of tools/pmc_knn8.sh over the same kernel and shape, not this run)"}
-    roofline = {"kernel": "knn_score8_kernel" if fp8 else "knn_score_kernel", "bound": "mfma", "achieved": round(achieved, 1),
+    roofline = {"kernel": {"fp6": "knn_score6_kernel", "fp8": "knn_score8_kernel"}.get(stage, "knn_score_kernel"), "bound": "mfma",
+                "achieved": round(achieved, 1),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None, "traffic_profiled": traffic_profiled,
-                "mfma_dtype": "fp8 e4m3, block-scaled 32x32x64" if fp8 else "bf16 32x32x16",
+                "mfma_dtype": {"fp6": "fp6 e2m3 (both operands), block-scaled 32x32x64", "fp8": "fp8 e4m3, block-scaled 32x32x64"}.get(stage, "bf16 32x32x16"),
+                "frac_of_fp8_peak": round(achieved / PEAK_FP8_TFLOPS, 4) if stage == "fp6" else None,
                 "launches": launches, "avg_launch_ms": round(ms / max(1, launches), 3),
                 "kernel_share_of_step": round(ms * 1e-3 / dt, 3), "search_ms": round(timer.search_ms(), 2),
                 "search_tiers_last_step": stats}
@@ -390,6 +394,26 @@ def main():
             roofline["uncorrelated_error"] = err
     timer.unwrap(library)
 
+    # The same step with the fp8 candidate stage, the default of rounds 2-4 (ALIVE_KNN_PREFILTER=fp8): same library object
+    if "fp8_prefilter" in legs and library.prefilter != "fp8":
+        def leg():
+            lib8 = library.with_prefilter("fp8")
+            t8 = ScoreTimer(nat)
+            t8.wrap(lib8)
+            conv.set_library(lib8)
+            try:
+                conv.convert_windows(windows, k=args.k, window_batch=args.window_batch)
+                t8.clear()
+                tb, o8 = timed_steps(step, 2)
+                ms8, fl8, n8 = t8.totals()
+                return {"ms_per_step": round(tb * 1e3, 2), "frames_per_s": round(frames_per_step / tb, 1),
+                        "scoring_tflops": round(fl8 / (ms8 * 1e-3) / 1e12, 1), "scoring_ms_per_launch": round(ms8 / n8, 3),
+                        "frac_of_fp8_peak": round(fl8 / (ms8 * 1e-3) / 1e12 / PEAK_FP8_TFLOPS, 4), "search_ms": round(t8.search_ms(), 2),
+                        "waveforms_equal_default_stage": bool(torch.equal(o8, out)), "search_tiers": lib8.search_stats()}
+            finally:
+                conv.set_library(library)
+        extra["fp8_prefilter"] = guarded(leg)
+
     # The same step with the bf16 candidate stage (ALIVE_KNN_PREFILTER=bf16): same library object, fp8 image unused
     if "bf16_prefilter" in legs:
         def leg():
@@ -438,7 +462,7 @@ def main():
             toks = ce_derived_tokens(conv, M, dev)
             res = {}
             outs = {}
-            for pf in ("fp8", "bf16"):
+            for pf in (library.prefilter, "bf16") if library.prefilter != "bf16" else ("fp8", "bf16"):
                 libc = PackedLibrary(toks, prefilter=pf)
                 tc = ScoreTimer(nat)
                 tc.wrap(libc)
@@ -452,8 +476,9 @@ def main():
                            "search_effective_tflops": round(flc / nc / (tc.search_ms() * 1e-3) / 1e12, 1),
                            "search_tiers": libc.search_stats()}
                 del libc
-            res["default_vs_bf16_prefilter"] = round(res["fp8"]["ms_per_step"] / res["bf16"]["ms_per_step"], 4)
-            res["waveforms_equal_across_stages"] = bool(torch.equal(outs["fp8"], outs["bf16"]))
+            first = [pf for pf in res if pf != "bf16"][0]
+            res["default_vs_bf16_prefilter"] = round(res[first]["ms_per_step"] / res["bf16"]["ms_per_step"], 4)
+            res["waveforms_equal_across_stages"] = bool(torch.equal(outs[first], outs["bf16"]))
             res["library"] = f"{M} content-encoder frames of synthetic audio of the bench batch's signal family (dense: SURVEY 8(d))"
             return res
         try:
@@ -640,9 +665,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("fp8 (e4m3) MFMA candidate scoring + exact f32 rescoring, every frame certified at 7 sigma of its measured "
-                      "stage error (statistical: audited against brute force, profiles/r03_knn_audit.json; ALIVE_KNN_STRICT=1 is the "
-                      "deterministic form)" if library.prefilter == "fp8" else
+            "dtype": ({"fp6": "fp6 (e2m3)", "fp8": "fp8 (e4m3)"}[library.prefilter] + " MFMA candidate scoring + exact f32 rescoring, every frame "
+                      "certified at 7 sigma of its measured stage error (statistical: audited against brute force on every frame of this "
+                      "batch, tests/test_gpu_knn_audit.py; ALIVE_KNN_STRICT=1 is the deterministic form)" if library.prefilter in ("fp8", "fp6") else
                       "bf16 MFMA scoring + exact f32 rescoring, certified per frame" + (" (deterministic bound)" if library.strict else "")) + "; 3-plane split-bf16 (fp32-grade) encoder GEMMs; 2-plane split-bf16 decoder GEMMs; f32 MFMA DFT / strided / small-channel convs; f64 phase scan",
             "data": "synthetic",
             "config": {"workload": f"{args.utterances} utterances x {args.seconds:g} s per GPU -> {n_win} windows x "

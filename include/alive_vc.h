@@ -126,7 +126,7 @@ int alive_knn_search_strict(const float* src, int N, int T,
  *   sent on to the exact scan  [2] probe sample size  [3] probe failures  [9] / [10] fp8 / bf16 blocks that started from seeds
  *   [11] / [12] the two limits just named (64, 256), written with the counters
  *   [4] 1 = the probe chose bf16 first  [7] the path taken: 1 streaming scan, 2 exact scan of every frame (k > 8),
- *   3 bf16 first, 4 fp8 first.  (alive_knn_search fills [1] and [7] only.)  The counters sit at the start of ws. */
+ *   3 bf16 first, 4 fp8 first, 5 fp6 first.  (alive_knn_search fills [1] and [7] only.)  The counters sit at the start of ws. */
 size_t alive_library_fp8_bytes(int64_t M);
 int alive_library_pack_fp8(const void* lib_bf16, int64_t M, void* lib_f8, void* stream);
 int alive_knn_search_fp8(const float* src, int N, int T,
@@ -143,6 +143,25 @@ int alive_knn_search_timed(const float* src, int N, int T,
                            float* out_val, int32_t* out_idx, void* ws, void* stream, void* ev_start, void* ev_stop);
 int alive_knn_search_fp8_timed(const float* src, int N, int T,
                                const void* lib_f8, const void* lib_bf16, const float* rows_f32, const float* norms,
+                               int64_t M, int64_t idx_base, int k,
+                               float* out_val, int32_t* out_idx, void* ws, void* stream, void* ev_start, void* ev_stop);
+
+/* Round 5: the same tiered search with the first candidate stage on the fp6 form of that MFMA (OCP e2m3 operands on both sides =
+ * normalised rows x 2^5, scales 2^0; /root/reference/module/common.py:100-105 is still what comes out).  The matrix pipe runs e2m3
+ * at twice the e4m3 rate, and for unit vectors a 1/8 grid is as accurate as three mantissa bits (score error 1.8e-3 in cosine
+ * against 1.35e-3): the per-frame certificate is the fp8 stage's with a prior of 2.0e-3, the lists are as deep (32 candidates per
+ * frame and library split), frames that fail go to the bf16 stage exactly as above.  A wave keeps 96 frames stationary (216
+ * registers) and a block 384, so one 32-byte LDS fragment feeds three MFMAs.
+ *   lib_f6[M_pad][D]: alive_library_fp8_bytes(M) bytes from alive_library_pack_fp6 -- every group of 32 features keeps its 32-byte
+ *   slot: 32 six-bit codes as a little-endian bit stream in the first 24 bytes, 8 bytes of zeros.
+ *   Workspace, outputs, counters (alive_knn_search_stats; [7] = 5: fp6 first) as for alive_knn_search_fp8. */
+int alive_library_pack_fp6(const void* lib_bf16, int64_t M, void* lib_f6, void* stream);
+int alive_knn_search_fp6(const float* src, int N, int T,
+                         const void* lib_f6, const void* lib_bf16, const float* rows_f32, const float* norms,
+                         int64_t M, int64_t idx_base, int k,
+                         float* out_val, int32_t* out_idx, void* ws, void* stream);
+int alive_knn_search_fp6_timed(const float* src, int N, int T,
+                               const void* lib_f6, const void* lib_bf16, const float* rows_f32, const float* norms,
                                int64_t M, int64_t idx_base, int k,
                                float* out_val, int32_t* out_idx, void* ws, void* stream, void* ev_start, void* ev_stop);
 

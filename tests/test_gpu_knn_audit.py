@@ -41,7 +41,7 @@ def run_case(env, name, frames, modes, k=4):
     bv, bi = A.brute_topk(qn, A.normalise_rows(toks.t().contiguous()), k + 1)
     out = {}
     for mode in modes:
-        lib = PackedLibrary(toks, prefilter="fp8" if mode == "fp8" else "bf16", strict=(mode == "strict"))
+        lib = PackedLibrary(toks, prefilter=mode if mode in ("fp8", "fp6") else "bf16", strict=(mode == "strict"))
         val, idx = lib.search(feat, k)
         r = A.compare(val, idx, bv, bi, k)
         r["tiers"] = lib.search_stats()
@@ -55,13 +55,14 @@ def run_case(env, name, frames, modes, k=4):
 @pytest.mark.parametrize("name", ["randn", "dense"])
 def test_every_frame_of_the_bench_batch_against_brute_force(env, name):
     """all 172 800 frames x 1 M rows, the bench's i.i.d. library and the dense content-encoder library"""
-    res = run_case(env, name, 172_800, ("fp8", "bf16", "strict"))
+    res = run_case(env, name, 172_800, ("fp6", "fp8", "bf16", "strict"))
     for mode, (r, _, _) in res.items():
         assert r["frames"] == 172_800 and r["safe_frames"] > 0.98 * r["frames"], (name, mode, r)
         assert r["mismatches"] == 0, (name, mode, r)
         assert r["max_abs_value_error"] <= 2e-6, (name, mode, r)
-    # the three searches return the same exact lists (ties to the lower index in every tier)
+    # the four searches return the same exact lists (ties to the lower index in every tier)
     assert torch.equal(res["fp8"][2], res["bf16"][2]) and torch.equal(res["fp8"][1], res["bf16"][1])
+    assert torch.equal(res["fp6"][2], res["bf16"][2]) and torch.equal(res["fp6"][1], res["bf16"][1])
     assert torch.equal(res["strict"][2], res["bf16"][2])
     assert res["strict"][0]["tiers"]["certificate"] == "deterministic"
     if name == "dense":              # round 4: the strict search's failed certificates (43 % of the frames: the deterministic 1.8e-3 band
@@ -77,6 +78,9 @@ def test_every_frame_of_the_bench_batch_against_brute_force(env, name):
         t8 = res["fp8"][0]["tiers"]
         assert t8["frames_researched_on_bf16"] == 0 and t8["frames_failed_fp8_certificate"] <= 16, t8
         assert 0 < t8["fp8_blocks_seeded"] <= 2 * 675, t8    # scheduling-dependent count (one non-blocking look per block)
+        t6 = res["fp6"][0]["tiers"]                          # the fp6 stage (default since round 5): 450 blocks of 384 frames x 5 splits
+        assert t6["frames_failed_fp8_certificate"] <= 256, t6        # (a few dozen: tier 1a of the bf16 re-search, or the exact scan)
+        assert 0 < t6["fp8_blocks_seeded"] <= 4 * 450, t6
 
 
 @pytest.mark.parametrize("name", ["randn_iid", "spiky", "spiky_self", "norms", "mixture", "lowrank", "self", "dense_self", "clusters"])
@@ -84,7 +88,7 @@ def test_adversarial_libraries_against_brute_force(env, name):
     """rows with 1-8 dominant coordinates, norms over six decades, a dense / spiky mixture with queries that carry a matching
     spike, rank-16 rows, queries that are library rows, clusters of near-copies denser than any stage's error"""
     frames = 450 * (8 if name == "clusters" else 48)             # clusters: every frame fails every certificate
-    res = run_case(env, name, frames, ("fp8", "bf16", "strict"))
+    res = run_case(env, name, frames, ("fp6", "fp8", "bf16", "strict"))
     for mode, (r, _, _) in res.items():
         assert r["mismatches"] == 0, (name, mode, r)
         assert r["max_abs_value_error"] <= 2e-6, (name, mode, r)
@@ -92,7 +96,7 @@ def test_adversarial_libraries_against_brute_force(env, name):
     if name == "clusters":           # clusters of 40 near-copies: every frame fails every certificate, and since round 4 the collect tiers
                                      # (64 rows per frame and split; the split-bf16 pass in the strict search) hold a whole cluster -- no frame
                                      # is left for the exact scan (round 3: all of them, 955 ms per search instead of 60 - 110)
-        for mode in ("fp8", "bf16", "strict"):
+        for mode in ("fp6", "fp8", "bf16", "strict"):
             t = res[mode][0]["tiers"]
             assert t["frames_failed_bf16_certificate"] > 0.95 * frames and t["frames_searched_exactly"] == 0, (mode, t)
         assert res["strict"][0]["tiers"]["frames_collected_on_split_bf16"] > 0.95 * frames
@@ -102,14 +106,15 @@ def test_adversarial_libraries_against_brute_force(env, name):
 def test_seeded_admission_on_adversarial_libraries_at_batch_scale(env, name):
     """The seeded admission of the fp8 stage (knn.hip: batches of >= 512 frame blocks) on the libraries whose fp8 errors are
     heavy-tailed: 138 150 frames (540 blocks) against brute force and against the bf16-first search, which has no seeds."""
-    res = run_case(env, name, 138_240, ("fp8", "bf16"))
+    res = run_case(env, name, 138_240, ("fp6", "fp8", "bf16"))
     for mode, (r, _, _) in res.items():
         assert r["frames"] == 138_150 and r["mismatches"] == 0, (name, mode, r)
         assert r["max_abs_value_error"] <= 2e-6, (name, mode, r)
-    assert torch.equal(res["fp8"][2], res["bf16"][2]) and torch.equal(res["fp8"][1], res["bf16"][1])
-    t8 = res["fp8"][0]["tiers"]
-    if not t8["probe_chose_bf16_first"]:
-        assert t8["fp8_blocks_seeded"] > 0, t8               # typically every block of the later splits; the count is scheduling-dependent
+    for low in ("fp8", "fp6"):
+        assert torch.equal(res[low][2], res["bf16"][2]) and torch.equal(res[low][1], res["bf16"][1])
+        t8 = res[low][0]["tiers"]
+        if not t8["probe_chose_bf16_first"]:
+            assert t8["fp8_blocks_seeded"] > 0, (low, t8)    # typically every block of the later splits; the count is scheduling-dependent
 
 
 def test_search_counters_do_not_depend_on_k(env):
@@ -119,14 +124,14 @@ def test_search_counters_do_not_depend_on_k(env):
     A, bench, conv, dev = env
     toks = torch.randn(768, 50_000, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
     feat = torch.randn(90, 768, 450, device=dev, generator=torch.Generator(device=dev).manual_seed(4))       # 40 500 frames
-    for pf in ("fp8", "bf16"):
+    for pf in ("fp6", "fp8", "bf16"):
         lib = PackedLibrary(toks, prefilter=pf)
         ref = None
         for k in (4, 8):
             val, idx = lib.search(feat, k)
             st = lib.search_stats()
             assert st["frames"] == 40_500 and 0 <= st["frames_searched_exactly"] <= 64, (pf, k, st)
-            if pf == "fp8":
+            if pf in ("fp8", "fp6"):
                 assert st["probe_sample"] == 1024 and 0 <= st["frames_researched_on_bf16"] <= 4096, (pf, k, st)
             if ref is not None:                                   # the k = 8 lists start with the k = 4 lists
                 assert torch.equal(idx[:, :4], ref)

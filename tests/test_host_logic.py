@@ -358,6 +358,20 @@ def test_fp8_scoring_kernel_listing_keeps_two_accumulator_sets(tmp_path):
     assert not moved, moved[:4]
     reads = sum("v_accvgpr_read" in body[i] for i in range(mf[0], mf[47]))
     assert reads == 64, reads                            # 32 per tile body: the explicit late copies and nothing else
+    # the fp6 kernel of round 5 (three column tiles per wave): three tile-pairs of accumulator tuples, 36 MFMAs per tile body on e2m3
+    # operands of SIX registers each (an eight-register operand class would not fit 96 stationary frames), no spills
+    start = [i for i, l in enumerate(ls) if "knn_score6_kernel" in l and l.startswith("_ZN") and ":" in l][0]
+    end = [i for i, l in enumerate(ls) if i > start and ".amdhsa_kernel" in l][0]
+    body = ls[start:end]
+    mf = [i for i, l in enumerate(body) if "v_mfma_scale_f32_32x32x64_f8f6f4" in l]
+    assert len(mf) == 108, len(mf)
+    assert all("cbsz:2 blgp:2" in body[i] for i in mf)
+    ops = [re.search(r"f8f6f4 (a\[\d+:\d+\]), ([av]\[(\d+):(\d+)\]), ([av]\[(\d+):(\d+)\])", body[i]) for i in mf]
+    assert all(o and int(o.group(4)) - int(o.group(3)) == 5 and int(o.group(7)) - int(o.group(6)) == 5 for o in ops)
+    assert len({o.group(1) for o in ops[:72]}) == 6
+    meta = "\n".join(ls)
+    m6 = re.search(r"\.name:\s+\S*knn_score6_kernel\S*\n(.*?)\.wavefront_size", meta, re.S).group(1)
+    assert re.search(r"\.vgpr_spill_count:\s+0\b", m6) and re.search(r"\.private_segment_fixed_size:\s+0\b", m6), m6
 
 
 def test_network_constructors_keep_the_reference_signature():

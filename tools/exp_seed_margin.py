@@ -6,8 +6,8 @@ from module.common import PackedLibrary
 dev = "cuda"; N, T, M = 384, 450, 1_000_000
 g = torch.Generator(device=dev).manual_seed(1)
 lib = PackedLibrary(torch.randn(768, M, device=dev, generator=g))
-mode = os.environ.get("EXP_MODE", "fp8")                 # fp8 | bf16 | strict
-if mode == "bf16": lib = lib.with_prefilter("bf16")
+mode = os.environ.get("EXP_MODE", "fp6")                 # fp6 | fp8 | bf16 | strict
+if mode in ("bf16", "fp8", "fp6"): lib = lib.with_prefilter(mode)
 if mode == "strict": lib = lib.with_strict()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record(); b.record()          # (created on first record: the C side records them again)
