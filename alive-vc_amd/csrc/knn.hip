@@ -1161,8 +1161,13 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
         }
         f32x16 v0, v1, v2;
         auto acc_read = [&](const f32x16& a_, int lo, int hi, f32x16& v) {
+#ifdef ALIVE_KNN_ABL_NOREAD            // ablation (timing only, WRONG results): what the 48 accumulator copies of a tile cost
+#pragma unroll
+            for (int r = lo; r < hi; ++r) v[r] = -INFINITY;
+#else
 #pragma unroll
             for (int r = lo; r < hi; ++r) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[r]) : "a"(a_[r]));
+#endif
         };
         auto acc_pin = [&]() { asm volatile("" : "+a"(c0), "+a"(c1), "+a"(c2)); };
         K8_STEP3(0, (void)0, (void)0, (void)0) K8_STEP3(1, (void)0, (void)0, (void)0) K8_STEP3(2, (void)0, (void)0, (void)0)
@@ -1175,7 +1180,7 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
         K8_STEP3(10, (acc_pin(), pm2 = max8(v2, 0, pm2)), pm2 = max8(v2, 8, pm2), fold_rare(v2, 2, tile - 1, pm2))
         K8_STEP3(11, (void)0, (void)0, (void)0)
 #undef K8_STEP3
-        asm volatile("" : "+a"(c0), "+a"(c1), "+a"(c2));
+        acc_pin();
         __syncthreads();
     };
     auto fold_now3 = [&](f32x16& p0, f32x16& p1, f32x16& p2, int tile) {
