@@ -19,6 +19,7 @@ Prints ONE JSON line on rank 0.  Secondary legs (`--legs`) sit beside the headli
 """
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -35,7 +36,7 @@ FRAME = 320
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_FP8_TFLOPS = 5000.0           # dense fp8 MFMA peak (block-scaled 32x32x64 e4m3), same table
 PEAK_FP6_TFLOPS = 10000.0          # dense fp6 / fp4 MFMA peak (block-scaled 32x32x64 e2m3: "FP6 at FP4 rate"), same table
-ALL_LEGS = ("uncorrelated", "fp8_prefilter", "bf16_prefilter", "strict_knn", "clustered_library", "overlap_shared", "context_trim", "cli_default", "pcie_inclusive", "e2e_24k", "config2",
+ALL_LEGS = ("uncorrelated", "fp8_prefilter", "bf16_prefilter", "strict_knn", "clustered_library", "overlap_shared", "context_trim", "cli_default", "library_build", "pcie_inclusive", "e2e_24k", "config2",
             "streaming", "cpu_baseline")
 
 
@@ -539,6 +540,36 @@ def main():
                             "encoder once per utterance (+ the f0 estimator on the two 14-frame edge blocks of every window), kNN match on "
                             "frames [cf-32, (per-1) cf + 2cf+16) of every utterance, decoder on frames [cf-32, 2cf+16) of every window"}
         extra["cli_default"] = guarded(leg)
+
+    # SURVEY 8 f3 at scale (never `value`): generate_voice_library.py's device work for a 200 000-vector bank -- the content encoder
+    # over a synthetic corpus of 25 000 clips of 7 680 samples (the reference's clip length: 24 frames each), eight frames per clip
+    # (the reference draws from frames 0..7), then --dedup 0.98 (the library's own kNN kernel against itself + alive_dedup_pass)
+    if "library_build" in legs:
+        def leg():
+            import generate_voice_library as G
+            n_clips, fpc = 25_000, 8
+            gl = torch.Generator(device=dev).manual_seed(77)
+            t = torch.arange(G.CLIP, device=dev, dtype=torch.float32) / 16000.0
+            toks = torch.empty(768, n_clips * fpc, device=dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for s0 in range(0, n_clips, 1000):
+                nb = min(1000, n_clips - s0)
+                f = 80.0 + 400.0 * torch.rand(nb, 1, device=dev, generator=gl)
+                clips = 0.4 * torch.sin(2 * math.pi * f * t) + 0.2 * torch.sin(2 * math.pi * 2.7 * f * t + 1.0) \
+                    + 0.05 * torch.randn(nb, G.CLIP, device=dev, generator=gl)
+                feats = conv.ce(G.spectrogram(clips))                           # [nb, 768, 24]
+                toks[:, s0 * fpc:(s0 + nb) * fpc] = feats[:, :, :fpc].permute(1, 0, 2).reshape(768, nb * fpc)
+            torch.cuda.synchronize()
+            t_enc = time.perf_counter() - t0
+            keep = G.dedup_mask(toks, 0.98)
+            torch.cuda.synchronize()
+            t_all = time.perf_counter() - t0
+            n = toks.shape[1]
+            return {"vectors": n, "kept_after_dedup": int(keep.sum()), "encode_s": round(t_enc, 3), "dedup_s": round(t_all - t_enc, 3),
+                    "vectors_per_s": round(n / t_all, 1), "frames_encoded": n_clips * 24,
+                    "note": "content encoder in batches of 1000 clips (24 frames each, 8 kept), greedy --dedup 0.98 through the k = 8 self-search of the bank"}
+        extra["library_build"] = guarded(leg)
 
     # PCIe-inclusive rate (never `value`): the same step with the windows arriving from pinned host memory and the
     # waveforms returned to it, as the CLI edge does (inference.py:88-94,134)

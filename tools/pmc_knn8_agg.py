@@ -1,12 +1,14 @@
-"""aggregate tools/pmc_knn8.sh passes -> profiles/knn_score8_pmc.json: python tools/pmc_knn8_agg.py gpurun_out/pmc8_<tag>
+"""aggregate tools/pmc_knn8.sh passes -> profiles/knn_score6_pmc.json: python tools/pmc_knn8_agg.py gpurun_out/pmc8_<tag> [kernel]
+(kernel: knn_score6_kernel, the default stage since round 5, or knn_score8_kernel with ALIVE_KNN_PREFILTER=fp8 in the passes)
 bench_knn.py launches the scoring kernel 1 (warm) + reps times; counters are averaged per launch."""
 import csv, glob, json, os, sys
 root = sys.argv[1]
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else "knn_score6_kernel"
 cnt, ms = {}, []
 for f in sorted(glob.glob(os.path.join(root, "pass*", "run_counter_collection.csv"))):
     seen = {}
     for r in csv.DictReader(open(f)):
-        if "knn_score8_kernel" not in r["Kernel_Name"]:
+        if KERNEL not in r["Kernel_Name"]:
             continue
         seen.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
         seen[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
@@ -26,20 +28,27 @@ try:
 except Exception:
     commit = ""
 out = {
-    "kernel": "knn_score8_kernel",
+    "kernel": KERNEL,
     "source_commit": commit,
-    "workload": "one launch: 172800 frames (384 windows x 450) x 1,000,000-vector library, split 3 (tools/bench_knn.py 384 450 1000000 1 biased; tools/pmc_knn8.sh, one counter group per pass)",
+    "workload": "one launch: 172800 frames (384 windows x 450) x 1,000,000-vector library (tools/bench_knn.py 384 450 1000000 1 biased; tools/pmc_knn8.sh, one counter group per pass); fp6: 450 blocks of 384 frames x 5 library splits, fp8: 675 blocks of 256 frames x 3 splits",
     "launch_ms_profiled": round(sum(ms) / max(1, len(ms)), 1),
     "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
     "hbm_bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024),
     "hbm_bytes_formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); separate --pmc passes; Infinity-Cache hits are included in FETCH_SIZE",
     "algorithmic_bytes_per_launch": M * 768 + Tt * 768,
-    "algorithmic_bytes_formula": "M*768 (fp8 library once) + T*768 (fp8 frames once)",
+    "algorithmic_bytes_formula": "M*768 (fp8 library once; fp6: the same 32-byte slots per 32 features, 24 bytes of them codes) + T*768 (frames once)",
     "counters_per_launch": {k: v for k, v in sorted(cnt.items())},
 }
 if "SQ_VALU_MFMA_BUSY_CYCLES" in cnt and "GRBM_GUI_ACTIVE" in cnt:
     out["mfma_pipe_utilisation"] = round(cnt["SQ_VALU_MFMA_BUSY_CYCLES"] / (cnt["GRBM_GUI_ACTIVE"] / 8 * 1024), 3)
     out["mfma_pipe_formula"] = "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)"
+if cnt.get("SQ_WAVE_CYCLES"):
+    for key, name in (("SQ_ACTIVE_INST_VALU", "valu_issue_share_of_wave_cycles"), ("SQ_ACTIVE_INST_LDS", "lds_issue_share_of_wave_cycles"),
+                      ("SQ_WAIT_INST_ANY", "wave_cycles_waiting_for_an_instruction")):
+        if key in cnt:
+            out[name] = round(cnt[key] / cnt["SQ_WAVE_CYCLES"], 3)
+if cnt.get("SQ_VALU_MFMA_BUSY_CYCLES") and "SQ_VALU_MFMA_COEXEC_CYCLES" in cnt:
+    out["mfma_cycles_with_valu_coexecuting"] = round(cnt["SQ_VALU_MFMA_COEXEC_CYCLES"] / cnt["SQ_VALU_MFMA_BUSY_CYCLES"], 3)
 if "TCC_HIT_sum" in cnt:
     out["l2_hit_rate"] = round(cnt["TCC_HIT_sum"] / (cnt["TCC_HIT_sum"] + cnt["TCC_MISS_sum"]), 3)
 if "SQ_LDS_BANK_CONFLICT" in cnt:
