@@ -1137,25 +1137,36 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
         const unsigned char* Ab = smem + buf * ABUF8;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { c0[r] = 0.0f; c1[r] = 0.0f; c2[r] = 0.0f; }
-        v8i a[2];
-        a[0] = load_a(Ab, 0);
+#ifndef ALIVE_KNN6_PD
+#define ALIVE_KNN6_PD 1                 // A fragments requested this many k-steps ahead of their MFMAs
+#endif
+        constexpr int PD6 = ALIVE_KNN6_PD, NA6 = PD6 + 1;
+        // ablation switches (timing only, WRONG results: tools/ab_build.sh x.so knn.hip -DALIVE_KNN6_ABL=<bits>): 1 no LDS-DMA of the next
+        // tile, 2 no fragment reads after the tile's first, 4 no barrier at the end of the tile
+#ifndef ALIVE_KNN6_ABL
+#define ALIVE_KNN6_ABL 0
+#endif
+        constexpr bool ABL_NODMA = (ALIVE_KNN6_ABL & 1) != 0, ABL_NOLDS = (ALIVE_KNN6_ABL & 2) != 0, ABL_NOBAR = (ALIVE_KNN6_ABL & 4) != 0;
+        v8i a[NA6];
+#pragma unroll
+        for (int i = 0; i < PD6; ++i) a[i] = load_a(Ab, i);
         float pm0 = -INFINITY, pm1 = -INFINITY, pm2 = -INFINITY;
         ALIVE_CHAIN_GAP(7);
 #define K8_STEP3(ks, AFTER0, AFTER1, AFTER2)                                                                                     \
         {                                                                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                                                   \
-            c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(ks) & 1], bq[0][ks], c0, FMT, FMT, 0, 127, 0, 127); \
+            c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(ks) % NA6], bq[0][ks], c0, FMT, FMT, 0, 127, 0, 127); \
             __builtin_amdgcn_sched_barrier(0);                                                                                   \
-            if ((ks) + 1 < NK64) a[((ks) + 1) & 1] = load_a(Ab, (ks) + 1);                                                       \
-            if ((ks) < D / 128)                                                                                                  \
+            if ((ks) + PD6 < NK64 && !ABL_NOLDS) a[((ks) + PD6) % NA6] = load_a(Ab, (ks) + PD6);                                 \
+            if ((ks) < D / 128 && !ABL_NODMA)                                                                                    \
                 __builtin_amdgcn_global_load_lds((gptr_t)(gnext + (ks) * 128), (lptr_t)(lnext + (ks) * 4 * PIECE), 16, 0, 0);    \
             AFTER0;                                                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                                                   \
-            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(ks) & 1], bq[1][ks], c1, FMT, FMT, 0, 127, 0, 127); \
+            c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(ks) % NA6], bq[1][ks], c1, FMT, FMT, 0, 127, 0, 127); \
             __builtin_amdgcn_sched_barrier(0);                                                                                   \
             AFTER1;                                                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                                                   \
-            c2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(ks) & 1], bq[2][ks], c2, FMT, FMT, 0, 127, 0, 127); \
+            c2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(ks) % NA6], bq[2][ks], c2, FMT, FMT, 0, 127, 0, 127); \
             __builtin_amdgcn_sched_barrier(0);                                                                                   \
             AFTER2;                                                                                                              \
         }
@@ -1181,7 +1192,7 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
         K8_STEP3(11, (void)0, (void)0, (void)0)
 #undef K8_STEP3
         acc_pin();
-        __syncthreads();
+        if (!ABL_NOBAR) __syncthreads();
     };
     auto fold_now3 = [&](f32x16& p0, f32x16& p1, f32x16& p2, int tile) {
         mask_ragged(p0, tile);
