@@ -127,6 +127,60 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
         }
         return;
     }
+    if constexpr (ACT == 4) {
+        // Magnitudes of (re, im) row pairs -> plane-packed channels (include/alive_vc.h, AliveGemm.act == 4).  The wave's 64 rows are
+        // 32 bins = exactly one k-block of the output planes (bin0 = (m0 + 64 wr) / 2 is a multiple of 32), so per plane the wave
+        // writes, for each of its 64 columns, one whole 64-byte row segment.  A lane holds PAIRS of bins (rows 8 g + 4 lh + {0..3} =
+        // re, im, re, im), so the tile goes through the wave's 2-KB LDS tile, one 32-column half and plane at a time: written as
+        // 4-byte words [column][32 bins] (16-byte chunks swizzled by (column >> 2) & 3), read back as 16-byte pieces, four lanes
+        // per column -- 16 columns x 64 B per store instruction, a contiguous 1-KB run of the k-blocked planes.
+        unsigned char* st = stage_small != nullptr ? stage_small : stage;
+        unsigned short* Po = (unsigned short*)p.Pout;
+        const int bins = p.Co >> 1;
+        const int bin0 = (m0 + wr * 64) >> 1;
+        const int lane = lr + 32 * lh;
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            float q[2][4][2];
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int bin = bin0 + 16 * ti + 4 * g + 2 * lh + e;
+                        const float m = hypotf(acc[ti][tj][4 * g + 2 * e], acc[ti][tj][4 * g + 2 * e + 1]);
+                        q[ti][g][e] = bin < bins ? m : 0.0f;
+                    }
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        // bins 16 ti + 4 g + 2 lh + {0, 1}: bytes 32 ti + 8 g + 4 lh of the column's 64
+                        const unsigned h = pack_bf16x2(q[ti][g][0], q[ti][g][1]);
+                        *(unsigned*)(st + lr * 64 + (((2 * ti + (g >> 1)) ^ ((lr >> 2) & 3)) << 4) + 8 * (g & 1) + 4 * lh) = h;
+                        q[ti][g][0] -= __uint_as_float(h << 16);
+                        q[ti][g][1] -= __uint_as_float(h & 0xffff0000u);
+                    }
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int idx = it * 64 + lane, cl = idx >> 2, chunk = idx & 3;
+                    const u32x4 v = *(const u32x4*)(st + cl * 64 + ((chunk ^ ((cl >> 2) & 3)) << 4));
+                    const int64_t col = c0 + wc * 64 + tj * 32 + cl;
+                    const int b = bin0 + chunk * 8;
+                    if (col < cols_pad && b < co_pad32) *(u32x4*)(Po + planes_at(pl, col, b, cols_pad, co_pad32)) = col < cols ? v : u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+        }
+        return;
+    }
+    // y_split (block-uniform): this tile's rows belong to the second output tensor
+    const bool second = p.y_split > 0 && m0 >= p.y_split;
+    float* const Yout = second ? p.Y2 : p.Y;
+    const int row_off = second ? p.y_split : 0;
+    const int co_out = p.y_split > 0 ? (second ? p.Co - p.y_split : p.y_split) : p.Co;
     unsigned obase[2];
     bool cok[2];
 #pragma unroll
@@ -134,7 +188,7 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
         const int64_t col = c0 + wc * 64 + tj * 32 + lr;
         cok[tj] = col < cols;
         const int64_t n = cok[tj] ? col / p.T : 0;
-        obase[tj] = (unsigned)(n * p.Co * p.T + (cok[tj] ? col - n * p.T : 0));
+        obase[tj] = (unsigned)(n * co_out * p.T + (cok[tj] ? col - n * p.T : 0)) - (unsigned)(row_off * p.T);
     }
     const bool full_rows = m0 + GM <= p.Co;            // block-uniform
     const float* __restrict__ bias = p.bias;
@@ -177,16 +231,16 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
                 if (p.residual != nullptr) x += res[tj][r];
                 vv[r] = x;
             }
-            if (p.Y != nullptr && cok[tj]) {
+            if (Yout != nullptr && cok[tj]) {
                 if (full_rows) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        p.Y[obase[tj] + (unsigned)((rbase + (r & 3) + 8 * (r >> 2)) * p.T)] = vv[r];
+                        Yout[obase[tj] + (unsigned)((rbase + (r & 3) + 8 * (r >> 2)) * p.T)] = vv[r];
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = rbase + (r & 3) + 8 * (r >> 2);
-                        if (row < p.Co) p.Y[obase[tj] + (unsigned)(row * p.T)] = vv[r];
+                        if (row < p.Co) Yout[obase[tj] + (unsigned)(row * p.T)] = vv[r];
                     }
                 }
             }
@@ -748,7 +802,7 @@ int launch_gemm_act(const AliveGemm& d, hipStream_t s) {
     const int n_mt = cdiv(d.Co, GM), n_ct = cdiv(cols, GN);
     const int ntiles = n_mt * n_ct;
     gemm_planes_kernel<NP, NS, MINB, ACT><<<ntiles, 256, LDS, s>>>(
-        d, n_mt, ntiles, cols, pad_cols(cols), (d.Co + 15) & ~15, pad32(d.Co), pad32(d.Ci), make_walk(d),
+        d, n_mt, ntiles, cols, pad_cols(cols), (d.Co + 15) & ~15, pad32(ACT == 4 ? d.Co / 2 : d.Co), pad32(d.Ci), make_walk(d),
         g_stamps);
     ALIVE_CHECK_LAUNCH("alive_gemm_planes");
     return ALIVE_OK;
@@ -767,8 +821,8 @@ int launch_gemm_lw_act(const AliveGemm& d, hipStream_t s) {
     }
     const int64_t cols = (int64_t)d.N * d.T;
     const int n_mt = cdiv(d.Co, GM), n_ct = cdiv(cols, GN);
-    gemm_planes_lw_kernel<NP, NS, ACT><<<256, 512, LDS, s>>>(d, n_mt, n_mt * n_ct, cols, pad_cols(cols), (d.Co + 15) & ~15, pad32(d.Co),
-                                                            pad32(d.Ci), make_walk(d));
+    gemm_planes_lw_kernel<NP, NS, ACT><<<256, 512, LDS, s>>>(d, n_mt, n_mt * n_ct, cols, pad_cols(cols), (d.Co + 15) & ~15,
+                                                            pad32(ACT == 4 ? d.Co / 2 : d.Co), pad32(d.Ci), make_walk(d));
     ALIVE_CHECK_LAUNCH("alive_gemm_planes(persistent)");
     return ALIVE_OK;
 }
@@ -776,6 +830,7 @@ int launch_gemm_lw_act(const AliveGemm& d, hipStream_t s) {
 template <int NP, int NS>
 int launch_gemm_lw(const AliveGemm& d, hipStream_t s) {
     if constexpr (NP == 3) { if (d.act == 3) return launch_gemm_lw_act<NP, NS, 3>(d, s); }
+    if constexpr (NP == 3) { if (d.act == 4) return launch_gemm_lw_act<NP, NS, 4>(d, s); }
     if (d.act == 1) return launch_gemm_lw_act<NP, NS, 1>(d, s);
     if (d.act == 2) return launch_gemm_lw_act<NP, NS, 2>(d, s);
     return launch_gemm_lw_act<NP, NS, 0>(d, s);
@@ -784,6 +839,7 @@ int launch_gemm_lw(const AliveGemm& d, hipStream_t s) {
 template <int NP, int NS, int MINB>
 int launch_gemm(const AliveGemm& d, hipStream_t s) {
     if constexpr (NP == 3) { if (d.act == 3) return launch_gemm_act<NP, NS, MINB, 3>(d, s); }
+    if constexpr (NP == 3) { if (d.act == 4) return launch_gemm_act<NP, NS, MINB, 4>(d, s); }
     if (d.act == 1) return launch_gemm_act<NP, NS, MINB, 1>(d, s);
     if (d.act == 2) return launch_gemm_act<NP, NS, MINB, 2>(d, s);
     return launch_gemm_act<NP, NS, MINB, 0>(d, s);
@@ -838,16 +894,21 @@ extern "C" int alive_gemm_planes(const AliveGemm* d, void* stream) {
     if (d->act == 3) {
         ALIVE_CHECK_ARG(d->planes == 3 && d->arg_val && d->arg_idx && !d->Y && !d->Pout && !d->residual && !d->post_add && !d->ch_scale,
                         "alive_gemm_planes: act 3 (argmax) takes 3 planes, arg_val / arg_idx and no other output or epilogue term");
+    } else if (d->act == 4) {
+        ALIVE_CHECK_ARG(d->planes == 3 && d->Pout && !d->Y && !d->bias && !d->residual && !d->post_add && !d->ch_scale && !d->y_split && (d->Co & 1) == 0,
+                        "alive_gemm_planes: act 4 (magnitude of row pairs) takes 3 planes, an even Co, Pout and no other output or epilogue term");
     } else {
         ALIVE_CHECK_ARG(d->Y || d->Pout, "alive_gemm_planes: no output");
     }
+    ALIVE_CHECK_ARG(d->y_split == 0 || (d->y_split % GM == 0 && d->y_split < d->Co && d->Y && d->Y2 && !d->residual && !d->Pout && d->act != 3),
+                    "alive_gemm_planes: y_split must be a multiple of %d below Co, with Y and Y2 and neither residual nor Pout", GM);
     ALIVE_CHECK_ARG(d->N > 0 && d->T > 0 && d->Ci > 0 && d->Co > 0, "alive_gemm_planes: bad shape");
     ALIVE_CHECK_ARG(d->planes == 2 || d->planes == 3, "alive_gemm_planes: planes must be 2 or 3, got %d", d->planes);
     ALIVE_CHECK_ARG(d->b_row == 0 || ((d->b_row | d->b_win | d->b_plane) & 7) == 0, "alive_gemm_planes: custom row placement must be in multiples of 8 elements");
     ALIVE_CHECK_ARG(d->b_row == 0 || (d->Ci & 31) == 0, "alive_gemm_planes: custom row placement needs Ci %% 32 == 0");
     ALIVE_CHECK_ARG(d->b_cblk >= 0 && (d->b_cblk == 0 || (d->b_row != 0 && (d->Ci / 32) % d->b_cblk == 0 && (d->b_blk & 7) == 0)),
                     "alive_gemm_planes: b_cblk %d (k-blocks per tap) must divide Ci / 32 = %d, with b_row and b_blk set", d->b_cblk, d->Ci / 32);
-    ALIVE_CHECK_ARG(d->act >= 0 && d->act <= 3, "alive_gemm_planes: activation %d", d->act);
+    ALIVE_CHECK_ARG(d->act >= 0 && d->act <= 4, "alive_gemm_planes: activation %d", d->act);
     ALIVE_CHECK_ARG(((((uintptr_t)d->W) | ((uintptr_t)d->P) | ((uintptr_t)d->Pout)) & 15) == 0,
                     "alive_gemm_planes: W / P / Pout must be 16-byte aligned");
     ALIVE_CHECK_ARG(!(d->Y || d->residual) || (int64_t)d->N * d->Co * d->T < (1ll << 30),

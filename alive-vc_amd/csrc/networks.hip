@@ -240,6 +240,28 @@ __global__ void dft_basis_planes_kernel(unsigned short* planes) {
     }
 }
 
+// the same basis with (re, im) of a bin in ADJACENT rows (row 2f = cos, 2f + 1 = -sin): the weight operand of the fused front end,
+// whose GEMM epilogue takes the magnitude of each row pair (AliveGemm.act == 4)
+__global__ void dft_basis_planes_il_kernel(unsigned short* planes) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= DFT_ROWS * NFFT) return;
+    int row = i / NFFT, j = i % NFFT;
+    float v = 0.0f;
+    if (row < 2 * BINS) {
+        int f = row >> 1;
+        int ph = (int)(((long long)f * j) % NFFT);
+        double sn, cs;
+        sincospi(2.0 * (double)ph / (double)NFFT, &sn, &cs);
+        v = (row & 1) == 0 ? (float)cs : (float)(-sn);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        const unsigned short h = f32_to_bf16_rn(v);
+        planes[planes_at(pl, row, j, DFT_ROWS, NFFT)] = h;
+        v -= __uint_as_float((unsigned)h << 16);
+    }
+}
+
 // wav[N][L] -> planes [3][N][L + 1280] of the centre-padded signal (reflect, torch.stft center=True)
 __global__ void wav_to_planes_kernel(const float* __restrict__ wav, int L, int Lpad, size_t plane_stride, unsigned short* __restrict__ P) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -258,11 +280,13 @@ __global__ void wav_to_planes_kernel(const float* __restrict__ wav, int L, int L
 }
 }  // namespace
 
-extern "C" size_t alive_dft_basis_bytes(void) { return BASIS_F32 * sizeof(float) + 3 * BASIS_F32 * sizeof(unsigned short); }
+// basis buffer: fp32 image, bf16 planes (rows re | im), bf16 planes (rows interleaved: the fused front end)
+extern "C" size_t alive_dft_basis_bytes(void) { return BASIS_F32 * sizeof(float) + 2 * 3 * BASIS_F32 * sizeof(unsigned short); }
 extern "C" int alive_dft_basis(float* basis, void* stream) {
     ALIVE_CHECK_ARG(basis, "alive_dft_basis: null");
     dft_basis_kernel<<<cdiv((int64_t)DFT_ROWS * NFFT, 256), 256, 0, (hipStream_t)stream>>>(basis);
     dft_basis_planes_kernel<<<cdiv((int64_t)DFT_ROWS * NFFT, 256), 256, 0, (hipStream_t)stream>>>((unsigned short*)(basis + BASIS_F32));
+    dft_basis_planes_il_kernel<<<cdiv((int64_t)DFT_ROWS * NFFT, 256), 256, 0, (hipStream_t)stream>>>((unsigned short*)(basis + BASIS_F32) + 3 * BASIS_F32);
     ALIVE_CHECK_LAUNCH("alive_dft_basis");
     return ALIVE_OK;
 }
@@ -321,6 +345,13 @@ EncBuffers enc_layout(void* ws, int N, int T, int C, int H, int logits) {
 }
 }  // namespace
 
+namespace {
+// the networks behind their input layers: b.x holds input_layer(spec) (content_encoder.py:22 / f0_estimator.py:23), t stands behind
+// the input layer's two table entries
+int ce_body(Table& t, EncBuffers& b, int N, int T, float* out, void* stream);
+int pe_body(Table& t, EncBuffers& b, int N, int T, float* f0, void* stream);
+}  // namespace
+
 extern "C" size_t alive_content_encoder_workspace_bytes(int N, int T) { return enc_layout(nullptr, N, T, CE_C, CE_H, 0).bytes; }
 extern "C" int alive_content_encoder(const float* const* w, const float* spec, int N, int T, float* out, void* ws, void* stream) {
     ALIVE_CHECK_ARG(w && spec && out && ws && N > 0 && T > 0, "alive_content_encoder: bad args");
@@ -328,6 +359,10 @@ extern "C" int alive_content_encoder(const float* const* w, const float* spec, i
     EncBuffers b = enc_layout(ws, N, T, CE_C, CE_H, 0);
     const float* inW = t.next(); const float* inb = t.next();
     RUN(pw_conv(inW, inb, spec, b.Pa, N, T, BINS, CE_C, 3, 0, nullptr, b.x, stream));
+    return ce_body(t, b, N, T, out, stream);
+}
+namespace {
+int ce_body(Table& t, EncBuffers& b, int N, int T, float* out, void* stream) {
     for (int i = 0; i < 4; ++i) {
         ConvNeXtW cw(t, false);
         RUN(convnext_layer(cw, b.x, b.y, b.h, b.Pa, b.Ph, N, CE_C, CE_H, T, nullptr, 0, 0, 0, 3, stream));
@@ -335,6 +370,7 @@ extern "C" int alive_content_encoder(const float* const* w, const float* spec, i
     const float* oW = t.next(); const float* ob = t.next();
     return pw_conv(oW, ob, b.x, b.Pa, N, T, CE_C, CE_OUT, 3, 0, nullptr, out, stream);
 }
+}  // namespace
 
 // ---- f0 estimator ----------------------------------------------------------------------------
 extern "C" size_t alive_f0_estimate_workspace_bytes(int N, int T) { return enc_layout(nullptr, N, T, PE_C, PE_H, PE_OUT).bytes; }
@@ -344,6 +380,10 @@ extern "C" int alive_f0_estimate(const float* const* w, const float* spec, int N
     EncBuffers b = enc_layout(ws, N, T, PE_C, PE_H, PE_OUT);
     const float* inW = t.next(); const float* inb = t.next();
     RUN(pw_conv(inW, inb, spec, b.Pa, N, T, BINS, PE_C, 3, 0, nullptr, b.x, stream));
+    return pe_body(t, b, N, T, f0, stream);
+}
+namespace {
+int pe_body(Table& t, EncBuffers& b, int N, int T, float* f0, void* stream) {
     for (int i = 0; i < 4; ++i) {
         ConvNeXtW cw(t, false);
         RUN(convnext_layer(cw, b.x, b.y, b.h, b.Pa, b.Ph, N, PE_C, PE_H, T, nullptr, 0, 0, 0, 3, stream));
@@ -368,6 +408,62 @@ extern "C" int alive_f0_estimate(const float* const* w, const float* spec, int N
         RUN(pw_conv(oW, ob, b.y, b.Pa, N, T, PE_C, PE_OUT, 3, 0, nullptr, b.lg, stream));
     }
     return alive_argmax_channels(b.lg, N, PE_OUT, T, f0, stream);
+}
+}  // namespace
+
+// ---- fused front end: waveform -> (content features, f0 classes) ------------------------------------------
+// spectrogram.py:5-10 + content_encoder.py:21-25 + f0_estimator.py:22-34 without an fp32 spectrogram: the DFT GEMM's epilogue takes
+// the magnitudes and writes them as the 3-plane k-blocked image both input layers read (AliveGemm.act == 4), and those two layers
+// run as ONE 641 -> 512 + 256 GEMM over it (AliveGemm.y_split).  Against alive_spectrogram + alive_f0_estimate +
+// alive_content_encoder: the [N][1282][T] re / im tensor, the [N][641][T] magnitudes and two alive_to_planes passes are gone
+// (1.5 GB of HBM traffic per 128 windows), every value is bitwise the same.  Batch path only (>= 96 frame columns, L % 8 == 0).
+//   w_in / b_in: the two input layers' packed weights concatenated along the rows ([3][672 / 32][768][32] bf16 planes: CE rows, then
+//   PE rows) and their biases [768] -- module/ops.py::front_end builds them once per pair of networks.
+namespace {
+struct FrontBuffers {
+    unsigned short* wp;      // padded signal planes
+    char* Ps;                // magnitude planes [3][672 / 32][cols_pad][32]
+    void *ce_ws, *pe_ws;
+    size_t bytes;
+};
+FrontBuffers front_layout(void* ws, int N, int L) {
+    Arena a(ws);
+    FrontBuffers b;
+    const int T = L / HOP;
+    b.wp = a.take<unsigned short>((size_t)3 * N * (L + NFFT));
+    b.Ps = a.take<char>(planes_bytes(N, T, BINS, 3));
+    b.ce_ws = a.take<char>(enc_layout(nullptr, N, T, CE_C, CE_H, 0).bytes);
+    b.pe_ws = a.take<char>(enc_layout(nullptr, N, T, PE_C, PE_H, PE_OUT).bytes);
+    b.bytes = a.used() + 1024;
+    return b;
+}
+}  // namespace
+extern "C" size_t alive_front_end_workspace_bytes(int N, int L) { return front_layout(nullptr, N, L).bytes; }
+extern "C" int alive_front_end(const float* basis, const float* const* ce_w, const float* const* pe_w, const void* w_in, const float* b_in,
+                               const float* wav, int N, int L, float* feat, float* f0, void* ws, void* stream) {
+    ALIVE_CHECK_ARG(basis && ce_w && pe_w && w_in && b_in && wav && feat && f0 && ws, "alive_front_end: null pointer");
+    ALIVE_CHECK_ARG(N > 0 && L > NFFT / 2 && L >= HOP, "alive_front_end: needs L > %d samples (reflect pad), got %d", NFFT / 2, L);
+    const int T = L / HOP;
+    ALIVE_CHECK_ARG(use_planes(N, T) && L % 8 == 0, "alive_front_end: batch path only (N * T >= %d frame columns, L %% 8 == 0): use alive_spectrogram + "
+                    "alive_f0_estimate + alive_content_encoder", (int)PLANES_MIN_COLS);
+    FrontBuffers fb = front_layout(ws, N, L);
+    const int Lpad = L + NFFT;
+    wav_to_planes_kernel<<<dim3(cdiv(Lpad, 256), N), 256, 0, (hipStream_t)stream>>>(wav, L, Lpad, (size_t)N * Lpad, fb.wp);
+    AliveGemm g;
+    memset(&g, 0, sizeof(g));
+    g.W = (const unsigned short*)(basis + BASIS_F32) + 3 * BASIS_F32; g.P = fb.wp; g.N = N; g.T = T; g.Ci = NFFT; g.Co = 2 * BINS; g.planes = 3;
+    g.act = 4; g.Pout = fb.Ps;
+    g.b_plane = (int64_t)N * Lpad; g.b_win = Lpad; g.b_row = HOP;
+    RUN(alive_gemm_planes(&g, stream));
+    EncBuffers ce = enc_layout(fb.ce_ws, N, T, CE_C, CE_H, 0), pe = enc_layout(fb.pe_ws, N, T, PE_C, PE_H, PE_OUT);
+    memset(&g, 0, sizeof(g));
+    g.W = w_in; g.bias = b_in; g.P = fb.Ps; g.N = N; g.T = T; g.Ci = BINS; g.Co = CE_C + PE_C; g.planes = 3;
+    g.Y = ce.x; g.Y2 = pe.x; g.y_split = CE_C;
+    RUN(alive_gemm_planes(&g, stream));
+    Table tc(ce_w), tp(pe_w);
+    tc.next(); tc.next(); tp.next(); tp.next();          // the input layers ran above
+    RUN(pe_body(tp, pe, N, T, f0, stream));
+    return ce_body(tc, ce, N, T, feat, stream);
 }
 
 // ---- decoder ---------------------------------------------------------------------------------

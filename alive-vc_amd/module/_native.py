@@ -37,6 +37,7 @@ class AliveGemm(C.Structure):
         ("Y", C.c_void_p), ("Pout", C.c_void_p),
         ("b_plane", C.c_int64), ("b_win", C.c_int64), ("b_row", C.c_int), ("b_cblk", C.c_int), ("b_blk", C.c_int64),
         ("arg_val", C.c_void_p), ("arg_idx", C.c_void_p),
+        ("Y2", C.c_void_p), ("y_split", C.c_int),
     ]
 
 
@@ -98,6 +99,8 @@ PROTOTYPES = {
     "alive_float_to_pcm16": (_I, [_VP, _I64, _VP, _VP]),
     "alive_weight_count": (_I, [_I]),
     "alive_weight_name": (C.c_char_p, [_I, _I]),
+    "alive_front_end_workspace_bytes": (_SZ, [_I, _I]),
+    "alive_front_end": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP]),
     "alive_content_encoder_workspace_bytes": (_SZ, [_I, _I]),
     "alive_content_encoder": (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP]),
     "alive_f0_estimate_workspace_bytes": (_SZ, [_I, _I]),
@@ -182,3 +185,7 @@ class WeightTable:
             if t.dtype not in (torch.float32, torch.bfloat16) or not t.is_contiguous() or not t.is_cuda:
                 raise RuntimeError(f"packed weight {n} must be a contiguous fp32 / bf16 HIP tensor")
         self.array = (C.c_void_p * len(names))(*[t.data_ptr() for t in self.tensors])
+        self.names = names
+
+    def tensor(self, name):
+        return self.tensors[self.names.index(name)]

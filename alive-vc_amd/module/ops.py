@@ -267,3 +267,44 @@ def dwconv_norm_planes(x, dw_w, dw_b, gain=None, offset=None, cond=None, scale_r
                                                  nat.ptr(gain), nat.ptr(offset), nat.ptr(cond), 0 if cond is None else cond.shape[1],
                                                  scale_row, shift_row, eps, planes, nat.ptr(P), nat.stream()), "alive_dwconv_norm_planes")
     return P
+
+
+_front = {}          # (id(ce table), id(pe table)) -> (merged input weights, merged biases, the two tables)
+_front_ws = nat.Workspace()
+
+
+def front_end(wave, ce, pe, out=None):
+    """wave [N, L] (16 kHz) -> (content features [N, 768, L // 320], f0 classes [N, 1, L // 320]) = ce(spectrogram(wave)) and
+    pe.estimate(spectrogram(wave)), bitwise -- through ONE entry point that never writes an fp32 spectrogram (alive_front_end:
+    the DFT GEMM's epilogue leaves the magnitudes as the plane-packed operand of the two input layers, which run as one GEMM).
+    /root/reference/module/spectrogram.py:5-10, content_encoder.py:21-25, f0_estimator.py:22-34.
+    out = (feat, f0) tensors to write into.  Shapes the fused path does not take (a handful of frames: the streaming ring;
+    non-default network sizes) go through the three separate calls."""
+    from .spectrogram import dft_basis, spectrogram
+    wave = wave.contiguous().float()
+    n, l = wave.shape
+    t = l // 320
+    if ce.generic or pe.generic or n * t < 96 or l % 8 != 0 or l <= 640:
+        spec = spectrogram(wave)
+        return ce(spec, out=None if out is None else out[0]), pe.estimate(spec, out=None if out is None else out[1])
+    L = nat.lib()
+    tc, tp = ce.table(), pe.table()
+    key = (id(tc), id(tp))
+    hit = _front.get(key)
+    if hit is None or hit[2] is not tc or hit[3] is not tp:
+        if len(_front) >= 4:
+            _front.pop(next(iter(_front)))
+        # plane-packed weights are [planes][K / 32][Co_pad][32]: concatenating along the rows is concatenating dim 2
+        w = torch.cat([tc.tensor("input.W"), tp.tensor("input.W")], dim=2).contiguous()
+        b = torch.cat([tc.tensor("input.b"), tp.tensor("input.b")]).contiguous()
+        torch.cuda.current_stream(wave.device).synchronize()      # (side streams read it: module/pipeline.py)
+        hit = _front[key] = (w, b, tc, tp)
+    feat = out[0] if out is not None else torch.empty(n, 768, t, device=wave.device)
+    f0 = out[1] if out is not None else torch.empty(n, 1, t, device=wave.device)
+    if tuple(feat.shape) != (n, 768, t) or tuple(f0.shape) != (n, 1, t) or not feat.is_contiguous() or not f0.is_contiguous() \
+            or feat.dtype != torch.float32 or f0.dtype != torch.float32:
+        raise ValueError("front_end: out must be contiguous fp32 ([N, 768, T], [N, 1, T]) tensors")
+    ws = _front_ws.get(L.alive_front_end_workspace_bytes(n, l), wave.device)
+    nat.check(L.alive_front_end(nat.ptr(dft_basis(wave.device)), tc.array, tp.array, nat.ptr(hit[0]), nat.ptr(hit[1]), nat.ptr(wave), n, l,
+                                nat.ptr(feat), nat.ptr(f0), nat.ptr(ws), nat.stream()), "alive_front_end")
+    return feat, f0

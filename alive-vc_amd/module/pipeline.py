@@ -71,11 +71,12 @@ class Converter:
         frames = (lo, hi): content features are only needed on [lo, hi) (context trimming): the encoder runs on that range
         plus its own receptive field; the other frames come back as zeros.  f0 always covers the whole window (the pitch
         transform uses the window's mean pitch, the oscillator accumulates phase from the first frame)."""
+        if frames is None:                 # the whole window: one fused call, no fp32 spectrogram (ops.front_end, SURVEY 8 f1)
+            feat, f0 = ops.front_end(windows, self.ce, self.pe, out=out)     # out = (feat, f0) batch slices to write into
+            return feat, ops.pitch_transform_(f0, 0, f0_rate=f0_rate, pitch_shift=pitch_shift, intonation=intonation)
         spec = spectrogram(windows)
-        f0 = self.pe.estimate(spec, out=None if out is None else out[1])     # out = (feat, f0) batch slices to write into
+        f0 = self.pe.estimate(spec, out=None if out is None else out[1])
         f0 = ops.pitch_transform_(f0, 0, f0_rate=f0_rate, pitch_shift=pitch_shift, intonation=intonation)
-        if frames is None:
-            return self.ce(spec, out=None if out is None else out[0]), f0
         lf = spec.shape[2]
         a, b = max(0, frames[0] - CE_MARGIN), min(lf, frames[1] + CE_MARGIN)
         feat = torch.zeros(spec.shape[0], 768, lf, device=spec.device)
@@ -107,9 +108,7 @@ class Converter:
         fu = torch.empty(m, 768, (group + 2) * cf, device=dev)
         pu = torch.empty(m, 1, (group + 2) * cf, device=dev)
         for i in range(0, m, utt_batch):                       # interior frames: one pass over each signal
-            spec = spectrogram(sig[i:i + utt_batch])
-            pu[i:i + utt_batch] = self.pe.estimate(spec)
-            fu[i:i + utt_batch] = self.ce(spec)
+            ops.front_end(sig[i:i + utt_batch], self.ce, self.pe, out=(fu[i:i + utt_batch], pu[i:i + utt_batch]))
         nl = EDGE + NET_MARGIN
         fe = torch.empty(n, 768, 2 * EDGE, device=dev)         # edge frames of every window: [0, EDGE) and [lf - EDGE, lf)
         pe_ = torch.empty(n, 1, 2 * EDGE, device=dev)

@@ -253,7 +253,7 @@ typedef struct AliveGemm {
     int N, T;              /* cols = N*T; fp32 outputs are [N][Co][T] */
     int Ci, Co;
     int planes;            /* 2: bf16x3, 3: bf16x6 (both operands) */
-    int act;               /* 0 none, 1 gelu, 2 exp, 3 argmax over Co (3 planes only): no Y / Pout, see arg_val */
+    int act;               /* 0 none, 1 gelu, 2 exp, 3 argmax over Co (3 planes only): no Y / Pout, see arg_val; 4: see the end of the struct */
     const float* post_add; /* [Co] or NULL */
     const float* ch_scale; /* [Co] or NULL */
     const float* residual; /* [N][Co][T] or NULL */
@@ -276,6 +276,15 @@ typedef struct AliveGemm {
      * 4096-class logits tensor. */
     float* arg_val;
     int32_t* arg_idx;
+    /* Round 5 (the front end without an fp32 spectrogram).  Fields appended: a zeroed struct of the old size means "off".
+     * y_split > 0: ONE GEMM for two consumers of the same input -- rows [0, y_split) go to Y as [N][y_split][T], rows [y_split, Co) to
+     *   Y2 as [N][Co - y_split][T] (y_split a multiple of 128; no residual).  The ContentEncoder / F0Estimator input layers
+     *   (content_encoder.py:22, f0_estimator.py:23) run as one 641 -> 512 + 256 GEMM this way.
+     * act == 4: the rows are (re, im) PAIRS of a DFT (row 2f = cos, 2f + 1 = -sin: alive_dft_basis's interleaved image); the epilogue
+     *   takes |re + i im| (hypotf, spectrogram.py:8) of each pair and leaves the Co / 2 magnitudes as plane-packed channels in Pout
+     *   ([planes][pad32(Co / 2) / 32][cols_pad][32]) -- the magnitude spectrogram never exists in fp32.  No Y, bias or other term. */
+    float* Y2;
+    int y_split;
 } AliveGemm;
 int alive_gemm_planes(const AliveGemm* desc, void* stream);
 /* out[col] = (float) row of the largest value over the nblk per-block candidates of column col (smallest row on ties) */
@@ -402,6 +411,15 @@ int alive_weight_count(int model);
 const char* alive_weight_name(int model, int index);
 
 /* ContentEncoder.forward (content_encoder.py:21-25): spec[N][641][T] -> out[N][768][T] */
+/* Fused front end (round 5): wav[N][L] at 16 kHz -> content features feat[N][768][L / 320] and f0 classes
+ * f0[N][1][L / 320] (the argmax of F0Estimator.estimate, before the class -> Hz map is applied by the caller exactly as after
+ * alive_f0_estimate), i.e. spectrogram.py:5-10 + content_encoder.py:21-25 + f0_estimator.py:22-34 in one call and without an
+ * fp32 spectrogram: bitwise alive_spectrogram + alive_f0_estimate + alive_content_encoder.  Batch path only (N * (L / 320) >= 96,
+ * L % 8 == 0).  w_in: the two input layers' plane-packed weights concatenated along the rows (CE's 512, then PE's 256:
+ * [3][672 / 32][768][32] bf16), b_in: their biases [768].  ws: alive_front_end_workspace_bytes(N, L). */
+size_t alive_front_end_workspace_bytes(int N, int L);
+int alive_front_end(const float* basis, const float* const* ce_weights, const float* const* pe_weights, const void* w_in,
+                    const float* b_in, const float* wav, int N, int L, float* feat, float* f0, void* ws, void* stream);
 size_t alive_content_encoder_workspace_bytes(int N, int T);
 int alive_content_encoder(const float* const* w, const float* spec, int N, int T,
                           float* out, void* ws, void* stream);

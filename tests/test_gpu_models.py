@@ -293,3 +293,46 @@ def test_encoders_with_non_default_sizes_run_the_generic_path(sizes):
     assert torch.equal(pe.estimate(spec.to(DEV))[:, 0].cpu()[safe], ref.argmax(1).float()[safe])
     with pytest.raises(RuntimeError):
         ContentEncoder(n_fft, c, hdim, out, layers, seed=5)(spec)          # no CPU path
+
+
+@pytest.mark.parametrize("n,t", [(1, 150), (3, 97), (2, 450), (130, 450)])
+def test_fused_front_end_equals_the_three_separate_calls_bitwise(nets, n, t):
+    """SURVEY 8 f1 (round 5): alive_front_end -- the DFT GEMM whose epilogue leaves the magnitudes as the plane-packed operand of
+    the input layers (no fp32 spectrogram), the ContentEncoder and F0Estimator input layers as ONE GEMM with two outputs -- against
+    spectrogram() -> ce() / pe.estimate() (/root/reference/module/spectrogram.py:5-10, content_encoder.py:21-25,
+    f0_estimator.py:22-34): same bits, inside its workspace, for ragged column counts (291 columns = 2 tiles + 35) and a batch
+    whose row / column tiles exceed one round of the chip."""
+    from module import _native as nat
+    from module import ops
+    from module import spectrogram as sp
+    ce, pe, _, _ = nets
+    wav = torch.stack([0.3 * synthetic.make_waveform(t * 320, 500 + i % 7)[0] * (1.0 + 0.01 * i) for i in range(n)]).to(DEV).contiguous()
+    spec = sp.spectrogram(wav)
+    feat_ref, f0_ref = ce(spec), pe.estimate(spec)
+    feat, f0 = ops.front_end(wav, ce, pe)
+    assert torch.equal(feat, feat_ref) and torch.equal(f0, f0_ref)
+    # caller-owned memory with guard bands, through the C ABI
+    L = nat.lib()
+    need = L.alive_front_end_workspace_bytes(n, t * 320)
+    G = 1 << 20
+    ws = torch.full((need + G,), 0xAB, dtype=torch.uint8, device=DEV)
+    o1 = torch.full((n * 768 * t + 4096,), 7.0, device=DEV)
+    o2 = torch.full((n * t + 4096,), 7.0, device=DEV)
+    w, b = ops._front[(id(ce.table()), id(pe.table()))][:2]
+    nat.check(L.alive_front_end(nat.ptr(sp.dft_basis(wav.device)), ce.table().array, pe.table().array, nat.ptr(w), nat.ptr(b), nat.ptr(wav),
+                                n, t * 320, o1.data_ptr(), o2.data_ptr(), ws.data_ptr(), nat.stream()), "alive_front_end")
+    torch.cuda.synchronize()
+    assert bool((ws[need:] == 0xAB).all()), "the fused front end wrote behind its workspace"
+    assert bool((o1[n * 768 * t:] == 7.0).all() and (o2[n * t:] == 7.0).all())
+    assert torch.equal(o1[:n * 768 * t].view(n, 768, t), feat_ref) and torch.equal(o2[:n * t].view(n, 1, t), f0_ref)
+
+
+def test_fused_front_end_falls_back_for_a_handful_of_frames(nets):
+    """fewer than 96 frame columns (the streaming ring) or a length that is not a multiple of 8: the three separate calls"""
+    from module import ops
+    from module import spectrogram as sp
+    ce, pe, _, _ = nets
+    wav = (0.3 * synthetic.make_waveform(8 * 320, 9)).to(DEV)
+    spec = sp.spectrogram(wav)
+    feat, f0 = ops.front_end(wav, ce, pe)
+    assert torch.equal(feat, ce(spec)) and torch.equal(f0, pe.estimate(spec))
