@@ -150,12 +150,24 @@ __global__ __launch_bounds__(64) void osc_synth_kernel(const float* __restrict__
     __syncthreads();
     for (int b0 = 0; b0 < g.sub; b0 += BT) {
         const int nb = (g.sub - b0) < BT ? (g.sub - b0) : BT;
+        // The (i0, i1) pair of F.interpolate changes once inside a frame (at its midpoint) and the batches of BT samples do not
+        // straddle it when seg / 2 is a multiple of BT (320 / 2 = 160): a batch whose first and last sample share the pair takes
+        // its four operands ONCE instead of selecting them per sample (12 compares / selects of ~50 instruction slots per element;
+        // same values, same arithmetic).  Wave-uniform test: the table is the same for every lane.
+        const unsigned pair0 = __builtin_amdgcn_readfirstlane(coord[b0].x), pair1 = __builtin_amdgcn_readfirstlane(coord[b0 + nb - 1].x);
+        const bool same = pair0 == pair1;
+        const int j0 = pair0 & 0xffff, j1 = pair0 >> 16;
+        const float fa_b = j0 == f ? fo_c : (j0 < f ? fo_m : fo_p), fb_b = j1 == f ? fo_c : (j1 < f ? fo_m : fo_p);
+        const float aa_b = j0 == f ? am_c : (j0 < f ? am_m : am_p), ab_b = j1 == f ? am_c : (j1 < f ? am_m : am_p);
         for (int i = 0; i < nb; ++i) {
             const uint2 xc = coord[b0 + i];
-            const int i0 = xc.x & 0xffff, i1 = xc.x >> 16;
             const float w1 = __uint_as_float(xc.y), w0 = 1.0f - w1;
-            const float fa = i0 == f ? fo_c : (i0 < f ? fo_m : fo_p), fb = i1 == f ? fo_c : (i1 < f ? fo_m : fo_p);
-            const float aa = i0 == f ? am_c : (i0 < f ? am_m : am_p), ab = i1 == f ? am_c : (i1 < f ? am_m : am_p);
+            float fa = fa_b, fb = fb_b, aa = aa_b, ab = ab_b;
+            if (!same) {                                       // wave-uniform branch: the batch that holds a change of the pair
+                const int i0 = xc.x & 0xffff, i1 = xc.x >> 16;
+                fa = i0 == f ? fo_c : (i0 < f ? fo_m : fo_p); fb = i1 == f ? fo_c : (i1 < f ? fo_m : fo_p);
+                aa = i0 == f ? am_c : (i0 < f ? am_m : am_p); ab = i1 == f ? am_c : (i1 < f ? am_m : am_p);
+            }
             float c = 0.0f;
             if (hv) {
                 acc += (double)div_rate(fmaf(w0, fa, w1 * fb), g.sample_rate);
