@@ -69,7 +69,7 @@ __device__ __forceinline__ unsigned pack2s(float a, float b) {
 }
 
 template <int C, bool FIRST, int PL = PLANE_BATCH>
-__global__ __launch_bounds__(256, 1) void filter_block_small_kernel(const float* __restrict__ U, int L, const float* __restrict__ wpack,
+__global__ __launch_bounds__(256, PL == 16384 ? 2 : 1) void filter_block_small_kernel(const float* __restrict__ U, int L, const float* __restrict__ wpack,
                                                                    const float* __restrict__ film, int film_rows, int Lf, int film_off,
                                                                    float ratio, int t_off, int f_off, int film_ld,
                                                                    const float* __restrict__ skip, float* __restrict__ out, long long* stamps) {
@@ -495,8 +495,16 @@ extern "C" int alive_filter_block_small_range(const float* U, int N, int C, int 
     // a signal that would be a handful of batch tiles runs on 8-KB planes (see Cfg)
     static const int pl_env = getenv("ALIVE_FBS_PLANE") ? atoi(getenv("ALIVE_FBS_PLANE")) : 0;
     const int big_tiles = cdiv(L, (C == 8 ? Cfg<8>::TT : Cfg<16>::TT)) * N;
-    const bool tiny = pl_env ? pl_env < PLANE_BATCH : big_tiles <= 16;
+    const bool tiny = pl_env ? pl_env < 16384 : big_tiles <= 16;
     hipStream_t s = (hipStream_t)stream;
+    // 16-KB planes (round 5): 77 KB of LDS per block and 256 registers per wave = TWO blocks per CU, one block's prologue / store
+    // under the other's convs, for 3 % (C = 8) / 6 % (C = 16) more halo work.  Measured per 64 windows: C = 8 1.03 -> 0.96 ms (243
+    // registers, the default for that scale); C = 16 1.03 -> 1.10 ms (it needs 284+ registers: 40 - 68 spilled) -- ALIVE_FBS_PLANE=16384
+    // forces it there, ALIVE_FBS_PLANE=32768 the one-block form for C = 8.  Same bits either way (tools/run_fused_once.py digests).
+    if (!tiny && (pl_env == 16384 || (pl_env == 0 && C == 8))) {
+        if (C == 8) return launch_small<8, 16384>(U, N, L, wpack, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, s);
+        return launch_small<16, 16384>(U, N, L, wpack, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, s);
+    }
     if (C == 8) return tiny ? launch_small<8, 8192>(U, N, L, wpack, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, s)
                             : launch_small<8, PLANE_BATCH>(U, N, L, wpack, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, s);
     return tiny ? launch_small<16, 8192>(U, N, L, wpack, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, s)

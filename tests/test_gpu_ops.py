@@ -500,10 +500,13 @@ def test_gemm_results_do_not_depend_on_the_tile_order():
 
 @pytest.mark.parametrize("c,l,n,switch,forms", [(64, 800, 1, "ALIVE_FB64_NT", ("4", "2")), (64, 1208, 2, "ALIVE_FB64_NT", ("4", "2")),
                                                 (16, 1600, 1, "ALIVE_FBS_PLANE", ("32768", "8192")),
-                                                (8, 3200, 1, "ALIVE_FBS_PLANE", ("32768", "8192"))])
+                                                (8, 3200, 1, "ALIVE_FBS_PLANE", ("32768", "8192")),
+                                                (8, 14400, 3, "ALIVE_FBS_PLANE", ("32768", "16384")),       # two blocks per CU (C = 8 default, round 5)
+                                                (16, 7200, 3, "ALIVE_FBS_PLANE", ("32768", "16384"))])
 def test_fused_filter_blocks_short_signal_tiles_are_bitwise_the_batch_tiles(c, l, n, switch, forms):
     """the short-signal tile forms of the fused FilterBlocks (filter_mid.hip: two column tiles per wave, with the drained first step of
-    the reflecting block; filter_small.hip: 8-KB planes) compute what the batch tiles compute, bit for bit"""
+    the reflecting block; filter_small.hip: 8-KB planes, and the 16-KB planes that put two blocks on a CU) compute what the batch tiles
+    compute, bit for bit"""
     tool = os.path.join(ROOT, "tools", "run_fused_once.py")
     ds = [_digest_of([tool, str(c), str(l), str(n)], {switch: f}) for f in forms]
     assert ds[0] == ds[1], ds
