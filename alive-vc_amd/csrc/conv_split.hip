@@ -47,18 +47,22 @@ constexpr int PROW = 64;          // PLANES = true: bytes per LDS row (32 channe
 // k5 conv at 128 windows (its LDS writes alone 0.12 ms); the fragment READS per tap, 80 % of the LDS read traffic, cost nothing.
 // The LDS image of a DMA is lane-linear, so the bank swizzle sits on the SOURCE address: 16-B chunk c of row r is stored at
 // chunk position c ^ ((r >> 2) & 3), which keeps every ds_read_b128 of a fragment conflict-free at any tap shift.
-template <int BM, int NP, bool PLANES = false>
+// W22 (BM = 128, round 5): the four waves as 2 x 2 of 64 rows x 64 columns instead of four stacked 32 x 128 -- a B fragment from LDS then
+// feeds two row tiles (0.33 instead of 0.67 fragment reads per MFMA: stacked, all four waves read the SAME 128 columns), an A fragment
+// from L2 two column tiles instead of four (two waves ask for the same weight rows: the second request hits the CU's L1).
+template <int BM, int NP, bool PLANES = false, bool W22 = false>
 __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(AliveConv p, float film_ratio) {
+    static_assert(!W22 || BM == 128, "the 2 x 2 wave arrangement is the 128-row tile's");
     // wave tile: (32 | 64) rows x (128 | 64) columns.  BM = 256 / 128: four waves stacked along the rows; BM = 64: 2 x 2.
-    constexpr int NR = BM >= 128 ? 4 : 2;         // 32-column MFMA tiles per wave
-    constexpr int MR = BM == 256 ? 2 : 1;         // 32-row MFMA tiles per wave
+    constexpr int NR = W22 ? 2 : (BM >= 128 ? 4 : 2);         // 32-column MFMA tiles per wave
+    constexpr int MR = W22 ? 2 : (BM == 256 ? 2 : 1);         // 32-row MFMA tiles per wave
 
     // X tile, double buffered: [2 buffers][2 planes][XROWS][PITCH]
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NP * XPLANE];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wrow = BM >= 128 ? wid : (wid >> 1);          // row block of this wave (32 * MR rows)
-    const int wcol = BM >= 128 ? 0 : (wid & 1) * 64;        // first column of this wave
+    const int wrow = (BM >= 128 && !W22) ? wid : (wid >> 1);          // row block of this wave (32 * MR rows)
+    const int wcol = (BM >= 128 && !W22) ? 0 : (wid & 1) * 64;        // first column of this wave
     const int lr = lane & 31, lh = lane >> 5;
     const int n = blockIdx.z, m0 = blockIdx.y * BM, t0 = blockIdx.x * BN;
     const int co_pad = (p.Co + 15) & ~15;
@@ -82,7 +86,11 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
     }
     bf16x8 a_cur[MR][2][NP], a_nxt[MR][2][NP];    // [row tile][k16 step][plane]
     auto load_A = [&](int cb, int j, bf16x8 (&a)[MR][2][NP]) {
+#ifdef ALIVE_CONV_ABL_SAMEA          // ablation (timing only, WRONG results): every k-step reads the weights of k-step 0 -- the L1 serves them
+        const int kcol = 0 * (j + cb);
+#else
         const int kcol = j * p.Ci_pad + cb * BKC;
+#endif
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
@@ -486,12 +494,14 @@ int alive_conv_split_launch(const AliveConv* d, float ratio, hipStream_t s) {
     // latencies of the single wave per SIMD, and no other block's main loop runs under the four epilogue passes.  Off by
     // default; ALIVE_CONV_TILE256=1 selects it (same results bit for bit).
     static const bool tile256 = getenv("ALIVE_CONV_TILE256") != nullptr && atoi(getenv("ALIVE_CONV_TILE256")) != 0;
+    static const bool w22 = getenv("ALIVE_CONV_W22") != nullptr && atoi(getenv("ALIVE_CONV_W22")) != 0;      // A/B: 2 x 2 waves (plane input)
     if (d->Co > 128 && d->Co % 256 == 0 && d->precision == 1 && tile256 && !d->Xp) {
         dim3 g(cdiv(d->Tout, BN), d->Co / 256, d->N);
         conv_split_kernel<256, 2><<<g, 256, 0, s>>>(*d, ratio);
     } else if (d->Co > 64) {
         dim3 g(cdiv(d->Tout, BN), cdiv(d->Co, 128), d->N);
         if (d->precision == 2) conv_split_kernel<128, 3><<<g, 256, 0, s>>>(*d, ratio);
+        else if (d->Xp && w22) conv_split_kernel<128, 2, true, true><<<g, 256, 0, s>>>(*d, ratio);
         else if (d->Xp) conv_split_kernel<128, 2, true><<<g, 256, 0, s>>>(*d, ratio);
         else conv_split_kernel<128, 2><<<g, 256, 0, s>>>(*d, ratio);
     } else {
