@@ -83,7 +83,10 @@ class PackedLibrary:
         self._ws = nat.Workspace()
 
     def _fp6_would_clip(self):
-        return self.M > 0 and float(self.lib_bf16[:self.M].abs().max()) > 7.75 / 32.0
+        if self.M == 0:
+            return False
+        lo, hi = torch.aminmax(self.lib_bf16[:self.M])        # (no |x| temporary: the image is 1.5 GB at 1 M rows)
+        return max(-float(lo), float(hi)) > 7.75 / 32.0
 
     def _pack_stage(self, prefilter):
         L = nat.lib()
