@@ -267,7 +267,11 @@ __global__ __launch_bounds__(256, PL == 16384 ? 2 : 1) void filter_block_small_k
     };
 
     f32x16 acc[2];
-    Epi EP[2];
+    // 16-KB planes (two blocks per CU, 256 registers per wave): ONE epilogue record, filled at the top of its step -- the two dependent LDS
+    // latencies that the prefetch one step ahead hides in the one-block form are covered by the co-resident block's wave here, and the
+    // second record's ~60 registers are what the 16-channel scale spilled
+    constexpr bool ONE_EPI = PL == 16384;
+    Epi EP[ONE_EPI ? 1 : 2];
     // ---- input_conv (1x1, one k-step): h = Win * U + b ----
     {
         bf16x8 ai[2];
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256, PL == 16384 ? 2 : 1) void filter_block_small_k
     }
     __syncthreads();
     STAMPS();
-    epi_begin(EP[0], 0, NT - 1);           // the pending item of the first step
+    if (!ONE_EPI) epi_begin(EP[0], 0, NT - 1);           // the pending item of the first step
 
     // ---- three FilterResBlocks: q = 2 j (c1), 2 j + 1 (c2), dilation 2^j    (decoder.py:128-134) ----
     // SECOND: the c2 of its block (adds into the residual stream); EMIT: a next conv exists and takes the modulated output -- a
@@ -364,8 +368,9 @@ __global__ __launch_bounds__(256, PL == 16384 ? 2 : 1) void filter_block_small_k
 #endif
             // the item's coordinates and first FiLM group were requested one step ago (two dependent LDS latencies that nothing
             // in a 9- or 15-MFMA step could cover); now the same for the next step's item, which is always tile i of this conv
-            Epi& E = EP[i & 1];
-            if (emit) epi_begin(EP[(i + 1) & 1], q + 1, i);
+            Epi& E = EP[ONE_EPI ? 0 : (i & 1)];
+            if (ONE_EPI) { if (it_emit) epi_begin(E, it_qf, it_t); }
+            else if (emit) epi_begin(EP[(i + 1) & 1], q + 1, i);
             acc[i & 1] = b16;
             bf16x8 fh[KS], fl[KS];
 #pragma unroll
@@ -497,11 +502,11 @@ extern "C" int alive_filter_block_small_range(const float* U, int N, int C, int 
     const int big_tiles = cdiv(L, (C == 8 ? Cfg<8>::TT : Cfg<16>::TT)) * N;
     const bool tiny = pl_env ? pl_env < 16384 : big_tiles <= 16;
     hipStream_t s = (hipStream_t)stream;
-    // 16-KB planes (round 5): 77 KB of LDS per block and 256 registers per wave = TWO blocks per CU, one block's prologue / store
-    // under the other's convs, for 3 % (C = 8) / 6 % (C = 16) more halo work.  Measured per 64 windows: C = 8 1.03 -> 0.96 ms (243
-    // registers, the default for that scale); C = 16 1.03 -> 1.10 ms (it needs 284+ registers: 40 - 68 spilled) -- ALIVE_FBS_PLANE=16384
-    // forces it there, ALIVE_FBS_PLANE=32768 the one-block form for C = 8.  Same bits either way (tools/run_fused_once.py digests).
-    if (!tiny && (pl_env == 16384 || (pl_env == 0 && C == 8))) {
+    // 16-KB planes (round 5, the batch default): 77 KB of LDS per block and 256 registers per wave = TWO blocks per CU, one block's
+    // prologue / store under the other's convs, for 3 % (C = 8) / 6 % (C = 16) more halo work.  Measured per 64 windows: C = 8 1.03 ->
+    // 0.96 ms, C = 16 1.03 -> 0.95 ms (with ONE epilogue record: with two it needs 284+ registers, spills 40 - 68 and runs 1.10 ms).
+    // ALIVE_FBS_PLANE=32768 forces the one-block form.  Same bits either way (tools/run_fused_once.py digests).
+    if (!tiny && (pl_env == 16384 || pl_env == 0)) {
         if (C == 8) return launch_small<8, 16384>(U, N, L, wpack, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, s);
         return launch_small<16, 16384>(U, N, L, wpack, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, s);
     }
