@@ -212,7 +212,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--chunk", type=int, default=48000)
     ap.add_argument("-k", type=int, default=4)
-    ap.add_argument("--window-batch", type=int, default=128)
+    ap.add_argument("--window-batch", type=int, default=192)      # (384 windows = 2 batches; 128 / 192 / 256 / 384: 188.4 / 187.4 / 187.4 / 188.5 ms per step, tools/sweep_streams.sh)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-oracle leg (0 = skip)")
     ap.add_argument("--legs", default="all", help="comma list of secondary legs (N = 1): " + ",".join(ALL_LEGS) + " | all | none")
     ap.add_argument("--no-nets-roofline", action="store_true", help="skip the separate timed passes of the networks (profiling runs: keeps the kernel trace to the steps)")
