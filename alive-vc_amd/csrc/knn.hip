@@ -988,6 +988,23 @@ __device__ __forceinline__ void knn_score8_body(const unsigned char* __restrict_
 
     auto load_a = [&](const unsigned char* Ab, int ks) {
         const unsigned char* q = Ab + (ks >> 1) * 4 * PIECE;
+#ifndef ALIVE_KNN6_READ32
+        if constexpr (FMT == 2) {
+            // Only the 24 code bytes of the 32-byte slot leave the LDS (the kernel moves 120 KB through the LDS per 1 152 MFMA cycles:
+            // 61.0 -> 57.7 ms per launch; -DALIVE_KNN6_READ32 restores the two b128 reads).  A compiler-visible ds_read_b64 of the tile
+            // buffer makes hipcc wait vmcnt(0) for the LDS-DMA in flight, so the 8-byte half goes through asm -- issued
+            // BEFORE the visible ds_read_b128 (whose address is tied to the asm): LDS reads of a wave return in order, so the wait
+            // hipcc places in front of the fragment's first use (the MFMA takes both halves) covers the asm read too; an unknown
+            // extra read in flight can only make hipcc's counted waits stricter.  tests/test_host_logic.py checks on the listing
+            // that no instruction touches an asm read's registers before an lgkmcnt wait.
+            unsigned off0 = (unsigned)(uintptr_t)(lptr_t)(q + a_off[ks & 1][0]);
+            const unsigned off1 = (unsigned)(uintptr_t)(lptr_t)(q + a_off[ks & 1][1]);
+            uint2 h8;
+            asm volatile("ds_read_b64 %0, %2" : "=v"(h8), "+v"(off0) : "v"(off1));
+            const u32x4 lo = *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)off0;
+            return v8i{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)h8.x, (int)h8.y, 0, 0};
+        }
+#endif
         const u32x4 lo = *(const u32x4*)(q + a_off[ks & 1][0]);
         const u32x4 hi = *(const u32x4*)(q + a_off[ks & 1][1]);
         return v8i{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};

@@ -369,6 +369,13 @@ def test_fp8_scoring_kernel_listing_keeps_two_accumulator_sets(tmp_path):
     ops = [re.search(r"f8f6f4 (a\[\d+:\d+\]), ([av]\[(\d+):(\d+)\]), ([av]\[(\d+):(\d+)\])", body[i]) for i in mf]
     assert all(o and int(o.group(4)) - int(o.group(3)) == 5 and int(o.group(7)) - int(o.group(6)) == 5 for o in ops)
     assert len({o.group(1) for o in ops[:72]}) == 6
+    # its fragment reads: per k-step one visible ds_read_b128 and one asm ds_read_b64 (24 of the slot's 32 bytes); nothing may touch an
+    # asm read's registers before an lgkmcnt wait (hipcc does not know the read exists)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import mfma_hazard_scan as hz
+    for kern in ("knn_score6_kernel", "knn_probe6_kernel"):
+        n_asm, unwaited = hz.asm_lds_reads_are_waited_for(str(out), kern)
+        assert n_asm == 36 and unwaited == 0, (kern, n_asm, unwaited)
     meta = "\n".join(ls)
     m6 = re.search(r"\.name:\s+\S*knn_score6_kernel\S*\n(.*?)\.wavefront_size", meta, re.S).group(1)
     assert re.search(r"\.vgpr_spill_count:\s+0\b", m6) and re.search(r"\.private_segment_fixed_size:\s+0\b", m6), m6

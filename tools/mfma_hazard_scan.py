@@ -207,3 +207,31 @@ def chain_gap_report(path, want=""):
     for k, a, b, c, idle in bad[:12]:
         print(f"   {k[:60]}: last MFMA of the finished chain at line {a}, first MFMA of the new chain at line {b}, late read at line {c}, idle {idle}")
     return r, bad
+
+
+
+def asm_lds_reads_are_waited_for(path, want=""):
+    """knn.hip (fp6 kernel): the 8-byte half of a fragment is read by an asm ds_read_b64 hipcc knows nothing about.  -> (reads found,
+    reads whose destination registers are touched before any s_waitcnt lgkmcnt behind them)"""
+    n = bad = 0
+    for name, ins in _kernels(path):
+        if want not in name:
+            continue
+        for i, (op, ops, no) in enumerate(ins):
+            if op != "ds_read_b64" or not ops:
+                continue
+            dst = regs(ops[0])
+            n += 1
+            waited = False
+            for j in range(i + 1, min(len(ins), i + 600)):
+                o, oo, _ = ins[j]
+                if o == "s_waitcnt" and any("lgkmcnt" in x for x in oo):
+                    waited = True
+                rd = set().union(*[regs(x) for x in (oo if o.startswith(_STORES) else oo[1:])]) if oo else set()
+                wr = regs(oo[0]) if oo and not o.startswith(("s_",) + _STORES) else set()
+                if rd & dst:
+                    bad += 0 if waited else 1
+                    break
+                if wr & dst:
+                    break
+    return n, bad
