@@ -17,13 +17,15 @@
 // module/common.py:48-51,88-92, content_encoder.py:15-19, f0_estimator.py:15-20,
 // decoder.py:16-17,41,61,108-110,141,164-182.
 #include "conv_epilogue.h"
+#include "planes_layout.h"
 
 namespace {
 
 constexpr int BK = 16;
 constexpr int A_LD = BK + 4;   // 20 floats = 80 B rows: keeps b128 reads 16-B aligned, spreads banks
 
-template <int BM, int BN, int WM, int WN, bool UPV = false>
+// YPL: Y is also written as two k-blocked bf16 planes (AliveConv.Yp) -- an instantiation of its own, like UPV
+template <int BM, int BN, int WM, int WN, bool UPV = false, bool YPL = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(AliveConv p, unsigned kw_magic, float film_ratio) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MR = TM / 16, NR = TN / 16;
@@ -192,6 +194,43 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(AliveConv p, unsigned kw
                 if (m0 + row_local >= p.Co) continue;
                 conv_epilogue_store<false>(p, n, m0 + row_local, row_local, t, acc[m][nn][r], lp, ft);
             }
+            if constexpr (YPL) {
+                // the lane's four consecutive channels of column t: 8 bytes per plane; the four row groups of a column fill 32 bytes, the
+                // next m the other half of the 64-byte k-block segment (hi = bf16(v), lo = bf16(v - hi): alive_to_planes's split)
+                const int row = m0 + wm * TM + m * 16 + lq * 4;
+                const int c_pad = (p.Co + 31) & ~31;
+                if (row < c_pad) {                                  // channels Co .. c_pad - 1: zeros, as alive_to_planes leaves them
+                    const int64_t cols_pad = (((int64_t)p.N * p.Tout + 127) / 128) * 128;
+                    float q[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) q[r] = row < p.Co ? acc[m][nn][r] : 0.0f;
+                    unsigned short* Po = (unsigned short*)p.Yp;
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                        const bf16x2_t p01 = {(__bf16)q[0], (__bf16)q[1]}, p23 = {(__bf16)q[2], (__bf16)q[3]};
+                        const unsigned h01 = __builtin_bit_cast(unsigned, p01), h23 = __builtin_bit_cast(unsigned, p23);
+                        *(uint2*)(Po + planes_at(pl, (int64_t)n * p.Tout + t, row, cols_pad, c_pad)) = make_uint2(h01, h23);
+                        q[0] -= __uint_as_float(h01 << 16);
+                        q[1] -= __uint_as_float(h01 & 0xffff0000u);
+                        q[2] -= __uint_as_float(h23 << 16);
+                        q[3] -= __uint_as_float(h23 & 0xffff0000u);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (YPL) {
+        // the padding columns N Tout .. cols_pad - 1 (fewer than 128): zeros, written by the block of the last column tile
+        if (n == p.N - 1 && blockIdx.x == gridDim.x - 1) {
+            const int c_pad = (p.Co + 31) & ~31;
+            const int64_t cols = (int64_t)p.N * p.Tout, cols_pad = ((cols + 127) / 128) * 128;
+            const int per_col = 2 * (c_pad / 4);                    // 8-byte pieces per column: planes x channel quads
+            unsigned short* Po = (unsigned short*)p.Yp;
+            for (int i = threadIdx.x; i < (int)(cols_pad - cols) * per_col; i += 256) {
+                const int c = i / per_col, w = i % per_col;
+                *(uint2*)(Po + planes_at(w / (c_pad / 4), cols + c, (w % (c_pad / 4)) * 4, cols_pad, c_pad)) = make_uint2(0u, 0u);
+            }
         }
     }
 }
@@ -212,6 +251,10 @@ extern "C" int alive_conv1d(const AliveConv* d, void* stream) {
     if (d->up > 1) {
         ALIVE_CHECK_ARG(d->Co % d->up == 0 && !d->residual && !d->skip && !d->Z && !d->Zp && d->Y, "alive_conv1d: transposed conv has a plain epilogue");
     }
+    if (d->Yp)
+        ALIVE_CHECK_ARG(d->precision == 0 && d->Y && d->up == 1 && d->act == 0 && !d->post_add && !d->ch_scale && !d->residual && !d->skip && !d->Z &&
+                        !d->Zp && d->Co > 16 && d->Co <= 64 && (d->Co & 3) == 0 && (((uintptr_t)d->Yp) & 15) == 0 && (int64_t)d->N * d->Tout >= 97,
+                        "alive_conv1d: Yp (plane image of Y) needs the exact kernel's plain conv with 16 < Co <= 64, Co %% 4 == 0, more than 96 columns");
     ALIVE_CHECK_ARG(d->pad_mode >= 0 && d->pad_mode <= 2, "alive_conv1d: pad_mode");
     if (d->pad_mode != 0) ALIVE_CHECK_ARG(d->pad_left < d->Tin, "alive_conv1d: reflect pad %d needs Tin > pad (Tin %d)", d->pad_left, d->Tin);
     if (d->Z || d->Zp) ALIVE_CHECK_ARG(d->film && d->Lf > 0, "alive_conv1d: Z needs film");
@@ -231,7 +274,8 @@ extern "C" int alive_conv1d(const AliveConv* d, void* stream) {
         conv_gemm_kernel<128, 128, 2, 2><<<g, 256, 0, s>>>(*d, magic, ratio);
     } else if (d->Co > 16) {
         dim3 g(cdiv(d->Tout, 128), cdiv(d->Co, 64), d->N);
-        conv_gemm_kernel<64, 128, 1, 4><<<g, 256, 0, s>>>(*d, magic, ratio);
+        if (d->Yp) conv_gemm_kernel<64, 128, 1, 4, false, true><<<g, 256, 0, s>>>(*d, magic, ratio);
+        else conv_gemm_kernel<64, 128, 1, 4><<<g, 256, 0, s>>>(*d, magic, ratio);
     } else {
         dim3 g(cdiv(d->Tout, 256), 1, d->N);
         if ((d->up == 2 || d->up == 4) && d->act == 0 && !d->post_add && !d->ch_scale)

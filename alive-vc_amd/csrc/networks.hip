@@ -568,7 +568,7 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
             // exact-fp32 kernel
             void* Pd = i == 2 ? (void*)b.U : (void*)b.Zz;             // both idle until the up path starts
             const int cpad = (dch[i] + 31) & ~31;
-            if (i == 2) RUN(alive_to_planes(dbuf[i], N, dch[i], len, 2, Pd, stream));      // i == 3: left there by downs[2]'s epilogue
+            // (i == 2: the planes of d1 were written by downs[1] beside the fp32 skip tensor, AliveConv.Yp; i == 3: left there by downs[2]'s epilogue)
             AliveGemm g;
             memset(&g, 0, sizeof(g));
             g.W = Wp; g.bias = bb; g.P = Pd; g.N = N; g.T = len / r; g.Ci = r * cpad; g.Co = dch[i + 1]; g.planes = 2;
@@ -582,6 +582,7 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
             RUN(alive_gemm_planes(&g, stream));
         } else {
             AliveConv d = conv_desc(W, bb, dbuf[i], N, dch[i], len, dch[i + 1], r, r, 1, 0, 0, len / r, dbuf[i + 1]);
+            if (i == 1 && b.Pa != nullptr) d.Yp = b.U;           // d1 also as the planes downs[2] reads (batch path)
             RUN(alive_conv1d(&d, stream));
         }
         len /= r;

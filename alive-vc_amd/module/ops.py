@@ -21,11 +21,12 @@ def _f(t):
 
 def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, out_len=None, act=None,
            post_add=None, ch_scale=None, residual=None, skip=None, film=None, film_scale_row=0, film_shift_row=0,
-           want_raw=True, transposed=False, precision="fp32", x_planes=None, z_planes=False):
+           want_raw=True, transposed=False, precision="fp32", x_planes=None, z_planes=False, y_planes=False):
     """Generic Conv1d / ConvTranspose1d(k == stride) through alive_conv1d.
     Returns (Y, Z): raw output (or None) and the gelu+FiLM modulated second output (or None).
     x_planes: the plane-packed form of x (to_planes(x, 2)) -- the split kernel then stages its input by LDS-DMA (AliveConv.Xp);
-    z_planes: Z comes back plane-packed (AliveConv.Zp; a uint8 buffer like to_planes gives) instead of fp32."""
+    z_planes: Z comes back plane-packed (AliveConv.Zp; a uint8 buffer like to_planes gives) instead of fp32;
+    y_planes: the exact kernel also writes Y as two planes (AliveConv.Yp) -- returned in Z's place."""
     x = _f(x)
     n, ci, tin = x.shape
     keep = []
@@ -83,6 +84,9 @@ def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, o
     if x_planes is not None:
         d.Xp, d.X = nat.ptr(x_planes), None
         keep.append(x_planes)
+    if y_planes:
+        Z = torch.empty(nat.lib().alive_planes_bytes(n * tout, co_out, 2), dtype=torch.uint8, device=x.device)
+        d.Yp = nat.ptr(Z)
     nat.check(nat.lib().alive_conv1d(C.byref(d), nat.stream()), "alive_conv1d")
     return Y, Z
 

@@ -229,6 +229,11 @@ typedef struct AliveConv {
      * The decoder's 256-channel FilterBlock chains its convs through these (networks.hip). */
     const void* Xp;
     void* Zp;
+    /* Round 5: Y ALSO as k-blocked bf16 planes (2 planes, [2][pad32(Co) / 32][cols_pad][32], cols = N * Tout), written by the exact
+     * fp32 kernel (precision 0) beside Y for a plain conv (no activation / post_add / ch_scale / residual / skip / Z, up 1,
+     * 16 < Co <= 64, Co % 4 == 0): the plane image of the Filter's 64-channel skip tensor comes from the conv that produces it
+     * (decoder.py:186-188) instead of an alive_to_planes pass over it.  Same bits as alive_to_planes(Y). */
+    void* Yp;
 } AliveConv;
 int alive_conv1d(const AliveConv* desc, void* stream);
 

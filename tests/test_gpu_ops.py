@@ -803,3 +803,25 @@ def test_conv1d_split_plane_operands_equal_the_fp32_staged_kernel(kw, dil, t, wi
     y3, zp3 = ops.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), z_planes=True, **kwargs)
     assert torch.equal(y3, y0) and torch.equal(zp3.view(torch.bfloat16).view(2, c // 32, cols_pad, 32)[:, :, :cols].contiguous().view(torch.int16),
                                             e.contiguous().view(torch.int16))
+
+
+@pytest.mark.parametrize("n,ci,co,r,t", [(3, 16, 64, 2, 4500), (1, 16, 64, 2, 260), (2, 8, 40, 4, 1000), (2, 16, 20, 2, 130)])
+def test_conv1d_exact_kernel_writes_its_output_as_planes_too(n, ci, co, r, t):
+    """AliveConv.Yp (round 5): the decoder's downs[1] (decoder.py:186-188, 16 -> 64 channels, stride 2) leaves the planes downs[2]'s
+    GEMM reads beside its fp32 skip tensor.  Y bitwise the conv without Yp; the planes bitwise alive_to_planes(Y) in the columns and
+    channels that exist (ragged column tile, Co that is not a multiple of 32 or 16)."""
+    from module import ops
+    x = g(f"ypx{n}{ci}{t}", (n, ci, t)).to(DEV)
+    w = g(f"ypw{ci}{co}{r}", (co, ci, r), scale=1.0 / np.sqrt(ci * r)).to(DEV)
+    b = g(f"ypb{co}", (co,), scale=0.1).to(DEV)
+    y0, _ = ops.conv1d(x, w, b, stride=r)
+    y1, yp = ops.conv1d(x, w, b, stride=r, y_planes=True)
+    assert torch.equal(y0, y1)
+    want = ops.to_planes(y0, 2)
+    tout = t // r
+    cols, cols_pad, cp = n * tout, (n * tout + 127) // 128 * 128, (co + 31) // 32 * 32
+    a = yp.view(torch.bfloat16).view(2, cp // 32, cols_pad, 32)[:, :, :cols].permute(0, 2, 1, 3).reshape(2, cols, cp)[:, :, :co]
+    e = want.view(torch.bfloat16).view(2, cp // 32, cols_pad, 32)[:, :, :cols].permute(0, 2, 1, 3).reshape(2, cols, cp)[:, :, :co]
+    assert torch.equal(a.contiguous().view(torch.int16), e.contiguous().view(torch.int16))
+    with pytest.raises(Exception, match="Yp"):
+        ops.conv1d(x, w, b, stride=r, y_planes=True, act="gelu")
