@@ -395,7 +395,7 @@ extern "C" int alive_dwconv_norm_planes(const float* X, int N, int C, int T, con
     ALIVE_CHECK_ARG(X && P && N > 0 && C > 1 && T > 0, "alive_dwconv_norm_planes: bad args");
     ALIVE_CHECK_ARG((dw_w == nullptr) == (dw_b == nullptr), "alive_dwconv_norm_planes: dw_w and dw_b go together");
     ALIVE_CHECK_ARG(affine_mode == 0 ? (gain && offset) : (cond != nullptr), "alive_dwconv_norm_planes: affine params");
-    ALIVE_CHECK_ARG((C & 31) == 0 && (planes == 2 || planes == 3), "alive_dwconv_norm_planes: C %d must be a multiple of 32, planes 2 or 3", C);
+    ALIVE_CHECK_ARG((C & 31) == 0 && planes >= 1 && planes <= 3, "alive_dwconv_norm_planes: C %d must be a multiple of 32, planes 1, 2 or 3", C);
     const int tw = C > 256 ? 32 : 64;                    // <= 68 KB of LDS per block: two blocks per CU
     const size_t lds = (size_t)C * (tw + 1) * sizeof(float);
     ALIVE_CHECK_ARG(lds <= 150 * 1024, "alive_dwconv_norm_planes: C %d does not fit the LDS tile", C);
@@ -403,7 +403,8 @@ extern "C" int alive_dwconv_norm_planes(const float* X, int N, int C, int T, con
     {
         static LdsOptIn optin;
         hipError_t e = optin.ensure({(const void*)dwconv_norm_planes_kernel<2, 32>, (const void*)dwconv_norm_planes_kernel<3, 32>,
-                                     (const void*)dwconv_norm_planes_kernel<2, 64>, (const void*)dwconv_norm_planes_kernel<3, 64>}, 150 * 1024);
+                                     (const void*)dwconv_norm_planes_kernel<2, 64>, (const void*)dwconv_norm_planes_kernel<3, 64>,
+                                     (const void*)dwconv_norm_planes_kernel<1, 32>, (const void*)dwconv_norm_planes_kernel<1, 64>}, 150 * 1024);
         if (e != hipSuccess) {
             alive_set_error("alive_dwconv_norm_planes: cannot reserve LDS: %s", hipGetErrorString(e));
             return ALIVE_ERR_LAUNCH;
@@ -414,7 +415,9 @@ extern "C" int alive_dwconv_norm_planes(const float* X, int N, int C, int T, con
     dwconv_norm_planes_kernel<NP_, TW_><<<g, NPT, lds, (hipStream_t)stream>>>(X, C, T, dw_w, dw_b, dw_w != nullptr, affine_mode, gain, \
                                                                              offset, cond, cond_rows, scale_row, shift_row, eps,  \
                                                                              (unsigned short*)P, cols_pad)
-    if (planes == 2 && tw == 32) LAUNCH_DNP(2, 32);
+    if (planes == 1 && tw == 32) LAUNCH_DNP(1, 32);         // one plane: the input of a plain-bf16 GEMM (alive_gemm_planes, planes = 1)
+    else if (planes == 1) LAUNCH_DNP(1, 64);
+    else if (planes == 2 && tw == 32) LAUNCH_DNP(2, 32);
     else if (planes == 3 && tw == 32) LAUNCH_DNP(3, 32);
     else if (planes == 2) LAUNCH_DNP(2, 64);
     else LAUNCH_DNP(3, 64);
@@ -449,7 +452,7 @@ template <bool PLANES>
 __global__ __launch_bounds__(256) void gelu_film_kernel(const float* __restrict__ H, int C, int L, const float* __restrict__ film,
                                                         int film_rows, int Lf, int scale_row, int shift_row, int t_off, int f_off,
                                                         int film_ld, float ratio, float* __restrict__ Z,
-                                                        unsigned short* __restrict__ Zp, int64_t cols_pad) {
+                                                        unsigned short* __restrict__ Zp, int64_t cols_pad, int n_planes) {
     __shared__ float tile[PLANES ? 64 : 1][PLANES ? 65 : 1];       // [channel][column]
     const int tid = threadIdx.x;
     const int n = blockIdx.z, c0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
@@ -507,6 +510,7 @@ __global__ __launch_bounds__(256) void gelu_film_kernel(const float* __restrict_
             typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
+                if (pl >= n_planes) break;                         // one plane: the plain-bf16 consumer (AliveConv.precision 3)
                 u32x4 o4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -523,8 +527,9 @@ __global__ __launch_bounds__(256) void gelu_film_kernel(const float* __restrict_
 }
 }  // namespace
 
-extern "C" int alive_gelu_film(const float* H, int N, int C, int L, const float* film, int film_rows, int Lf, int scale_row,
-                               int shift_row, int t0, int f0, int film_ld, float* Z, void* Zp, void* stream) {
+// planes: 2, or 1 = plane 0 alone (the k-blocked layout puts it first: the one-plane image of the same values)
+int alive_gelu_film_impl(const float* H, int N, int C, int L, const float* film, int film_rows, int Lf, int scale_row,
+                         int shift_row, int t0, int f0, int film_ld, float* Z, void* Zp, int planes, void* stream) {
     ALIVE_CHECK_ARG(H && film && (Z != nullptr) != (Zp != nullptr) && N > 0 && C > 0 && L > 0 && Lf > 0, "alive_gelu_film: bad args (one of Z / Zp)");
     ALIVE_CHECK_ARG(film_ld > 0 && t0 >= 0 && f0 >= 0, "alive_gelu_film: bad frame range");
     ALIVE_CHECK_ARG(((((uintptr_t)H) | ((uintptr_t)Z) | ((uintptr_t)Zp)) & 15) == 0, "alive_gelu_film: H / Z / Zp must be 16-byte aligned");
@@ -533,11 +538,16 @@ extern "C" int alive_gelu_film(const float* H, int N, int C, int L, const float*
     dim3 g(cdiv(L, 64), cdiv(C, 64), N);
     const int64_t cols_pad = ((int64_t)N * L + 127) / 128 * 128;
     if (Zp) gelu_film_kernel<true><<<g, 256, 0, (hipStream_t)stream>>>(H, C, L, film, film_rows, Lf, scale_row, shift_row, t0, f0, film_ld, ratio,
-                                                                     nullptr, (unsigned short*)Zp, cols_pad);
+                                                                     nullptr, (unsigned short*)Zp, cols_pad, planes);
     else gelu_film_kernel<false><<<g, 256, 0, (hipStream_t)stream>>>(H, C, L, film, film_rows, Lf, scale_row, shift_row, t0, f0, film_ld, ratio, Z,
-                                                                    nullptr, 0);
+                                                                    nullptr, 0, 0);
     ALIVE_CHECK_LAUNCH("alive_gelu_film");
     return ALIVE_OK;
+}
+
+extern "C" int alive_gelu_film(const float* H, int N, int C, int L, const float* film, int film_rows, int Lf, int scale_row,
+                               int shift_row, int t0, int f0, int film_ld, float* Z, void* Zp, void* stream) {
+    return alive_gelu_film_impl(H, N, C, L, film, film_rows, Lf, scale_row, shift_row, t0, f0, film_ld, Z, Zp, 2, stream);
 }
 
 extern "C" int alive_argmax_channels(const float* X, int N, int C, int T, float* out, void* stream) {

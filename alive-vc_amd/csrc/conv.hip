@@ -245,7 +245,7 @@ extern "C" int alive_conv1d(const AliveConv* d, void* stream) {
     ALIVE_CHECK_ARG(d->N > 0 && d->Ci > 0 && d->Co > 0 && d->Tin > 0 && d->Tout > 0, "alive_conv1d: bad sizes");
     ALIVE_CHECK_ARG(d->KW >= 1 && (d->KW <= 16 || d->Ci == 1) && d->stride >= 1 && d->dil >= 1 && d->up >= 1, "alive_conv1d: bad geometry");
     ALIVE_CHECK_ARG(d->precision >= 1 || (d->K_pad % 16 == 0 && d->K_pad >= d->Ci * d->KW), "alive_conv1d: K_pad %d for K %d", d->K_pad, d->Ci * d->KW);
-    ALIVE_CHECK_ARG(d->precision >= 0 && d->precision <= 2, "alive_conv1d: precision");
+    ALIVE_CHECK_ARG(d->precision >= 0 && d->precision <= 3, "alive_conv1d: precision");
     ALIVE_CHECK_ARG(d->Ci * d->KW < 32768, "alive_conv1d: K too large");
     ALIVE_CHECK_ARG(d->Y || d->Z || d->Zp, "alive_conv1d: no output");
     if (d->up > 1) {
@@ -258,7 +258,7 @@ extern "C" int alive_conv1d(const AliveConv* d, void* stream) {
     ALIVE_CHECK_ARG(d->pad_mode >= 0 && d->pad_mode <= 2, "alive_conv1d: pad_mode");
     if (d->pad_mode != 0) ALIVE_CHECK_ARG(d->pad_left < d->Tin, "alive_conv1d: reflect pad %d needs Tin > pad (Tin %d)", d->pad_left, d->Tin);
     if (d->Z || d->Zp) ALIVE_CHECK_ARG(d->film && d->Lf > 0, "alive_conv1d: Z needs film");
-    if (d->Xp || d->Zp) ALIVE_CHECK_ARG(d->precision == 1, "alive_conv1d: plane-packed operands need the split kernel (precision 1)");
+    if (d->Xp || d->Zp) ALIVE_CHECK_ARG(d->precision == 1 || d->precision == 3, "alive_conv1d: plane-packed operands need the split kernel (precision 1 or 3)");
     {
         int rc;
         if (d->film_ld == 0 && !d->Xp && !d->Zp && alive_conv_skinny_try(d, (hipStream_t)stream, &rc)) return rc;      // few columns (streaming)

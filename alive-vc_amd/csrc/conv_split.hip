@@ -54,6 +54,11 @@ constexpr int PROW = 64;          // PLANES = true: bytes per LDS row (32 channe
 // W22 (BM = 128, round 5): the four waves as 2 x 2 of 64 rows x 64 columns instead of four stacked 32 x 128 -- a B fragment from LDS then
 // feeds two row tiles (0.33 instead of 0.67 fragment reads per MFMA: stacked, all four waves read the SAME 128 columns), an A fragment
 // from L2 two column tiles instead of four (two waves ask for the same weight rows: the second request hits the CU's L1).
+// NP = 1 (round 5, AliveConv.precision 3): plain bf16 operands, ONE MFMA per product -- the weights are plane 0 of the two-plane pack, the
+// activations (Xp / Zp) one plane.  Used by the decoder for the six k = 5 convs of its 256-channel FilterBlock, whose inputs are
+// gelu + FiLM outputs consumed by nothing else (1.7e-5 of waveform RMS error against the 1e-3 bar).  At one product per
+// fragment pair the stacked 128-row form would read 1 KB of LDS per MFMA (the LDS peak): NP = 1 runs as the 2 x 2 form of BM = 128 (a B
+// fragment feeds two row tiles; 144 registers, three blocks per CU).
 template <int BM, int NP, bool PLANES = false, bool W22 = false>
 __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(AliveConv p, float film_ratio) {
     static_assert(!W22 || BM == 128, "the 2 x 2 wave arrangement is the 128-row tile's");
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
     constexpr int MR = W22 ? 2 : (BM == 256 ? 2 : 1);         // 32-row MFMA tiles per wave
 
     // X tile, double buffered: [2 buffers][2 planes][XROWS][PITCH]
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NP * XPLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (NP > 1 ? NP : 2) * XPLANE];      // (NP = 1: the epilogue's staging needs the 46 KB)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wrow = (BM >= 128 && !W22) ? wid : (wid >> 1);          // row block of this wave (32 * MR rows)
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
             bf16x2_t lp = {(__bf16)r0, (__bf16)r1};
             *(unsigned*)(Xs + r * PITCH + pair * 4) = h;
             const unsigned l = __builtin_bit_cast(unsigned, lp);
-            *(unsigned*)(Xs + XPLANE + r * PITCH + pair * 4) = l;
+            if (NP >= 2) *(unsigned*)(Xs + XPLANE + r * PITCH + pair * 4) = l;
             if (NP == 3) {
                 float q0 = r0 - __uint_as_float(l << 16), q1 = r1 - __uint_as_float(l & 0xffff0000u);
                 bf16x2_t tp = {(__bf16)q0, (__bf16)q1};
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
         }
     };
 
-    // ---- PLANES: DMA pieces of this wave (piece q = wid + 4 i < 18: plane q / 9, 16-row group q % 9) ----
+    // ---- PLANES: DMA pieces of this wave (piece q = wid + 4 i < 9 NP: plane q / 9, 16-row group q % 9) ----
     unsigned dma_src[5];          // byte offset of this lane's 16 B inside Xp for channel block 0
     [[maybe_unused]] const size_t cols_pad = PLANES ? (((size_t)p.N * p.Tin + 127) & ~(size_t)127) : 0;
     if constexpr (PLANES) {
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int q = wid + 4 * i;
-            if (q < 18)
+            if (q < 9 * NP)
                 __builtin_amdgcn_global_load_lds((gptr_t)(base + dma_src[i]),
                                                  (lptr_t)(smem + (buf * NP + q / 9) * XPLANE + (q % 9) * 1024), 16, 0, 0);
         }
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
                     }
                     unsigned short* dst = Zp + planes_at(0, (int64_t)n * p.Tout + t, row0, zcols_pad, co_pad32);
                     *(u32x4*)dst = u32x4{hi[0], hi[1], hi[2], hi[3]};
-                    *(u32x4*)(dst + zcols_pad * co_pad32) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+                    if (NP >= 2) *(u32x4*)(dst + zcols_pad * co_pad32) = u32x4{lo[0], lo[1], lo[2], lo[3]};     // (NP = 1: the consumer reads one plane)
                 }
             }
         } else if (upvec) {
@@ -497,15 +502,15 @@ int alive_conv_split_launch(const AliveConv* d, float ratio, hipStream_t s) {
     if (d->Zp) {
         const double span = (double)(d->film_ld ? d->film_ld : d->Lf) / (double)d->Tout * BN + 3.0;
         ALIVE_CHECK_ARG(span <= FILM_NF && d->film, "alive_conv1d(split): plane second output needs FiLM rows and Tout >= ~8 Lf");
-        ALIVE_CHECK_ARG(d->up == 1 && (d->Tout & 3) == 0 && d->Co % 64 == 0 && d->Co > 64 && d->precision == 1 &&
+        ALIVE_CHECK_ARG(d->up == 1 && (d->Tout & 3) == 0 && d->Co % 64 == 0 && d->Co > 64 && (d->precision == 1 || d->precision == 3) &&
                         (((uintptr_t)d->Zp) & 15) == 0,
-                        "alive_conv1d(split): plane second output needs up 1, Tout %% 4 == 0, Co a multiple of 64 above 64, 2 planes");
+                        "alive_conv1d(split): plane second output needs up 1, Tout %% 4 == 0, Co a multiple of 64 above 64, precision 1 or 3");
     }
     if (d->Xp) {
-        ALIVE_CHECK_ARG(d->precision == 1 && d->Co > 64 && d->Ci % BKC == 0 && d->Ci_pad == d->Ci && (d->pad_mode == 1 || d->pad_left == 0) &&
+        ALIVE_CHECK_ARG((d->precision == 1 || d->precision == 3) && d->Co > 64 && d->Ci % BKC == 0 && d->Ci_pad == d->Ci && (d->pad_mode == 1 || d->pad_left == 0) &&
                         (((uintptr_t)d->Xp) & 15) == 0 && d->Tout <= d->Tin &&
                         (int64_t)(d->Tout - 1) * d->stride + (int64_t)(d->KW - 1) * d->dil - d->pad_left < d->Tin,
-                        "alive_conv1d(split): plane input needs 2 planes, Co > 64, Ci a multiple of 32, reflect-left padding and no valid "
+                        "alive_conv1d(split): plane input needs precision 1 or 3, Co > 64, Ci a multiple of 32, reflect-left padding and no valid "
                         "output column that reads past the signal (the kernel clamps rows >= Tin instead of zero-filling them)");
     }
     ALIVE_CHECK_ARG(d->Tout <= d->Tin + d->pad_left, "alive_conv1d(split): Tout");
@@ -515,7 +520,20 @@ int alive_conv_split_launch(const AliveConv* d, float ratio, hipStream_t s) {
     // default; ALIVE_CONV_TILE256=1 selects it (same results bit for bit).
     static const bool tile256 = getenv("ALIVE_CONV_TILE256") != nullptr && atoi(getenv("ALIVE_CONV_TILE256")) != 0;
     static const bool w22 = getenv("ALIVE_CONV_W22") != nullptr && atoi(getenv("ALIVE_CONV_W22")) != 0;      // A/B: 2 x 2 waves (plane input)
-    if (d->Co > 128 && d->Co % 256 == 0 && d->precision == 1 && tile256 && !d->Xp) {
+    if (d->precision == 3) {
+        // plain bf16 (one plane per operand): the 2 x 2 form of the 128-row tile.  Measured (tools/bench_conv256.py, 128 windows x 4500 columns,
+        // k5 + FiLM + residual + Y / k5 + FiLM / 1x1 + FiLM + Y / k5 + residual + Y): 0.895 / 0.697 / 0.548 / 0.661 ms against the two-plane
+        // form's 1.353 / 1.182 / 0.664 / 1.063; as one 256-row block per column tile (256 registers at two blocks per CU, 122 of them
+        // spilled in the four epilogue passes) 1.625 / 1.319 / 1.239 / 0.747 -- not instantiated.
+        if (d->Co > 64) {
+            dim3 g(cdiv(d->Tout, BN), cdiv(d->Co, 128), d->N);
+            if (d->Xp) conv_split_kernel<128, 1, true, true><<<g, 256, 0, s>>>(*d, ratio);
+            else conv_split_kernel<128, 1, false, true><<<g, 256, 0, s>>>(*d, ratio);
+        } else {
+            dim3 g(cdiv(d->Tout, BN), 1, d->N);
+            conv_split_kernel<64, 1><<<g, 256, 0, s>>>(*d, ratio);
+        }
+    } else if (d->Co > 128 && d->Co % 256 == 0 && d->precision == 1 && tile256 && !d->Xp) {
         dim3 g(cdiv(d->Tout, BN), d->Co / 256, d->N);
         conv_split_kernel<256, 2><<<g, 256, 0, s>>>(*d, ratio);
     } else if (d->Co > 64) {

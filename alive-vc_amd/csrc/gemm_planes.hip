@@ -903,7 +903,8 @@ extern "C" int alive_gemm_planes(const AliveGemm* d, void* stream) {
     ALIVE_CHECK_ARG(d->y_split == 0 || (d->y_split % GM == 0 && d->y_split < d->Co && d->Y && d->Y2 && !d->residual && !d->Pout && d->act != 3),
                     "alive_gemm_planes: y_split must be a multiple of %d below Co, with Y and Y2 and neither residual nor Pout", GM);
     ALIVE_CHECK_ARG(d->N > 0 && d->T > 0 && d->Ci > 0 && d->Co > 0, "alive_gemm_planes: bad shape");
-    ALIVE_CHECK_ARG(d->planes == 2 || d->planes == 3, "alive_gemm_planes: planes must be 2 or 3, got %d", d->planes);
+    ALIVE_CHECK_ARG(d->planes >= 1 && d->planes <= 3, "alive_gemm_planes: planes must be 1, 2 or 3, got %d", d->planes);
+    ALIVE_CHECK_ARG(d->planes != 1 || (d->act != 3 && d->act != 4), "alive_gemm_planes: one plane (plain bf16) has no argmax / magnitude epilogue");
     ALIVE_CHECK_ARG(d->b_row == 0 || ((d->b_row | d->b_win | d->b_plane) & 7) == 0, "alive_gemm_planes: custom row placement must be in multiples of 8 elements");
     ALIVE_CHECK_ARG(d->b_row == 0 || (d->Ci & 31) == 0, "alive_gemm_planes: custom row placement needs Ci %% 32 == 0");
     ALIVE_CHECK_ARG(d->b_cblk >= 0 && (d->b_cblk == 0 || (d->b_row != 0 && (d->Ci / 32) % d->b_cblk == 0 && (d->b_blk & 7) == 0)),
@@ -923,6 +924,11 @@ extern "C" int alive_gemm_planes(const AliveGemm* d, void* stream) {
     const bool can_persist = ntiles >= persist_min && variant != 1 &&
                              (d->b_row == 0 ? (int64_t)d->planes * pad_cols((int64_t)d->N * d->T) * pad32(d->Ci)
                                             : (int64_t)d->planes * d->b_plane) * 2 < (1ll << 32);          // 32-bit DMA offsets
+    if (d->planes == 1) {
+        // one plane = plain bf16 operands, one MFMA per product (round 5): W and P may be the first plane of two- or three-plane images
+        // (the k-blocked layout puts plane 0 first).  Stages of 16 KB, four in the ring, two blocks per CU.
+        return launch_gemm<1, 4, 2>(*d, (hipStream_t)stream);
+    }
     if (d->planes == 2) {
         // two planes: the one-tile kernel with two blocks per CU (one block's epilogue under the other's MFMAs) beats one persistent block
         if (can_persist && variant == 2 && nsteps >= 4) return launch_gemm_lw<2, 4>(*d, (hipStream_t)stream);

@@ -30,7 +30,7 @@ def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, o
     x = _f(x)
     n, ci, tin = x.shape
     keep = []
-    split = precision in ("bf16x3", "bf16x6")
+    split = precision in ("bf16x3", "bf16x6", "bf16")          # "bf16": one MFMA per product on plane 0 of the two-plane weights
     planes = 3 if precision == "bf16x6" else 2
     if split and transposed:
         r = weight.shape[2]
@@ -61,7 +61,7 @@ def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, o
     d = nat.AliveConv()
     d.W, d.bias, d.X = nat.ptr(W), nat.ptr(b), nat.ptr(x)
     d.N, d.Ci, d.Tin, d.Co, d.K_pad = n, ci, tin, co_rows, (W.shape[-1] if W.dim() == 2 else W.shape[1] * 32)
-    d.precision, d.Ci_pad = (planes - 1, (ci + 31) // 32 * 32) if split else (0, 0)
+    d.precision, d.Ci_pad = (3 if precision == "bf16" else planes - 1, (ci + 31) // 32 * 32) if split else (0, 0)
     d.KW, d.stride, d.dil, d.pad_left, d.pad_mode = kw, stride_, dilation, pad_left, pad_mode
     d.Tout, d.up, d.act = tout, up, ACT[act]
     post_add, ch_scale, residual, skip, film = map(_f, (post_add, ch_scale, residual, skip, film))
@@ -71,7 +71,7 @@ def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, o
     Z = None
     if film is not None:
         if z_planes:
-            Z = torch.empty(nat.lib().alive_planes_bytes(n * tout, co_out, 2), dtype=torch.uint8, device=x.device)
+            Z = torch.empty(nat.lib().alive_planes_bytes(n * tout, co_out, 1 if precision == "bf16" else 2), dtype=torch.uint8, device=x.device)
         else:
             Z = torch.empty(n, co_out, tout, device=x.device)
         d.film, d.film_rows, d.Lf = nat.ptr(film), film.shape[1], film.shape[2]
@@ -125,7 +125,7 @@ def gemm_planes(P, n, t, weight, bias=None, planes=2, act=None, post_add=None, c
                 want_fp32=True, want_planes=False):
     """1x1 conv on a plane-packed input through alive_gemm_planes.  Returns (Y fp32 [n][co][t] or None, Pout or None)."""
     co, ci = weight.shape[0], weight.shape[1]
-    W = pack_conv_split(weight, planes)
+    W = pack_conv_split(weight, max(planes, 2))           # planes = 1 (plain bf16) reads plane 0 of the two-plane pack
     b, post_add, ch_scale, residual = map(_f, (bias, post_add, ch_scale, residual))
     d = nat.AliveGemm()
     d.W, d.bias, d.P = nat.ptr(W), nat.ptr(b), nat.ptr(P)
@@ -312,3 +312,9 @@ def front_end(wave, ce, pe, out=None):
     nat.check(L.alive_front_end(nat.ptr(dft_basis(wave.device)), tc.array, tp.array, nat.ptr(hit[0]), nat.ptr(hit[1]), nat.ptr(wave), n, l,
                                 nat.ptr(feat), nat.ptr(f0), nat.ptr(ws), nat.stream()), "alive_front_end")
     return feat, f0
+
+
+def decoder_precision(mode=0):
+    """Arithmetic of the six k = 5 convs of the decoder's 256-channel FilterBlock on the batch path (alive_decoder_precision):
+    1 = plain bf16 operands (default since round 5), 2 = two-plane split bf16 (rounds 1 - 4), 0 = query.  Returns the mode in force."""
+    return int(nat.lib().alive_decoder_precision(int(mode)))

@@ -68,6 +68,40 @@ def test_decoder_stage_errors_are_small(nets):
     assert rms(wave, ref) < 2e-4, rms(wave, ref)
 
 
+def test_decoder_precision_modes(golden_dir, nets):
+    """Round 5: the six k = 5 convs of the 256-channel FilterBlock (decoder.py:128-134 at the coarsest scale) and the pointwise convs of
+    the feature extractor's ConvNeXt layers (common.py:74-82) run on plain bf16 operands by default (alive_decoder_precision 1), on
+    two-plane split bf16 in mode 2 (rounds 1 - 4).  Both against the oracle on the same decoder inputs, and against the reference's
+    fixture of 450 frames: mode 1 stays inside 2e-4 (a fifth of the 1e-3 bar; measured 1.19e-4), mode 2 inside 2e-5 (5.0e-6); the
+    difference between the modes is the measured price of the plain form."""
+    from module import ops
+    ce, pe, dec, cpu = nets
+    x = synthetic.gaussian("dx", 4, (3, 768, 40))
+    f0 = (100 + 300 * torch.from_numpy(synthetic.uniform01("df0", 4, 120)).float()).view(3, 1, 40)
+    f0[1, 0, 10:14] = 0
+    ref, _ = O.decoder(cpu[2], x, f0)
+    z = np.load(os.path.join(golden_dir, "full_T450.npz"))
+    spec = torch.from_numpy(z["spec"]) if "spec" in z.files else O.spectrogram(torch.from_numpy(z["wav"]))
+    feat450 = O.content_encoder(cpu[0], spec).to(DEV)
+    f0_450 = torch.from_numpy(z["f0_dec"]).to(DEV)
+    if os.environ.get("ALIVE_DECODER_PRECISION") is None:
+        assert ops.decoder_precision(0) == 1
+    out = {}
+    try:
+        for mode in (1, 2):
+            assert ops.decoder_precision(mode) == mode
+            out[mode] = (dec(x.to(DEV), f0.to(DEV))[0].cpu(), dec(feat450, f0_450)[0].cpu())
+    finally:
+        ops.decoder_precision(1 if os.environ.get("ALIVE_DECODER_PRECISION") != "2" else 2)
+    e1, e2, d12 = rms(out[1][0], ref), rms(out[2][0], ref), rms(out[1][0], out[2][0])
+    f1, f2 = rms(out[1][1], torch.from_numpy(z["wave"])), rms(out[2][1], torch.from_numpy(z["wave"]))
+    print(f"decoder precision modes: 40 frames vs oracle plain {e1:.3e} split {e2:.3e} (plain - split {d12:.3e}); "
+          f"450-frame fixture plain {f1:.3e} split {f2:.3e} (plain - split {rms(out[1][1], out[2][1]):.3e})")
+    assert e2 < 2e-5 and e1 < 1e-4 and d12 < 1e-4, (e1, e2, d12)
+    assert f1 < 2e-4 and f2 < 2e-5, (f1, f2)
+    assert d12 > 1e-7                                  # the two modes really are different kernels
+
+
 def test_realtime_two_steps(golden_dir, nets):
     """realtime_inference.py:146-167: phase carried through phi[:, :, end_of_output]."""
     from module.common import match_features
