@@ -120,12 +120,16 @@ AliveConv split(AliveConv d) {
 //       their inputs are gelu + FiLM outputs that nothing else reads, their outputs are added to an fp32 residual stream;
 //   (b) the two pointwise convs of the feature extractor's four AdaptiveConvNeXt1d layers (common.py:74-82; alive_gemm_planes with
 //       planes = 1): inputs are a channel-normalised tensor and a gelu output, the output is scaled and added to the fp32 stream.
-//   Everything else -- the FiLM projections (the waveform is 20 x more sensitive to them), input layer, to_amps, the strided and
-//   transposed convs, the fused 64 / 16 / 8-channel FilterBlocks -- stays on two-plane split bf16 or exact fp32.  Measured on the
+//   (c) the projection of the f0 encoding onto the AdaptiveChannelNorm scales / shifts (common.py:35-41, 512 -> 4096), the Filter's two
+//       coarsest down convs (decoder.py:186-188, 64 -> 256 k8 and 256 -> 256 k10) and its mid conv (decoder.py:190).
+//   Everything else -- the FiLM projections and the input layer (the waveform is 15 x more sensitive to them than to (a)), to_amps,
+//   the transposed convs, the fused 64 / 16 / 8-channel FilterBlocks -- stays on two-plane split bf16 or exact fp32.  Measured on the
 //   reference's 450-frame fixture: decoder waveform RMS error 5.0e-6 (mode 2) -> 1.19e-4 (mode 1; (a) alone 1.12e-4), whole
 //   conversion 1.1e-4 -> 1.2e-4, against the bar of 1e-3 (tests/test_gpu_models.py::test_decoder_precision_modes).
 // mode 2: two-plane split bf16 for these too (rounds 1 - 4).  ALIVE_DECODER_PRECISION=2 or alive_decoder_precision(2).
-// ALIVE_DECODER_BF16_MASK (experiments): which of (a) = 1, (b) = 2 mode 1 covers (default 3).
+// ALIVE_DECODER_BF16_MASK (experiments): which of (a) = 1, (b) = 2, (c) = 4 mode 1 covers (default 7).
+// Sensitivities (oracle with the operands of one group rounded to bf16, 450-frame fixture, waveform RMS 0.66): (a) 1.11e-4, (b) 2.7e-5,
+// (c) 2.2e-5 + 8.3e-6 + 1.3e-6; not adopted: FiLM projections 1.6e-3, input layer 1.5e-3, 64-channel FilterBlock 2.2e-4, up convs 8.1e-5.
 int g_decoder_precision = 0;      // 0: not decided yet (environment, else 1)
 int decoder_precision() {
     if (g_decoder_precision == 0) {
@@ -135,7 +139,7 @@ int decoder_precision() {
     return g_decoder_precision;
 }
 int decoder_bf16_mask() {
-    static const int m = getenv("ALIVE_DECODER_BF16_MASK") ? atoi(getenv("ALIVE_DECODER_BF16_MASK")) : 3;
+    static const int m = getenv("ALIVE_DECODER_BF16_MASK") ? atoi(getenv("ALIVE_DECODER_BF16_MASK")) : 7;
     return decoder_precision() == 1 ? m : 0;
 }
 
@@ -560,7 +564,12 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
     { AliveConv d = pw_desc(c1W, c1b, f0, N, 1, Lf, DEC_C, b.sinb); d.act = 3; RUN(alive_conv1d(&d, stream)); }
     RUN(pw_conv(c2W, c2b, b.sinb, b.Pa, N, Lf, DEC_C, DEC_C, 2, 0, nullptr, b.cond, stream));
     const float* nfW = t.next(); const float* nfb = t.next();
-    RUN(pw_conv(nfW, nfb, b.cond, b.Pa, N, Lf, DEC_C, 4096, 2, 0, nullptr, b.normfilm, stream));
+    if (b.Pa != nullptr && (decoder_bf16_mask() & 4)) {      // (c) plain bf16: plane 0 of the two-plane image of cond
+        RUN(alive_to_planes(b.cond, N, DEC_C, Lf, 2, b.Pa, stream));
+        RUN(pw_gemm(nfW, nfb, b.Pa, N, Lf, DEC_C, 4096, 1, 0, nullptr, nullptr, nullptr, b.normfilm, nullptr, stream));
+    } else {
+        RUN(pw_conv(nfW, nfb, b.cond, b.Pa, N, Lf, DEC_C, 4096, 2, 0, nullptr, b.normfilm, stream));
+    }
     for (int i = 0; i < 4; ++i) {
         ConvNeXtW cw(t, true);
         RUN(convnext_layer(cw, b.x, b.y, b.h, b.Pa, b.Ph, N, DEC_C, DEC_H, Lf, b.normfilm, 4096, i * 1024, i * 1024 + 512, 2, stream));
@@ -599,7 +608,8 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
             // (i == 2: the planes of d1 were written by downs[1] beside the fp32 skip tensor, AliveConv.Yp; i == 3: left there by downs[2]'s epilogue)
             AliveGemm g;
             memset(&g, 0, sizeof(g));
-            g.W = Wp; g.bias = bb; g.P = Pd; g.N = N; g.T = len / r; g.Ci = r * cpad; g.Co = dch[i + 1]; g.planes = 2;
+            g.W = Wp; g.bias = bb; g.P = Pd; g.N = N; g.T = len / r; g.Ci = r * cpad; g.Co = dch[i + 1];
+            g.planes = (decoder_bf16_mask() & 4) ? 1 : 2;            // (c) plain bf16: plane 0 of d1's / one plane of d2's image
             g.Y = dbuf[i + 1];
             if (i == 2) g.Pout = b.Zz;                                 // d2 as planes too: the input of downs[3]
             g.b_plane = (int64_t)(alive_planes_bytes((int64_t)N * len, dch[i], 2) / 4);      // elements per plane
@@ -618,6 +628,7 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
     const float* mW = t.next(); const float* mb = t.next();
     {   // mid CausalConv1d(256,256,5) + skips[3]   (decoder.py:190-191)
         AliveConv d = split(conv_desc(mW, mb, b.d3, N, 256, Lf, 256, 5, 1, 1, 4, 1, Lf, b.m));
+        if (decoder_bf16_mask() & 4) d.precision = 3;                // (c)
         d.skip = b.d3;
         RUN(alive_conv1d(&d, stream));
     }
