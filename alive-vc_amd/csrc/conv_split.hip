@@ -20,7 +20,8 @@
 #include <stdlib.h>
 
 #ifndef ALIVE_CONV_ABL
-#define ALIVE_CONV_ABL 0             // ablation bits (timing only, WRONG results): 1 no epilogue, 2 B fragments read once per channel block, 4 no X DMA after the first
+#define ALIVE_CONV_ABL 0             // ablation bits (timing only, WRONG results): 1 no epilogue, 2 B fragments read once per channel block, 4 no X DMA after the first,
+                                     // 8 weight fragments loaded once, 16 no gelu, 32 FiLM without the interpolation, 64 no transposed plane leave
 #endif
 
 namespace {
@@ -218,8 +219,12 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
     advance();
     if constexpr (!PLANES) store_X(0);
     __syncthreads();
+#ifdef ALIVE_CONV_PRIO
+    __builtin_amdgcn_s_setprio(ALIVE_CONV_PRIO);              // the k-loop of this wave before the epilogue of a co-resident block's
+#endif
     for (int cb = 0; cb < ncb; ++cb) {
         const bool more_cb = cb + 1 < ncb;
+        if (ALIVE_CONV_ABL & 8) pcb = ncb;                     // no further weight loads
         if constexpr (PLANES) {
             if (more_cb && !(ALIVE_CONV_ABL & 4)) dma_X(cb + 1, (cb + 1) & 1);          // lands under this block's taps; the barrier below waits for it
         } else {
@@ -286,6 +291,9 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
         if (sx == 12345.678f && p.Y != nullptr) p.Y[0] = sx;
         return;
     }
+#ifdef ALIVE_CONV_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // ---- epilogue: accumulators -> LDS -> cooperative row-wise pass ----
     // Staging the tile through LDS turns the MFMA layout (a lane owns 16 scattered rows of one column) into
     // whole rows: every global access of the epilogue (residual, skip, Y, Z) is a 16-B vector per thread on
@@ -359,20 +367,28 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
                 if (p.Z != nullptr || p.Zp != nullptr) {
                     const float* fs = Ft + pr * 2 * FILM_NF - f_lo;
                     f32x4 z;
+#if ALIVE_CONV_ABL & 16
+                    const float gv[4] = {v[0], v[1], v[2], v[3]};
+#else
                     const f32x2 g0 = gelu_fast2(f32x2{v[0], v[1]}), g1 = gelu_fast2(f32x2{v[2], v[3]});
                     const float gv[4] = {g0[0], g0[1], g1[0], g1[1]};
+#endif
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
+#if ALIVE_CONV_ABL & 32
+                        z[q] = gv[q] * fs[q] + fs[FILM_NF + q];
+#else
                         Lerp lp = lerp_coord(t + q + p.film_t0, film_ratio, p.Lf);
                         float sc = lerp_apply(lp, fs[lp.i0], fs[lp.i1]);
                         float sh = lerp_apply(lp, fs[FILM_NF + lp.i0], fs[FILM_NF + lp.i1]);
                         z[q] = gv[q] * sc + sh;
+#endif
                     }
                     if (p.Z != nullptr) *(f32x4*)(p.Z + o) = z;
                     if (p.Zp != nullptr) *(f32x4*)&Ct[pr * CP + (c4 ^ zsw(pr))] = z;      // in place: this thread's own four values
                 }
             }
-            if (p.Zp != nullptr) {
+            if (p.Zp != nullptr && !(ALIVE_CONV_ABL & 64)) {
                 // transposed leave: thread = (column, 8 channels); 8 lanes write the 128 B of a column's 64 channels per plane
                 __syncthreads();
                 unsigned short* Zp = (unsigned short*)p.Zp;

@@ -364,10 +364,11 @@ def main():
         fl_dec = (18.12 + 0.07 + 78.40) * 1e6 * frames_per_step
         # decoder precision mode 1 (default since round 5): the four ConvNeXt layers' pointwise convs (4 x 2 x 2*512*1536 = 12.58 MFLOP per
         # frame) and the six k = 5 convs of the 256-channel FilterBlock (6 x 2*256*256*5 x 10 columns = 39.32) run ONE bf16 MFMA per
-        # product, priced at 2.5 PF; the other 44.69 MFLOP three.  The family's peak is the blend: its FLOP / its ideal time.
+        # product, and so do the norm-FiLM projection (4.19), the two coarse down convs (2.62 + 1.31) and the mid conv (0.66): 60.68 MFLOP
+        # priced at 2.5 PF; the other 35.91 MFLOP run three.  The family's peak is the blend: its FLOP / its ideal time.
         from module import ops as _ops
         dec_mode = _ops.decoder_precision(0)
-        fl_dec_plain = (12.58 + 39.32) * 1e6 * frames_per_step if dec_mode == 1 else 0.0
+        fl_dec_plain = (12.58 + 39.32 + 4.19 + 2.62 + 1.31 + 0.66) * 1e6 * frames_per_step if dec_mode == 1 else 0.0
         dec_ideal_s = fl_dec_plain / (PEAK_BF16_TFLOPS * 1e12) + (fl_dec - fl_dec_plain) / (PEAK_BF16_TFLOPS / 3 * 1e12)
         pk_enc, pk_dec = PEAK_BF16_TFLOPS / 6, fl_dec / dec_ideal_s / 1e12
         fl_knn = 2.0 * 768 * M * frames_per_step
@@ -378,8 +379,8 @@ def main():
         return {"bound": "mfma", "timing": "HIP events on the launching stream, each family alone, one stream (the step overlaps window batches on side streams)",
                 "counters": "profiles/nets_pmc.json (per kernel: MFMA-pipe utilisation, bytes beyond L2, LDS conflicts, VALU co-execution; tools/pmc_nets.sh)",
                 "front_end": fam(ms_enc, fl_enc, pk_enc, "spectrogram (DFT as a GEMM) + F0Estimator + ContentEncoder: 3-plane split bf16, 6 MFMAs per product"),
-                "decoder": dict(fam(ms_dec, fl_dec, pk_dec, ("FeatureExtractor + HarmonicOscillator + Filter: plain bf16 (1 MFMA per product) for the ConvNeXt pointwise convs and the six k5 convs of the 256-channel FilterBlock "
-                                                              "(51.9 of the 96.6 MFLOP per frame), 2-plane split bf16 (3 MFMAs per product) for the rest; peak = the blend, FLOP / ideal time" if dec_mode == 1 else
+                "decoder": dict(fam(ms_dec, fl_dec, pk_dec, ("FeatureExtractor + HarmonicOscillator + Filter: plain bf16 (1 MFMA per product) for the ConvNeXt pointwise convs, the six k5 convs of the 256-channel FilterBlock, the norm-FiLM projection, the two coarse down convs and the mid conv "
+                                                              "(60.7 of the 96.6 MFLOP per frame), 2-plane split bf16 (3 MFMAs per product) for the rest; peak = the blend, FLOP / ideal time" if dec_mode == 1 else
                                                               "FeatureExtractor + HarmonicOscillator + Filter: 2-plane split bf16, 3 MFMAs per product") +
                                                              " (fused FilterBlocks at 64 / 16 / 8 channels on the same MFMA; exact f32 MFMA only for the strided / transposed convs of the two finest scales)"),
                                 precision_mode=dec_mode, frac_of_split_bf16_peak=round(fl_dec / (ms_dec * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS / 3), 4)),
@@ -712,7 +713,7 @@ def main():
             "dtype": ({"fp6": "fp6 (e2m3)", "fp8": "fp8 (e4m3)"}[library.prefilter] + " MFMA candidate scoring + exact f32 rescoring, every frame "
                       "certified at 7 sigma of its measured stage error (statistical: audited against brute force on every frame of this "
                       "batch, tests/test_gpu_knn_audit.py; ALIVE_KNN_STRICT=1 is the deterministic form)" if library.prefilter in ("fp8", "fp6") else
-                      "bf16 MFMA scoring + exact f32 rescoring, certified per frame" + (" (deterministic bound)" if library.strict else "")) + "; 3-plane split-bf16 (fp32-grade) encoder GEMMs; decoder: " + ("plain bf16 (one MFMA per product, fp32 accumulate and residual streams) for the ConvNeXt pointwise convs and the 256-channel FilterBlock's k5 convs -- decoder waveform RMS error 1.2e-4 on the reference's 450-frame fixture against the 1e-3 bar, ALIVE_DECODER_PRECISION=2 restores split bf16 (5e-6) --, 2-plane split-bf16 for its other GEMMs" if decoder_mode == 1 else "2-plane split-bf16 GEMMs (ALIVE_DECODER_PRECISION=2)") + "; f32 MFMA DFT / strided / small-channel convs; f64 phase scan",
+                      "bf16 MFMA scoring + exact f32 rescoring, certified per frame" + (" (deterministic bound)" if library.strict else "")) + "; 3-plane split-bf16 (fp32-grade) encoder GEMMs; decoder: " + ("plain bf16 (one MFMA per product, fp32 accumulate and residual streams) for the ConvNeXt pointwise convs, the 256-channel FilterBlock's k5 convs and four smaller layers (60.7 of its 96.6 MFLOP per frame) -- decoder waveform RMS error 1.2e-4 on the reference's 450-frame fixture against the 1e-3 bar, ALIVE_DECODER_PRECISION=2 restores split bf16 (5e-6) --, 2-plane split-bf16 for its other GEMMs" if decoder_mode == 1 else "2-plane split-bf16 GEMMs (ALIVE_DECODER_PRECISION=2)") + "; f32 MFMA DFT / strided / small-channel convs; f64 phase scan",
             "data": "synthetic",
             "config": {"workload": f"{args.utterances} utterances x {args.seconds:g} s per GPU -> {n_win} windows x "
                                    f"{L // FRAME} frames per step, {M}-vector library (BASELINE config 3/4 shape)",
