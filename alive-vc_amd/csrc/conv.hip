@@ -194,28 +194,41 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(AliveConv p, unsigned kw
                 if (m0 + row_local >= p.Co) continue;
                 conv_epilogue_store<false>(p, n, m0 + row_local, row_local, t, acc[m][nn][r], lp, ft);
             }
-            if constexpr (YPL) {
-                // the lane's four consecutive channels of column t: 8 bytes per plane; the four row groups of a column fill 32 bytes, the
-                // next m the other half of the 64-byte k-block segment (hi = bf16(v), lo = bf16(v - hi): alive_to_planes's split)
-                const int row = m0 + wm * TM + m * 16 + lq * 4;
-                const int c_pad = (p.Co + 31) & ~31;
-                if (row < c_pad) {                                  // channels Co .. c_pad - 1: zeros, as alive_to_planes leaves them
-                    const int64_t cols_pad = (((int64_t)p.N * p.Tout + 127) / 128) * 128;
-                    float q[4];
+        }
+        if constexpr (YPL) {
+            // Planes of this column: a lane holds, per 16-row group m, four consecutive channels (lq * 4 ..) -- 8 bytes per plane.  The
+            // groups m, m + 1 of a 32-channel k-block are exchanged between the lanes lq, lq ^ 1 (same column: lane ^ 16) so that an even
+            // lq owns channels lq * 4 .. + 7 and an odd one 16 + (lq - 1) * 4 .. + 7: one 16-byte store per lane, plane and k-block, and a
+            // wave's store instruction writes 16 columns x 64 B = one contiguous 1-KB run (8-byte stores touched 32 B of every line twice:
+            // 1.93 -> 3.25 ms per step for this conv).  hi = bf16(v), lo = bf16(v - hi): alive_to_planes's split.
+            static_assert(!YPL || (MR % 2) == 0, "the plane image pairs the 16-row groups");
+            const int c_pad = (p.Co + 31) & ~31;
+            const int64_t cols_pad = (((int64_t)p.N * p.Tout + 127) / 128) * 128;
+            unsigned short* Po = (unsigned short*)p.Yp;
+            const bool odd = (lq & 1) != 0;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) q[r] = row < p.Co ? acc[m][nn][r] : 0.0f;
-                    unsigned short* Po = (unsigned short*)p.Yp;
+            for (int mp = 0; mp < MR; mp += 2) {
+                const int rbase = m0 + wm * TM + mp * 16;                 // first channel of the k-block (wave-uniform)
+                if (rbase >= c_pad) continue;                              // (channels Co .. c_pad - 1: zeros, as alive_to_planes leaves them)
+                float qa[4], qb[4];
 #pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) {
-                        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-                        const bf16x2_t p01 = {(__bf16)q[0], (__bf16)q[1]}, p23 = {(__bf16)q[2], (__bf16)q[3]};
-                        const unsigned h01 = __builtin_bit_cast(unsigned, p01), h23 = __builtin_bit_cast(unsigned, p23);
-                        *(uint2*)(Po + planes_at(pl, (int64_t)n * p.Tout + t, row, cols_pad, c_pad)) = make_uint2(h01, h23);
-                        q[0] -= __uint_as_float(h01 << 16);
-                        q[1] -= __uint_as_float(h01 & 0xffff0000u);
-                        q[2] -= __uint_as_float(h23 << 16);
-                        q[3] -= __uint_as_float(h23 & 0xffff0000u);
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    qa[r] = rbase + lq * 4 < p.Co ? acc[mp][nn][r] : 0.0f;
+                    qb[r] = rbase + 16 + lq * 4 < p.Co ? acc[mp + 1][nn][r] : 0.0f;
+                }
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                    auto pk = [](float a, float b) { const bf16x2_t h = {(__bf16)a, (__bf16)b}; return __builtin_bit_cast(unsigned, h); };
+                    const unsigned a01 = pk(qa[0], qa[1]), a23 = pk(qa[2], qa[3]), b01 = pk(qb[0], qb[1]), b23 = pk(qb[2], qb[3]);
+                    const unsigned rx = (unsigned)__shfl_xor((int)(odd ? a01 : b01), 16), ry = (unsigned)__shfl_xor((int)(odd ? a23 : b23), 16);
+                    const u32x4 o = odd ? u32x4{rx, ry, b01, b23} : u32x4{a01, a23, rx, ry};
+                    const int ch = rbase + (odd ? 16 + (lq - 1) * 4 : lq * 4);
+                    *(u32x4*)(Po + planes_at(pl, (int64_t)n * p.Tout + t, ch, cols_pad, c_pad)) = o;
+                    qa[0] -= __uint_as_float(a01 << 16); qa[1] -= __uint_as_float(a01 & 0xffff0000u);
+                    qa[2] -= __uint_as_float(a23 << 16); qa[3] -= __uint_as_float(a23 & 0xffff0000u);
+                    qb[0] -= __uint_as_float(b01 << 16); qb[1] -= __uint_as_float(b01 & 0xffff0000u);
+                    qb[2] -= __uint_as_float(b23 << 16); qb[3] -= __uint_as_float(b23 & 0xffff0000u);
                 }
             }
         }
