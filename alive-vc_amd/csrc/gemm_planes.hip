@@ -927,6 +927,10 @@ extern "C" int alive_gemm_planes(const AliveGemm* d, void* stream) {
     if (d->planes == 1) {
         // one plane = plain bf16 operands, one MFMA per product (round 5): W and P may be the first plane of two- or three-plane images
         // (the k-blocked layout puts plane 0 first).  Stages of 16 KB, four in the ring, two blocks per CU.
+        static const int form1 = getenv("ALIVE_GEMM1_FORM") ? atoi(getenv("ALIVE_GEMM1_FORM")) : 0;      // A/B: ring depth x blocks per CU
+        if (form1 == 1) return launch_gemm<1, 3, 3>(*d, (hipStream_t)stream);
+        if (form1 == 2) return launch_gemm<1, 6, 2>(*d, (hipStream_t)stream);
+        if (form1 == 3) return launch_gemm<1, 2, 4>(*d, (hipStream_t)stream);
         return launch_gemm<1, 4, 2>(*d, (hipStream_t)stream);
     }
     if (d->planes == 2) {

@@ -36,7 +36,7 @@ FRAME = 320
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_FP8_TFLOPS = 5000.0           # dense fp8 MFMA peak (block-scaled 32x32x64 e4m3), same table
 PEAK_FP6_TFLOPS = 10000.0          # dense fp6 / fp4 MFMA peak (block-scaled 32x32x64 e2m3: "FP6 at FP4 rate"), same table
-ALL_LEGS = ("uncorrelated", "fp8_prefilter", "bf16_prefilter", "strict_knn", "clustered_library", "overlap_shared", "context_trim", "cli_default", "library_build", "pcie_inclusive", "e2e_24k", "config2",
+ALL_LEGS = ("uncorrelated", "fp8_prefilter", "decoder_split_bf16", "bf16_prefilter", "strict_knn", "clustered_library", "overlap_shared", "context_trim", "cli_default", "library_build", "pcie_inclusive", "e2e_24k", "config2",
             "streaming", "cpu_baseline")
 
 
@@ -426,6 +426,28 @@ def main():
             finally:
                 conv.set_library(library)
         extra["fp8_prefilter"] = guarded(leg)
+
+    # The same step with the decoder's plain-bf16 layers back on two-plane split bf16 (alive_decoder_precision 2, the arithmetic of rounds
+    # 1 - 4): what the default mode buys, and how far its waveforms are from the split form's
+    if "decoder_split_bf16" in legs:
+        def leg():
+            from module import ops as _ops
+            mode0 = _ops.decoder_precision(0)
+            if mode0 != 1:
+                return {"skipped": "the headline already runs decoder precision mode %d" % mode0}
+            _ops.decoder_precision(2)
+            try:
+                conv.convert_windows(windows, k=args.k, window_batch=args.window_batch)
+                t2, o2 = timed_steps(step, 2)
+            finally:
+                _ops.decoder_precision(mode0)
+            d = (o2.double() - out.double())
+            return {"ms_per_step": round(t2 * 1e3, 2), "frames_per_s": round(frames_per_step / t2, 1),
+                    "waveform_rms": round(float(o2.double().pow(2).mean().sqrt()), 5),
+                    "headline_minus_this_rms": float("%.3e" % d.pow(2).mean().sqrt().item()), "headline_minus_this_max": float("%.3e" % d.abs().max().item()),
+                    "note": "ALIVE_DECODER_PRECISION=2: every decoder GEMM on two-plane split bf16 (3 MFMAs per product); the headline runs the "
+                            "ConvNeXt pointwise convs, the 256-channel FilterBlock's k5 convs and four smaller layers on plain bf16"}
+        extra["decoder_split_bf16"] = guarded(leg)
 
     # The same step with the bf16 candidate stage (ALIVE_KNN_PREFILTER=bf16): same library object, fp8 image unused
     if "bf16_prefilter" in legs:
