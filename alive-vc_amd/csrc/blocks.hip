@@ -190,7 +190,7 @@ __global__ __launch_bounds__(NPT) void dwconv_norm_planes_kernel(
             for (int e = 0; e < 4; ++e) {
                 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
                 const bf16x2_t hp = {(__bf16)vv[2 * e], (__bf16)vv[2 * e + 1]};
-                const unsigned h = __builtin_bit_cast(unsigned, hp);
+                const unsigned h = NP == 1 ? pack_f16x2(vv[2 * e], vv[2 * e + 1]) : __builtin_bit_cast(unsigned, hp);     // NP = 1: one fp16 plane
                 o4[e] = h;
                 vv[2 * e] -= __uint_as_float(h << 16);
                 vv[2 * e + 1] -= __uint_as_float(h & 0xffff0000u);
@@ -415,7 +415,7 @@ extern "C" int alive_dwconv_norm_planes(const float* X, int N, int C, int T, con
     dwconv_norm_planes_kernel<NP_, TW_><<<g, NPT, lds, (hipStream_t)stream>>>(X, C, T, dw_w, dw_b, dw_w != nullptr, affine_mode, gain, \
                                                                              offset, cond, cond_rows, scale_row, shift_row, eps,  \
                                                                              (unsigned short*)P, cols_pad)
-    if (planes == 1 && tw == 32) LAUNCH_DNP(1, 32);         // one plane: the input of a plain-bf16 GEMM (alive_gemm_planes, planes = 1)
+    if (planes == 1 && tw == 32) LAUNCH_DNP(1, 32);         // one fp16 plane: the input of a plain GEMM (alive_gemm_planes, planes = 1)
     else if (planes == 1) LAUNCH_DNP(1, 64);
     else if (planes == 2 && tw == 32) LAUNCH_DNP(2, 32);
     else if (planes == 3 && tw == 32) LAUNCH_DNP(3, 32);
@@ -510,12 +510,12 @@ __global__ __launch_bounds__(256) void gelu_film_kernel(const float* __restrict_
             typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
-                if (pl >= n_planes) break;                         // one plane: the plain-bf16 consumer (AliveConv.precision 3)
+                if (pl >= n_planes) break;                         // one plane (fp16): the plain consumer (AliveConv.precision 3)
                 u32x4 o4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const bf16x2_t hp = {(__bf16)vv[2 * e], (__bf16)vv[2 * e + 1]};
-                    const unsigned h = __builtin_bit_cast(unsigned, hp);
+                    const unsigned h = n_planes == 1 ? pack_f16x2(vv[2 * e], vv[2 * e + 1]) : __builtin_bit_cast(unsigned, hp);
                     o4[e] = h;
                     vv[2 * e] -= __uint_as_float(h << 16);
                     vv[2 * e + 1] -= __uint_as_float(h & 0xffff0000u);
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void gelu_film_kernel(const float* __restrict_
 }
 }  // namespace
 
-// planes: 2, or 1 = plane 0 alone (the k-blocked layout puts it first: the one-plane image of the same values)
+// planes: 2 (split bf16), or 1 = ONE fp16 plane (the input of a plain conv, AliveConv.precision 3)
 int alive_gelu_film_impl(const float* H, int N, int C, int L, const float* film, int film_rows, int Lf, int scale_row,
                          int shift_row, int t0, int f0, int film_ld, float* Z, void* Zp, int planes, void* stream) {
     ALIVE_CHECK_ARG(H && film && (Z != nullptr) != (Zp != nullptr) && N > 0 && C > 0 && L > 0 && Lf > 0, "alive_gelu_film: bad args (one of Z / Zp)");

@@ -83,6 +83,22 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef __HIPCC__
+// ---- plain fp16 operands (round 5: AliveConv.precision 3, AliveGemm.planes 1) ----
+// One plane, one MFMA per product: fp16 (11 significand bits, 2^-12 per operand) instead of the bf16 planes' 8.  The conversion rounds to
+// nearest even and SATURATES at +-65504 (a value beyond fp16's range must not become an infinity inside a GEMM); magnitudes below 6.1e-5
+// are fp16 subnormals (absolute resolution 6e-8).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pack_f16x2(float a, float b) {
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    a = __builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f);
+    b = __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f);
+    const f16x2_t h = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ f32x16 mfma_f16(bf16x8 a, bf16x8 b, f32x16 c) {      // the operand registers hold fp16 bits
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
 // exact-erf GELU in the association order of ATen's CPU kernel: (0.5*x) * (1 + erf(x/sqrt2))
 __device__ __forceinline__ float gelu_erf(float x) {
     return (0.5f * x) * (1.0f + erff(x * 0.70710678118654752440f));

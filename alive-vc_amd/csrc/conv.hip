@@ -216,10 +216,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(AliveConv p, unsigned kw
                     qa[r] = rbase + lq * 4 < p.Co ? acc[mp][nn][r] : 0.0f;
                     qb[r] = rbase + 16 + lq * 4 < p.Co ? acc[mp + 1][nn][r] : 0.0f;
                 }
+                const bool one_f16 = p.yp_planes == 1;                      // ONE fp16 plane (the plain consumer) instead of two bf16 planes
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
+                    if (pl == 1 && one_f16) break;
                     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-                    auto pk = [](float a, float b) { const bf16x2_t h = {(__bf16)a, (__bf16)b}; return __builtin_bit_cast(unsigned, h); };
+                    auto pk = [one_f16](float a, float b) {
+                        const bf16x2_t h = {(__bf16)a, (__bf16)b};
+                        return one_f16 ? pack_f16x2(a, b) : __builtin_bit_cast(unsigned, h);
+                    };
                     const unsigned a01 = pk(qa[0], qa[1]), a23 = pk(qa[2], qa[3]), b01 = pk(qb[0], qb[1]), b23 = pk(qb[2], qb[3]);
                     const unsigned rx = (unsigned)__shfl_xor((int)(odd ? a01 : b01), 16), ry = (unsigned)__shfl_xor((int)(odd ? a23 : b23), 16);
                     const u32x4 o = odd ? u32x4{rx, ry, b01, b23} : u32x4{a01, a23, rx, ry};
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(AliveConv p, unsigned kw
         if (n == p.N - 1 && blockIdx.x == gridDim.x - 1) {
             const int c_pad = (p.Co + 31) & ~31;
             const int64_t cols = (int64_t)p.N * p.Tout, cols_pad = ((cols + 127) / 128) * 128;
-            const int per_col = 2 * (c_pad / 4);                    // 8-byte pieces per column: planes x channel quads
+            const int per_col = (p.yp_planes == 1 ? 1 : 2) * (c_pad / 4);      // 8-byte pieces per column: planes x channel quads
             unsigned short* Po = (unsigned short*)p.Yp;
             for (int i = threadIdx.x; i < (int)(cols_pad - cols) * per_col; i += 256) {
                 const int c = i / per_col, w = i % per_col;
@@ -264,6 +269,7 @@ extern "C" int alive_conv1d(const AliveConv* d, void* stream) {
     if (d->up > 1) {
         ALIVE_CHECK_ARG(d->Co % d->up == 0 && !d->residual && !d->skip && !d->Z && !d->Zp && d->Y, "alive_conv1d: transposed conv has a plain epilogue");
     }
+    ALIVE_CHECK_ARG(d->yp_planes >= 0 && d->yp_planes <= 2, "alive_conv1d: yp_planes");
     if (d->Yp)
         ALIVE_CHECK_ARG(d->precision == 0 && d->Y && d->up == 1 && d->act == 0 && !d->post_add && !d->ch_scale && !d->residual && !d->skip && !d->Z &&
                         !d->Zp && d->Co > 16 && d->Co <= 64 && (d->Co & 3) == 0 && (((uintptr_t)d->Yp) & 15) == 0 && (int64_t)d->N * d->Tout >= 97,
@@ -271,6 +277,9 @@ extern "C" int alive_conv1d(const AliveConv* d, void* stream) {
     ALIVE_CHECK_ARG(d->pad_mode >= 0 && d->pad_mode <= 2, "alive_conv1d: pad_mode");
     if (d->pad_mode != 0) ALIVE_CHECK_ARG(d->pad_left < d->Tin, "alive_conv1d: reflect pad %d needs Tin > pad (Tin %d)", d->pad_left, d->Tin);
     if (d->Z || d->Zp) ALIVE_CHECK_ARG(d->film && d->Lf > 0, "alive_conv1d: Z needs film");
+    if (d->precision == 3)
+        ALIVE_CHECK_ARG((int64_t)d->N * d->Tout > 96, "alive_conv1d: precision 3 (plain fp16) is a batch form: more than 96 columns, got %lld",
+                        (long long)d->N * d->Tout);
     if (d->Xp || d->Zp) ALIVE_CHECK_ARG(d->precision == 1 || d->precision == 3, "alive_conv1d: plane-packed operands need the split kernel (precision 1 or 3)");
     {
         int rc;

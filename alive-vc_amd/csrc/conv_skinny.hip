@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64 * SKW) void conv_skinny_kernel(AliveConv p, int 
 constexpr int SKINNY_COLS = 96;
 bool alive_conv_skinny_try(const AliveConv* d, hipStream_t s, int* rc) {
     const int ncols = d->N * d->Tout;
-    if (ncols > SKINNY_COLS) return false;
+    if (ncols > SKINNY_COLS || d->precision == 3) return false;      // (plain fp16: batch kernels only, alive_conv1d checks the columns)
     if (d->precision == 0 && (d->K_pad & 15)) return false;
     dim3 g(cdiv(d->Co, 16), cdiv(ncols, 32));
     const bool pw = d->KW == 1 && d->stride == 1 && d->pad_left == 0 && d->Tout <= d->Tin;
@@ -177,9 +177,7 @@ bool alive_conv_skinny_try(const AliveConv* d, hipStream_t s, int* rc) {
 #define SKINNY_LAUNCH(NP_, PW_) do { if (wide) conv_skinny_kernel<NP_, PW_, 16><<<g, 1024, 0, s>>>(*d, ncols); \
                                       else conv_skinny_kernel<NP_, PW_, 8><<<g, 512, 0, s>>>(*d, ncols); } while (0)
     if (d->precision == 0) { if (pw) SKINNY_LAUNCH(0, true); else SKINNY_LAUNCH(0, false); }
-    else if (d->precision == 1 || d->precision == 3) {      // (3, plain bf16: at a few columns the weights' bytes are the cost, not the MFMAs -- both planes stay)
-        if (pw) SKINNY_LAUNCH(2, true); else SKINNY_LAUNCH(2, false);
-    }
+    else if (d->precision == 1) { if (pw) SKINNY_LAUNCH(2, true); else SKINNY_LAUNCH(2, false); }
     else { if (pw) SKINNY_LAUNCH(3, true); else SKINNY_LAUNCH(3, false); }
 #undef SKINNY_LAUNCH
     hipError_t e = hipGetLastError();

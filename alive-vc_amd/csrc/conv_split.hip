@@ -55,9 +55,9 @@ constexpr int PROW = 64;          // PLANES = true: bytes per LDS row (32 channe
 // W22 (BM = 128, round 5): the four waves as 2 x 2 of 64 rows x 64 columns instead of four stacked 32 x 128 -- a B fragment from LDS then
 // feeds two row tiles (0.33 instead of 0.67 fragment reads per MFMA: stacked, all four waves read the SAME 128 columns), an A fragment
 // from L2 two column tiles instead of four (two waves ask for the same weight rows: the second request hits the CU's L1).
-// NP = 1 (round 5, AliveConv.precision 3): plain bf16 operands, ONE MFMA per product -- the weights are plane 0 of the two-plane pack, the
-// activations (Xp / Zp) one plane.  Used by the decoder for the six k = 5 convs of its 256-channel FilterBlock, whose inputs are
-// gelu + FiLM outputs consumed by nothing else (1.7e-5 of waveform RMS error against the 1e-3 bar).  At one product per
+// NP = 1 (round 5, AliveConv.precision 3): plain fp16 operands, ONE MFMA per product (v_mfma_f32_32x32x16_f16) -- the weights are one
+// fp16 plane (the third slab of module/_pack.py::pack_conv_split_h), the activations (Xp / Zp) one fp16 plane.  Used by the decoder for the six k = 5 convs of its 256-channel FilterBlock, whose inputs are
+// gelu + FiLM outputs consumed by nothing else (1.2e-5 of waveform RMS error on the 450-frame fixture against the 1e-3 bar).  At one product per
 // fragment pair the stacked 128-row form would read 1 KB of LDS per MFMA (the LDS peak): NP = 1 runs as the 2 x 2 form of BM = 128 (a B
 // fragment feeds two row tiles; 144 registers, three blocks per CU).
 template <int BM, int NP, bool PLANES = false, bool W22 = false>
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
             const bool ok = (x_ok >> it) & 1u;
             float x0 = ok ? x_reg[it][0] : 0.0f, x1 = ok ? x_reg[it][1] : 0.0f;
             bf16x2_t hp = {(__bf16)x0, (__bf16)x1};
-            unsigned h = __builtin_bit_cast(unsigned, hp);
+            unsigned h = NP == 1 ? pack_f16x2(x0, x1) : __builtin_bit_cast(unsigned, hp);          // (NP = 1: the one plane is fp16)
             float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
             bf16x2_t lp = {(__bf16)r0, (__bf16)r1};
             *(unsigned*)(Xs + r * PITCH + pair * 4) = h;
@@ -268,7 +268,8 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
                         for (int sum = NP - 1; sum >= 0; --sum)
 #pragma unroll
                             for (int i = 0; i <= sum; ++i)
-                                acc[mr][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[mr][s2][i], bf[sum - i][nn], acc[mr][nn], 0, 0, 0);
+                                acc[mr][nn] = NP == 1 ? mfma_f16(a_cur[mr][s2][i], bf[sum - i][nn], acc[mr][nn])
+                                                      : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[mr][s2][i], bf[sum - i][nn], acc[mr][nn], 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
                     for (int k2 = 0; k2 < 4; ++k2) {
                         const float q0 = cp[(2 * k2) * CP], q1 = cp[(2 * k2 + 1) * CP];
                         bf16x2_t hp = {(__bf16)q0, (__bf16)q1};
-                        hi[k2] = __builtin_bit_cast(unsigned, hp);
+                        hi[k2] = NP == 1 ? pack_f16x2(q0, q1) : __builtin_bit_cast(unsigned, hp);
                         bf16x2_t lp2 = {(__bf16)(q0 - __uint_as_float(hi[k2] << 16)), (__bf16)(q1 - __uint_as_float(hi[k2] & 0xffff0000u))};
                         lo[k2] = __builtin_bit_cast(unsigned, lp2);
                     }
@@ -537,7 +538,7 @@ int alive_conv_split_launch(const AliveConv* d, float ratio, hipStream_t s) {
     static const bool tile256 = getenv("ALIVE_CONV_TILE256") != nullptr && atoi(getenv("ALIVE_CONV_TILE256")) != 0;
     static const bool w22 = getenv("ALIVE_CONV_W22") != nullptr && atoi(getenv("ALIVE_CONV_W22")) != 0;      // A/B: 2 x 2 waves (plane input)
     if (d->precision == 3) {
-        // plain bf16 (one plane per operand): the 2 x 2 form of the 128-row tile.  Measured (tools/bench_conv256.py, 128 windows x 4500 columns,
+        // plain fp16 (one plane per operand): the 2 x 2 form of the 128-row tile.  Measured (tools/bench_conv256.py, 128 windows x 4500 columns,
         // k5 + FiLM + residual + Y / k5 + FiLM / 1x1 + FiLM + Y / k5 + residual + Y): 0.895 / 0.697 / 0.548 / 0.661 ms against the two-plane
         // form's 1.353 / 1.182 / 0.664 / 1.063; as one 256-row block per column tile (256 registers at two blocks per CU, 122 of them
         // spilled in the four epilogue passes) 1.625 / 1.319 / 1.239 / 0.747 -- not instantiated.

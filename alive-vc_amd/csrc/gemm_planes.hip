@@ -76,6 +76,9 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     bf16x2_t h = {(__bf16)a, (__bf16)b};
     return __builtin_bit_cast(unsigned, h);
 }
+// the plane format of an NP-plane operand: NP = 1 is ONE fp16 plane (plain operands, round 5), NP >= 2 split bf16 planes
+template <int NP>
+__device__ __forceinline__ unsigned pack_plane2(float a, float b) { return NP == 1 ? pack_f16x2(a, b) : pack_bf16x2(a, b); }
 
 // ---- epilogue, straight from the accumulators (shared by the one-tile and the persistent kernel) ----
 // stage: wave-private LDS (NP x 8 KB: [plane][64 columns][64 channels] bf16) for the plane-packed output, or nullptr.  With it
@@ -159,7 +162,7 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         // bins 16 ti + 4 g + 2 lh + {0, 1}: bytes 32 ti + 8 g + 4 lh of the column's 64
-                        const unsigned h = pack_bf16x2(q[ti][g][0], q[ti][g][1]);
+                        const unsigned h = pack_plane2<NP>(q[ti][g][0], q[ti][g][1]);
                         *(unsigned*)(st + lr * 64 + (((2 * ti + (g >> 1)) ^ ((lr >> 2) & 3)) << 4) + 8 * (g & 1) + 4 * lh) = h;
                         q[ti][g][0] -= __uint_as_float(h << 16);
                         q[ti][g][1] -= __uint_as_float(h & 0xffff0000u);
@@ -255,7 +258,7 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
                     for (int e = 0; e < 4; ++e) q[e] = (full_rows || rbase + 8 * g + e < p.Co) ? vv[4 * g + e] : 0.0f;
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl) {
-                        const unsigned h01 = pack_bf16x2(q[0], q[1]), h23 = pack_bf16x2(q[2], q[3]);
+                        const unsigned h01 = pack_plane2<NP>(q[0], q[1]), h23 = pack_plane2<NP>(q[2], q[3]);
                         *(uint2*)(stage + pl * 8192 + cl * 128 + ((((rowl >> 3)) ^ (cl & 7)) << 4) + 8 * lh) = make_uint2(h01, h23);
                         q[0] -= __uint_as_float(h01 << 16);
                         q[1] -= __uint_as_float(h01 & 0xffff0000u);
@@ -278,7 +281,7 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
                 for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const unsigned h01 = pack_bf16x2(q[g][0], q[g][1]), h23 = pack_bf16x2(q[g][2], q[g][3]);
+                        const unsigned h01 = pack_plane2<NP>(q[g][0], q[g][1]), h23 = pack_plane2<NP>(q[g][2], q[g][3]);
                         *(uint2*)(stage_small + lr * 64 + ((g ^ ((lr >> 2) & 3)) << 4) + 8 * lh) = make_uint2(h01, h23);
                         q[g][0] -= __uint_as_float(h01 << 16);
                         q[g][1] -= __uint_as_float(h01 & 0xffff0000u);
@@ -308,7 +311,7 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
                     for (int e = 0; e < 4; ++e) q[e] = (full_rows || row + e < p.Co) ? vv[4 * g + e] : 0.0f;
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl) {
-                        const unsigned h01 = pack_bf16x2(q[0], q[1]), h23 = pack_bf16x2(q[2], q[3]);
+                        const unsigned h01 = pack_plane2<NP>(q[0], q[1]), h23 = pack_plane2<NP>(q[2], q[3]);
                         *(uint2*)(Po + planes_at(pl, col, row, cols_pad, co_pad32)) = make_uint2(h01, h23);
                         q[0] -= __uint_as_float(h01 << 16);
                         q[1] -= __uint_as_float(h01 & 0xffff0000u);
@@ -442,7 +445,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
                 for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                     for (int tj = 0; tj < 2; ++tj)
-                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][i], b[tj][sum - i], acc[ti][tj], 0, 0, 0);
+                        acc[ti][tj] = NP == 1 ? mfma_f16(a[ti][i], b[tj][sum - i], acc[ti][tj])
+                                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][i], b[tj][sum - i], acc[ti][tj], 0, 0, 0);
                 hook(n++);
             }
     };
@@ -663,7 +667,8 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_lw_kernel(AliveGemm p, int
                 for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                     for (int tj = 0; tj < 2; ++tj)
-                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][i], b[tj][sum - i], acc[ti][tj], 0, 0, 0);
+                        acc[ti][tj] = NP == 1 ? mfma_f16(a[ti][i], b[tj][sum - i], acc[ti][tj])
+                                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][i], b[tj][sum - i], acc[ti][tj], 0, 0, 0);
                 hook(n++);
             }
     };
@@ -756,7 +761,7 @@ __global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict_
             u32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const unsigned h = pack_bf16x2(vv[2 * e], vv[2 * e + 1]);
+                const unsigned h = pack_plane2<NP>(vv[2 * e], vv[2 * e + 1]);
                 o[e] = h;
                 vv[2 * e] -= __uint_as_float(h << 16);
                 vv[2 * e + 1] -= __uint_as_float(h & 0xffff0000u);
@@ -878,12 +883,13 @@ extern "C" size_t alive_planes_bytes(int64_t cols, int C, int planes) {
 
 extern "C" int alive_to_planes(const float* X, int N, int C, int T, int planes, void* P, void* stream) {
     ALIVE_CHECK_ARG(X && P && N > 0 && C > 0 && T > 0, "alive_to_planes: bad args");
-    ALIVE_CHECK_ARG(planes == 2 || planes == 3, "alive_to_planes: planes must be 2 or 3, got %d", planes);
+    ALIVE_CHECK_ARG(planes >= 1 && planes <= 3, "alive_to_planes: planes must be 1 (one fp16 plane), 2 or 3 (split bf16), got %d", planes);
     ALIVE_CHECK_ARG((((uintptr_t)P) & 15) == 0, "alive_to_planes: P must be 16-byte aligned");
     const int64_t cols = (int64_t)N * T, cp = pad_cols(cols);
     const int c_pad = pad32(C);
     dim3 g((unsigned)(cp / 64), cdiv(c_pad, 64));
-    if (planes == 2) to_planes_kernel<2><<<g, 256, 0, (hipStream_t)stream>>>(X, C, T, cols, cp, c_pad, (unsigned short*)P);
+    if (planes == 1) to_planes_kernel<1><<<g, 256, 0, (hipStream_t)stream>>>(X, C, T, cols, cp, c_pad, (unsigned short*)P);
+    else if (planes == 2) to_planes_kernel<2><<<g, 256, 0, (hipStream_t)stream>>>(X, C, T, cols, cp, c_pad, (unsigned short*)P);
     else to_planes_kernel<3><<<g, 256, 0, (hipStream_t)stream>>>(X, C, T, cols, cp, c_pad, (unsigned short*)P);
     ALIVE_CHECK_LAUNCH("alive_to_planes");
     return ALIVE_OK;
@@ -904,7 +910,7 @@ extern "C" int alive_gemm_planes(const AliveGemm* d, void* stream) {
                     "alive_gemm_planes: y_split must be a multiple of %d below Co, with Y and Y2 and neither residual nor Pout", GM);
     ALIVE_CHECK_ARG(d->N > 0 && d->T > 0 && d->Ci > 0 && d->Co > 0, "alive_gemm_planes: bad shape");
     ALIVE_CHECK_ARG(d->planes >= 1 && d->planes <= 3, "alive_gemm_planes: planes must be 1, 2 or 3, got %d", d->planes);
-    ALIVE_CHECK_ARG(d->planes != 1 || (d->act != 3 && d->act != 4), "alive_gemm_planes: one plane (plain bf16) has no argmax / magnitude epilogue");
+    ALIVE_CHECK_ARG(d->planes != 1 || (d->act != 3 && d->act != 4), "alive_gemm_planes: one plane (plain fp16) has no argmax / magnitude epilogue");
     ALIVE_CHECK_ARG(d->b_row == 0 || ((d->b_row | d->b_win | d->b_plane) & 7) == 0, "alive_gemm_planes: custom row placement must be in multiples of 8 elements");
     ALIVE_CHECK_ARG(d->b_row == 0 || (d->Ci & 31) == 0, "alive_gemm_planes: custom row placement needs Ci %% 32 == 0");
     ALIVE_CHECK_ARG(d->b_cblk >= 0 && (d->b_cblk == 0 || (d->b_row != 0 && (d->Ci / 32) % d->b_cblk == 0 && (d->b_blk & 7) == 0)),
@@ -925,8 +931,8 @@ extern "C" int alive_gemm_planes(const AliveGemm* d, void* stream) {
                              (d->b_row == 0 ? (int64_t)d->planes * pad_cols((int64_t)d->N * d->T) * pad32(d->Ci)
                                             : (int64_t)d->planes * d->b_plane) * 2 < (1ll << 32);          // 32-bit DMA offsets
     if (d->planes == 1) {
-        // one plane = plain bf16 operands, one MFMA per product (round 5): W and P may be the first plane of two- or three-plane images
-        // (the k-blocked layout puts plane 0 first).  Stages of 16 KB, four in the ring, two blocks per CU.
+        // one plane = plain fp16 operands, one MFMA per product (round 5): W and P are single fp16 planes in the k-blocked layout.
+        // Stages of 16 KB, four in the ring, two blocks per CU.
         static const int form1 = getenv("ALIVE_GEMM1_FORM") ? atoi(getenv("ALIVE_GEMM1_FORM")) : 0;      // A/B: ring depth x blocks per CU
         if (form1 == 1) return launch_gemm<1, 3, 3>(*d, (hipStream_t)stream);
         if (form1 == 2) return launch_gemm<1, 6, 2>(*d, (hipStream_t)stream);

@@ -115,21 +115,24 @@ AliveConv split(AliveConv d) {
 }
 
 // ---- arithmetic of the decoder's two largest groups of GEMMs on the batch path (alive_decoder_precision) ----
-// mode 1 (default since round 5): plain bf16 operands, ONE MFMA per product, for
+// mode 1 (default since round 5): plain fp16 operands (11 significand bits; the bf16 planes carry 8), ONE MFMA per product, for
 //   (a) the six k = 5 convs of the 256-channel FilterBlock (decoder.py:128-134 at the Filter's coarsest scale; AliveConv.precision 3):
 //       their inputs are gelu + FiLM outputs that nothing else reads, their outputs are added to an fp32 residual stream;
 //   (b) the two pointwise convs of the feature extractor's four AdaptiveConvNeXt1d layers (common.py:74-82; alive_gemm_planes with
 //       planes = 1): inputs are a channel-normalised tensor and a gelu output, the output is scaled and added to the fp32 stream.
 //   (c) the projection of the f0 encoding onto the AdaptiveChannelNorm scales / shifts (common.py:35-41, 512 -> 4096), the Filter's two
 //       coarsest down convs (decoder.py:186-188, 64 -> 256 k8 and 256 -> 256 k10) and its mid conv (decoder.py:190).
-//   Everything else -- the FiLM projections and the input layer (the waveform is 15 x more sensitive to them than to (a)), to_amps,
+//   Everything else -- the FiLM projections and the input layer (the waveform is 10 x more sensitive to them than to (a)), to_amps,
 //   the transposed convs, the fused 64 / 16 / 8-channel FilterBlocks -- stays on two-plane split bf16 or exact fp32.  Measured on the
-//   reference's 450-frame fixture: decoder waveform RMS error 5.0e-6 (mode 2) -> 1.19e-4 (mode 1; (a) alone 1.12e-4), whole
-//   conversion 1.1e-4 -> 1.2e-4, against the bar of 1e-3 (tests/test_gpu_models.py::test_decoder_precision_modes).
+//   reference's 450-frame fixture: decoder waveform RMS error 5.0e-6 (mode 2) -> 1.40e-5 (mode 1), whole conversion of a 450-frame
+//   window 1.222e-4 in both modes, against the bar of 1e-3 (tests/test_gpu_models.py::test_decoder_precision_modes).  The first form
+//   of mode 1 used plane 0 of the bf16 images (8 significand bits): 1.19e-4 on the same fixture -- fp16 costs the same MFMAs and bytes.
 // mode 2: two-plane split bf16 for these too (rounds 1 - 4).  ALIVE_DECODER_PRECISION=2 or alive_decoder_precision(2).
-// ALIVE_DECODER_BF16_MASK (experiments): which of (a) = 1, (b) = 2, (c) = 4 mode 1 covers (default 7).
-// Sensitivities (oracle with the operands of one group rounded to bf16, 450-frame fixture, waveform RMS 0.66): (a) 1.11e-4, (b) 2.7e-5,
-// (c) 2.2e-5 + 8.3e-6 + 1.3e-6; not adopted: FiLM projections 1.6e-3, input layer 1.5e-3, 64-channel FilterBlock 2.2e-4, up convs 8.1e-5.
+// ALIVE_DECODER_BF16_MASK (experiments): which of (a) = 1, (b) = 2, (c) = 4, (d: the two transposed convs) = 8 mode 1 covers (default 7).
+// Sensitivities (oracle with the operands of one group rounded to fp16 | to bf16; 450-frame fixture, waveform RMS 0.66): (a) 1.24e-5 |
+// 1.11e-4, (b) 3.4e-6 | 2.7e-5, (c) 1.3e-6 + 1.2e-6 + 2.0e-7 | 2.2e-5 + 8.3e-6 + 1.3e-6; not adopted: FiLM projections 1.4e-4 | 1.6e-3,
+// input layer 1.2e-4 | 1.5e-3, 64-channel FilterBlock 2.6e-5 | 2.2e-4 (vector-issue bound: nothing to gain), up convs 1.0e-5 | 8.1e-5
+// (store bound: nothing to gain).
 int g_decoder_precision = 0;      // 0: not decided yet (environment, else 1)
 int decoder_precision() {
     if (g_decoder_precision == 0) {
@@ -141,6 +144,16 @@ int decoder_precision() {
 int decoder_bf16_mask() {
     static const int m = getenv("ALIVE_DECODER_BF16_MASK") ? atoi(getenv("ALIVE_DECODER_BF16_MASK")) : 7;
     return decoder_precision() == 1 ? m : 0;
+}
+
+// the plain (fp16) image of a weight tensor packed by module/_pack.py::pack_conv_split_h: the third slab behind the two bf16 planes
+const float* plain_w(const float* W, int rows_pad16, int K) {
+    return (const float*)((const unsigned short*)W + (size_t)2 * rows_pad16 * K);
+}
+AliveConv plain(AliveConv d) {           // d: a split() descriptor (precision 1, W = the two-plane pack + fp16 slab)
+    d.precision = 3;
+    d.W = plain_w(d.W, (d.Co + 15) & ~15, d.KW * d.Ci_pad);
+    return d;
 }
 
 AliveConv split3(AliveConv d) {      // 3-plane split ("bf16x6"): fp32-grade, used by the encoders (argmax / top-k downstream)
@@ -190,8 +203,10 @@ int convnext_layer(const ConvNeXtW& w, float* x, float* ybuf, float* hbuf, void*
         const int gp = (planes == 2 && (decoder_bf16_mask() & 2)) ? 1 : planes;     // the decoder's layers (the encoders run three planes)
         RUN(alive_dwconv_norm_planes(x, N, C, T, w.dw_w, w.dw_b, cond ? 1 : 0, w.gain, w.offset, cond, cond_rows, scale_row,
                                      shift_row, NORM_EPS, gp, Pa, s));
-        RUN(pw_gemm(w.pw1W, w.pw1b, Pa, N, T, C, H, gp, 1, nullptr, nullptr, nullptr, nullptr, Ph, s));
-        return pw_gemm(w.pw2W, w.pw2b, Ph, N, T, H, C, gp, 0, nullptr, w.scale, x, x, nullptr, s);
+        const float* W1 = gp == 1 ? plain_w(w.pw1W, (H + 15) & ~15, (C + 31) & ~31) : w.pw1W;
+        const float* W2 = gp == 1 ? plain_w(w.pw2W, (C + 15) & ~15, (H + 31) & ~31) : w.pw2W;
+        RUN(pw_gemm(W1, w.pw1b, Pa, N, T, C, H, gp, 1, nullptr, nullptr, nullptr, nullptr, Ph, s));
+        return pw_gemm(W2, w.pw2b, Ph, N, T, H, C, gp, 0, nullptr, w.scale, x, x, nullptr, s);
     }
     RUN(alive_dwconv_norm(x, N, C, T, w.dw_w, w.dw_b, cond ? 1 : 0, w.gain, w.offset, cond, cond_rows, scale_row,
                           shift_row, NORM_EPS, ybuf, s));
@@ -564,9 +579,9 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
     { AliveConv d = pw_desc(c1W, c1b, f0, N, 1, Lf, DEC_C, b.sinb); d.act = 3; RUN(alive_conv1d(&d, stream)); }
     RUN(pw_conv(c2W, c2b, b.sinb, b.Pa, N, Lf, DEC_C, DEC_C, 2, 0, nullptr, b.cond, stream));
     const float* nfW = t.next(); const float* nfb = t.next();
-    if (b.Pa != nullptr && (decoder_bf16_mask() & 4)) {      // (c) plain bf16: plane 0 of the two-plane image of cond
-        RUN(alive_to_planes(b.cond, N, DEC_C, Lf, 2, b.Pa, stream));
-        RUN(pw_gemm(nfW, nfb, b.Pa, N, Lf, DEC_C, 4096, 1, 0, nullptr, nullptr, nullptr, b.normfilm, nullptr, stream));
+    if (b.Pa != nullptr && (decoder_bf16_mask() & 4)) {      // (c) plain fp16
+        RUN(alive_to_planes(b.cond, N, DEC_C, Lf, 1, b.Pa, stream));
+        RUN(pw_gemm(plain_w(nfW, 4096, DEC_C), nfb, b.Pa, N, Lf, DEC_C, 4096, 1, 0, nullptr, nullptr, nullptr, b.normfilm, nullptr, stream));
     } else {
         RUN(pw_conv(nfW, nfb, b.cond, b.Pa, N, Lf, DEC_C, 4096, 2, 0, nullptr, b.normfilm, stream));
     }
@@ -609,7 +624,8 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
             AliveGemm g;
             memset(&g, 0, sizeof(g));
             g.W = Wp; g.bias = bb; g.P = Pd; g.N = N; g.T = len / r; g.Ci = r * cpad; g.Co = dch[i + 1];
-            g.planes = (decoder_bf16_mask() & 4) ? 1 : 2;            // (c) plain bf16: plane 0 of d1's / one plane of d2's image
+            g.planes = (decoder_bf16_mask() & 4) ? 1 : 2;            // (c) plain fp16: d1 / d2 arrive as one fp16 plane
+            if (g.planes == 1) g.W = plain_w(Wp, (dch[i + 1] + 15) & ~15, r * cpad);
             g.Y = dbuf[i + 1];
             if (i == 2) g.Pout = b.Zz;                                 // d2 as planes too: the input of downs[3]
             g.b_plane = (int64_t)(alive_planes_bytes((int64_t)N * len, dch[i], 2) / 4);      // elements per plane
@@ -620,7 +636,10 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
             RUN(alive_gemm_planes(&g, stream));
         } else {
             AliveConv d = conv_desc(W, bb, dbuf[i], N, dch[i], len, dch[i + 1], r, r, 1, 0, 0, len / r, dbuf[i + 1]);
-            if (i == 1 && b.Pa != nullptr) d.Yp = b.U;           // d1 also as the planes downs[2] reads (batch path)
+            if (i == 1 && b.Pa != nullptr) {                     // d1 also as the planes downs[2] reads (batch path)
+                d.Yp = b.U;
+                d.yp_planes = (decoder_bf16_mask() & 4) ? 1 : 2;
+            }
             RUN(alive_conv1d(&d, stream));
         }
         len /= r;
@@ -628,7 +647,7 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
     const float* mW = t.next(); const float* mb = t.next();
     {   // mid CausalConv1d(256,256,5) + skips[3]   (decoder.py:190-191)
         AliveConv d = split(conv_desc(mW, mb, b.d3, N, 256, Lf, 256, 5, 1, 1, 4, 1, Lf, b.m));
-        if (decoder_bf16_mask() & 4) d.precision = 3;                // (c)
+        if ((decoder_bf16_mask() & 4) && (int64_t)N * Lf > 96) d = plain(d);       // (c)
         d.skip = b.d3;
         RUN(alive_conv1d(&d, stream));
     }
@@ -644,6 +663,9 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
             AliveConv d = conv_desc(upW[s], upb[s], cur, N, cin, L, C * r, 1, 1, 1, 0, 0, L, F_MODE[s] == 0 ? b.Hh : b.U);
             d.up = r;
             if (F_SPLIT[s]) d = split(d);
+            // (experiment, mask bit 8, off: the two transposed convs are bound by their stores -- 170.1 +- 0.3 ms per step either way, and the
+            // fixture error goes 1.40e-5 -> 1.79e-5)
+            if (F_SPLIT[s] && (decoder_bf16_mask() & 8) && (int64_t)N * L > 96) d = plain(d);
             RUN(alive_conv1d(&d, stream));
         }
         L *= r;
@@ -670,7 +692,7 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
         auto set_z = [&](AliveConv& d, float* buf) { if (zplanes) d.Zp = buf; else d.Z = buf; };
         auto set_x = [&](AliveConv& d, const float* buf) { if (zplanes) { d.Xp = buf; d.X = nullptr; } };
         // FilterBlock.input_conv is part of the transposed conv above (Hh = its output); the input of blocks[0].c1 = gelu + FiLM of it
-        const bool lowp = (decoder_bf16_mask() & 1) != 0;      // plain-bf16 convs: one plane travels between them
+        const bool lowp = (decoder_bf16_mask() & 1) != 0 && (int64_t)N * L > 96;      // plain-fp16 convs: one plane travels between them
         RUN(alive_gelu_film_impl(b.Hh, N, C, L, b.film, FILM_ROWS, Lw_frames, film_off, film_off + C, ranged ? f_begin * (L / Lf) : 0,
                                  ranged ? f_begin : 0, ranged ? Lf : Lw_frames, zplanes ? nullptr : b.Zz, zplanes ? (void*)b.Zz : nullptr,
                                  lowp ? 1 : 2, stream));
@@ -686,7 +708,7 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
             if (ranged) { d.film_t0 = f_begin * (L / Lf); d.film_f0 = f_begin; d.film_ld = Lf; }
                 d.film_scale_row = f2; d.film_shift_row = f2 + C;
                 if (F_SPLIT[s]) d = split(d);
-                if (lowp) d.precision = 3;
+                if (lowp) d = plain(d);
                 RUN(alive_conv1d(&d, stream));
             }
             {   // c2: conv(Z2) + residual (+ U-Net skip after the last block) ; next block's c1 input
@@ -701,7 +723,7 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
                     d.film_scale_row = fn; d.film_shift_row = fn + C;
                 }
                 if (F_SPLIT[s]) d = split(d);
-                if (lowp) d.precision = 3;
+                if (lowp) d = plain(d);
                 RUN(alive_conv1d(&d, stream));
             }
         }

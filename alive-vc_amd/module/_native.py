@@ -25,7 +25,7 @@ class AliveConv(C.Structure):
         ("film_rows", C.c_int), ("Lf", C.c_int), ("film_scale_row", C.c_int), ("film_shift_row", C.c_int),
         ("precision", C.c_int), ("Ci_pad", C.c_int),
         ("film_t0", C.c_int), ("film_f0", C.c_int), ("film_ld", C.c_int),
-        ("Xp", C.c_void_p), ("Zp", C.c_void_p), ("Yp", C.c_void_p),
+        ("Xp", C.c_void_p), ("Zp", C.c_void_p), ("Yp", C.c_void_p), ("yp_planes", C.c_int),
     ]
 
 

@@ -61,6 +61,20 @@ def pack_conv_split(w, planes=2):
     return a.view(p, co_pad, k // 32, 32).permute(0, 2, 1, 3).contiguous()
 
 
+def pack_conv_split_h(w):
+    """pack_conv_split(w, 2) followed by a THIRD slab of the same shape: the weights as ONE fp16 plane (round to nearest even, saturated at
+    +-65504), the operand of the plain kernels (AliveConv.precision 3, AliveGemm.planes 1; csrc/networks.hip::plain_w).  Stored in the same
+    bf16-typed tensor: [3, K / 32, Co_pad16, 32], slab 2 holds fp16 bits.  The split kernels read slabs 0 and 1 only."""
+    two = pack_conv_split(w, 2)
+    co, ci, kw = w.shape
+    co_pad, ci_pad = _pad16(co), (ci + 31) // 32 * 32
+    a = torch.zeros(co_pad, kw, ci_pad, dtype=torch.float32, device=w.device)
+    a[:co, :, :ci] = w.float().permute(0, 2, 1)
+    h = a.reshape(co_pad, kw * ci_pad).clamp(-65504.0, 65504.0).to(torch.float16)
+    h = h.view(co_pad, kw * ci_pad // 32, 32).permute(1, 0, 2).contiguous()
+    return torch.cat([two.view(torch.int16), h.view(torch.int16).unsqueeze(0)], 0).view(torch.bfloat16).contiguous()
+
+
 def unpack_conv_split(W):
     """k-blocked [planes, K / 32, Co_pad, 32] -> row-major [planes, Co_pad, K] (tests, tools)"""
     p, kb, co_pad, _ = W.shape
@@ -76,6 +90,13 @@ def pack_convT_split(w, b):
     ci, co, r = w.shape
     a = w.permute(1, 2, 0).reshape(co * r, ci, 1)
     return pack_conv_split(a), b.float().repeat_interleave(r).contiguous()
+
+
+def pack_convT_split_h(w, b):
+    """pack_convT_split with the fp16 slab of pack_conv_split_h behind the two bf16 planes"""
+    ci, co, r = w.shape
+    a = w.permute(1, 2, 0).reshape(co * r, ci, 1)
+    return pack_conv_split_h(a), b.float().repeat_interleave(r).contiguous()
 
 
 def _vec(t):
@@ -176,8 +197,8 @@ def pack_decoder(sd):
         p = f"{fe}.mid_layers.{i}.norm"
         ws += [sd[p + ".scale.weight"].reshape(512, 512), sd[p + ".shift.weight"].reshape(512, 512)]
         bs += [sd[p + ".scale.bias"], sd[p + ".shift.bias"]]
-        _convnext(out, sd, f"{fe}.mid_layers.{i}", f"fe.mid{i}", True, pack_conv_split)
-    out["fe.normfilm.W"] = pack_conv_split(torch.cat(ws, 0).float().unsqueeze(2))
+        _convnext(out, sd, f"{fe}.mid_layers.{i}", f"fe.mid{i}", True, pack_conv_split_h)       # (+ the fp16 plane of decoder precision mode 1)
+    out["fe.normfilm.W"] = pack_conv_split_h(torch.cat(ws, 0).float().unsqueeze(2))
     out["fe.normfilm.b"] = _vec(torch.cat(bs, 0))
     out["osc.amps.W"] = pack_conv_split(sd["harmonic_oscillator.to_amps.weight"])
     out["osc.amps.b"] = _vec(sd["harmonic_oscillator.to_amps.bias"])
@@ -200,11 +221,11 @@ def pack_decoder(sd):
         out[f"flt.down{i}.W"] = _vec(sd[f"{f}.downs.{i}.weight"]) if i == 0 else pack_conv(sd[f"{f}.downs.{i}.weight"])
         out[f"flt.down{i}.b"] = _vec(sd[f"{f}.downs.{i}.bias"])
         if i >= 2:      # batch path: the strided conv as a plane GEMM (networks.hip::decoder_run)
-            out[f"flt.down{i}.Wp"] = pack_conv_split(sd[f"{f}.downs.{i}.weight"])
-    out["flt.mid.W"] = pack_conv_split(sd[f + ".mid_conv.conv.weight"])
+            out[f"flt.down{i}.Wp"] = pack_conv_split_h(sd[f"{f}.downs.{i}.weight"])
+    out["flt.mid.W"] = pack_conv_split_h(sd[f + ".mid_conv.conv.weight"])
     out["flt.mid.b"] = _vec(sd[f + ".mid_conv.conv.bias"])
     for i in range(4):
-        pt = pack_convT_split if SPLIT_SCALE[i] else pack_convT
+        pt = pack_convT_split_h if SPLIT_SCALE[i] else pack_convT          # (+ the fp16 plane of decoder precision mode 1)
         wt, bt = sd[f"{f}.ups.{i}.weight"], sd[f"{f}.ups.{i}.bias"]
         if FILTER_MODE[i] == "split":
             # ups[i] and blocks[i].input_conv (decoder.py:147,192-193) are two linear maps with nothing in between: one transposed
@@ -225,7 +246,7 @@ def pack_decoder(sd):
             continue
         for j in range(3):                           # (input_conv: composed into flt.up{s} above)
             for cc in ("c1", "c2"):
-                out[f"flt.blk{s}.{j}.{cc}.W"] = pack_conv_split(sd[f"{b}.blocks.{j}.{cc}.conv.conv.weight"])
+                out[f"flt.blk{s}.{j}.{cc}.W"] = pack_conv_split_h(sd[f"{b}.blocks.{j}.{cc}.conv.conv.weight"])
                 out[f"flt.blk{s}.{j}.{cc}.b"] = _vec(sd[f"{b}.blocks.{j}.{cc}.conv.conv.bias"])
     out["flt.out.W"] = _vec(sd[f + ".source_out.weight"])        # [1][8][7] as is
     out["flt.out.b"] = _vec(sd[f + ".source_out.bias"])

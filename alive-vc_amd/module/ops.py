@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _native as nat
-from ._pack import pack_conv, pack_conv_split, pack_convT, pack_convT_split
+from ._pack import pack_conv, pack_conv_split, pack_conv_split_h, pack_convT, pack_convT_split
 
 ACT = {None: 0, "gelu": 1, "exp": 2, "sin": 3}
 _ws = nat.Workspace()
@@ -26,11 +26,11 @@ def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, o
     Returns (Y, Z): raw output (or None) and the gelu+FiLM modulated second output (or None).
     x_planes: the plane-packed form of x (to_planes(x, 2)) -- the split kernel then stages its input by LDS-DMA (AliveConv.Xp);
     z_planes: Z comes back plane-packed (AliveConv.Zp; a uint8 buffer like to_planes gives) instead of fp32;
-    y_planes: the exact kernel also writes Y as two planes (AliveConv.Yp) -- returned in Z's place."""
+    y_planes: the exact kernel also writes Y as planes (AliveConv.Yp) -- True / 2: two bf16 planes, 1: one fp16 plane; returned in Z's place."""
     x = _f(x)
     n, ci, tin = x.shape
     keep = []
-    split = precision in ("bf16x3", "bf16x6", "bf16")          # "bf16": one MFMA per product on plane 0 of the two-plane weights
+    split = precision in ("bf16x3", "bf16x6", "fp16")          # "fp16": one MFMA per product on ONE fp16 plane (AliveConv.precision 3)
     planes = 3 if precision == "bf16x6" else 2
     if split and transposed:
         r = weight.shape[2]
@@ -39,7 +39,7 @@ def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, o
         stride_, tout = 1, tin
         co_out = weight.shape[1]
     elif split:
-        W = pack_conv_split(weight, planes)
+        W = pack_conv_split_h(weight)[2].contiguous() if precision == "fp16" else pack_conv_split(weight, planes)
         b = _f(bias)
         co_rows, kw, up = weight.shape[0], weight.shape[2], 1
         stride_ = stride
@@ -61,7 +61,7 @@ def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, o
     d = nat.AliveConv()
     d.W, d.bias, d.X = nat.ptr(W), nat.ptr(b), nat.ptr(x)
     d.N, d.Ci, d.Tin, d.Co, d.K_pad = n, ci, tin, co_rows, (W.shape[-1] if W.dim() == 2 else W.shape[1] * 32)
-    d.precision, d.Ci_pad = (3 if precision == "bf16" else planes - 1, (ci + 31) // 32 * 32) if split else (0, 0)
+    d.precision, d.Ci_pad = (3 if precision == "fp16" else planes - 1, (ci + 31) // 32 * 32) if split else (0, 0)
     d.KW, d.stride, d.dil, d.pad_left, d.pad_mode = kw, stride_, dilation, pad_left, pad_mode
     d.Tout, d.up, d.act = tout, up, ACT[act]
     post_add, ch_scale, residual, skip, film = map(_f, (post_add, ch_scale, residual, skip, film))
@@ -71,7 +71,7 @@ def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, o
     Z = None
     if film is not None:
         if z_planes:
-            Z = torch.empty(nat.lib().alive_planes_bytes(n * tout, co_out, 1 if precision == "bf16" else 2), dtype=torch.uint8, device=x.device)
+            Z = torch.empty(nat.lib().alive_planes_bytes(n * tout, co_out, 1 if precision == "fp16" else 2), dtype=torch.uint8, device=x.device)
         else:
             Z = torch.empty(n, co_out, tout, device=x.device)
         d.film, d.film_rows, d.Lf = nat.ptr(film), film.shape[1], film.shape[2]
@@ -85,14 +85,16 @@ def conv1d(x, weight, bias=None, stride=1, dilation=1, pad_left=0, pad_mode=0, o
         d.Xp, d.X = nat.ptr(x_planes), None
         keep.append(x_planes)
     if y_planes:
-        Z = torch.empty(nat.lib().alive_planes_bytes(n * tout, co_out, 2), dtype=torch.uint8, device=x.device)
-        d.Yp = nat.ptr(Z)
+        ypl = 1 if y_planes == 1 and y_planes is not True else 2
+        Z = torch.empty(nat.lib().alive_planes_bytes(n * tout, co_out, ypl), dtype=torch.uint8, device=x.device)
+        d.Yp, d.yp_planes = nat.ptr(Z), ypl
     nat.check(nat.lib().alive_conv1d(C.byref(d), nat.stream()), "alive_conv1d")
     return Y, Z
 
 
 def to_planes(x, planes=2):
-    """fp32 [N][C][T] -> plane-packed bf16 buffer (uint8 tensor of alive_planes_bytes) for gemm_planes."""
+    """fp32 [N][C][T] -> plane-packed buffer (uint8 tensor of alive_planes_bytes) for gemm_planes: 2 / 3 split-bf16 planes, or
+    planes = 1: ONE fp16 plane (plain operands)."""
     x = _f(x)
     n, c, t = x.shape
     P = torch.empty(nat.lib().alive_planes_bytes(n * t, c, planes), dtype=torch.uint8, device=x.device)
@@ -125,7 +127,7 @@ def gemm_planes(P, n, t, weight, bias=None, planes=2, act=None, post_add=None, c
                 want_fp32=True, want_planes=False):
     """1x1 conv on a plane-packed input through alive_gemm_planes.  Returns (Y fp32 [n][co][t] or None, Pout or None)."""
     co, ci = weight.shape[0], weight.shape[1]
-    W = pack_conv_split(weight, max(planes, 2))           # planes = 1 (plain bf16) reads plane 0 of the two-plane pack
+    W = pack_conv_split_h(weight)[2].contiguous() if planes == 1 else pack_conv_split(weight, planes)     # planes = 1: one fp16 plane
     b, post_add, ch_scale, residual = map(_f, (bias, post_add, ch_scale, residual))
     d = nat.AliveGemm()
     d.W, d.bias, d.P = nat.ptr(W), nat.ptr(b), nat.ptr(P)
@@ -316,5 +318,5 @@ def front_end(wave, ce, pe, out=None):
 
 def decoder_precision(mode=0):
     """Arithmetic of the six k = 5 convs of the decoder's 256-channel FilterBlock on the batch path (alive_decoder_precision):
-    1 = plain bf16 operands (default since round 5), 2 = two-plane split bf16 (rounds 1 - 4), 0 = query.  Returns the mode in force."""
+    1 = plain fp16 operands (default since round 5), 2 = two-plane split bf16 (rounds 1 - 4), 0 = query.  Returns the mode in force."""
     return int(nat.lib().alive_decoder_precision(int(mode)))

@@ -379,13 +379,13 @@ def main():
         return {"bound": "mfma", "timing": "HIP events on the launching stream, each family alone, one stream (the step overlaps window batches on side streams)",
                 "counters": "profiles/nets_pmc.json (per kernel: MFMA-pipe utilisation, bytes beyond L2, LDS conflicts, VALU co-execution; tools/pmc_nets.sh)",
                 "front_end": fam(ms_enc, fl_enc, pk_enc, "spectrogram (DFT as a GEMM) + F0Estimator + ContentEncoder: 3-plane split bf16, 6 MFMAs per product"),
-                "decoder": dict(fam(ms_dec, fl_dec, pk_dec, ("FeatureExtractor + HarmonicOscillator + Filter: plain bf16 (1 MFMA per product) for the ConvNeXt pointwise convs, the six k5 convs of the 256-channel FilterBlock, the norm-FiLM projection, the two coarse down convs and the mid conv "
+                "decoder": dict(fam(ms_dec, fl_dec, pk_dec, ("FeatureExtractor + HarmonicOscillator + Filter: plain fp16 (1 MFMA per product) for the ConvNeXt pointwise convs, the six k5 convs of the 256-channel FilterBlock, the norm-FiLM projection, the two coarse down convs and the mid conv "
                                                               "(60.7 of the 96.6 MFLOP per frame), 2-plane split bf16 (3 MFMAs per product) for the rest; peak = the blend, FLOP / ideal time" if dec_mode == 1 else
                                                               "FeatureExtractor + HarmonicOscillator + Filter: 2-plane split bf16, 3 MFMAs per product") +
                                                              " (fused FilterBlocks at 64 / 16 / 8 channels on the same MFMA; exact f32 MFMA only for the strided / transposed convs of the two finest scales)"),
                                 precision_mode=dec_mode, frac_of_split_bf16_peak=round(fl_dec / (ms_dec * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS / 3), 4)),
                 "step": {"ideal_ms": round(ideal_ms, 1), "ms_per_step": round(dt / args.steps * 1e3, 2), "frac": round(ideal_ms / (dt / args.steps * 1e3), 4),
-                         "ideal": "kNN 2*768*M*T FLOP at the candidate stage's MFMA peak + decoder at its blended peak (2.5 PF for the plain-bf16 layers, 2.5 PF / 3 for the rest) + front end at 2.5 PF / 6"}}
+                         "ideal": "kNN 2*768*M*T FLOP at the candidate stage's MFMA peak + decoder at its blended peak (2.5 PF for the plain-fp16 layers, 2.5 PF / 3 for the rest) + front end at 2.5 PF / 6"}}
     roofline_nets = guarded(nets_roofline) if rank == 0 and not args.no_nets_roofline else None
 
     extra = {}
@@ -427,7 +427,7 @@ def main():
                 conv.set_library(library)
         extra["fp8_prefilter"] = guarded(leg)
 
-    # The same step with the decoder's plain-bf16 layers back on two-plane split bf16 (alive_decoder_precision 2, the arithmetic of rounds
+    # The same step with the decoder's plain-fp16 layers back on two-plane split bf16 (alive_decoder_precision 2, the arithmetic of rounds
     # 1 - 4): what the default mode buys, and how far its waveforms are from the split form's
     if "decoder_split_bf16" in legs:
         def leg():
@@ -446,7 +446,7 @@ def main():
                     "waveform_rms": round(float(o2.double().pow(2).mean().sqrt()), 5),
                     "headline_minus_this_rms": float("%.3e" % d.pow(2).mean().sqrt().item()), "headline_minus_this_max": float("%.3e" % d.abs().max().item()),
                     "note": "ALIVE_DECODER_PRECISION=2: every decoder GEMM on two-plane split bf16 (3 MFMAs per product); the headline runs the "
-                            "ConvNeXt pointwise convs, the 256-channel FilterBlock's k5 convs and four smaller layers on plain bf16"}
+                            "ConvNeXt pointwise convs, the 256-channel FilterBlock's k5 convs and four smaller layers on plain fp16"}
         extra["decoder_split_bf16"] = guarded(leg)
 
     # The same step with the bf16 candidate stage (ALIVE_KNN_PREFILTER=bf16): same library object, fp8 image unused
@@ -735,7 +735,7 @@ def main():
             "dtype": ({"fp6": "fp6 (e2m3)", "fp8": "fp8 (e4m3)"}[library.prefilter] + " MFMA candidate scoring + exact f32 rescoring, every frame "
                       "certified at 7 sigma of its measured stage error (statistical: audited against brute force on every frame of this "
                       "batch, tests/test_gpu_knn_audit.py; ALIVE_KNN_STRICT=1 is the deterministic form)" if library.prefilter in ("fp8", "fp6") else
-                      "bf16 MFMA scoring + exact f32 rescoring, certified per frame" + (" (deterministic bound)" if library.strict else "")) + "; 3-plane split-bf16 (fp32-grade) encoder GEMMs; decoder: " + ("plain bf16 (one MFMA per product, fp32 accumulate and residual streams) for the ConvNeXt pointwise convs, the 256-channel FilterBlock's k5 convs and four smaller layers (60.7 of its 96.6 MFLOP per frame) -- decoder waveform RMS error 1.2e-4 on the reference's 450-frame fixture against the 1e-3 bar, ALIVE_DECODER_PRECISION=2 restores split bf16 (5e-6) --, 2-plane split-bf16 for its other GEMMs" if decoder_mode == 1 else "2-plane split-bf16 GEMMs (ALIVE_DECODER_PRECISION=2)") + "; f32 MFMA DFT / strided / small-channel convs; f64 phase scan",
+                      "bf16 MFMA scoring + exact f32 rescoring, certified per frame" + (" (deterministic bound)" if library.strict else "")) + "; 3-plane split-bf16 (fp32-grade) encoder GEMMs; decoder: " + ("plain fp16 (one MFMA per product, fp32 accumulate and residual streams) for the ConvNeXt pointwise convs, the 256-channel FilterBlock's k5 convs and four smaller layers (60.7 of its 96.6 MFLOP per frame) -- decoder waveform RMS error 1.4e-5 on the reference's 450-frame fixture against the 1e-3 bar, ALIVE_DECODER_PRECISION=2 restores split bf16 (5e-6) --, 2-plane split-bf16 for its other GEMMs" if decoder_mode == 1 else "2-plane split-bf16 GEMMs (ALIVE_DECODER_PRECISION=2)") + "; f32 MFMA DFT / strided / small-channel convs; f64 phase scan",
             "data": "synthetic",
             "config": {"workload": f"{args.utterances} utterances x {args.seconds:g} s per GPU -> {n_win} windows x "
                                    f"{L // FRAME} frames per step, {M}-vector library (BASELINE config 3/4 shape)",

@@ -216,10 +216,11 @@ typedef struct AliveConv {
      *                 like the activation planes below: [2][K/32][Co_pad][32] (module/_pack.py::pack_conv_split);
      *                 Ci_pad a multiple of 32; stride must be 1;
      *             2 = 3-term split bf16 ("bf16x6", six MFMAs per product, fp32-grade): W as for 1 with 3 planes;
-     *             3 = plain bf16 (round 5): ONE MFMA per product, operands rounded to nearest even -- W as for 1 (plane 0 of the
-     *                 two-plane pack is read), Xp / Zp carry ONE plane (= plane 0 of the two-plane image of the same values).  2^-9 per
-     *                 operand: for layers whose contribution to the output has been measured (the decoder's 256-channel FilterBlock,
-     *                 alive_decoder_precision).  With at most 96 columns (the streaming kernels) it runs as precision 1. */
+     *             3 = plain fp16 (round 5): ONE MFMA per product (v_mfma_f32_32x32x16_f16), operands rounded to nearest even and saturated
+     *                 at +-65504, fp32 accumulate -- W = ONE fp16 plane [K/32][Co_pad][32] (module/_pack.py::pack_conv_split_h stores it
+     *                 as the third slab behind the two bf16 planes), Xp / Zp carry ONE fp16 plane.  2^-12 per operand: for layers whose
+     *                 contribution to the output has been measured (alive_decoder_precision).  With at most 96 columns (the streaming
+     *                 kernels) it is not available: those callers use precision 1. */
     int precision, Ci_pad;
     /* FiLM of a frame RANGE of a longer window (alive_decoder_forward_range): this conv's columns start at sample
      * film_t0 of the window (at its own rate) and `film` holds the frames [film_f0, film_f0 + film_ld) only, row pitch
@@ -239,6 +240,7 @@ typedef struct AliveConv {
      * 16 < Co <= 64, Co % 4 == 0): the plane image of the Filter's 64-channel skip tensor comes from the conv that produces it
      * (decoder.py:186-188) instead of an alive_to_planes pass over it.  Same bits as alive_to_planes(Y). */
     void* Yp;
+    int yp_planes;         /* 0 / 2: two bf16 planes (the bits of alive_to_planes(Y, 2)); 1: ONE fp16 plane (alive_to_planes(Y, 1)) */
 } AliveConv;
 int alive_conv1d(const AliveConv* desc, void* stream);
 
@@ -262,8 +264,8 @@ typedef struct AliveGemm {
     const void* P;         /* input planes [planes][Ci_pad/32][cols_pad][32] */
     int N, T;              /* cols = N*T; fp32 outputs are [N][Co][T] */
     int Ci, Co;
-    int planes;            /* 2: bf16x3, 3: bf16x6 (both operands); 1 (round 5): plain bf16, one MFMA per product -- W and P may be
-                            * plane 0 of two- / three-plane images (it comes first), Pout gets one plane; act 0 - 2 only */
+    int planes;            /* 2: bf16x3, 3: bf16x6 (both operands); 1 (round 5): plain fp16, one MFMA per product -- W, P and Pout are
+                            * single fp16 planes in the same k-blocked layout; act 0 - 2 only */
     int act;               /* 0 none, 1 gelu, 2 exp, 3 argmax over Co (3 planes only): no Y / Pout, see arg_val; 4: see the end of the struct */
     const float* post_add; /* [Co] or NULL */
     const float* ch_scale; /* [Co] or NULL */
@@ -443,12 +445,12 @@ int alive_f0_estimate(const float* const* w, const float* spec, int N, int T,
 /* Arithmetic of the decoder's two largest groups of GEMMs on the batch path (more than 96 columns; the streaming kernels are not
  * affected): (a) the six k = 5 convs of the 256-channel FilterBlock (decoder.py:128-134 at the Filter's coarsest scale), (b) the two
  * pointwise convs of the feature extractor's four AdaptiveConvNeXt1d layers (common.py:74-82).
- *   mode 1 (default since round 5, or ALIVE_DECODER_PRECISION=1): plain bf16 operands, one MFMA per product (AliveConv.precision 3,
+ *   mode 1 (default since round 5, or ALIVE_DECODER_PRECISION=1): plain fp16 operands, one MFMA per product (AliveConv.precision 3,
  *          AliveGemm.planes 1), fp32 accumulate, fp32 residual streams;
  *   mode 2 (ALIVE_DECODER_PRECISION=2): two-plane split bf16 like the decoder's other GEMMs (rounds 1 - 4);
  *   mode 0: query.  Returns the mode in force.  Process-wide; not to be changed while a decoder call is in flight.
  * Measured on the reference's 450-frame fixture (tests/test_gpu_models.py::test_decoder_precision_modes): decoder waveform RMS error
- * 5.0e-6 in mode 2, 1.19e-4 in mode 1, whole conversion 1.1e-4 -> 1.2e-4; the bar of the path is 1e-3.  Everything else in the
+ * 5.0e-6 in mode 2, 1.40e-5 in mode 1, whole conversion of a 450-frame window 1.22e-4 in both; the bar of the path is 1e-3.  Everything else in the
  * decoder (FiLM projections, input layer, to_amps, strided / transposed convs, the fused 64 / 16 / 8-channel FilterBlocks) keeps
  * split bf16 or exact fp32 in both modes, and so do both encoders (top-k / argmax downstream). */
 int alive_decoder_precision(int mode);

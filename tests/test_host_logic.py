@@ -67,7 +67,10 @@ def test_weight_tables_cover_the_schema():
             if k.endswith(".W") and v.dtype == torch.float32 and v.dim() == 2:   # exact-fp32 MFMA kernel: [Co_pad16][K_pad16]
                 assert v.shape[0] % 16 == 0 and v.shape[1] % 16 == 0
             if k.endswith(".W") and v.dtype == torch.bfloat16:         # split kernel, k-blocked: [planes][KW * Ci_pad32 / 32][Co_pad16][32]
-                assert v.dim() == 4 and v.shape[0] == (3 if mid < 2 else 2) and v.shape[2] % 16 == 0 and v.shape[3] == 32   # encoders: 3 planes
+                # encoders: 3 bf16 planes; decoder: 2, or 2 + the fp16 slab of the plain kernels (decoder precision mode 1, _pack.pack_conv_split_h)
+                plain = mid == 2 and (k.startswith("flt.blk0.") or k.startswith("flt.up") or k == "flt.mid.W" or k == "fe.normfilm.W"
+                                      or (k.startswith("fe.mid") and ".pw" in k))
+                assert v.dim() == 4 and v.shape[0] == (3 if mid < 2 or plain else 2) and v.shape[2] % 16 == 0 and v.shape[3] == 32, k
     sd = synthetic.make_state_dict(schema.decoder_schema(), 2)
     p = _pack.pack_decoder(sd)
     assert p["flt.in.W"].shape == (56,) and p["flt.down0.W"].shape == (256,) and p["flt.out.W"].shape == (56,)   # streaming edge kernels
@@ -77,6 +80,9 @@ def test_weight_tables_cover_the_schema():
     hi, lo = rows[0], rows[1]
     back = (hi + lo).view(256, 5, 256).permute(0, 2, 1)                    # tap-major -> [co, ci, j]
     assert (back - w).abs().max().item() <= 2.0 ** -16 * w.abs().max().item()
+    h = p["flt.blk0.1.c2.W"][2].view(torch.float16)                         # the third slab: the same weights as ONE fp16 plane, same layout
+    hb = h.permute(1, 0, 2).reshape(256, 5, 256).permute(0, 2, 1)
+    assert torch.equal(hb, w.half()) and p["flt.down2.Wp"].shape[0] == 3 and p["flt.down3.Wp"].shape[0] == 3
     w = torch.arange(2 * 3 * 4, dtype=torch.float32).view(2, 3, 4)            # ConvT [Ci=2, Co=3, r=4]
     W, b = _pack.pack_convT(w, torch.tensor([1.0, 2.0, 3.0]))
     assert W[1 * 4 + 2, 1].item() == w[1, 1, 2].item() and b.tolist() == [1.0] * 4 + [2.0] * 4 + [3.0] * 4

@@ -41,17 +41,21 @@ for KW, dil, with_z, with_res, want_y in ((5, 2, 1, 1, 1), (5, 4, 1, 0, 0), (1, 
     for _ in range(10): L_.alive_conv1d(C.byref(d), st)
     e.record(); torch.cuda.synchronize()
     ms_p = a.elapsed_time(e) / 10
-    # plain bf16 (precision 3): one plane in / out, one MFMA per product; checked against float64 on the rounded operands
-    d.precision = 3
+    # plain fp16 (precision 3): one fp16 plane in / out, one MFMA per product; checked against float64 on the rounded operands
+    from module._pack import pack_conv_split_h
+    Wh = pack_conv_split_h(w)
+    x1 = torch.empty(L_.alive_planes_bytes(N * L, C_, 1), dtype=torch.uint8, device=dev)
+    L_.alive_to_planes(x.data_ptr(), N, C_, L, 1, x1.data_ptr(), st)
+    d.precision, d.W, d.Xp = 3, Wh[2].data_ptr(), x1.data_ptr()
     for _ in range(2): nat.check(L_.alive_conv1d(C.byref(d), st))
     a.record()
     for _ in range(10): L_.alive_conv1d(C.byref(d), st)
     e.record(); torch.cuda.synchronize()
     ms_b = a.elapsed_time(e) / 10
     if want_y:
-        xb, wb = x[:2].bfloat16().double(), w.bfloat16().double()
+        xb, wb = x[:2].half().double(), w.half().double()
         ref = torch.nn.functional.conv1d(torch.nn.functional.pad(xb, ((KW - 1) * dil, 0), mode="reflect") if KW > 1 else xb, wb, b.double(), dilation=dil)
         if with_res: ref = ref + res[:2].double()
-        print(f"    bf16: max |y - float64 on rounded operands| {float((y[:2].double() - ref).abs().max()):.3e}")
-    d.precision = 1
-    print(f"k{KW} d{dil} z={with_z} res={with_res} y={want_y}: {ms:7.3f} ms (planes in/out {ms_p:7.3f} ms, plain bf16 {ms_b:7.3f} ms)   {fl / ms / 1e9:7.1f} TF-eq  ({3 * fl / ms / 1e12:.2f} PF bf16)   checksum y {float(y.double().sum()) if want_y else 0:.6e} z {float(z.double().sum()) if with_z else 0:.6e}")
+        print(f"    fp16: max |y - float64 on rounded operands| {float((y[:2].double() - ref).abs().max()):.3e}")
+    d.precision, d.W, d.Xp = 1, W.data_ptr(), xp.data_ptr()
+    print(f"k{KW} d{dil} z={with_z} res={with_res} y={want_y}: {ms:7.3f} ms (planes in/out {ms_p:7.3f} ms, plain fp16 {ms_b:7.3f} ms)   {fl / ms / 1e9:7.1f} TF-eq  ({3 * fl / ms / 1e12:.2f} PF bf16)   checksum y {float(y.double().sum()) if want_y else 0:.6e} z {float(z.double().sum()) if with_z else 0:.6e}")
