@@ -341,7 +341,10 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
     }
 }
 
-template <int NP, int NS, int MINB, int ACT>
+// KB2 (NP = 2 only; round 5): ONE fp16 plane per operand with a K-step of 64 -- the two "planes" of a stage are the two k-blocks of the
+// step, the products are (block 0 x block 0) + (block 1 x block 1) on v_mfma_f32_32x32x16_f16, the output is one fp16 plane.  The plain
+// (planes = 1) GEMM in the two-plane kernel's slot layout: 16 MFMAs between two block barriers instead of the 8 of a 32-deep step.
+template <int NP, int NS, int MINB, int ACT, bool KB2 = false>
 __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int n_mt, int ntiles, int64_t cols,
                                                              int64_t cols_pad, int co_pad, int co_pad32, int kpad,
                                                              GemmWalk gw, long long* stamps) {
@@ -351,7 +354,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SLOT = 2 * NP * PLANE_BYTES;
     constexpr int NI = 4 * NP;                    // DMA pieces per wave per step
-    constexpr int NPROD = NP * (NP + 1) / 2;
+    constexpr int NPROD = KB2 ? 2 : NP * (NP + 1) / 2;
+    static_assert(!KB2 || NP == 2, "the 64-deep one-plane form lives in the two-plane kernel's slots");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
     tile_of(v, n_mt, gw, mt, ct);
     const int m0 = mt * GM;
     const int64_t c0 = (int64_t)ct * GN;
-    const int nsteps = kpad / GK;
+    const int nsteps = kpad / (KB2 ? 2 * GK : GK);
 
     // ---- DMA geometry: piece q = w + 4 i  ->  (operand, plane, 16-row group) ----
     const int prow = lane >> 2;
@@ -379,27 +383,35 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
     for (int i = 0; i < NI; ++i) {
         const int q = w + 4 * i;
         const int op = q / (8 * NP), pl = (q % (8 * NP)) / 8, g = q % 8;
+        const int spl = KB2 ? 0 : pl;                    // KB2: slot "plane" 1 is the step's second k-block of the ONE plane (walk1 below)
         const int r = g * 16 + prow;
         if (op == 0) {
             int row = m0 + r;
             row = row < co_pad ? row : co_pad - 1;
-            src[i] = (const unsigned short*)p.W + planes_at(pl, row, 0, co_pad, kpad) + pchunk * 8;
+            src[i] = (const unsigned short*)p.W + planes_at(spl, row, 0, co_pad, kpad) + pchunk * 8;
         } else if (p.b_row == 0) {
             int64_t col = c0 + r;
             col = col < cols_pad ? col : cols_pad - 1;
-            src[i] = (const unsigned short*)p.P + planes_at(pl, col, 0, cols_pad, kpad) + pchunk * 8;
+            src[i] = (const unsigned short*)p.P + planes_at(spl, col, 0, cols_pad, kpad) + pchunk * 8;
         } else {                                         // custom row placement (overlapping rows: the STFT)
             int64_t col = c0 + r;
             col = col < cols ? col : cols - 1;
             const int64_t nn = col / p.T;
-            src[i] = (const unsigned short*)p.P + (size_t)pl * p.b_plane + (size_t)nn * p.b_win + (size_t)(col - nn * p.T) * p.b_row + pchunk * 8;
+            src[i] = (const unsigned short*)p.P + (size_t)spl * p.b_plane + (size_t)nn * p.b_win + (size_t)(col - nn * p.T) * p.b_row + pchunk * 8;
         }
         ldst[i] = (op * NP + pl) * PLANE_BYTES + g * 1024;
     }
     // the steps are issued in order: `walk` holds the offsets of the next step to issue (pieces i < 2 NP are W's, the rest B's)
-    StepWalk walk;
+    StepWalk walk, walk1;                                // walk1 (KB2): one k-block further -- the slot's second half
+    if constexpr (KB2) walk1.advance(gw);
     auto issue = [&](int step, int i) {
-        __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (i < 2 * NP ? walk.a : walk.b)), (lptr_t)(smem + (step % NS) * SLOT + ldst[i]), 16, 0, 0);
+        // (q = w + 4 i with w < 4: the plane of piece i is (i >> 1) & 1 at NP = 2)
+        const StepWalk& wk = (KB2 && ((i >> 1) & 1)) ? walk1 : walk;
+        __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (i < 2 * NP ? wk.a : wk.b)), (lptr_t)(smem + (step % NS) * SLOT + ldst[i]), 16, 0, 0);
+    };
+    auto next_step = [&]() {
+        walk.advance(gw);
+        if constexpr (KB2) { walk.advance(gw); walk1.advance(gw); walk1.advance(gw); }
     };
 
     // the bias joins in the epilogue: nothing but the DMA issue stands between the launch and the first MFMA
@@ -414,7 +426,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
         if (s < nsteps) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) issue(s, i);
-            walk.advance(gw);
+            next_step();
         }
 
     // fragment byte offsets inside a plane: row * 64 + ((2 ks + lh) ^ ((row >> 2) & 3)) * 16 ; ks = 1 flips bit 5
@@ -437,6 +449,17 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
     // that dependent MFMAs are four issues apart.  `hook(n)` runs after the n-th group of four (DMA issue slots).
     auto mma = [&](bf16x8 (&a)[2][NP], bf16x8 (&b)[2][NP], auto&& hook) {
         int n = 0;
+        if constexpr (KB2) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = mfma_f16(a[ti][kb], b[tj][kb], acc[ti][tj]);
+                hook(n++);
+            }
+            return;
+        }
 #pragma unroll
         for (int sum = NP - 1; sum >= 0; --sum)
 #pragma unroll
@@ -494,7 +517,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
             for (int i = 0; i < NI; ++i)
                 if (i * NPROD / NI == n && refill) issue(s + NS, i);
         });
-        walk.advance(gw);
+        next_step();
         __builtin_amdgcn_sched_barrier(0);
     }
     wait_vmcnt<0>();
@@ -510,7 +533,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
             stage = smem + w * (NP * 8192);
         }
     }
-    gemm_epilogue<NP, ACT>(p, acc, m0, c0, wr, wc, lr, lh, cols, cols_pad, co_pad32, stage);
+    gemm_epilogue<KB2 ? 1 : NP, ACT>(p, acc, m0, c0, wr, wc, lr, lh, cols, cols_pad, co_pad32, stage);
 #ifdef ALIVE_STAMPS
     if (stamps != nullptr && tid == 0) {
         long long* o = stamps + (size_t)blockIdx.x * 8;
@@ -792,12 +815,12 @@ inline GemmWalk make_walk(const AliveGemm& d) {
     return g;
 }
 
-template <int NP, int NS, int MINB, int ACT>
+template <int NP, int NS, int MINB, int ACT, bool KB2 = false>
 int launch_gemm_act(const AliveGemm& d, hipStream_t s) {
     constexpr int LDS = NS * 2 * NP * PLANE_BYTES;
     {
         static LdsOptIn optin;
-        hipError_t e = optin.ensure({(const void*)gemm_planes_kernel<NP, NS, MINB, ACT>}, LDS);
+        hipError_t e = optin.ensure({(const void*)gemm_planes_kernel<NP, NS, MINB, ACT, KB2>}, LDS);
         if (e != hipSuccess) {
             alive_set_error("alive_gemm_planes: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return ALIVE_ERR_LAUNCH;
@@ -806,7 +829,7 @@ int launch_gemm_act(const AliveGemm& d, hipStream_t s) {
     const int64_t cols = (int64_t)d.N * d.T;
     const int n_mt = cdiv(d.Co, GM), n_ct = cdiv(cols, GN);
     const int ntiles = n_mt * n_ct;
-    gemm_planes_kernel<NP, NS, MINB, ACT><<<ntiles, 256, LDS, s>>>(
+    gemm_planes_kernel<NP, NS, MINB, ACT, KB2><<<ntiles, 256, LDS, s>>>(
         d, n_mt, ntiles, cols, pad_cols(cols), (d.Co + 15) & ~15, pad32(ACT == 4 ? d.Co / 2 : d.Co), pad32(d.Ci), make_walk(d),
         g_stamps);
     ALIVE_CHECK_LAUNCH("alive_gemm_planes");
@@ -934,6 +957,12 @@ extern "C" int alive_gemm_planes(const AliveGemm* d, void* stream) {
         // one plane = plain fp16 operands, one MFMA per product (round 5): W and P are single fp16 planes in the k-blocked layout.
         // Stages of 16 KB, four in the ring, two blocks per CU.
         static const int form1 = getenv("ALIVE_GEMM1_FORM") ? atoi(getenv("ALIVE_GEMM1_FORM")) : 0;      // A/B: ring depth x blocks per CU
+        // K a multiple of 64: the 64-deep step in the two-plane kernel's slots (form 4 forces the 32-deep kernel)
+        if ((pad32(d->Ci) & 63) == 0 && pad32(d->Ci) >= 128 && form1 == 0) {
+            if (d->act == 1) return launch_gemm_act<2, 2, 2, 1, true>(*d, (hipStream_t)stream);
+            if (d->act == 2) return launch_gemm_act<2, 2, 2, 2, true>(*d, (hipStream_t)stream);
+            return launch_gemm_act<2, 2, 2, 0, true>(*d, (hipStream_t)stream);
+        }
         if (form1 == 1) return launch_gemm<1, 3, 3>(*d, (hipStream_t)stream);
         if (form1 == 2) return launch_gemm<1, 6, 2>(*d, (hipStream_t)stream);
         if (form1 == 3) return launch_gemm<1, 2, 4>(*d, (hipStream_t)stream);

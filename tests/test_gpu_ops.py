@@ -887,7 +887,8 @@ def test_to_planes_one_plane_is_fp16(n, c, t):
     assert raw[n * t:].float().abs().sum().item() == 0.0 and raw[:, c:].float().abs().sum().item() == 0.0
 
 
-@pytest.mark.parametrize("co,ci,n,t,act", [(1536, 512, 2, 450, "gelu"), (512, 1536, 3, 37, None), (64, 512, 2, 24, None)])
+@pytest.mark.parametrize("co,ci,n,t,act", [(1536, 512, 2, 450, "gelu"), (512, 1536, 3, 37, None), (64, 512, 2, 24, None),
+                                           (200, 96, 2, 130, "gelu"), (256, 2560, 2, 450, None)])     # K = 96: the 32-deep kernel; the others 64-deep steps
 def test_gemm_planes_one_plane_is_the_float64_product_of_the_fp16_operands(co, ci, n, t, act):
     """AliveGemm.planes = 1 (round 5; the pointwise convs of the decoder's ConvNeXt layers, common.py:74-82): plain fp16 operands (one
     plane each), fp32 accumulate; the plane output is ONE fp16 plane = alive_to_planes(Y, 1)."""
