@@ -93,7 +93,8 @@ template <int NP, int TW>
 __global__ __launch_bounds__(NPT) void dwconv_norm_planes_kernel(
     const float* __restrict__ X, int C, int T, const float* __restrict__ dw_w, const float* __restrict__ dw_b, int dw,
     int affine_mode, const float* __restrict__ gain, const float* __restrict__ offset, const float* __restrict__ cond,
-    int cond_rows, int scale_row, int shift_row, float eps, unsigned short* __restrict__ P, int64_t cols_pad) {
+    int cond_rows, int scale_row, int shift_row, float eps, unsigned short* __restrict__ P, int64_t cols_pad, float f16_scale) {
+    // f16_scale != 0 (NP = 2): the planes are fp16 (hi, lo) of f16_scale * value (AliveGemm.f16s), else bf16 (NP = 1: one fp16 plane)
     extern __shared__ float tile[];                      // [C][TW + 1]
     constexpr int CPW = 64 / TW;                         // channels per wave row
     constexpr int NR = NPT / 64 * CPW;                   // channel rows in flight per block
@@ -182,6 +183,11 @@ __global__ __launch_bounds__(NPT) void dwconv_norm_planes_kernel(
         float vv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) vv[e] = tile[(ck * 8 + e) * PT + cl];
+        const bool f16s = NP == 2 && f16_scale != 0.0f;
+        if (f16s) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vv[e] *= f16_scale;
+        }
         const int64_t col = (int64_t)n * T + t0 + cl;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
@@ -190,10 +196,17 @@ __global__ __launch_bounds__(NPT) void dwconv_norm_planes_kernel(
             for (int e = 0; e < 4; ++e) {
                 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
                 const bf16x2_t hp = {(__bf16)vv[2 * e], (__bf16)vv[2 * e + 1]};
-                const unsigned h = NP == 1 ? pack_f16x2(vv[2 * e], vv[2 * e + 1]) : __builtin_bit_cast(unsigned, hp);     // NP = 1: one fp16 plane
+                const unsigned h = (NP == 1 || f16s) ? pack_f16x2(vv[2 * e], vv[2 * e + 1]) : __builtin_bit_cast(unsigned, hp);     // NP = 1: one fp16 plane
                 o4[e] = h;
-                vv[2 * e] -= __uint_as_float(h << 16);
-                vv[2 * e + 1] -= __uint_as_float(h & 0xffff0000u);
+                if (f16s) {
+                    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+                    const f16x2_t hv = __builtin_bit_cast(f16x2_t, h);
+                    vv[2 * e] -= (float)hv[0];
+                    vv[2 * e + 1] -= (float)hv[1];
+                } else {
+                    vv[2 * e] -= __uint_as_float(h << 16);
+                    vv[2 * e + 1] -= __uint_as_float(h & 0xffff0000u);
+                }
             }
             *(u32x4*)(P + planes_at(pl, col, ck * 8, cols_pad, C)) = o4;
         }
@@ -388,10 +401,11 @@ extern "C" int alive_dwconv_norm(const float* X, int N, int C, int T, const floa
 }
 
 // dw conv (or none: dw_w == NULL) + (Adaptive)ChannelNorm with plane-packed output; C a multiple of 32
-extern "C" int alive_dwconv_norm_planes(const float* X, int N, int C, int T, const float* dw_w, const float* dw_b,
-                                        int affine_mode, const float* gain, const float* offset, const float* cond,
-                                        int cond_rows, int scale_row, int shift_row, float eps, int planes, void* P,
-                                        void* stream) {
+namespace {
+int dwconv_norm_planes_impl(const float* X, int N, int C, int T, const float* dw_w, const float* dw_b,
+                            int affine_mode, const float* gain, const float* offset, const float* cond,
+                            int cond_rows, int scale_row, int shift_row, float eps, int planes, float f16_scale, void* P,
+                            void* stream) {
     ALIVE_CHECK_ARG(X && P && N > 0 && C > 1 && T > 0, "alive_dwconv_norm_planes: bad args");
     ALIVE_CHECK_ARG((dw_w == nullptr) == (dw_b == nullptr), "alive_dwconv_norm_planes: dw_w and dw_b go together");
     ALIVE_CHECK_ARG(affine_mode == 0 ? (gain && offset) : (cond != nullptr), "alive_dwconv_norm_planes: affine params");
@@ -414,7 +428,7 @@ extern "C" int alive_dwconv_norm_planes(const float* X, int N, int C, int T, con
 #define LAUNCH_DNP(NP_, TW_)                                                                                                   \
     dwconv_norm_planes_kernel<NP_, TW_><<<g, NPT, lds, (hipStream_t)stream>>>(X, C, T, dw_w, dw_b, dw_w != nullptr, affine_mode, gain, \
                                                                              offset, cond, cond_rows, scale_row, shift_row, eps,  \
-                                                                             (unsigned short*)P, cols_pad)
+                                                                             (unsigned short*)P, cols_pad, f16_scale)
     if (planes == 1 && tw == 32) LAUNCH_DNP(1, 32);         // one fp16 plane: the input of a plain GEMM (alive_gemm_planes, planes = 1)
     else if (planes == 1) LAUNCH_DNP(1, 64);
     else if (planes == 2 && tw == 32) LAUNCH_DNP(2, 32);
@@ -424,6 +438,24 @@ extern "C" int alive_dwconv_norm_planes(const float* X, int N, int C, int T, con
 #undef LAUNCH_DNP
     ALIVE_CHECK_LAUNCH("alive_dwconv_norm_planes");
     return ALIVE_OK;
+}
+}  // namespace
+
+extern "C" int alive_dwconv_norm_planes(const float* X, int N, int C, int T, const float* dw_w, const float* dw_b,
+                                        int affine_mode, const float* gain, const float* offset, const float* cond,
+                                        int cond_rows, int scale_row, int shift_row, float eps, int planes, void* P,
+                                        void* stream) {
+    return dwconv_norm_planes_impl(X, N, C, T, dw_w, dw_b, affine_mode, gain, offset, cond, cond_rows, scale_row, shift_row, eps, planes, 0.0f,
+                                   P, stream);
+}
+
+extern "C" int alive_dwconv_norm_planes_f16s(const float* X, int N, int C, int T, const float* dw_w, const float* dw_b,
+                                             int affine_mode, const float* gain, const float* offset, const float* cond,
+                                             int cond_rows, int scale_row, int shift_row, float eps, float scale, void* P,
+                                             void* stream) {
+    ALIVE_CHECK_ARG(scale > 0.0f, "alive_dwconv_norm_planes_f16s: scale must be a positive power of two");
+    return dwconv_norm_planes_impl(X, N, C, T, dw_w, dw_b, affine_mode, gain, offset, cond, cond_rows, scale_row, shift_row, eps, 2, scale,
+                                   P, stream);
 }
 
 extern "C" int alive_channel_norm(const float* X, int N, int C, int T, const float* gain, const float* offset, float eps,

@@ -79,6 +79,23 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 // the plane format of an NP-plane operand: NP = 1 is ONE fp16 plane (plain operands, round 5), NP >= 2 split bf16 planes
 template <int NP>
 __device__ __forceinline__ unsigned pack_plane2(float a, float b) { return NP == 1 ? pack_f16x2(a, b) : pack_bf16x2(a, b); }
+// one plane of a split: the packed pair, (a, b) left as the remainders.  F16S: fp16 planes (AliveGemm.f16s), else bf16 (NP = 1: plain fp16)
+template <int NP, bool F16S>
+__device__ __forceinline__ unsigned split_step(float& a, float& b) {
+    if constexpr (F16S) {
+        typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+        const unsigned h = pack_f16x2(a, b);
+        const f16x2_t hv = __builtin_bit_cast(f16x2_t, h);
+        a -= (float)hv[0];
+        b -= (float)hv[1];
+        return h;
+    } else {
+        const unsigned h = pack_plane2<NP>(a, b);
+        a -= __uint_as_float(h << 16);
+        b -= __uint_as_float(h & 0xffff0000u);
+        return h;
+    }
+}
 
 // ---- epilogue, straight from the accumulators (shared by the one-tile and the persistent kernel) ----
 // stage: wave-private LDS (NP x 8 KB: [plane][64 columns][64 channels] bf16) for the plane-packed output, or nullptr.  With it
@@ -86,7 +103,7 @@ __device__ __forceinline__ unsigned pack_plane2(float a, float b) { return NP ==
 // accumulator layout -- 8 B per lane, 16-B chunk index XOR-ed with column & 7 -- and read back transposed); without it a lane
 // stores its 8-byte pieces directly, one per column and store instruction: 64 separate 64-B lines touched per instruction.
 // By ablation (tools/experiments/README.md) the epilogue was 41 % of a 512 -> 1536 + GELU -> planes layer.
-template <int NP, int ACT>
+template <int NP, int ACT, bool F16S = false>
 __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[2][2], int m0, int64_t c0, int wr, int wc, int lr,
                                               int lh, int64_t cols, int64_t cols_pad, int co_pad32, unsigned char* stage = nullptr,
                                               unsigned char* stage_small = nullptr) {
@@ -194,6 +211,9 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
         obase[tj] = (unsigned)(n * co_out * p.T + (cok[tj] ? col - n * p.T : 0)) - (unsigned)(row_off * p.T);
     }
     const bool full_rows = m0 + GM <= p.Co;            // block-uniform
+    // fp16 split planes: the operands were multiples s_W, s_P of the values -- the accumulator is brought back before the bias
+    const float oscale = F16S ? p.wscale[0] * p.in_unscale : 1.0f;
+    const float pscale = F16S ? p.pout_scale : 1.0f;
     const float* __restrict__ bias = p.bias;
     const float* __restrict__ post_add = p.post_add;
     const float* __restrict__ ch_scale = p.ch_scale;
@@ -227,7 +247,7 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
             float vv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float x = acc[ti][tj][r] + bia[r >> 2][r & 3];
+                float x = F16S ? fmaf(acc[ti][tj][r], oscale, bia[r >> 2][r & 3]) : acc[ti][tj][r] + bia[r >> 2][r & 3];
                 if (ACT == 1) x = gelu_fast(x);
                 else if (ACT == 2) x = expf(x);
                 x = (x + pad[r >> 2][r & 3]) * scl[r >> 2][r & 3];
@@ -255,15 +275,11 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
                     const int rowl = ti * 32 + 8 * g + 4 * lh;                 // channel inside the wave's 64
                     float q[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) q[e] = (full_rows || rbase + 8 * g + e < p.Co) ? vv[4 * g + e] : 0.0f;
+                    for (int e = 0; e < 4; ++e) q[e] = (full_rows || rbase + 8 * g + e < p.Co) ? vv[4 * g + e] * pscale : 0.0f;
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl) {
-                        const unsigned h01 = pack_plane2<NP>(q[0], q[1]), h23 = pack_plane2<NP>(q[2], q[3]);
+                        const unsigned h01 = split_step<NP, F16S>(q[0], q[1]), h23 = split_step<NP, F16S>(q[2], q[3]);
                         *(uint2*)(stage + pl * 8192 + cl * 128 + ((((rowl >> 3)) ^ (cl & 7)) << 4) + 8 * lh) = make_uint2(h01, h23);
-                        q[0] -= __uint_as_float(h01 << 16);
-                        q[1] -= __uint_as_float(h01 & 0xffff0000u);
-                        q[2] -= __uint_as_float(h23 << 16);
-                        q[3] -= __uint_as_float(h23 & 0xffff0000u);
                     }
                 }
             } else if (p.Pout != nullptr && stage_small != nullptr) {
@@ -275,18 +291,14 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) q[g][e] = (full_rows || rbase + 8 * g + e < p.Co) ? vv[4 * g + e] : 0.0f;
+                    for (int e = 0; e < 4; ++e) q[g][e] = (full_rows || rbase + 8 * g + e < p.Co) ? vv[4 * g + e] * pscale : 0.0f;
                 const int lane = lr + 32 * lh;
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const unsigned h01 = pack_plane2<NP>(q[g][0], q[g][1]), h23 = pack_plane2<NP>(q[g][2], q[g][3]);
+                        const unsigned h01 = split_step<NP, F16S>(q[g][0], q[g][1]), h23 = split_step<NP, F16S>(q[g][2], q[g][3]);
                         *(uint2*)(stage_small + lr * 64 + ((g ^ ((lr >> 2) & 3)) << 4) + 8 * lh) = make_uint2(h01, h23);
-                        q[g][0] -= __uint_as_float(h01 << 16);
-                        q[g][1] -= __uint_as_float(h01 & 0xffff0000u);
-                        q[g][2] -= __uint_as_float(h23 << 16);
-                        q[g][3] -= __uint_as_float(h23 & 0xffff0000u);
                     }
 #pragma unroll
                     for (int it = 0; it < 2; ++it) {
@@ -308,15 +320,11 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
                     if (row >= co_pad32) continue;
                     float q[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) q[e] = (full_rows || row + e < p.Co) ? vv[4 * g + e] : 0.0f;
+                    for (int e = 0; e < 4; ++e) q[e] = (full_rows || row + e < p.Co) ? vv[4 * g + e] * pscale : 0.0f;
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl) {
-                        const unsigned h01 = pack_plane2<NP>(q[0], q[1]), h23 = pack_plane2<NP>(q[2], q[3]);
+                        const unsigned h01 = split_step<NP, F16S>(q[0], q[1]), h23 = split_step<NP, F16S>(q[2], q[3]);
                         *(uint2*)(Po + planes_at(pl, col, row, cols_pad, co_pad32)) = make_uint2(h01, h23);
-                        q[0] -= __uint_as_float(h01 << 16);
-                        q[1] -= __uint_as_float(h01 & 0xffff0000u);
-                        q[2] -= __uint_as_float(h23 << 16);
-                        q[3] -= __uint_as_float(h23 & 0xffff0000u);
                     }
                 }
             }
@@ -344,7 +352,9 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
 // KB2 (NP = 2 only; round 5): ONE fp16 plane per operand with a K-step of 64 -- the two "planes" of a stage are the two k-blocks of the
 // step, the products are (block 0 x block 0) + (block 1 x block 1) on v_mfma_f32_32x32x16_f16, the output is one fp16 plane.  The plain
 // (planes = 1) GEMM in the two-plane kernel's slot layout: 16 MFMAs between two block barriers instead of the 8 of a 32-deep step.
-template <int NP, int NS, int MINB, int ACT, bool KB2 = false>
+// F16S (NP = 2; round 5): the two planes are fp16 (hi, lo) of a power-of-two multiple of the values (AliveGemm.f16s): the same three
+// products on v_mfma_f32_32x32x16_f16, the accumulator rescaled in the epilogue.
+template <int NP, int NS, int MINB, int ACT, bool KB2 = false, bool F16S = false>
 __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int n_mt, int ntiles, int64_t cols,
                                                              int64_t cols_pad, int co_pad, int co_pad32, int kpad,
                                                              GemmWalk gw, long long* stamps) {
@@ -356,6 +366,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
     constexpr int NI = 4 * NP;                    // DMA pieces per wave per step
     constexpr int NPROD = KB2 ? 2 : NP * (NP + 1) / 2;
     static_assert(!KB2 || NP == 2, "the 64-deep one-plane form lives in the two-plane kernel's slots");
+    static_assert(!F16S || (NP == 2 && !KB2), "fp16 split planes: two planes, 32-deep steps");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -468,8 +479,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
                 for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                     for (int tj = 0; tj < 2; ++tj)
-                        acc[ti][tj] = NP == 1 ? mfma_f16(a[ti][i], b[tj][sum - i], acc[ti][tj])
-                                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][i], b[tj][sum - i], acc[ti][tj], 0, 0, 0);
+                        acc[ti][tj] = (NP == 1 || F16S) ? mfma_f16(a[ti][i], b[tj][sum - i], acc[ti][tj])
+                                                        : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][i], b[tj][sum - i], acc[ti][tj], 0, 0, 0);
                 hook(n++);
             }
     };
@@ -533,7 +544,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_planes_kernel(AliveGemm p, int
             stage = smem + w * (NP * 8192);
         }
     }
-    gemm_epilogue<KB2 ? 1 : NP, ACT>(p, acc, m0, c0, wr, wc, lr, lh, cols, cols_pad, co_pad32, stage);
+    gemm_epilogue<KB2 ? 1 : NP, ACT, F16S>(p, acc, m0, c0, wr, wc, lr, lh, cols, cols_pad, co_pad32, stage);
 #ifdef ALIVE_STAMPS
     if (stamps != nullptr && tid == 0) {
         long long* o = stamps + (size_t)blockIdx.x * 8;
@@ -815,12 +826,12 @@ inline GemmWalk make_walk(const AliveGemm& d) {
     return g;
 }
 
-template <int NP, int NS, int MINB, int ACT, bool KB2 = false>
+template <int NP, int NS, int MINB, int ACT, bool KB2 = false, bool F16S = false>
 int launch_gemm_act(const AliveGemm& d, hipStream_t s) {
     constexpr int LDS = NS * 2 * NP * PLANE_BYTES;
     {
         static LdsOptIn optin;
-        hipError_t e = optin.ensure({(const void*)gemm_planes_kernel<NP, NS, MINB, ACT, KB2>}, LDS);
+        hipError_t e = optin.ensure({(const void*)gemm_planes_kernel<NP, NS, MINB, ACT, KB2, F16S>}, LDS);
         if (e != hipSuccess) {
             alive_set_error("alive_gemm_planes: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return ALIVE_ERR_LAUNCH;
@@ -829,7 +840,7 @@ int launch_gemm_act(const AliveGemm& d, hipStream_t s) {
     const int64_t cols = (int64_t)d.N * d.T;
     const int n_mt = cdiv(d.Co, GM), n_ct = cdiv(cols, GN);
     const int ntiles = n_mt * n_ct;
-    gemm_planes_kernel<NP, NS, MINB, ACT, KB2><<<ntiles, 256, LDS, s>>>(
+    gemm_planes_kernel<NP, NS, MINB, ACT, KB2, F16S><<<ntiles, 256, LDS, s>>>(
         d, n_mt, ntiles, cols, pad_cols(cols), (d.Co + 15) & ~15, pad32(ACT == 4 ? d.Co / 2 : d.Co), pad32(d.Ci), make_walk(d),
         g_stamps);
     ALIVE_CHECK_LAUNCH("alive_gemm_planes");
@@ -967,6 +978,14 @@ extern "C" int alive_gemm_planes(const AliveGemm* d, void* stream) {
         if (form1 == 2) return launch_gemm<1, 6, 2>(*d, (hipStream_t)stream);
         if (form1 == 3) return launch_gemm<1, 2, 4>(*d, (hipStream_t)stream);
         return launch_gemm<1, 4, 2>(*d, (hipStream_t)stream);
+    }
+    ALIVE_CHECK_ARG(!d->f16s || (d->planes == 2 && d->wscale != nullptr && d->in_unscale > 0.0f && d->act >= 0 && d->act <= 2 &&
+                                 (d->Pout == nullptr || d->pout_scale > 0.0f) && d->y_split == 0),
+                    "alive_gemm_planes: f16s (fp16 split planes) takes planes = 2, wscale, in_unscale > 0, act 0 - 2 and pout_scale > 0 with Pout");
+    if (d->planes == 2 && d->f16s) {
+        if (d->act == 1) return launch_gemm_act<2, 2, 2, 1, false, true>(*d, (hipStream_t)stream);
+        if (d->act == 2) return launch_gemm_act<2, 2, 2, 2, false, true>(*d, (hipStream_t)stream);
+        return launch_gemm_act<2, 2, 2, 0, false, true>(*d, (hipStream_t)stream);
     }
     if (d->planes == 2) {
         // two planes: the one-tile kernel with two blocks per CU (one block's epilogue under the other's MFMAs) beats one persistent block

@@ -44,6 +44,7 @@ void convnext_names(Names& n, const std::string& p, bool adaptive) {
     n.add(p + ".dw_w"); n.add(p + ".dw_b");
     if (!adaptive) { n.add(p + ".norm_gain"); n.add(p + ".norm_offset"); }
     n.add(p + ".pw1.W"); n.add(p + ".pw1.b"); n.add(p + ".pw2.W"); n.add(p + ".pw2.b"); n.add(p + ".scale");
+    if (!adaptive) { n.add(p + ".pw1.ws"); n.add(p + ".pw2.ws"); }      // encoders: 1 / scale of the fp16 split weight images
 }
 
 const Names& names_of(int model) {
@@ -169,12 +170,13 @@ AliveConv split3(AliveConv d) {      // 3-plane split ("bf16x6"): fp32-grade, us
     } while (0)
 
 struct ConvNeXtW {
-    const float *dw_w, *dw_b, *gain, *offset, *pw1W, *pw1b, *pw2W, *pw2b, *scale;
+    const float *dw_w, *dw_b, *gain, *offset, *pw1W, *pw1b, *pw2W, *pw2b, *scale, *ws1, *ws2;
     ConvNeXtW(Table& t, bool adaptive) {
         dw_w = t.next(); dw_b = t.next();
-        gain = offset = nullptr;
+        gain = offset = ws1 = ws2 = nullptr;
         if (!adaptive) { gain = t.next(); offset = t.next(); }
         pw1W = t.next(); pw1b = t.next(); pw2W = t.next(); pw2b = t.next(); scale = t.next();
+        if (!adaptive) { ws1 = t.next(); ws2 = t.next(); }
     }
 };
 
@@ -197,8 +199,44 @@ int pw_gemm(const float* W, const float* b, const void* P, int N, int T, int Ci,
 
 // x <- x + scale * pw2(gelu(pw1(norm(dw(x)))))      (common.py:54-62 / 74-82)
 // Pa / Ph: plane-packed scratch for the normalised input and the hidden layer (nullptr: fp32-activation path via hbuf)
+// ---- arithmetic of the encoders' ConvNeXt pointwise convs on the batch path (alive_encoder_precision) ----
+// mode 1 (default since round 5): fp16 SPLIT planes -- hi = fp16(s v), lo = fp16(s v - hi) of a power-of-two multiple of the values, three
+//   MFMAs per product (hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_f16), 22 significand bits per operand -- instead of three bf16 planes
+//   and six MFMAs (24 bits).  The operands are what a ChannelNorm and a gelu leave: bounded, so a fixed activation scale of 2^8 keeps
+//   them in fp16's range (saturation at +-65504 = |v| > 255 would need a norm gain above 11); elements below 2^-11 / s lose relative,
+//   not absolute, precision (error < 2^-33).  Weights carry a per-tensor scale (module/_pack.py::pack_conv_split_f16s).
+// mode 2: the three-plane bf16 form (rounds 1 - 4).  ALIVE_ENCODER_PRECISION=2 or alive_encoder_precision(2).
+// The DFT, the input / output layers and the classifier stay on three bf16 planes in both modes: their inputs (waveform, magnitudes)
+// have no normalisation in front and bf16 planes keep fp32's range.
+int g_encoder_precision = 0;
+int encoder_precision() {
+    if (g_encoder_precision == 0) {
+        const char* e = getenv("ALIVE_ENCODER_PRECISION");
+        g_encoder_precision = (e != nullptr && atoi(e) == 2) ? 2 : 1;
+    }
+    return g_encoder_precision;
+}
+constexpr float F16S_ACT_SCALE = 256.0f;      // activations of the fp16 split form: 2^8
+
 int convnext_layer(const ConvNeXtW& w, float* x, float* ybuf, float* hbuf, void* Pa, void* Ph, int N, int C, int H, int T,
                    const float* cond, int cond_rows, int scale_row, int shift_row, int planes, void* s) {
+    if (Pa != nullptr && planes == 3 && w.ws1 != nullptr && encoder_precision() == 1) {
+        RUN(alive_dwconv_norm_planes_f16s(x, N, C, T, w.dw_w, w.dw_b, cond ? 1 : 0, w.gain, w.offset, cond, cond_rows, scale_row,
+                                          shift_row, NORM_EPS, F16S_ACT_SCALE, Pa, s));
+        AliveGemm g;
+        memset(&g, 0, sizeof(g));
+        // (the fp16 pair sits behind the three bf16 planes of the same tensor)
+        g.W = (const float*)((const unsigned short*)w.pw1W + (size_t)3 * ((H + 15) & ~15) * ((C + 31) & ~31));
+        g.bias = w.pw1b; g.P = Pa; g.N = N; g.T = T; g.Ci = C; g.Co = H; g.planes = 2; g.act = 1; g.Pout = Ph;
+        g.f16s = 1; g.wscale = w.ws1; g.in_unscale = 1.0f / F16S_ACT_SCALE; g.pout_scale = F16S_ACT_SCALE;
+        RUN(alive_gemm_planes(&g, s));
+        memset(&g, 0, sizeof(g));
+        g.W = (const float*)((const unsigned short*)w.pw2W + (size_t)3 * ((C + 15) & ~15) * ((H + 31) & ~31));
+        g.bias = w.pw2b; g.P = Ph; g.N = N; g.T = T; g.Ci = H; g.Co = C; g.planes = 2; g.act = 0;
+        g.ch_scale = w.scale; g.residual = x; g.Y = x;
+        g.f16s = 1; g.wscale = w.ws2; g.in_unscale = 1.0f / F16S_ACT_SCALE;
+        return alive_gemm_planes(&g, s);
+    }
     if (Pa != nullptr) {
         const int gp = (planes == 2 && (decoder_bf16_mask() & 2)) ? 1 : planes;     // the decoder's layers (the encoders run three planes)
         RUN(alive_dwconv_norm_planes(x, N, C, T, w.dw_w, w.dw_b, cond ? 1 : 0, w.gain, w.offset, cond, cond_rows, scale_row,
@@ -739,6 +777,11 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
 extern "C" int alive_decoder_precision(int mode) {
     if (mode == 1 || mode == 2) g_decoder_precision = mode;
     return decoder_precision();
+}
+
+extern "C" int alive_encoder_precision(int mode) {
+    if (mode == 1 || mode == 2) g_encoder_precision = mode;
+    return encoder_precision();
 }
 
 extern "C" int alive_decoder_forward(const float* const* w, const float* x_in, const float* f0, const float* phi_in, int crop0,

@@ -38,6 +38,7 @@ class AliveGemm(C.Structure):
         ("b_plane", C.c_int64), ("b_win", C.c_int64), ("b_row", C.c_int), ("b_cblk", C.c_int), ("b_blk", C.c_int64),
         ("arg_val", C.c_void_p), ("arg_idx", C.c_void_p),
         ("Y2", C.c_void_p), ("y_split", C.c_int),
+        ("f16s", C.c_int), ("wscale", C.c_void_p), ("in_unscale", C.c_float), ("pout_scale", C.c_float),
     ]
 
 
@@ -68,6 +69,7 @@ PROTOTYPES = {
     "alive_knn_merge_gather": (_I, [_VP, _VP, _I, _I, _D, _VP, _VP, _I, _I, _VP, _VP, _VP]),
     "alive_conv1d": (_I, [C.POINTER(AliveConv), _VP]),
     "alive_decoder_precision": (_I, [_I]),
+    "alive_encoder_precision": (_I, [_I]),
     "alive_gelu_film": (_I, [_VP, _I, _I, _I, _VP, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "alive_planes_bytes": (_SZ, [_I64, _I, _I]),
     "alive_to_planes": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
@@ -83,6 +85,7 @@ PROTOTYPES = {
     "alive_filter_source_out": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP]),
     "alive_dwconv_norm": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP]),
     "alive_dwconv_norm_planes": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _VP, _I, _I, _I, _F, _I, _VP, _VP]),
+    "alive_dwconv_norm_planes_f16s": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _VP, _I, _I, _I, _F, _F, _VP, _VP]),
     "alive_channel_norm": (_I, [_VP, _I, _I, _I, _VP, _VP, _F, _VP, _VP]),
     "alive_argmax_channels": (_I, [_VP, _I, _I, _I, _VP, _VP]),
     "alive_oscillator_workspace_bytes": (_SZ, [_I, _I, _I]),

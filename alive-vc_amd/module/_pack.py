@@ -75,6 +75,27 @@ def pack_conv_split_h(w):
     return torch.cat([two.view(torch.int16), h.view(torch.int16).unsqueeze(0)], 0).view(torch.bfloat16).contiguous()
 
 
+def pack_conv_split_f16s(w):
+    """pack_conv_split(w, 3) followed by TWO fp16 slabs of the same shape -- hi = fp16(s w), lo = fp16(s w - hi), s = 2^e the largest power
+    of two with s max|w| <= 16384 -- and the fp32 scalar 1 / s: the weight operand of alive_gemm_planes with AliveGemm.f16s (three MFMAs
+    per product at 22 significand bits; csrc/networks.hip::convnext_layer).  -> ([5, K / 32, Co_pad16, 32] bf16-typed, [1] fp32)"""
+    three = pack_conv_split(w, 3)
+    co, ci, kw = w.shape
+    co_pad, ci_pad = _pad16(co), (ci + 31) // 32 * 32
+    a = torch.zeros(co_pad, kw, ci_pad, dtype=torch.float32, device=w.device)
+    a[:co, :, :ci] = w.float().permute(0, 2, 1)
+    a = a.reshape(co_pad, kw * ci_pad)
+    m = float(a.abs().max())
+    e = 0 if not (m > 0.0) or m != m or m == float("inf") else int(torch.floor(torch.log2(torch.tensor(16384.0 / m, dtype=torch.float64))))
+    e = max(-24, min(24, e))
+    sc = a * (2.0 ** e)                                                     # exact: a power of two
+    hi = sc.clamp(-65504.0, 65504.0).to(torch.float16)
+    lo = (sc - hi.float()).clamp(-65504.0, 65504.0).to(torch.float16)
+    kb = lambda t: t.view(co_pad, kw * ci_pad // 32, 32).permute(1, 0, 2).contiguous().view(torch.int16).unsqueeze(0)
+    W = torch.cat([three.view(torch.int16), kb(hi), kb(lo)], 0).view(torch.bfloat16).contiguous()
+    return W, torch.tensor([2.0 ** -e], dtype=torch.float32, device=w.device)
+
+
 def unpack_conv_split(W):
     """k-blocked [planes, K / 32, Co_pad, 32] -> row-major [planes, Co_pad, K] (tests, tools)"""
     p, kb, co_pad, _ = W.shape
@@ -114,6 +135,9 @@ def _convnext(out, sd, src, dst, adaptive, pc=pack_conv):
     out[dst + ".pw2.W"] = pc(sd[src + ".pw_conv2.weight"])
     out[dst + ".pw2.b"] = _vec(sd[src + ".pw_conv2.bias"])
     out[dst + ".scale"] = _vec(sd[src + ".scale"])
+    if pc is pack_conv_split3:       # the encoders: + the fp16 split image of the pointwise weights and its scale (alive_encoder_precision 1)
+        out[dst + ".pw1.W"], out[dst + ".pw1.ws"] = pack_conv_split_f16s(sd[src + ".pw_conv1.weight"])
+        out[dst + ".pw2.W"], out[dst + ".pw2.ws"] = pack_conv_split_f16s(sd[src + ".pw_conv2.weight"])
 
 
 def pack_content_encoder(sd):

@@ -320,3 +320,9 @@ def decoder_precision(mode=0):
     """Arithmetic of the six k = 5 convs of the decoder's 256-channel FilterBlock on the batch path (alive_decoder_precision):
     1 = plain fp16 operands (default since round 5), 2 = two-plane split bf16 (rounds 1 - 4), 0 = query.  Returns the mode in force."""
     return int(nat.lib().alive_decoder_precision(int(mode)))
+
+
+def encoder_precision(mode=0):
+    """Arithmetic of the encoders' ConvNeXt pointwise convs on the batch path (alive_encoder_precision): 1 = fp16 split planes, three MFMAs
+    per product (default since round 5), 2 = three bf16 planes, six MFMAs (rounds 1 - 4), 0 = query.  Returns the mode in force."""
+    return int(nat.lib().alive_encoder_precision(int(mode)))

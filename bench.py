@@ -36,7 +36,7 @@ FRAME = 320
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_FP8_TFLOPS = 5000.0           # dense fp8 MFMA peak (block-scaled 32x32x64 e4m3), same table
 PEAK_FP6_TFLOPS = 10000.0          # dense fp6 / fp4 MFMA peak (block-scaled 32x32x64 e2m3: "FP6 at FP4 rate"), same table
-ALL_LEGS = ("uncorrelated", "fp8_prefilter", "decoder_split_bf16", "bf16_prefilter", "strict_knn", "clustered_library", "overlap_shared", "context_trim", "cli_default", "library_build", "pcie_inclusive", "e2e_24k", "config2",
+ALL_LEGS = ("uncorrelated", "fp8_prefilter", "decoder_split_bf16", "encoder_bf16x6", "bf16_prefilter", "strict_knn", "clustered_library", "overlap_shared", "context_trim", "cli_default", "library_build", "pcie_inclusive", "e2e_24k", "config2",
             "streaming", "cpu_baseline")
 
 
@@ -370,22 +370,30 @@ def main():
         dec_mode = _ops.decoder_precision(0)
         fl_dec_plain = (12.58 + 39.32 + 4.19 + 2.62 + 1.31 + 0.66) * 1e6 * frames_per_step if dec_mode == 1 else 0.0
         dec_ideal_s = fl_dec_plain / (PEAK_BF16_TFLOPS * 1e12) + (fl_dec - fl_dec_plain) / (PEAK_BF16_TFLOPS / 3 * 1e12)
-        pk_enc, pk_dec = PEAK_BF16_TFLOPS / 6, fl_dec / dec_ideal_s / 1e12
+        # encoder precision mode 1 (default since round 5): the ConvNeXt pointwise convs (CE 12.58 + PE 2.10 MFLOP per frame) run three fp16
+        # MFMAs per product, the rest of the front end (DFT, input / output layers, classifier: 7.21 MFLOP) six bf16 MFMAs
+        enc_mode = _ops.encoder_precision(0)
+        fl_enc_3 = (12.58 + 2.10) * 1e6 * frames_per_step if enc_mode == 1 else 0.0
+        enc_ideal_s = fl_enc_3 / (PEAK_BF16_TFLOPS / 3 * 1e12) + (fl_enc - fl_enc_3) / (PEAK_BF16_TFLOPS / 6 * 1e12)
+        pk_enc, pk_dec = fl_enc / enc_ideal_s / 1e12, fl_dec / dec_ideal_s / 1e12
         fl_knn = 2.0 * 768 * M * frames_per_step
-        ideal_ms = (fl_knn / (peak * 1e12) + dec_ideal_s + fl_enc / (pk_enc * 1e12)) * 1e3
+        ideal_ms = (fl_knn / (peak * 1e12) + dec_ideal_s + enc_ideal_s) * 1e3
         fam = lambda ms_, fl, pk, what: {"what": what, "ms_per_step": round(ms_, 2), "algorithmic_tflop": round(fl / 1e12, 2),
                                          "achieved": round(fl / (ms_ * 1e-3) / 1e12, 1), "peak": round(pk, 1), "unit": "TFLOP/s",
                                          "frac": round(fl / (ms_ * 1e-3) / 1e12 / pk, 4)}
         return {"bound": "mfma", "timing": "HIP events on the launching stream, each family alone, one stream (the step overlaps window batches on side streams)",
                 "counters": "profiles/nets_pmc.json (per kernel: MFMA-pipe utilisation, bytes beyond L2, LDS conflicts, VALU co-execution; tools/pmc_nets.sh)",
-                "front_end": fam(ms_enc, fl_enc, pk_enc, "spectrogram (DFT as a GEMM) + F0Estimator + ContentEncoder: 3-plane split bf16, 6 MFMAs per product"),
+                "front_end": dict(fam(ms_enc, fl_enc, pk_enc, ("spectrogram (DFT as a GEMM) + F0Estimator + ContentEncoder: fp16 split planes (3 MFMAs per product, fp32-grade) for the ConvNeXt pointwise convs "
+                                                                "(14.7 of the 21.9 MFLOP per frame), 3-plane split bf16 (6 MFMAs per product) for the DFT, the input / output layers and the classifier; peak = the blend" if enc_mode == 1 else
+                                                                "spectrogram (DFT as a GEMM) + F0Estimator + ContentEncoder: 3-plane split bf16, 6 MFMAs per product")),
+                                  precision_mode=enc_mode, frac_of_bf16x6_peak=round(fl_enc / (ms_enc * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS / 6), 4)),
                 "decoder": dict(fam(ms_dec, fl_dec, pk_dec, ("FeatureExtractor + HarmonicOscillator + Filter: plain fp16 (1 MFMA per product) for the ConvNeXt pointwise convs, the six k5 convs of the 256-channel FilterBlock, the norm-FiLM projection, the two coarse down convs and the mid conv "
                                                               "(60.7 of the 96.6 MFLOP per frame), 2-plane split bf16 (3 MFMAs per product) for the rest; peak = the blend, FLOP / ideal time" if dec_mode == 1 else
                                                               "FeatureExtractor + HarmonicOscillator + Filter: 2-plane split bf16, 3 MFMAs per product") +
                                                              " (fused FilterBlocks at 64 / 16 / 8 channels on the same MFMA; exact f32 MFMA only for the strided / transposed convs of the two finest scales)"),
                                 precision_mode=dec_mode, frac_of_split_bf16_peak=round(fl_dec / (ms_dec * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS / 3), 4)),
                 "step": {"ideal_ms": round(ideal_ms, 1), "ms_per_step": round(dt / args.steps * 1e3, 2), "frac": round(ideal_ms / (dt / args.steps * 1e3), 4),
-                         "ideal": "kNN 2*768*M*T FLOP at the candidate stage's MFMA peak + decoder at its blended peak (2.5 PF for the plain-fp16 layers, 2.5 PF / 3 for the rest) + front end at 2.5 PF / 6"}}
+                         "ideal": "kNN 2*768*M*T FLOP at the candidate stage's MFMA peak + decoder at its blended peak (2.5 PF for the plain-fp16 layers, 2.5 PF / 3 for the rest) + front end at its blended peak (2.5 PF / 3 for the fp16-split layers, 2.5 PF / 6 for the rest)"}}
     roofline_nets = guarded(nets_roofline) if rank == 0 and not args.no_nets_roofline else None
 
     extra = {}
@@ -448,6 +456,30 @@ def main():
                     "note": "ALIVE_DECODER_PRECISION=2: every decoder GEMM on two-plane split bf16 (3 MFMAs per product); the headline runs the "
                             "ConvNeXt pointwise convs, the 256-channel FilterBlock's k5 convs and four smaller layers on plain fp16"}
         extra["decoder_split_bf16"] = guarded(leg)
+
+    # The same step with the encoders' ConvNeXt pointwise convs back on three bf16 planes, six MFMAs per product (alive_encoder_precision 2,
+    # the arithmetic of rounds 1 - 4); the headline runs them on fp16 split planes, three MFMAs per product, both fp32-grade
+    if "encoder_bf16x6" in legs:
+        def leg():
+            from module import ops as _ops
+            mode0 = _ops.encoder_precision(0)
+            if mode0 != 1:
+                return {"skipped": "the headline already runs encoder precision mode %d" % mode0}
+            _ops.encoder_precision(2)
+            try:
+                conv.convert_windows(windows, k=args.k, window_batch=args.window_batch)
+                t2, o2 = timed_steps(step, 2)
+            finally:
+                _ops.encoder_precision(mode0)
+            d = (o2.double() - out.double())
+            return {"ms_per_step": round(t2 * 1e3, 2), "frames_per_s": round(frames_per_step / t2, 1),
+                    "headline_minus_this_rms": float("%.3e" % d.pow(2).mean().sqrt().item()),
+                    "windows_bitwise_equal": int((d.abs().amax(dim=-1) == 0).sum().item()), "windows": int(d.shape[0]),
+                    "note": "ALIVE_ENCODER_PRECISION=2: the ConvNeXt pointwise convs of ContentEncoder / F0Estimator on three bf16 planes (6 MFMAs per "
+                            "product); the headline runs them on fp16 split planes (3 MFMAs per product).  Both reproduce the reference's content "
+                            "features to 7.7e-7 of their RMS and all 450 f0 classes of the fixture (tools/enc_precision_check.py); a window differs "
+                            "where a feature ulp moves a near-tied neighbour or an f0 class"}
+        extra["encoder_bf16x6"] = guarded(leg)
 
     # The same step with the bf16 candidate stage (ALIVE_KNN_PREFILTER=bf16): same library object, fp8 image unused
     if "bf16_prefilter" in legs:
@@ -725,6 +757,7 @@ def main():
         audio_s = world * args.utterances * args.seconds
         from module import ops as _ops
         decoder_mode = _ops.decoder_precision(0)
+        encoder_mode = _ops.encoder_precision(0)
         line = {
             "metric": "VC frames/sec + RTF @24kHz, 1M-vec library; 1/2/4/8 MI355X",
             "value": round(world * frames_per_step * args.steps / dt, 1),
@@ -735,7 +768,7 @@ def main():
             "dtype": ({"fp6": "fp6 (e2m3)", "fp8": "fp8 (e4m3)"}[library.prefilter] + " MFMA candidate scoring + exact f32 rescoring, every frame "
                       "certified at 7 sigma of its measured stage error (statistical: audited against brute force on every frame of this "
                       "batch, tests/test_gpu_knn_audit.py; ALIVE_KNN_STRICT=1 is the deterministic form)" if library.prefilter in ("fp8", "fp6") else
-                      "bf16 MFMA scoring + exact f32 rescoring, certified per frame" + (" (deterministic bound)" if library.strict else "")) + "; 3-plane split-bf16 (fp32-grade) encoder GEMMs; decoder: " + ("plain fp16 (one MFMA per product, fp32 accumulate and residual streams) for the ConvNeXt pointwise convs, the 256-channel FilterBlock's k5 convs and four smaller layers (60.7 of its 96.6 MFLOP per frame) -- decoder waveform RMS error 1.4e-5 on the reference's 450-frame fixture against the 1e-3 bar, ALIVE_DECODER_PRECISION=2 restores split bf16 (5e-6) --, 2-plane split-bf16 for its other GEMMs" if decoder_mode == 1 else "2-plane split-bf16 GEMMs (ALIVE_DECODER_PRECISION=2)") + "; f32 MFMA DFT / strided / small-channel convs; f64 phase scan",
+                      "bf16 MFMA scoring + exact f32 rescoring, certified per frame" + (" (deterministic bound)" if library.strict else "")) + "; encoders (fp32-grade): " + ("fp16 split planes (hi + scaled lo, 3 MFMAs per product, 22 significand bits) for the ConvNeXt pointwise convs, 3-plane split bf16 (6 MFMAs) for the DFT / input / output / classifier GEMMs" if encoder_mode == 1 else "3-plane split-bf16 GEMMs (ALIVE_ENCODER_PRECISION=2)") + "; decoder: " + ("plain fp16 (one MFMA per product, fp32 accumulate and residual streams) for the ConvNeXt pointwise convs, the 256-channel FilterBlock's k5 convs and four smaller layers (60.7 of its 96.6 MFLOP per frame) -- decoder waveform RMS error 1.4e-5 on the reference's 450-frame fixture against the 1e-3 bar, ALIVE_DECODER_PRECISION=2 restores split bf16 (5e-6) --, 2-plane split-bf16 for its other GEMMs" if decoder_mode == 1 else "2-plane split-bf16 GEMMs (ALIVE_DECODER_PRECISION=2)") + "; f32 MFMA DFT / strided / small-channel convs; f64 phase scan",
             "data": "synthetic",
             "config": {"workload": f"{args.utterances} utterances x {args.seconds:g} s per GPU -> {n_win} windows x "
                                    f"{L // FRAME} frames per step, {M}-vector library (BASELINE config 3/4 shape)",
@@ -745,7 +778,7 @@ def main():
             "useful_frames_per_s": round(world * useful_frames * args.steps / dt, 1),
             "rtf": round((dt / args.steps) / audio_s, 6),
             "roofline": roofline,
-            "decoder_precision_mode": decoder_mode,
+            "decoder_precision_mode": decoder_mode, "encoder_precision_mode": encoder_mode,
             "roofline_nets": roofline_nets,
             "cpu_baseline": cpu,
         }

@@ -298,6 +298,17 @@ typedef struct AliveGemm {
      *   ([planes][pad32(Co / 2) / 32][cols_pad][32]) -- the magnitude spectrogram never exists in fp32.  No Y, bias or other term. */
     float* Y2;
     int y_split;
+    /* Round 5: fp16 split planes (planes == 2 only; fields appended, all 0 = the bf16 planes above).  f16s != 0: both operands are TWO
+     * fp16 planes of a power-of-two multiple of the values -- hi = fp16(s v), lo = fp16(s v - hi), round to nearest even, saturated at
+     * +-65504 -- in the same k-blocked layout, multiplied as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16: 22 significand bits per
+     * operand (the two bf16 planes carry 16) for elements above 2^-11 / s, an absolute error below 2^-25 / s for smaller ones -- fp32-grade
+     * at three MFMAs per product instead of the six of the three-plane bf16 form.  The accumulator is multiplied by *wscale * in_unscale
+     * before the bias (wscale: device pointer to 1 / s_W of this weight tensor, module/_pack.py::pack_conv_split_f16s; in_unscale =
+     * 1 / s_P, the scale the producer of P used); Pout, if set, is written in the same format with the scale pout_scale.
+     * Used by the ConvNeXt pointwise convs of both encoders (alive_encoder_precision). */
+    int f16s;
+    const float* wscale;
+    float in_unscale, pout_scale;
 } AliveGemm;
 int alive_gemm_planes(const AliveGemm* desc, void* stream);
 /* out[col] = (float) row of the largest value over the nblk per-block candidates of column col (smallest row on ties) */
@@ -355,6 +366,12 @@ int alive_dwconv_norm_planes(const float* X, int N, int C, int T, const float* d
                              int affine_mode, const float* gain, const float* offset,
                              const float* cond, int cond_rows, int scale_row, int shift_row,
                              float eps, int planes, void* P, void* stream);
+/* the same with fp16 split planes: TWO planes hi = fp16(s y), lo = fp16(s y - hi) with s = scale (a power of two), saturated at
+ * +-65504 -- the input format of alive_gemm_planes with f16s (AliveGemm.in_unscale = 1 / scale) */
+int alive_dwconv_norm_planes_f16s(const float* X, int N, int C, int T, const float* dw_w, const float* dw_b,
+                                  int affine_mode, const float* gain, const float* offset,
+                                  const float* cond, int cond_rows, int scale_row, int shift_row,
+                                  float eps, float scale, void* P, void* stream);
 /* z = gelu(h) * interp(film[scale_row + c]) + interp(film[shift_row + c])  (decoder.py:112-117,130-132: F.gelu, then the FiLM of a
  * ModulatedCausalConv1d with F.interpolate(mode='linear')), the arithmetic of alive_conv1d's second output.  H [N][C][L];
  * film [N][film_rows][film_ld] holds the frames from f0 on of a window of Lf frames, t0 = first sample of H in the window at this
@@ -454,6 +471,14 @@ int alive_f0_estimate(const float* const* w, const float* spec, int N, int T,
  * decoder (FiLM projections, input layer, to_amps, strided / transposed convs, the fused 64 / 16 / 8-channel FilterBlocks) keeps
  * split bf16 or exact fp32 in both modes, and so do both encoders (top-k / argmax downstream). */
 int alive_decoder_precision(int mode);
+/* Arithmetic of the pointwise convs of the ConvNeXt layers of ContentEncoder / F0Estimator on the batch path (common.py:54-62):
+ *   mode 1 (default since round 5, or ALIVE_ENCODER_PRECISION=1): fp16 split planes, three MFMAs per product (AliveGemm.f16s; 22
+ *          significand bits per operand);
+ *   mode 2 (ALIVE_ENCODER_PRECISION=2): three bf16 planes, six MFMAs per product (24 bits; rounds 1 - 4);
+ *   mode 0: query.  Both are fp32-grade: content features agree with the reference fixture to < 1e-5 of their RMS in either mode and
+ * the f0 classes outside the 1e-4 margin are identical (tests/test_gpu_models.py).  The DFT, the input / output layers and the
+ * classifier stay on three bf16 planes (their inputs are not range-limited by a normalisation). */
+int alive_encoder_precision(int mode);
 
 /* Decoder.forward (decoder.py:205-210) at harmonics_scale == 1:
  *   x[N][768][Lf], f0[N][Lf], phi_in[N][64] or NULL (phi = 0), crop0,

@@ -904,3 +904,72 @@ def test_gemm_planes_one_plane_is_the_float64_product_of_the_fp16_operands(co, c
     e = ops.to_planes(y, 1).view(torch.int16).view(1, cp // 32, cols_pad, 32)[0, :, :cols]
     a = pout.view(torch.int16).view(1, cp // 32, cols_pad, 32)[0, :, :cols]
     assert torch.equal(a.contiguous(), e.contiguous())
+
+
+@pytest.mark.parametrize("co,ci,n,t,act", [(1536, 512, 2, 450, "gelu"), (512, 1536, 3, 37, None), (200, 96, 2, 130, None)])
+def test_gemm_planes_fp16_split_is_fp32_grade(co, ci, n, t, act):
+    """AliveGemm.f16s (round 5; the pointwise convs of the encoders' ConvNeXt layers, common.py:54-62): both operands as two fp16 planes
+    of a power-of-two multiple of the values, three MFMAs per product.  Against float64: the error of the three-plane bf16 form
+    (six MFMAs) within a factor of a few -- fp32-grade -- and two orders below the two-plane bf16 form; the plane output in the same
+    format reproduces the fp32 output to 22 bits."""
+    import ctypes as C
+    from module import ops, _native as nat
+    from module._pack import pack_conv_split_f16s
+    x = g(f"fsx{co}{ci}{t}", (n, ci, t)); w = g(f"fsw{co}{ci}{t}", (co, ci, 1), scale=1.0 / np.sqrt(ci)); b = g(f"fsb{co}", (co,), scale=0.1)
+    x[0, 0, 0], x[0, 1, 1] = 3.0e-6, 200.0                          # a tiny and a large activation
+    want = torch.einsum("oc,nct->not", w[:, :, 0].double(), x.double()) + b.double().view(1, -1, 1)
+    if act == "gelu":
+        want = torch.nn.functional.gelu(want)
+    scale = 256.0
+    L = nat.lib()
+    xd = x.to(DEV)
+    # the producer of the format: dw conv off, norm off is not available -- build the planes from alive_to_planes's arithmetic on the host
+    cp, cols, cols_pad = (ci + 31) // 32 * 32, n * t, (n * t + 127) // 128 * 128
+    flat = torch.zeros(cols_pad, cp, dtype=torch.float32)
+    flat[:cols, :ci] = x.permute(0, 2, 1).reshape(cols, ci) * scale
+    hi = flat.clamp(-65504, 65504).half(); lo = (flat - hi.float()).clamp(-65504, 65504).half()
+    P = torch.stack([hi, lo], 0).view(2, cols_pad, cp // 32, 32).permute(0, 2, 1, 3).contiguous().to(DEV)
+    W5, ws = pack_conv_split_f16s(w.to(DEV))
+    bd = b.to(DEV)
+    y = torch.empty(n, co, t, device=DEV)
+    cop = (co + 31) // 32 * 32
+    pout = torch.zeros(2, cop // 32, cols_pad, 32, dtype=torch.float16, device=DEV)
+    d = nat.AliveGemm()
+    d.W, d.bias, d.P = W5[3:].contiguous().data_ptr(), bd.data_ptr(), P.data_ptr()
+    keep = W5[3:].contiguous(); d.W = keep.data_ptr()
+    d.N, d.T, d.Ci, d.Co, d.planes, d.act = n, t, ci, co, 2, ops.ACT[act]
+    d.Y, d.Pout = y.data_ptr(), pout.data_ptr()
+    d.f16s, d.wscale, d.in_unscale, d.pout_scale = 1, ws.data_ptr(), 1.0 / scale, scale
+    nat.check(L.alive_gemm_planes(C.byref(d), nat.stream()), "alive_gemm_planes")
+    ref_scale = max(1.0, want.abs().max().item())
+    err = (y.cpu().double() - want).abs().max().item()
+    y3, _ = ops.gemm_planes(ops.to_planes(xd, 3), n, t, w.to(DEV), bd, planes=3, act=act)
+    y2, _ = ops.gemm_planes(ops.to_planes(xd, 2), n, t, w.to(DEV), bd, planes=2, act=act)
+    e3, e2 = (y3.cpu().double() - want).abs().max().item(), (y2.cpu().double() - want).abs().max().item()
+    # fp32-grade = what the three-plane bf16 form reaches on the same data (with K = 1536 and an activation of 200 both sit on the fp32
+    # accumulation, 2.2e-5); the two-plane bf16 form is 3 - 60 x worse
+    assert err <= 4e-6 * ref_scale and err <= 2 * e3 + 1e-7 * ref_scale and err < 0.5 * e2, (err, e3, e2)
+    back = (pout[0].float() + pout[1].float()).permute(1, 0, 2).reshape(cols_pad, cop)[:cols, :co] / scale
+    back = back.view(n, t, co).permute(0, 2, 1)
+    assert (back.cpu().double() - y.cpu().double()).abs().max().item() <= 2.0 ** -20 * ref_scale
+
+
+def test_dwconv_norm_planes_fp16_split():
+    """alive_dwconv_norm_planes_f16s: the two fp16 planes of 256 x the normalised tensor reproduce alive_dwconv_norm's fp32 output to
+    22 bits of its largest element; padding is zero."""
+    from module import ops, _native as nat
+    n, c, t = 2, 512, 333
+    x = g("fsn", (n, c, t)).to(DEV)
+    dw_w, dw_b = g("fsnw", (c, 1, 7), scale=0.3).to(DEV), g("fsnb", (c,), scale=0.1).to(DEV)
+    gain, off = (1.0 + g("fsng", (c,), scale=0.1)).to(DEV), g("fsno", (c,), scale=0.1).to(DEV)
+    y = ops.dwconv_norm(x, dw_w, dw_b, gain=gain, offset=off)
+    cols, cols_pad = n * t, (n * t + 127) // 128 * 128
+    P = torch.zeros(2, c // 32, cols_pad, 32, dtype=torch.float16, device=DEV)
+    fl = lambda v: nat.ptr(v.reshape(-1).contiguous())
+    w7, keep = dw_w.reshape(-1).contiguous(), [gain.contiguous(), off.contiguous()]
+    nat.check(nat.lib().alive_dwconv_norm_planes_f16s(nat.ptr(x), n, c, t, nat.ptr(w7), nat.ptr(dw_b), 0, nat.ptr(keep[0]), nat.ptr(keep[1]),
+                                                      None, 0, 0, 0, 1e-4, 256.0, nat.ptr(P), nat.stream()), "alive_dwconv_norm_planes_f16s")
+    back = ((P[0].float() + P[1].float()) / 256.0).permute(1, 0, 2).reshape(cols_pad, c)
+    assert back[cols:].abs().sum().item() == 0.0
+    got = back[:cols].view(n, t, c).permute(0, 2, 1)
+    assert (got - y).abs().max().item() <= 2.0 ** -21 * y.abs().max().item()

@@ -70,7 +70,10 @@ def test_weight_tables_cover_the_schema():
                 # encoders: 3 bf16 planes; decoder: 2, or 2 + the fp16 slab of the plain kernels (decoder precision mode 1, _pack.pack_conv_split_h)
                 plain = mid == 2 and (k.startswith("flt.blk0.") or k.startswith("flt.up") or k == "flt.mid.W" or k == "fe.normfilm.W"
                                       or (k.startswith("fe.mid") and ".pw" in k))
-                assert v.dim() == 4 and v.shape[0] == (3 if mid < 2 or plain else 2) and v.shape[2] % 16 == 0 and v.shape[3] == 32, k
+                f16s = mid < 2 and ".pw" in k              # encoders' pointwise convs: 3 bf16 planes + the fp16 (hi, lo) pair (_pack.pack_conv_split_f16s)
+                assert v.dim() == 4 and v.shape[0] == (5 if f16s else 3 if mid < 2 or plain else 2) and v.shape[2] % 16 == 0 and v.shape[3] == 32, k
+            if k.endswith(".ws"):                          # 1 / scale of that pair: a power of two
+                assert v.shape == (1,) and v.dtype == torch.float32 and float(torch.log2(v)[0]) == round(float(torch.log2(v)[0]))
     sd = synthetic.make_state_dict(schema.decoder_schema(), 2)
     p = _pack.pack_decoder(sd)
     assert p["flt.in.W"].shape == (56,) and p["flt.down0.W"].shape == (256,) and p["flt.out.W"].shape == (56,)   # streaming edge kernels
@@ -83,6 +86,15 @@ def test_weight_tables_cover_the_schema():
     h = p["flt.blk0.1.c2.W"][2].view(torch.float16)                         # the third slab: the same weights as ONE fp16 plane, same layout
     hb = h.permute(1, 0, 2).reshape(256, 5, 256).permute(0, 2, 1)
     assert torch.equal(hb, w.half()) and p["flt.down2.Wp"].shape[0] == 3 and p["flt.down3.Wp"].shape[0] == 3
+    sdc = synthetic.make_state_dict(schema.content_encoder_schema(), 2)
+    pc = _pack.pack_content_encoder(sdc)
+    w = sdc["mid_layers.1.pw_conv1.weight"]                                   # [1536, 512, 1]
+    W5, ws = pc["mid1.pw1.W"], pc["mid1.pw1.ws"]
+    sc = 1.0 / float(ws)
+    assert 8192.0 < float(w.abs().max()) * sc <= 16384.0
+    hi = W5[3].view(torch.float16).permute(1, 0, 2).reshape(1536, 512).double()
+    lo = W5[4].view(torch.float16).permute(1, 0, 2).reshape(1536, 512).double()
+    assert ((hi + lo) / sc - w[:, :, 0].double()).abs().max().item() <= 2.0 ** -21 * float(w.abs().max())     # 22 bits of the largest element
     w = torch.arange(2 * 3 * 4, dtype=torch.float32).view(2, 3, 4)            # ConvT [Ci=2, Co=3, r=4]
     W, b = _pack.pack_convT(w, torch.tensor([1.0, 2.0, 3.0]))
     assert W[1 * 4 + 2, 1].item() == w[1, 1, 2].item() and b.tolist() == [1.0] * 4 + [2.0] * 4 + [3.0] * 4
