@@ -126,9 +126,10 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
             for (int r = 0; r < 16; ++r) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 const float b = p.bias != nullptr ? p.bias[row < p.Co ? row : p.Co - 1] : 0.0f;
+                const float osc = F16S ? p.wscale[0] * p.in_unscale : 1.0f;
 #pragma unroll
                 for (int tj = 0; tj < 2; ++tj) {
-                    const float x = acc[ti][tj][r] + b;
+                    const float x = F16S ? fmaf(acc[ti][tj][r], osc, b) : acc[ti][tj][r] + b;
                     if (row < p.Co && take(x, row, bv[tj], bi[tj])) { bv[tj] = x; bi[tj] = row; }
                 }
             }
@@ -932,8 +933,9 @@ extern "C" int alive_to_planes(const float* X, int N, int C, int T, int planes, 
 extern "C" int alive_gemm_planes(const AliveGemm* d, void* stream) {
     ALIVE_CHECK_ARG(d && d->W && d->P, "alive_gemm_planes: null pointer");
     if (d->act == 3) {
-        ALIVE_CHECK_ARG(d->planes == 3 && d->arg_val && d->arg_idx && !d->Y && !d->Pout && !d->residual && !d->post_add && !d->ch_scale,
-                        "alive_gemm_planes: act 3 (argmax) takes 3 planes, arg_val / arg_idx and no other output or epilogue term");
+        ALIVE_CHECK_ARG((d->planes == 3 || (d->planes == 2 && d->f16s)) && d->arg_val && d->arg_idx && !d->Y && !d->Pout && !d->residual &&
+                        !d->post_add && !d->ch_scale,
+                        "alive_gemm_planes: act 3 (argmax) takes 3 planes (or fp16 split planes), arg_val / arg_idx and no other output or epilogue term");
     } else if (d->act == 4) {
         ALIVE_CHECK_ARG(d->planes == 3 && d->Pout && !d->Y && !d->bias && !d->residual && !d->post_add && !d->ch_scale && !d->y_split && (d->Co & 1) == 0,
                         "alive_gemm_planes: act 4 (magnitude of row pairs) takes 3 planes, an even Co, Pout and no other output or epilogue term");
@@ -979,10 +981,11 @@ extern "C" int alive_gemm_planes(const AliveGemm* d, void* stream) {
         if (form1 == 3) return launch_gemm<1, 2, 4>(*d, (hipStream_t)stream);
         return launch_gemm<1, 4, 2>(*d, (hipStream_t)stream);
     }
-    ALIVE_CHECK_ARG(!d->f16s || (d->planes == 2 && d->wscale != nullptr && d->in_unscale > 0.0f && d->act >= 0 && d->act <= 2 &&
+    ALIVE_CHECK_ARG(!d->f16s || (d->planes == 2 && d->wscale != nullptr && d->in_unscale > 0.0f && d->act >= 0 && d->act <= 3 &&
                                  (d->Pout == nullptr || d->pout_scale > 0.0f) && d->y_split == 0),
-                    "alive_gemm_planes: f16s (fp16 split planes) takes planes = 2, wscale, in_unscale > 0, act 0 - 2 and pout_scale > 0 with Pout");
+                    "alive_gemm_planes: f16s (fp16 split planes) takes planes = 2, wscale, in_unscale > 0, act 0 - 3 and pout_scale > 0 with Pout");
     if (d->planes == 2 && d->f16s) {
+        if (d->act == 3) return launch_gemm_act<2, 2, 2, 3, false, true>(*d, (hipStream_t)stream);
         if (d->act == 1) return launch_gemm_act<2, 2, 2, 1, false, true>(*d, (hipStream_t)stream);
         if (d->act == 2) return launch_gemm_act<2, 2, 2, 2, false, true>(*d, (hipStream_t)stream);
         return launch_gemm_act<2, 2, 2, 0, false, true>(*d, (hipStream_t)stream);

@@ -55,7 +55,7 @@ const Names& names_of(int model) {
         ce.add("output.W"); ce.add("output.b");
         pe.add("input.W"); pe.add("input.b");
         for (int i = 0; i < 4; ++i) convnext_names(pe, "mid" + std::to_string(i), false);
-        pe.add("last_norm.gain"); pe.add("last_norm.offset"); pe.add("output.W"); pe.add("output.b");
+        pe.add("last_norm.gain"); pe.add("last_norm.offset"); pe.add("output.W"); pe.add("output.b"); pe.add("output.ws");
         dec.add("fe.input.W"); dec.add("fe.input.b");
         dec.add("fe.f0c1.W"); dec.add("fe.f0c1.b"); dec.add("fe.f0c2.W"); dec.add("fe.f0c2.b");
         dec.add("fe.normfilm.W"); dec.add("fe.normfilm.b");
@@ -474,7 +474,22 @@ int pe_body(Table& t, EncBuffers& b, int N, int T, float* f0, void* stream) {
         RUN(convnext_layer(cw, b.x, b.y, b.h, b.Pa, b.Ph, N, PE_C, PE_H, T, nullptr, 0, 0, 0, 3, stream));
     }
     const float* g = t.next(); const float* of = t.next();
-    const float* oW = t.next(); const float* ob = t.next();
+    const float* oW = t.next(); const float* ob = t.next(); const float* ows = t.next();
+    if (b.Pa != nullptr && encoder_precision() == 1) {
+        // the classifier on fp16 split planes (its input is what last_norm leaves: bounded), argmax in the epilogue as below
+        RUN(alive_dwconv_norm_planes_f16s(b.x, N, PE_C, T, nullptr, nullptr, 0, g, of, nullptr, 0, 0, 0, NORM_EPS, F16S_ACT_SCALE, b.Pa, stream));
+        const int64_t cols = (int64_t)N * T;
+        const int nblk = (PE_OUT + 63) / 64;
+        AliveGemm gm;
+        memset(&gm, 0, sizeof(gm));
+        gm.W = (const float*)((const unsigned short*)oW + (size_t)3 * ((PE_OUT + 15) & ~15) * ((PE_C + 31) & ~31));
+        gm.bias = ob; gm.P = b.Pa; gm.N = N; gm.T = T; gm.Ci = PE_C; gm.Co = PE_OUT; gm.planes = 2; gm.act = 3;
+        gm.f16s = 1; gm.wscale = ows; gm.in_unscale = 1.0f / F16S_ACT_SCALE;
+        gm.arg_val = b.lg;
+        gm.arg_idx = (int32_t*)(b.lg + (size_t)nblk * cols);
+        RUN(alive_gemm_planes(&gm, stream));
+        return alive_argmax_merge(gm.arg_val, gm.arg_idx, nblk, cols, f0, stream);
+    }
     if (b.Pa != nullptr) {
         RUN(alive_dwconv_norm_planes(b.x, N, PE_C, T, nullptr, nullptr, 0, g, of, nullptr, 0, 0, 0, NORM_EPS, 3, b.Pa, stream));
         // 256 -> 4096 classes with the argmax in the GEMM's epilogue: the logits (16 KB per frame) are never stored;

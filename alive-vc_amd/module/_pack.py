@@ -154,6 +154,7 @@ def pack_f0_estimator(sd):
     out = pack_content_encoder(sd)
     out["last_norm.gain"] = _vec(sd["last_norm.scale"])
     out["last_norm.offset"] = _vec(sd["last_norm.shift"])
+    out["output.W"], out["output.ws"] = pack_conv_split_f16s(sd["output_layer.weight"])       # the classifier: + its fp16 split image
     return out
 
 

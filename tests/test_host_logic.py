@@ -70,7 +70,7 @@ def test_weight_tables_cover_the_schema():
                 # encoders: 3 bf16 planes; decoder: 2, or 2 + the fp16 slab of the plain kernels (decoder precision mode 1, _pack.pack_conv_split_h)
                 plain = mid == 2 and (k.startswith("flt.blk0.") or k.startswith("flt.up") or k == "flt.mid.W" or k == "fe.normfilm.W"
                                       or (k.startswith("fe.mid") and ".pw" in k))
-                f16s = mid < 2 and ".pw" in k              # encoders' pointwise convs: 3 bf16 planes + the fp16 (hi, lo) pair (_pack.pack_conv_split_f16s)
+                f16s = mid < 2 and (".pw" in k or (mid == 1 and k == "output.W"))      # encoders' pointwise convs, the f0 classifier: 3 bf16 planes + the fp16 (hi, lo) pair (_pack.pack_conv_split_f16s)
                 assert v.dim() == 4 and v.shape[0] == (5 if f16s else 3 if mid < 2 or plain else 2) and v.shape[2] % 16 == 0 and v.shape[3] == 32, k
             if k.endswith(".ws"):                          # 1 / scale of that pair: a power of two
                 assert v.shape == (1,) and v.dtype == torch.float32 and float(torch.log2(v)[0]) == round(float(torch.log2(v)[0]))
