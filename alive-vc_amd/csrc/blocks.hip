@@ -609,3 +609,5 @@ int alive_magnitude(const float* ri, int N, int B, int T, float* out, hipStream_
     ALIVE_CHECK_LAUNCH("alive_magnitude");
     return ALIVE_OK;
 }
+
+ALIVE_F16_SAT_GETTER(alive_f16_sat_blocks)

@@ -88,8 +88,19 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // nearest even and SATURATES at +-65504 (a value beyond fp16's range must not become an infinity inside a GEMM); magnitudes below 6.1e-5
 // are fp16 subnormals (absolute resolution 6e-8).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// Saturations are COUNTED (one counter per translation unit, summed by alive_f16_saturations): a checkpoint or an input whose activations
+// leave fp16's range must not pass silently -- module/pipeline.py reads the counter at the end of a conversion and refuses the result.
+static __device__ unsigned alive_f16_sat_count;
+#define ALIVE_F16_SAT_GETTER(NAME)                                                                        \
+    int NAME(int reset) {                                                                                 \
+        unsigned v = 0, z = 0;                                                                            \
+        if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(alive_f16_sat_count), sizeof(v)) != hipSuccess) return -1; \
+        if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(alive_f16_sat_count), &z, sizeof(z));               \
+        return (int)(v > 0x7fffffffu ? 0x7fffffffu : v);                                                  \
+    }
 __device__ __forceinline__ unsigned pack_f16x2(float a, float b) {
     typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    if (__builtin_expect(fabsf(a) > 65504.0f || fabsf(b) > 65504.0f, 0)) atomicAdd(&alive_f16_sat_count, 1u);
     a = __builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f);
     b = __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f);
     const f16x2_t h = {(_Float16)a, (_Float16)b};

@@ -308,3 +308,5 @@ extern "C" int alive_conv1d(const AliveConv* d, void* stream) {
     ALIVE_CHECK_LAUNCH("alive_conv1d");
     return ALIVE_OK;
 }
+
+ALIVE_F16_SAT_GETTER(alive_f16_sat_conv)

@@ -567,3 +567,5 @@ int alive_conv_split_launch(const AliveConv* d, float ratio, hipStream_t s) {
     ALIVE_CHECK_LAUNCH("alive_conv1d(split)");
     return ALIVE_OK;
 }
+
+ALIVE_F16_SAT_GETTER(alive_f16_sat_conv_split)

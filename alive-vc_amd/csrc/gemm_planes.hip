@@ -998,3 +998,5 @@ extern "C" int alive_gemm_planes(const AliveGemm* d, void* stream) {
     if (can_persist && nsteps >= 3) return launch_gemm_lw<3, 3>(*d, (hipStream_t)stream);
     return launch_gemm<3, 3, 1>(*d, (hipStream_t)stream);
 }
+
+ALIVE_F16_SAT_GETTER(alive_f16_sat_gemm)

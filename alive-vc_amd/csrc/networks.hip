@@ -794,6 +794,14 @@ extern "C" int alive_decoder_precision(int mode) {
     return decoder_precision();
 }
 
+int alive_f16_sat_conv_split(int), alive_f16_sat_gemm(int), alive_f16_sat_blocks(int), alive_f16_sat_conv(int);
+extern "C" int alive_f16_saturations(int reset) {
+    const int a = alive_f16_sat_conv_split(reset), b = alive_f16_sat_gemm(reset), c = alive_f16_sat_blocks(reset), d = alive_f16_sat_conv(reset);
+    if (a < 0 || b < 0 || c < 0 || d < 0) return -1;
+    const long long t = (long long)a + b + c + d;
+    return (int)(t > 0x7fffffff ? 0x7fffffff : t);
+}
+
 extern "C" int alive_encoder_precision(int mode) {
     if (mode == 1 || mode == 2) g_encoder_precision = mode;
     return encoder_precision();

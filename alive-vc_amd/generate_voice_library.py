@@ -105,6 +105,8 @@ def main(argv=None):
                 if filled < args.num_tokens:
                     VL.tokens[0, :, filled] = feats[b, :, fr]
                     filled += 1
+    from module.pipeline import Converter
+    Converter.check_fp16_range()          # the encoder's fp16 split planes count saturated activations: none may have occurred
     if args.dedup is not None and filled > 1:
         keep = dedup_mask(VL.tokens[0, :, :filled].to(device), args.dedup)
         kept = VL.tokens[0, :, :filled][:, keep.cpu()]

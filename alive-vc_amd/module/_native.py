@@ -70,6 +70,7 @@ PROTOTYPES = {
     "alive_conv1d": (_I, [C.POINTER(AliveConv), _VP]),
     "alive_decoder_precision": (_I, [_I]),
     "alive_encoder_precision": (_I, [_I]),
+    "alive_f16_saturations": (_I, [_I]),
     "alive_gelu_film": (_I, [_VP, _I, _I, _I, _VP, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "alive_planes_bytes": (_SZ, [_I64, _I, _I]),
     "alive_to_planes": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),

@@ -326,3 +326,8 @@ def encoder_precision(mode=0):
     """Arithmetic of the encoders' ConvNeXt pointwise convs on the batch path (alive_encoder_precision): 1 = fp16 split planes, three MFMAs
     per product (default since round 5), 2 = three bf16 planes, six MFMAs (rounds 1 - 4), 0 = query.  Returns the mode in force."""
     return int(nat.lib().alive_encoder_precision(int(mode)))
+
+
+def f16_saturations(reset=False):
+    """values saturated at +-65504 while an fp16 plane was written (alive_f16_saturations); synchronises the device"""
+    return int(nat.lib().alive_f16_saturations(1 if reset else 0))

@@ -296,4 +296,18 @@ class Converter:
             if share == "auto" and self.library is not None:
                 ok = ok and n * (1.0 + self.library.M / 5e5) >= 45.0
             kw["share_overlap"] = n if ok else None
-        return stitch(self.convert_windows(windows, keep_frames=keep, **kw), total, chunk)
+        out = stitch(self.convert_windows(windows, keep_frames=keep, **kw), total, chunk)
+        self.check_fp16_range()
+        return out
+
+    @staticmethod
+    def check_fp16_range():
+        """The encoders' fp16 split planes and the decoder's plain fp16 planes (alive_encoder_precision / alive_decoder_precision, modes 1)
+        saturate at +-65504 and count it: a checkpoint or an input that drives an activation out of fp16's range must not pass for the
+        reference's result.  One 4-byte device read per kernel file (synchronises)."""
+        from . import ops
+        n = ops.f16_saturations(reset=True)
+        if n > 0:
+            raise RuntimeError(f"{n} activation value(s) left fp16's range and were saturated in the fp16 forms of the encoder / decoder GEMMs: "
+                               "this checkpoint (or input scale) needs ALIVE_ENCODER_PRECISION=2 and ALIVE_DECODER_PRECISION=2 "
+                               "(module.ops.encoder_precision(2), decoder_precision(2)): bf16 planes keep fp32's range")

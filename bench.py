@@ -779,6 +779,7 @@ def main():
             "rtf": round((dt / args.steps) / audio_s, 6),
             "roofline": roofline,
             "decoder_precision_mode": decoder_mode, "encoder_precision_mode": encoder_mode,
+            "fp16_saturations": _ops.f16_saturations(),      # values the fp16 forms had to saturate over the whole run (alive_f16_saturations): 0
             "roofline_nets": roofline_nets,
             "cpu_baseline": cpu,
         }

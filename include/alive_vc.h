@@ -479,6 +479,11 @@ int alive_decoder_precision(int mode);
  * the f0 classes outside the 1e-4 margin are identical (tests/test_gpu_models.py).  The DFT, the input / output layers and the
  * classifier stay on three bf16 planes (their inputs are not range-limited by a normalisation). */
 int alive_encoder_precision(int mode);
+/* Values that left fp16's range (|scaled value| > 65504) while an fp16 plane was written by any kernel of modes 1 above since the last
+ * reset -- they were saturated, not turned into infinities, but the result is then not the reference's.  Synchronises the device (a
+ * 4-byte read per kernel file); 0 on every tested checkpoint and input.  reset != 0 clears the counters.  -1: read error.
+ * module/pipeline.py::Converter.convert checks it once per conversion and raises. */
+int alive_f16_saturations(int reset);
 
 /* Decoder.forward (decoder.py:205-210) at harmonics_scale == 1:
  *   x[N][768][Lf], f0[N][Lf], phi_in[N][64] or NULL (phi = 0), crop0,

@@ -973,3 +973,21 @@ def test_dwconv_norm_planes_fp16_split():
     assert back[cols:].abs().sum().item() == 0.0
     got = back[:cols].view(n, t, c).permute(0, 2, 1)
     assert (got - y).abs().max().item() <= 2.0 ** -21 * y.abs().max().item()
+
+
+def test_fp16_saturations_are_counted_and_refused():
+    """alive_f16_saturations: every value a producer of fp16 planes had to saturate is counted (one counter per kernel file), and
+    Converter.check_fp16_range turns a non-zero count into an error -- an out-of-range activation never passes silently."""
+    from module import ops
+    from module.pipeline import Converter
+    ops.f16_saturations(reset=True)
+    x = g("sat", (2, 64, 130))
+    ops.to_planes(x.to(DEV), 1)
+    assert ops.f16_saturations() == 0
+    x[1, 3, 7], x[0, 5, 9] = 7.0e4, -1.0e9
+    ops.to_planes(x.to(DEV), 1)
+    assert ops.f16_saturations() >= 2                     # (counted per converted pair)
+    with pytest.raises(RuntimeError, match="fp16"):
+        Converter.check_fp16_range()
+    assert ops.f16_saturations() == 0                     # the check resets the counters
+    Converter.check_fp16_range()
