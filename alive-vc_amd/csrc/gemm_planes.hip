@@ -575,7 +575,7 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_lw_kernel(AliveGemm p, int
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SLOT = 2 * NP * PLANE_BYTES;
     constexpr int NI = 4 * NP;
-    constexpr int NPROD = NP * (NP + 1) / 2;
+    [[maybe_unused]] constexpr int NPROD = NP * (NP + 1) / 2;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
