@@ -102,6 +102,26 @@ def test_decoder_precision_modes(golden_dir, nets):
     assert d12 > 1e-7                                  # the two modes really are different kernels
 
 
+@pytest.mark.parametrize("n,lf", [(2, 27), (1, 15), (3, 33)])
+def test_decoder_odd_frame_counts_in_both_precision_modes(nets, n, lf):
+    """Odd frame counts: the 256-channel scale then has L = 10 Lf columns with L % 4 == 2, so its convs run WITHOUT plane operands -- the
+    plain-fp16 kernel stages fp32 inputs itself (conv_split_kernel<128, 1, false, true>) and emits an fp32 second output; (1, 15) also
+    keeps the frame-rate GEMMs on the fp32-activation path (15 columns) while the filter runs the batch kernels."""
+    from module import ops
+    ce, pe, dec, cpu = nets
+    x = synthetic.gaussian(f"dxo{n}{lf}", 4, (n, 768, lf))
+    f0 = (100 + 300 * torch.from_numpy(synthetic.uniform01(f"dfo{n}{lf}", 4, n * lf)).float()).view(n, 1, lf)
+    ref, _ = O.decoder(cpu[2], x, f0)
+    try:
+        for mode, bar in ((1, 3e-5), (2, 2e-5)):
+            ops.decoder_precision(mode)
+            wave, _ = dec(x.to(DEV), f0.to(DEV))
+            assert rms(wave, ref) < bar, (mode, rms(wave, ref))
+    finally:
+        ops.decoder_precision(1 if os.environ.get("ALIVE_DECODER_PRECISION") != "2" else 2)
+    assert ops.f16_saturations() == 0
+
+
 def test_realtime_two_steps(golden_dir, nets):
     """realtime_inference.py:146-167: phase carried through phi[:, :, end_of_output]."""
     from module.common import match_features
