@@ -348,6 +348,30 @@ def test_no_listing_starts_an_mfma_chain_beside_an_unread_accumulator_without_th
     assert seen["filter_mid"][1] >= 20 and seen["filter_small"][1] >= 40 and seen["knn"][1] >= 4, seen
     assert seen["gemm_planes"][1] == seen["conv_split"][1] == seen["conv"][1] == 0, seen
     assert seen["filter_mid_nogap"][2] >= 20 and seen["filter_small_nogap"][2] >= 40, seen
+    # round 5: the fp16 forms really run on the fp16 MFMA with the saturating conversion, without spills, at the occupancy DESIGN 3.2d / 3.2e
+    # state (two blocks per CU for the GEMMs, three for the plain conv)
+    import re
+
+    def kernels(path, pattern):
+        txt = open(path).read()
+        out = {}
+        for m in re.finditer(r"^(_Z\w*" + pattern + r"\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel", txt, re.S | re.M):
+            body = m.group(2)
+            out[m.group(1)] = {"f16": body.count("v_mfma_f32_32x32x16_f16"), "bf16": body.count("v_mfma_f32_32x32x16_bf16"),
+                               "cvt": body.count("v_cvt_pk_f16_f32"), "scratch": body.count("scratch_"),
+                               "vgpr": int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", body).group(1))}
+        return out
+    conv = kernels(lst["conv_split"], "conv_split_kernelILi128ELi1ELb1ELb1E")          # <128, 1, PLANES, W22>: the decoder's 256-channel convs
+    assert len(conv) == 1, list(conv)
+    for k, v in conv.items():
+        assert v["f16"] >= 8 and v["bf16"] == 0 and v["cvt"] >= 4 and v["scratch"] == 0 and v["vgpr"] <= 168, (k, v)       # <= 168: three waves per SIMD
+    gem = kernels(lst["gemm_planes"], "gemm_planes_kernelILi2ELi2ELi2ELi[0-3]ELb[01]ELb[01]E")
+    f16s = {k: v for k, v in gem.items() if k.endswith("Lb0ELb1EEEv9AliveGemmiilliiiNS_8GemmWalkEPx")}         # <2, 2, 2, ACT, false, F16S>
+    kb2 = {k: v for k, v in gem.items() if k.endswith("Lb1ELb0EEEv9AliveGemmiilliiiNS_8GemmWalkEPx")}          # <2, 2, 2, ACT, KB2, false>
+    assert len(f16s) == 4 and len(kb2) == 3, (list(gem))
+    for k, v in list(f16s.items()) + list(kb2.items()):
+        assert v["f16"] >= 8 and v["bf16"] == 0 and v["scratch"] == 0 and v["vgpr"] <= 256, (k, v)                # two blocks of four waves per CU
+    assert all(v["cvt"] >= 4 for k, v in f16s.items() if "ELi3ELb0ELb1E" not in k)           # (the argmax form writes no planes)
 
 
 def test_fp8_scoring_kernel_listing_keeps_two_accumulator_sets(tmp_path):
