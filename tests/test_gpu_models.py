@@ -390,3 +390,33 @@ def test_fused_front_end_falls_back_for_a_handful_of_frames(nets):
     spec = sp.spectrogram(wav)
     feat, f0 = ops.front_end(wav, ce, pe)
     assert torch.equal(feat, ce(spec)) and torch.equal(f0, pe.estimate(spec))
+
+
+def test_a_checkpoint_outside_fp16_range_is_refused_not_mis_converted():
+    """The encoders' fp16 split planes hold 256 x the normalised activations: a ChannelNorm gain beyond ~11 CAN drive them past 65504 (beyond ~60 it does on ordinary data).  Such a
+    checkpoint is saturated AND counted (alive_f16_saturations); Converter.check_fp16_range raises, and encoder precision mode 2 (three bf16
+    planes: fp32's range) converts it like the oracle does."""
+    from module import ops
+    from module.content_encoder import ContentEncoder
+    from module.pipeline import Converter
+    sd = synthetic.make_state_dict(schema.content_encoder_schema(), 2)
+    sd["mid_layers.1.norm.scale"] = sd["mid_layers.1.norm.scale"] * 200.0         # normalised values reach ~4: |y| ~ 800 > 255 = 65504 / 2^8
+    ce = ContentEncoder()
+    ce.load_state_dict(sd)
+    ce = ce.to(DEV)
+    spec = O.spectrogram(synthetic.make_waveform(144000, 5))
+    ref = O.content_encoder(sd, spec)
+    ops.f16_saturations(reset=True)
+    try:
+        ops.encoder_precision(1)
+        ce(spec.to(DEV))
+        assert ops.f16_saturations() > 0
+        with pytest.raises(RuntimeError, match="fp16"):
+            Converter.check_fp16_range()
+        ops.encoder_precision(2)
+        feat = ce(spec.to(DEV)).cpu()
+        assert ops.f16_saturations() == 0
+        assert rms(feat, ref) < 1e-5 * max(1.0, ref.pow(2).mean().sqrt().item())
+    finally:
+        ops.encoder_precision(1 if os.environ.get("ALIVE_ENCODER_PRECISION") != "2" else 2)
+        ops.f16_saturations(reset=True)
