@@ -109,62 +109,79 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void conv_split_kernel(Aliv
                 for (int pl = 0; pl < NP; ++pl) a[mr][s2][pl] = *(const bf16x8*)(Wrow[mr][pl] + (size_t)kcol * co_pad + s2 * 16);   // kcol / 32 blocks of co_pad * 32
     };
 
-    // ---- X staging: 9 (row, channel-pair) items per thread per 32-channel block.  Everything that does not depend on
-    // the channel block is hoisted: the clamped row offset, the validity mask, the LDS address.  Loads are
-    // unconditional on clamped addresses (no branch per element), the split uses the hardware f32->bf16 pack
-    // (v_cvt_pk_bf16_f32): ~16 VALU per item instead of ~120, which matters because at KW = 1 this staging is the only
-    // work between two rounds of 24 MFMAs.
-    float x_reg[9][2];
-    int x_off[9];                 // pair*2*Tin + clamped tin  (element offset inside the channel block)
+    // ---- X staging: 3 (row, 8-channel group) items per thread per 32-channel block (144 rows x 4 groups = 576 items).  Everything that
+    // does not depend on the channel block is hoisted: the clamped row offset, the validity mask, the LDS address.  Loads are
+    // unconditional on clamped addresses (no branch per element; lanes = consecutive rows, so every load is coalesced along time), the
+    // split uses the hardware f32->bf16 pack (v_cvt_pk_bf16_f32), and an item leaves as ONE 16-byte LDS write per plane.  Until round
+    // 5 an item was a channel PAIR (4-byte writes at the row pitch of 80 B = 20 banks: consecutive rows cycle through 8 of the 32 banks,
+    // a 4-way conflict on every write -- 43 % of this kernel's LDS cycles in profiles/r05_nets_pmc.json); a 16-byte write of
+    // consecutive rows starts on those 8 banks and covers 4 each: all 32, conflict-free.  Same values, same LDS image.
+    constexpr int XIT = 3;
+    float x_reg[XIT][8];
+    int x_off[XIT];               // group*8*Tin + clamped tin  (element offset inside the channel block)
     unsigned x_ok = 0;            // bit it: row inside the tile and inside the signal
+    unsigned x_in = 0;            // bit it: the item exists (it * 256 + tid < 576)
 #pragma unroll
-    for (int it = 0; it < 9; ++it) {
+    for (int it = 0; it < XIT; ++it) {
         int i = it * 256 + tid;
-        int r = i % XROWS, pair = i / XROWS;
+        const bool in = i < XROWS * 4;
+        i = in ? i : 0;
+        int r = i % XROWS, grp = i / XROWS;
         int tin = t0 - p.pad_left + r;
         if (tin < 0 && p.pad_mode != 0) tin = -tin;
         bool ok = r < xrows && tin >= 0 && tin < p.Tin;
         tin = tin < 0 ? 0 : (tin < p.Tin ? tin : p.Tin - 1);
-        x_off[it] = pair * 2 * p.Tin + tin;
-        x_ok |= (ok ? 1u : 0u) << it;
+        x_off[it] = grp * 8 * p.Tin + tin;
+        x_ok |= ((ok && in) ? 1u : 0u) << it;
+        x_in |= (in ? 1u : 0u) << it;
     }
     const bool ragged_ci = (p.Ci % BKC) != 0;
     auto load_X = [&](int cb) {
         const float* Xc = Xn + (size_t)cb * BKC * p.Tin;
         const bool tail = ragged_ci && (cb + 1) * BKC > p.Ci;          // block-uniform
 #pragma unroll
-        for (int it = 0; it < 9; ++it) {
+        for (int it = 0; it < XIT; ++it) {
+            if (!((x_in >> it) & 1u)) continue;
             if (!tail) {
-                x_reg[it][0] = Xc[x_off[it]];
-                x_reg[it][1] = Xc[x_off[it] + p.Tin];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) x_reg[it][c] = Xc[x_off[it] + c * p.Tin];
             } else {
-                int pair = (it * 256 + tid) / XROWS;
-                int ci = cb * BKC + pair * 2;
-                x_reg[it][0] = ci < p.Ci ? Xc[x_off[it]] : 0.0f;
-                x_reg[it][1] = ci + 1 < p.Ci ? Xc[x_off[it] + p.Tin] : 0.0f;
+                const int grp = (it * 256 + tid) / XROWS;
+                const int ci = cb * BKC + grp * 8;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) x_reg[it][c] = ci + c < p.Ci ? Xc[x_off[it] + c * p.Tin] : 0.0f;
             }
         }
     };
     auto store_X = [&](int buf) {
         unsigned char* Xs = smem + buf * NP * XPLANE;
 #pragma unroll
-        for (int it = 0; it < 9; ++it) {
-            int i = it * 256 + tid;
-            int r = i % XROWS, pair = i / XROWS;
+        for (int it = 0; it < XIT; ++it) {
+            if (!((x_in >> it) & 1u)) continue;
+            const int i = it * 256 + tid;
+            const int r = i % XROWS, grp = i / XROWS;
             const bool ok = (x_ok >> it) & 1u;
-            float x0 = ok ? x_reg[it][0] : 0.0f, x1 = ok ? x_reg[it][1] : 0.0f;
-            bf16x2_t hp = {(__bf16)x0, (__bf16)x1};
-            unsigned h = NP == 1 ? pack_f16x2(x0, x1) : __builtin_bit_cast(unsigned, hp);          // (NP = 1: the one plane is fp16)
-            float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-            bf16x2_t lp = {(__bf16)r0, (__bf16)r1};
-            *(unsigned*)(Xs + r * PITCH + pair * 4) = h;
-            const unsigned l = __builtin_bit_cast(unsigned, lp);
-            if (NP >= 2) *(unsigned*)(Xs + XPLANE + r * PITCH + pair * 4) = l;
-            if (NP == 3) {
-                float q0 = r0 - __uint_as_float(l << 16), q1 = r1 - __uint_as_float(l & 0xffff0000u);
-                bf16x2_t tp = {(__bf16)q0, (__bf16)q1};
-                *(unsigned*)(Xs + 2 * XPLANE + r * PITCH + pair * 4) = __builtin_bit_cast(unsigned, tp);
+            u32x4 hv, lv, tv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = ok ? x_reg[it][2 * e] : 0.0f, x1 = ok ? x_reg[it][2 * e + 1] : 0.0f;
+                bf16x2_t hp = {(__bf16)x0, (__bf16)x1};
+                const unsigned h = NP == 1 ? pack_f16x2(x0, x1) : __builtin_bit_cast(unsigned, hp);          // (NP = 1: the one plane is fp16)
+                const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+                bf16x2_t lp = {(__bf16)r0, (__bf16)r1};
+                const unsigned l = __builtin_bit_cast(unsigned, lp);
+                hv[e] = h;
+                lv[e] = l;
+                if (NP == 3) {
+                    const float q0 = r0 - __uint_as_float(l << 16), q1 = r1 - __uint_as_float(l & 0xffff0000u);
+                    bf16x2_t tp = {(__bf16)q0, (__bf16)q1};
+                    tv[e] = __builtin_bit_cast(unsigned, tp);
+                }
             }
+            unsigned char* dst = Xs + r * PITCH + grp * 16;
+            *(u32x4*)dst = hv;
+            if (NP >= 2) *(u32x4*)(dst + XPLANE) = lv;
+            if (NP == 3) *(u32x4*)(dst + 2 * XPLANE) = tv;
         }
     };
 
