@@ -98,9 +98,10 @@ static __device__ unsigned alive_f16_sat_count;
         if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(alive_f16_sat_count), &z, sizeof(z));               \
         return (int)(v > 0x7fffffffu ? 0x7fffffffu : v);                                                  \
     }
-__device__ __forceinline__ unsigned pack_f16x2(float a, float b) {
+// count = false: the values are known to be don't-cares (the halo columns of a fused tile hold whatever their dependency cone left)
+__device__ __forceinline__ unsigned pack_f16x2(float a, float b, bool count = true) {
     typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-    if (__builtin_expect(fabsf(a) > 65504.0f || fabsf(b) > 65504.0f, 0)) atomicAdd(&alive_f16_sat_count, 1u);
+    if (__builtin_expect(count && (fabsf(a) > 65504.0f || fabsf(b) > 65504.0f), 0)) atomicAdd(&alive_f16_sat_count, 1u);
     a = __builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f);
     b = __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f);
     const f16x2_t h = {(_Float16)a, (_Float16)b};

@@ -73,6 +73,7 @@ constexpr int PLANE = BL * ROWB;        // 32 KB
 constexpr int BUF = 2 * PLANE;          // hi + lo
 constexpr int W_IN = 2 * C * C;         // bf16 elements of the input conv [2][64][64]
 constexpr int W_K5 = 2 * C * 5 * C;     // bf16 elements of a k5 conv [2][64][320]
+constexpr int W_K5H = C * 5 * C;        // fp16 elements of a k5 conv [64][320]: the slab behind the bf16 packs (H16 below)
 constexpr int NT = 4;                   // column tiles of 32 per wave
 constexpr int TROW = 32 * ROWB;         // bytes per column tile in a plane
 constexpr int TSTEP = 2 * TROW;         // a wave's consecutive tiles are two column tiles apart
@@ -89,7 +90,10 @@ __device__ __forceinline__ int swz(int r) { return (r >> 1) & 7; }
 // NTT = column tiles of 32 per wave: 4 on the batch path (256-column tiles, 200 outputs), 2 for a signal of a few such tiles (the
 // streaming step: 800 samples = four batch tiles on four CUs, 72 us of a 0.8-ms step): 128-column tiles, 72 outputs, twelve blocks with
 // half the serial chain each.  The halo is then 44 % of a tile -- irrelevant where the chip is empty.
-template <bool FIRST, int NTT = 4>
+// H16 (round 5, decoder precision mode 1 with ALIVE_DECODER_BF16_MASK bit 16): the six k5 convs multiply ONE fp16 plane of the modulated
+// tensor by ONE fp16 plane of the weights -- a third of the MFMAs, no lo plane in LDS, half the weight registers.  The 1x1 input conv
+// keeps the split form (its operand is the raw residual stream).
+template <bool FIRST, int NTT = 4, bool H16 = false>
 __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __restrict__ U, int L,
                                                                 const unsigned short* __restrict__ W16,
                                                                 const float* __restrict__ biases,
@@ -268,21 +272,33 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
             for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(E.z[e]));
         } else {
             const float* z = E.z;
-            const unsigned h01 = pack2(z[0], z[1]), h23 = pack2(z[2], z[3]);
-            const unsigned l01 = pack2(z[0] - __uint_as_float(h01 << 16), z[1] - __uint_as_float(h01 & 0xffff0000u));
-            const unsigned l23 = pack2(z[2] - __uint_as_float(h23 << 16), z[3] - __uint_as_float(h23 & 0xffff0000u));
             unsigned char* p = dstp + st_off[g] + t * TSTEP;
-            *(uint2*)p = make_uint2(h01, h23);
-            *(uint2*)(p + PLANE) = make_uint2(l01, l23);
+            if constexpr (H16) {
+                // one fp16 plane, saturating; saturations are counted in the tile's OUTPUT columns only: the halo columns are its
+                // neighbour's outputs, and left of their dependency cone they hold arbitrary values
+                const bool cnt = colw + 64 * t >= HALO;
+                *(uint2*)p = make_uint2(pack_f16x2(z[0], z[1], cnt), pack_f16x2(z[2], z[3], cnt));
+            } else {
+                const unsigned h01 = pack2(z[0], z[1]), h23 = pack2(z[2], z[3]);
+                const unsigned l01 = pack2(z[0] - __uint_as_float(h01 << 16), z[1] - __uint_as_float(h01 & 0xffff0000u));
+                const unsigned l23 = pack2(z[2] - __uint_as_float(h23 << 16), z[3] - __uint_as_float(h23 & 0xffff0000u));
+                *(uint2*)p = make_uint2(h01, h23);
+                *(uint2*)(p + PLANE) = make_uint2(l01, l23);
+            }
         }
     };
 
     // weights of the k5 convs: k-step s = 4 j + cb (tap j, 16-channel block cb), k = j * 64 + cb * 16 + 8 lh
     bf16x8 a[20][2];
     auto load_weights_step = [&](int q, int s) {
-        const unsigned short* Wq = W16 + W_IN + (size_t)q * W_K5 + (size_t)(32 * rg + n32) * (5 * C) + 8 * lh;
+        if constexpr (H16) {
+            const unsigned short* Wq = W16 + W_IN + (size_t)NCONV * W_K5 + (size_t)q * W_K5H + (size_t)(32 * rg + n32) * (5 * C) + 8 * lh;
+            a[s][0] = *(const bf16x8*)(Wq + s * 16);
+        } else {
+            const unsigned short* Wq = W16 + W_IN + (size_t)q * W_K5 + (size_t)(32 * rg + n32) * (5 * C) + 8 * lh;
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) a[s][pl] = *(const bf16x8*)(Wq + (size_t)pl * C * 5 * C + s * 16);
+            for (int pl = 0; pl < 2; ++pl) a[s][pl] = *(const bf16x8*)(Wq + (size_t)pl * C * 5 * C + s * 16);
+        }
     };
 
     // ---- input_conv (1x1, K = 64 = 4 k-steps): h = Win * U + b ----
@@ -379,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
         auto frag_load = [&](int i, int s, int slot) {
             const unsigned char* bp = in + frag_off(i, s);
             fh[slot] = *(const bf16x8*)bp;
-            fl[slot] = *(const bf16x8*)(bp + PLANE);
+            if constexpr (!H16) fl[slot] = *(const bf16x8*)(bp + PLANE);
         };
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -413,9 +429,13 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
 #pragma unroll
             for (int s = 0; s < 20; ++s) {
                 if (s + PF < 20) frag_load(i, s + PF, (s + PF) % NSLOT);
-                acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], fh[s % NSLOT], acc[i & 1], 0, 0, 0);
-                acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], fl[s % NSLOT], acc[i & 1], 0, 0, 0);
-                acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], fh[s % NSLOT], acc[i & 1], 0, 0, 0);
+                if constexpr (H16) {
+                    acc[i & 1] = mfma_f16(a[s][0], fh[s % NSLOT], acc[i & 1]);
+                } else {
+                    acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], fh[s % NSLOT], acc[i & 1], 0, 0, 0);
+                    acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], fl[s % NSLOT], acc[i & 1], 0, 0, 0);
+                    acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], fh[s % NSLOT], acc[i & 1], 0, 0, 0);
+                }
                 if (i == NT - 1 && emit) load_weights_step(q + 1, s);     // a[s] is dead: the next conv's weights travel under the rest of the step
                 if (!drain_first) epi_stage(E, it_second, it_emit, it_qf, it_dst, it_t, it_acc, s / 5, s % 5);
 #ifdef ALIVE_FB64_DUP_STAGE           // diagnostic (timing only): one stage's work a second time -- the increment prices the stage
@@ -491,16 +511,18 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
 }  // namespace
 
 extern "C" void alive_debug_set_stamps64(long long* p) { g_stamps64 = p; }
-extern "C" int64_t alive_filter_block64_weights(void) { return (int64_t)W_IN + (int64_t)NCONV * W_K5; }
+extern "C" int64_t alive_filter_block64_weights(void) { return (int64_t)W_IN + (int64_t)NCONV * W_K5 + (int64_t)NCONV * W_K5H; }
 
 extern "C" int alive_filter_block64(const float* U, int N, int L, const void* W16, const float* biases, const float* film,
                                     int film_rows, int Lf, int film_off, const float* skip, float* out, void* stream) {
     return alive_filter_block64_range(U, N, L, W16, biases, film, film_rows, Lf, film_off, 0, 0, Lf, skip, out, stream);
 }
 
-extern "C" int alive_filter_block64_range(const float* U, int N, int L, const void* W16, const float* biases, const float* film,
-                                          int film_rows, int Lf, int film_off, int t0, int f0, int film_ld, const float* skip,
-                                          float* out, void* stream) {
+namespace {
+template <bool H16>
+int filter_block64_impl(const float* U, int N, int L, const void* W16, const float* biases, const float* film,
+                        int film_rows, int Lf, int film_off, int t0, int f0, int film_ld, const float* skip,
+                        float* out, void* stream) {
     ALIVE_CHECK_ARG(U && W16 && biases && film && out, "alive_filter_block64: null pointer");
     ALIVE_CHECK_ARG(N > 0 && L > 16 && Lf > 0, "alive_filter_block64: bad sizes (L must exceed the largest reflect pad, 16)");
     ALIVE_CHECK_ARG(U != out, "alive_filter_block64: in-place not supported (tiles read a halo of their left neighbour)");
@@ -510,8 +532,8 @@ extern "C" int alive_filter_block64_range(const float* U, int N, int L, const vo
     ALIVE_CHECK_ARG((double)BL * film_ld / L + 3.0 <= NFP, "alive_filter_block64: tile spans more than %d frames (L %d, frames %d)", NFP, L, film_ld);
     {
         static LdsOptIn optin;
-        hipError_t e = optin.ensure({(const void*)filter_block64_kernel<false>, (const void*)filter_block64_kernel<true>,
-                                     (const void*)filter_block64_kernel<true, 2>}, LDS_BYTES);
+        hipError_t e = optin.ensure({(const void*)filter_block64_kernel<false, 4, H16>, (const void*)filter_block64_kernel<true, 4, H16>,
+                                     (const void*)filter_block64_kernel<true, 2, H16>}, LDS_BYTES);
         if (e != hipSuccess) {
             alive_set_error("alive_filter_block64: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(e));
             return ALIVE_ERR_LAUNCH;
@@ -523,7 +545,7 @@ extern "C" int alive_filter_block64_range(const float* U, int N, int L, const vo
     if (nt_env ? nt_env == 2 : (int64_t)tiles * N <= 16) {
         // a handful of batch tiles: 128-column tiles (72 outputs) through the FIRST form, three times the blocks
         constexpr int TT2 = 128 - HALO, LDS2 = GUARD + 2 * (2 * 128 * ROWB) + NCONV * C * NFS * 8 + 128 * 8;
-        filter_block64_kernel<true, 2><<<dim3(cdiv(L, TT2), N), 256, LDS2, (hipStream_t)stream>>>(
+        filter_block64_kernel<true, 2, H16><<<dim3(cdiv(L, TT2), N), 256, LDS2, (hipStream_t)stream>>>(
             U, L, (const unsigned short*)W16, biases, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld, skip, out, g_stamps64);
         ALIVE_CHECK_LAUNCH("alive_filter_block64");
         return ALIVE_OK;
@@ -533,11 +555,26 @@ extern "C" int alive_filter_block64_range(const float* U, int N, int L, const vo
     // slower -- so a problem that does not fill the chip anyway (the streaming ring: 4 tiles) runs ALL its tiles in that one launch
     // instead of two dependent ones.
     const bool small = (int64_t)tiles * N <= 256;
-    filter_block64_kernel<true><<<dim3(small ? tiles : 1, N), 256, LDS_BYTES, (hipStream_t)stream>>>(
+    filter_block64_kernel<true, 4, H16><<<dim3(small ? tiles : 1, N), 256, LDS_BYTES, (hipStream_t)stream>>>(
         U, L, (const unsigned short*)W16, biases, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld, skip, out, g_stamps64);
     if (tiles > 1 && !small)
-        filter_block64_kernel<false><<<dim3(tiles - 1, N), 256, LDS_BYTES, (hipStream_t)stream>>>(
+        filter_block64_kernel<false, 4, H16><<<dim3(tiles - 1, N), 256, LDS_BYTES, (hipStream_t)stream>>>(
             U, L, (const unsigned short*)W16, biases, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld, skip, out, g_stamps64);
     ALIVE_CHECK_LAUNCH("alive_filter_block64");
     return ALIVE_OK;
 }
+}  // namespace
+
+extern "C" int alive_filter_block64_range(const float* U, int N, int L, const void* W16, const float* biases, const float* film,
+                                          int film_rows, int Lf, int film_off, int t0, int f0, int film_ld, const float* skip,
+                                          float* out, void* stream) {
+    return filter_block64_impl<false>(U, N, L, W16, biases, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, stream);
+}
+extern "C" int alive_filter_block64_range_fp16(const float* U, int N, int L, const void* W16, const float* biases, const float* film,
+                                               int film_rows, int Lf, int film_off, int t0, int f0, int film_ld, const float* skip,
+                                               float* out, void* stream) {
+    return filter_block64_impl<true>(U, N, L, W16, biases, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, stream);
+}
+
+ALIVE_F16_SAT_GETTER(alive_f16_sat_filter_mid)
+

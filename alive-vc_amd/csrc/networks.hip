@@ -122,18 +122,22 @@ AliveConv split(AliveConv d) {
 //   (b) the two pointwise convs of the feature extractor's four AdaptiveConvNeXt1d layers (common.py:74-82; alive_gemm_planes with
 //       planes = 1): inputs are a channel-normalised tensor and a gelu output, the output is scaled and added to the fp32 stream.
 //   (c) the projection of the f0 encoding onto the AdaptiveChannelNorm scales / shifts (common.py:35-41, 512 -> 4096), the Filter's two
-//       coarsest down convs (decoder.py:186-188, 64 -> 256 k8 and 256 -> 256 k10) and its mid conv (decoder.py:190).
+//       coarsest down convs (decoder.py:186-188, 64 -> 256 k8 and 256 -> 256 k10) and its mid conv (decoder.py:190);
+//   (e) the six k = 5 convs of the fused 64-channel FilterBlock (filter_mid.hip, H16: a third of its MFMAs, no lo plane in its LDS image;
+//       its 1x1 input conv keeps the split form).
 //   Everything else -- the FiLM projections and the input layer (the waveform is 10 x more sensitive to them than to (a)), to_amps,
-//   the transposed convs, the fused 64 / 16 / 8-channel FilterBlocks -- stays on two-plane split bf16 or exact fp32.  Measured on the
-//   reference's 450-frame fixture: decoder waveform RMS error 5.0e-6 (mode 2) -> 1.40e-5 (mode 1), whole conversion of a 450-frame
-//   window 1.222e-4 in both modes, against the bar of 1e-3 (tests/test_gpu_models.py::test_decoder_precision_modes).  The first form
+//   the transposed convs, the fused 16 / 8-channel FilterBlocks -- stays on two-plane split bf16 or exact fp32.  Measured on the
+//   reference's 450-frame fixture: decoder waveform RMS error 5.0e-6 (mode 2) -> 2.90e-5 (mode 1; 1.40e-5 without (e)), whole
+//   conversion of a 450-frame window 1.22e-4 in both modes, against the bar of 1e-3
+//   (tests/test_gpu_models.py::test_decoder_precision_modes).  The first form
 //   of mode 1 used plane 0 of the bf16 images (8 significand bits): 1.19e-4 on the same fixture -- fp16 costs the same MFMAs and bytes.
 // mode 2: two-plane split bf16 for these too (rounds 1 - 4).  ALIVE_DECODER_PRECISION=2 or alive_decoder_precision(2).
-// ALIVE_DECODER_BF16_MASK (experiments): which of (a) = 1, (b) = 2, (c) = 4, (d: the two transposed convs) = 8 mode 1 covers (default 7).
+// ALIVE_DECODER_BF16_MASK (experiments): which of (a) = 1, (b) = 2, (c) = 4, (d: the two transposed convs) = 8, (e) = 16 mode 1 covers
+// (default 23).
 // Sensitivities (oracle with the operands of one group rounded to fp16 | to bf16; 450-frame fixture, waveform RMS 0.66): (a) 1.24e-5 |
 // 1.11e-4, (b) 3.4e-6 | 2.7e-5, (c) 1.3e-6 + 1.2e-6 + 2.0e-7 | 2.2e-5 + 8.3e-6 + 1.3e-6; not adopted: FiLM projections 1.4e-4 | 1.6e-3,
-// input layer 1.2e-4 | 1.5e-3, 64-channel FilterBlock 2.6e-5 | 2.2e-4 (vector-issue bound: nothing to gain), up convs 1.0e-5 | 8.1e-5
-// (store bound: nothing to gain).
+// input layer 1.2e-4 | 1.5e-3, up convs 1.0e-5 | 8.1e-5 (store bound: nothing to gain); (e) 2.6e-5 | 2.2e-4 -- adopted last, for
+// 3.7 ms per step (the block is vector-issue bound, but a k-step with one MFMA instead of three is 30 % shorter).
 int g_decoder_precision = 0;      // 0: not decided yet (environment, else 1)
 int decoder_precision() {
     if (g_decoder_precision == 0) {
@@ -143,7 +147,7 @@ int decoder_precision() {
     return g_decoder_precision;
 }
 int decoder_bf16_mask() {
-    static const int m = getenv("ALIVE_DECODER_BF16_MASK") ? atoi(getenv("ALIVE_DECODER_BF16_MASK")) : 7;
+    static const int m = getenv("ALIVE_DECODER_BF16_MASK") ? atoi(getenv("ALIVE_DECODER_BF16_MASK")) : 23;
     return decoder_precision() == 1 ? m : 0;
 }
 
@@ -729,8 +733,13 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
                                                    skips[s], b.Hh, stream));
             } else {
                 const float* w16 = t.next(); const float* bias = t.next();
-                RUN(alive_filter_block64_range(b.U, N, L, w16, bias, b.film, FILM_ROWS, Lw_frames, film_off, f_begin * (L / Lf), f_begin, Lf,
-                                               skips[s], b.Hh, stream));
+                // (e) decoder precision mode 1: the block's six k5 convs on one fp16 plane
+                if ((decoder_bf16_mask() & 16) && b.Pa != nullptr)          // (batch path only, like the other groups)
+                    RUN(alive_filter_block64_range_fp16(b.U, N, L, w16, bias, b.film, FILM_ROWS, Lw_frames, film_off, f_begin * (L / Lf), f_begin, Lf,
+                                                        skips[s], b.Hh, stream));
+                else
+                    RUN(alive_filter_block64_range(b.U, N, L, w16, bias, b.film, FILM_ROWS, Lw_frames, film_off, f_begin * (L / Lf), f_begin, Lf,
+                                                   skips[s], b.Hh, stream));
             }
             film_off += 6 * 2 * C;
             cur = b.Hh;
@@ -794,11 +803,12 @@ extern "C" int alive_decoder_precision(int mode) {
     return decoder_precision();
 }
 
-int alive_f16_sat_conv_split(int), alive_f16_sat_gemm(int), alive_f16_sat_blocks(int), alive_f16_sat_conv(int);
+int alive_f16_sat_conv_split(int), alive_f16_sat_gemm(int), alive_f16_sat_blocks(int), alive_f16_sat_conv(int), alive_f16_sat_filter_mid(int);
 extern "C" int alive_f16_saturations(int reset) {
     const int a = alive_f16_sat_conv_split(reset), b = alive_f16_sat_gemm(reset), c = alive_f16_sat_blocks(reset), d = alive_f16_sat_conv(reset);
-    if (a < 0 || b < 0 || c < 0 || d < 0) return -1;
-    const long long t = (long long)a + b + c + d;
+    const int e = alive_f16_sat_filter_mid(reset);
+    if (a < 0 || b < 0 || c < 0 || d < 0 || e < 0) return -1;
+    const long long t = (long long)a + b + c + d + e;
     return (int)(t > 0x7fffffff ? 0x7fffffff : t);
 }
 

@@ -168,14 +168,18 @@ SPLIT_SCALE = [m != "small" for m in FILTER_MODE]      # ConvTranspose in front 
 
 def pack_filter_mid(sd, prefix):
     """FilterBlock weights for the fused 64-channel kernel (csrc/filter_mid.hip):
-    -> (bf16 flat: input conv [2][64][64], then 6 x [2][64][k = j*64 + ci]; fp32 biases [7][64])"""
+    -> (bf16-typed flat: input conv [2][64][64], then 6 x [2][64][k = j*64 + ci], then 6 x [64][k] holding fp16 bits; fp32 biases [7][64])"""
     ws = [_split_rows(sd[prefix + ".input_conv.weight"]).reshape(-1)]
     bs = [sd[prefix + ".input_conv.bias"].float()]
+    hs = []                                  # the k5 convs once more as ONE fp16 plane each [64][k = j*64 + ci] (the plain form, H16)
     for j in range(3):
         for cc in ("c1", "c2"):
-            ws.append(_split_rows(sd[f"{prefix}.blocks.{j}.{cc}.conv.conv.weight"]).reshape(-1))
+            w = sd[f"{prefix}.blocks.{j}.{cc}.conv.conv.weight"]
+            ws.append(_split_rows(w).reshape(-1))
             bs.append(sd[f"{prefix}.blocks.{j}.{cc}.conv.conv.bias"].float())
-    return torch.cat(ws).contiguous(), torch.stack(bs, 0).contiguous()
+            co, ci, kw = w.shape
+            hs.append(w.float().permute(0, 2, 1).reshape(co, kw * ci).clamp(-65504.0, 65504.0).to(torch.float16).view(torch.bfloat16).reshape(-1))
+    return torch.cat(ws + hs).contiguous(), torch.stack(bs, 0).contiguous()
 
 
 def pack_filter_small(sd, prefix):

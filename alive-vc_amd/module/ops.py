@@ -227,8 +227,9 @@ def filter_block_small(x, sd, prefix, film, film_off, skip=None):
     return out
 
 
-def filter_block64(x, sd, prefix, film, film_off, skip=None):
-    """fused FilterBlock for C = 64 (split-bf16 MFMA): x[N,64,L], reference-layout weights sd[prefix + ...]."""
+def filter_block64(x, sd, prefix, film, film_off, skip=None, plain=False):
+    """fused FilterBlock for C = 64 (split-bf16 MFMA): x[N,64,L], reference-layout weights sd[prefix + ...].
+    plain: the six k5 convs on one fp16 plane per operand (alive_filter_block64_range_fp16; decoder precision mode 1)."""
     from ._pack import pack_filter_mid
     x, film, skip = _f(x), _f(film), _f(skip)
     n, c, l = x.shape
@@ -236,6 +237,11 @@ def filter_block64(x, sd, prefix, film, film_off, skip=None):
     w, b = w.to(x.device), b.to(x.device)
     assert w.numel() == nat.lib().alive_filter_block64_weights()
     out = torch.empty_like(x)
+    if plain:
+        nat.check(nat.lib().alive_filter_block64_range_fp16(nat.ptr(x), n, l, nat.ptr(w), nat.ptr(b), nat.ptr(film), film.shape[1], film.shape[2],
+                                                            film_off, 0, 0, film.shape[2], nat.ptr(skip), nat.ptr(out), nat.stream()),
+                  "alive_filter_block64_range_fp16")
+        return out
     nat.check(nat.lib().alive_filter_block64(nat.ptr(x), n, l, nat.ptr(w), nat.ptr(b), nat.ptr(film), film.shape[1], film.shape[2],
                                              film_off, nat.ptr(skip), nat.ptr(out), nat.stream()), "alive_filter_block64")
     return out

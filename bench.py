@@ -368,7 +368,8 @@ def main():
         # priced at 2.5 PF; the other 35.91 MFLOP run three.  The family's peak is the blend: its FLOP / its ideal time.
         from module import ops as _ops
         dec_mode = _ops.decoder_precision(0)
-        fl_dec_plain = (12.58 + 39.32 + 4.19 + 2.62 + 1.31 + 0.66) * 1e6 * frames_per_step if dec_mode == 1 else 0.0
+        # ... and the six k5 convs of the fused 64-channel FilterBlock (6 x 2*64*64*5 x 80 columns = 19.66)
+        fl_dec_plain = (12.58 + 39.32 + 4.19 + 2.62 + 1.31 + 0.66 + 19.66) * 1e6 * frames_per_step if dec_mode == 1 else 0.0
         dec_ideal_s = fl_dec_plain / (PEAK_BF16_TFLOPS * 1e12) + (fl_dec - fl_dec_plain) / (PEAK_BF16_TFLOPS / 3 * 1e12)
         # encoder precision mode 1 (default since round 5): the ConvNeXt pointwise convs (CE 12.58 + PE 2.10 MFLOP per frame) run three fp16
         # MFMAs per product, the rest of the front end (DFT, input / output layers, classifier: 7.21 MFLOP) six bf16 MFMAs
@@ -387,8 +388,8 @@ def main():
                                                                 "(14.7 of the 21.9 MFLOP per frame), 3-plane split bf16 (6 MFMAs per product) for the DFT, the input / output layers and the classifier; peak = the blend" if enc_mode == 1 else
                                                                 "spectrogram (DFT as a GEMM) + F0Estimator + ContentEncoder: 3-plane split bf16, 6 MFMAs per product")),
                                   precision_mode=enc_mode, frac_of_bf16x6_peak=round(fl_enc / (ms_enc * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS / 6), 4)),
-                "decoder": dict(fam(ms_dec, fl_dec, pk_dec, ("FeatureExtractor + HarmonicOscillator + Filter: plain fp16 (1 MFMA per product) for the ConvNeXt pointwise convs, the six k5 convs of the 256-channel FilterBlock, the norm-FiLM projection, the two coarse down convs and the mid conv "
-                                                              "(60.7 of the 96.6 MFLOP per frame), 2-plane split bf16 (3 MFMAs per product) for the rest; peak = the blend, FLOP / ideal time" if dec_mode == 1 else
+                "decoder": dict(fam(ms_dec, fl_dec, pk_dec, ("FeatureExtractor + HarmonicOscillator + Filter: plain fp16 (1 MFMA per product) for the ConvNeXt pointwise convs, the k5 convs of the 256- and 64-channel FilterBlocks, the norm-FiLM projection, the two coarse down convs and the mid conv "
+                                                              "(80.3 of the 96.6 MFLOP per frame), 2-plane split bf16 (3 MFMAs per product) for the rest; peak = the blend, FLOP / ideal time" if dec_mode == 1 else
                                                               "FeatureExtractor + HarmonicOscillator + Filter: 2-plane split bf16, 3 MFMAs per product") +
                                                              " (fused FilterBlocks at 64 / 16 / 8 channels on the same MFMA; exact f32 MFMA only for the strided / transposed convs of the two finest scales)"),
                                 precision_mode=dec_mode, frac_of_split_bf16_peak=round(fl_dec / (ms_dec * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS / 3), 4)),
@@ -454,7 +455,7 @@ def main():
                     "waveform_rms": round(float(o2.double().pow(2).mean().sqrt()), 5),
                     "headline_minus_this_rms": float("%.3e" % d.pow(2).mean().sqrt().item()), "headline_minus_this_max": float("%.3e" % d.abs().max().item()),
                     "note": "ALIVE_DECODER_PRECISION=2: every decoder GEMM on two-plane split bf16 (3 MFMAs per product); the headline runs the "
-                            "ConvNeXt pointwise convs, the 256-channel FilterBlock's k5 convs and four smaller layers on plain fp16"}
+                            "ConvNeXt pointwise convs, the 256-channel FilterBlock's k5 convs and four smaller layers, and the 64-channel FilterBlock's k5 convs, on plain fp16"}
         extra["decoder_split_bf16"] = guarded(leg)
 
     # The same step with the encoders' ConvNeXt pointwise convs back on three bf16 planes, six MFMAs per product (alive_encoder_precision 2,
@@ -768,7 +769,7 @@ def main():
             "dtype": ({"fp6": "fp6 (e2m3)", "fp8": "fp8 (e4m3)"}[library.prefilter] + " MFMA candidate scoring + exact f32 rescoring, every frame "
                       "certified at 7 sigma of its measured stage error (statistical: audited against brute force on every frame of this "
                       "batch, tests/test_gpu_knn_audit.py; ALIVE_KNN_STRICT=1 is the deterministic form)" if library.prefilter in ("fp8", "fp6") else
-                      "bf16 MFMA scoring + exact f32 rescoring, certified per frame" + (" (deterministic bound)" if library.strict else "")) + "; encoders (fp32-grade): " + ("fp16 split planes (hi + scaled lo, 3 MFMAs per product, 22 significand bits) for the ConvNeXt pointwise convs, 3-plane split bf16 (6 MFMAs) for the DFT / input / output / classifier GEMMs" if encoder_mode == 1 else "3-plane split-bf16 GEMMs (ALIVE_ENCODER_PRECISION=2)") + "; decoder: " + ("plain fp16 (one MFMA per product, fp32 accumulate and residual streams) for the ConvNeXt pointwise convs, the 256-channel FilterBlock's k5 convs and four smaller layers (60.7 of its 96.6 MFLOP per frame) -- decoder waveform RMS error 1.4e-5 on the reference's 450-frame fixture against the 1e-3 bar, ALIVE_DECODER_PRECISION=2 restores split bf16 (5e-6) --, 2-plane split-bf16 for its other GEMMs" if decoder_mode == 1 else "2-plane split-bf16 GEMMs (ALIVE_DECODER_PRECISION=2)") + "; f32 MFMA DFT / strided / small-channel convs; f64 phase scan",
+                      "bf16 MFMA scoring + exact f32 rescoring, certified per frame" + (" (deterministic bound)" if library.strict else "")) + "; encoders (fp32-grade): " + ("fp16 split planes (hi + scaled lo, 3 MFMAs per product, 22 significand bits) for the ConvNeXt pointwise convs, 3-plane split bf16 (6 MFMAs) for the DFT / input / output / classifier GEMMs" if encoder_mode == 1 else "3-plane split-bf16 GEMMs (ALIVE_ENCODER_PRECISION=2)") + "; decoder: " + ("plain fp16 (one MFMA per product, fp32 accumulate and residual streams) for the ConvNeXt pointwise convs, the 256- and 64-channel FilterBlocks' k5 convs and four smaller layers (80.3 of its 96.6 MFLOP per frame) -- decoder waveform RMS error 2.9e-5 on the reference's 450-frame fixture against the 1e-3 bar, ALIVE_DECODER_PRECISION=2 restores split bf16 (5e-6) --, 2-plane split-bf16 for its other GEMMs" if decoder_mode == 1 else "2-plane split-bf16 GEMMs (ALIVE_DECODER_PRECISION=2)") + "; f32 MFMA DFT / strided / small-channel convs; f64 phase scan",
             "data": "synthetic",
             "config": {"workload": f"{args.utterances} utterances x {args.seconds:g} s per GPU -> {n_win} windows x "
                                    f"{L // FRAME} frames per step, {M}-vector library (BASELINE config 3/4 shape)",

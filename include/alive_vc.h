@@ -344,6 +344,12 @@ int alive_filter_block64(const float* U, int N, int L, const void* W16, const fl
 int alive_filter_block64_range(const float* U, int N, int L, const void* W16, const float* biases, const float* film,
                                int film_rows, int Lf, int film_off, int t0, int f0, int film_ld, const float* skip,
                                float* out, void* stream);
+/* the same with the six k5 convs on ONE fp16 plane per operand (one MFMA per product, v_mfma_f32_32x32x16_f16; the 1x1 input conv keeps
+ * split bf16): W16 = the pack of alive_filter_block64_weights() elements, whose last 6 x 64 x 320 hold the k5 weights as fp16
+ * (module/_pack.py::pack_filter_mid).  Part of alive_decoder_precision mode 1. */
+int alive_filter_block64_range_fp16(const float* U, int N, int L, const void* W16, const float* biases, const float* film,
+                               int film_rows, int Lf, int film_off, int t0, int f0, int film_ld, const float* skip,
+                               float* out, void* stream);
 
 /* The waveform-rate edges of Filter.forward (decoder.py:164,182,186-188,194) as streaming kernels:
  *   alive_filter_source_in : downs[0](source_in(src)):  src[N][Lw] -> d0[N][16][Lw/2]
@@ -461,14 +467,15 @@ int alive_f0_estimate(const float* const* w, const float* spec, int N, int T,
 
 /* Arithmetic of the decoder's two largest groups of GEMMs on the batch path (more than 96 columns; the streaming kernels are not
  * affected): (a) the six k = 5 convs of the 256-channel FilterBlock (decoder.py:128-134 at the Filter's coarsest scale), (b) the two
- * pointwise convs of the feature extractor's four AdaptiveConvNeXt1d layers (common.py:74-82).
+ * pointwise convs of the feature extractor's four AdaptiveConvNeXt1d layers (common.py:74-82), (c) the norm-FiLM projection, the two
+ * coarse down convs and the mid conv, (e) the six k = 5 convs of the fused 64-channel FilterBlock.
  *   mode 1 (default since round 5, or ALIVE_DECODER_PRECISION=1): plain fp16 operands, one MFMA per product (AliveConv.precision 3,
  *          AliveGemm.planes 1), fp32 accumulate, fp32 residual streams;
  *   mode 2 (ALIVE_DECODER_PRECISION=2): two-plane split bf16 like the decoder's other GEMMs (rounds 1 - 4);
  *   mode 0: query.  Returns the mode in force.  Process-wide; not to be changed while a decoder call is in flight.
  * Measured on the reference's 450-frame fixture (tests/test_gpu_models.py::test_decoder_precision_modes): decoder waveform RMS error
- * 5.0e-6 in mode 2, 1.40e-5 in mode 1, whole conversion of a 450-frame window 1.22e-4 in both; the bar of the path is 1e-3.  Everything else in the
- * decoder (FiLM projections, input layer, to_amps, strided / transposed convs, the fused 64 / 16 / 8-channel FilterBlocks) keeps
+ * 5.0e-6 in mode 2, 2.90e-5 in mode 1, whole conversion of a 450-frame window 1.22e-4 in both; the bar of the path is 1e-3.  Everything else in the
+ * decoder (FiLM projections, input layer, to_amps, strided / transposed convs, the fused 16 / 8-channel FilterBlocks) keeps
  * split bf16 or exact fp32 in both modes, and so do both encoders (top-k / argmax downstream). */
 int alive_decoder_precision(int mode);
 /* Arithmetic of the pointwise convs of the ConvNeXt layers of ContentEncoder / F0Estimator on the batch path (common.py:54-62):
