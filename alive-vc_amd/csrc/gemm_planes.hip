@@ -78,19 +78,21 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 }
 // the plane format of an NP-plane operand: NP = 1 is ONE fp16 plane (plain operands, round 5), NP >= 2 split bf16 planes
 template <int NP>
-__device__ __forceinline__ unsigned pack_plane2(float a, float b) { return NP == 1 ? pack_f16x2(a, b) : pack_bf16x2(a, b); }
+__device__ __forceinline__ unsigned pack_plane2(float a, float b, bool count = true) { return NP == 1 ? pack_f16x2(a, b, count) : pack_bf16x2(a, b); }
 // one plane of a split: the packed pair, (a, b) left as the remainders.  F16S: fp16 planes (AliveGemm.f16s), else bf16 (NP = 1: plain fp16)
+// count: fp16 saturations are counted for real outputs only (a column past the end of the problem is computed from whatever the padding of
+// its operand buffer holds and is skipped on the way out)
 template <int NP, bool F16S>
-__device__ __forceinline__ unsigned split_step(float& a, float& b) {
+__device__ __forceinline__ unsigned split_step(float& a, float& b, bool count = true) {
     if constexpr (F16S) {
         typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-        const unsigned h = pack_f16x2(a, b);
+        const unsigned h = pack_f16x2(a, b, count);
         const f16x2_t hv = __builtin_bit_cast(f16x2_t, h);
         a -= (float)hv[0];
         b -= (float)hv[1];
         return h;
     } else {
-        const unsigned h = pack_plane2<NP>(a, b);
+        const unsigned h = pack_plane2<NP>(a, b, count);
         a -= __uint_as_float(h << 16);
         b -= __uint_as_float(h & 0xffff0000u);
         return h;
@@ -279,7 +281,7 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
                     for (int e = 0; e < 4; ++e) q[e] = (full_rows || rbase + 8 * g + e < p.Co) ? vv[4 * g + e] * pscale : 0.0f;
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl) {
-                        const unsigned h01 = split_step<NP, F16S>(q[0], q[1]), h23 = split_step<NP, F16S>(q[2], q[3]);
+                        const unsigned h01 = split_step<NP, F16S>(q[0], q[1], cok[tj]), h23 = split_step<NP, F16S>(q[2], q[3], cok[tj]);
                         *(uint2*)(stage + pl * 8192 + cl * 128 + ((((rowl >> 3)) ^ (cl & 7)) << 4) + 8 * lh) = make_uint2(h01, h23);
                     }
                 }
@@ -298,7 +300,7 @@ __device__ __forceinline__ void gemm_epilogue(const AliveGemm& p, f32x16 (&acc)[
                 for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const unsigned h01 = split_step<NP, F16S>(q[g][0], q[g][1]), h23 = split_step<NP, F16S>(q[g][2], q[g][3]);
+                        const unsigned h01 = split_step<NP, F16S>(q[g][0], q[g][1], cok[tj]), h23 = split_step<NP, F16S>(q[g][2], q[g][3], cok[tj]);
                         *(uint2*)(stage_small + lr * 64 + ((g ^ ((lr >> 2) & 3)) << 4) + 8 * lh) = make_uint2(h01, h23);
                     }
 #pragma unroll

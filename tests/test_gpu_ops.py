@@ -1001,3 +1001,19 @@ def test_fp16_saturations_are_counted_and_refused():
         Converter.check_fp16_range()
     assert ops.f16_saturations() == 0                     # the check resets the counters
     Converter.check_fp16_range()
+
+
+def test_fp16_saturation_count_ignores_padding_columns_of_a_gemm():
+    """A plane buffer's padding columns (cols .. cols_pad - 1) hold whatever was there: the GEMM computes them (and skips them on the way
+    out), but what it saturates THERE is not counted -- only real outputs can trip Converter.check_fp16_range."""
+    from module import ops
+    n, ci, co, t = 3, 512, 256, 37                                   # 111 columns in a 128-column buffer
+    x = g("padx", (n, ci, t)); w = g("padw", (co, ci, 1), scale=1.0 / np.sqrt(ci)); b = g("padb", (co,), scale=0.1)
+    P = ops.to_planes(x.to(DEV), 1)
+    v = P.view(torch.int16).view(ci // 32, 128, 32)
+    v[:, n * t:, :] = 0x7BFF                                           # 65504 in every padding element: their outputs saturate
+    ops.f16_saturations(reset=True)
+    y, pout = ops.gemm_planes(P, n, t, w.to(DEV), b.to(DEV), planes=1, want_planes=True)
+    assert ops.f16_saturations() == 0
+    want = torch.einsum("oc,nct->not", w[:, :, 0].half().double(), x.half().double()) + b.double().view(1, -1, 1)
+    assert (y.cpu().double() - want).abs().max().item() <= 3e-5 * max(1.0, want.abs().max().item())
