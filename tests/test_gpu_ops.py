@@ -674,10 +674,12 @@ def test_dwconv_norm_planes_single_pass(planes, n, c, t, adaptive, dw):
     assert relerr(got, ref) < (1e-5 if planes == 2 else 2e-6)
 
 
-@pytest.mark.parametrize("c,l", [(64, 36000), (16, 72000), (8, 144000)])
+@pytest.mark.parametrize("c,l", [(64, 36000), (-64, 36000), (16, 72000), (8, 144000)])
 def test_fused_filter_blocks_are_deterministic_at_batch_scale(c, l):
     """128 windows (the bench's window batch), 100 launches on the same inputs: every output bitwise the first one
-    (the scheduling fence of filter_block64_kernel was guarded by 3 repetitions on tiny shapes only)"""
+    (the scheduling fence of filter_block64_kernel was guarded by 3 repetitions on tiny shapes only).  c = -64: the
+    64-channel block with its k5 convs on one fp16 plane (alive_filter_block64_range_fp16, the default of decoder precision mode 1)."""
+    plain, c = c < 0, abs(c)
     from module import _native as nat
     N, lf = 128, 450
     L_ = nat.lib()
@@ -692,8 +694,12 @@ def test_fused_filter_blocks_are_deterministic_at_batch_scale(c, l):
         b = torch.randn(7, 64, device=DEV, generator=gen) * 0.1
 
         def run():
-            nat.check(L_.alive_filter_block64(x.data_ptr(), N, l, w.data_ptr(), b.data_ptr(), film.data_ptr(), 4128, lf, 3072,
-                                              skip.data_ptr(), out.data_ptr(), st))
+            if plain:
+                nat.check(L_.alive_filter_block64_range_fp16(x.data_ptr(), N, l, w.data_ptr(), b.data_ptr(), film.data_ptr(), 4128, lf, 3072,
+                                                             0, 0, lf, skip.data_ptr(), out.data_ptr(), st))
+            else:
+                nat.check(L_.alive_filter_block64(x.data_ptr(), N, l, w.data_ptr(), b.data_ptr(), film.data_ptr(), 4128, lf, 3072,
+                                                  skip.data_ptr(), out.data_ptr(), st))
     else:
         nw = L_.alive_filter_block_small_weights(c)
         w = (torch.cat([torch.randn(224, device=DEV, generator=gen) * 0.1,        # fp32 biases [7][32], then bf16 weight pairs in fp32 words
