@@ -89,14 +89,24 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // are fp16 subnormals (absolute resolution 6e-8).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // Saturations are COUNTED (one counter per translation unit, summed by alive_f16_saturations): a checkpoint or an input whose activations
-// leave fp16's range must not pass silently -- module/pipeline.py reads the counter at the end of a conversion and refuses the result.
+// leave fp16's range must not pass silently -- module/pipeline.py clears the counters when a conversion starts, reads them when it ends
+// and repeats the batch on bf16 planes (fp32's range) when they are not zero.
+// The getter SYNCHRONISES THE DEVICE before it reads (the callers' streams are non-blocking torch streams: a read on the null stream
+// alone could overtake GEMMs still running), reads the CURRENT device's counter, and returns -1 when any runtime call fails; the clear
+// form is an asynchronous 4-byte copy in the order of `stream` (graph-capturable, no synchronisation).
 static __device__ unsigned alive_f16_sat_count;
-#define ALIVE_F16_SAT_GETTER(NAME)                                                                        \
-    int NAME(int reset) {                                                                                 \
-        unsigned v = 0, z = 0;                                                                            \
-        if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(alive_f16_sat_count), sizeof(v)) != hipSuccess) return -1; \
-        if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(alive_f16_sat_count), &z, sizeof(z));               \
-        return (int)(v > 0x7fffffffu ? 0x7fffffffu : v);                                                  \
+#define ALIVE_F16_SAT_GETTER(NAME)                                                                                          \
+    int NAME(int reset) {                                                                                                   \
+        unsigned v = 0, z = 0;                                                                                              \
+        if (hipDeviceSynchronize() != hipSuccess) return -1;                                                                \
+        if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(alive_f16_sat_count), sizeof(v)) != hipSuccess) return -1;                   \
+        if (reset && hipMemcpyToSymbol(HIP_SYMBOL(alive_f16_sat_count), &z, sizeof(z)) != hipSuccess) return -1;            \
+        return (int)(v > 0x7fffffffu ? 0x7fffffffu : v);                                                                    \
+    }                                                                                                                       \
+    int NAME##_clear(void* stream) {                                                                                        \
+        void* p = nullptr;                                                                                                  \
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(alive_f16_sat_count)) != hipSuccess) return -1;                              \
+        return hipMemsetAsync(p, 0, sizeof(unsigned), (hipStream_t)stream) == hipSuccess ? 0 : -1;                          \
     }
 // count = false: the values are known to be don't-cares (the halo columns of a fused tile hold whatever their dependency cone left)
 __device__ __forceinline__ unsigned pack_f16x2(float a, float b, bool count = true) {

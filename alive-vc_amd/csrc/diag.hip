@@ -245,8 +245,58 @@ extern "C" int alive_debug_mfma_filler(const void* rnd, int blocks, int iters, i
     return ALIVE_OK;
 }
 
+// Round 6: does a SECOND wave on a SIMD double the vector issue rate?  (MI355X_MICROARCH.md: v_fma_f32 2 cycles per SIMD-32, "one wave
+// alone: 4".)  The same loop as mfma_filler_kernel KIND 0 / a loop without MFMAs (MF = 0), launched with 256 threads (one wave per SIMD)
+// or 512 (two): per-wave shader cycles per slot (slot = one MFMA or none + NF independent v_fma_f32).  tools/valu_pairs.py.
 namespace {
+template <int NF, int MF>
+__global__ __launch_bounds__(512, 1) void valu_pair_kernel(const unsigned short* __restrict__ rnd, int iters, long long* cycles, float* sink) {
+    const int tid = threadIdx.x;
+    bf16x8 a = *(const bf16x8*)(rnd + (tid * 8) % 32768), b = *(const bf16x8*)(rnd + (tid * 8 + 4096) % 32768);
+    f32x16 acc0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = 0.0f;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = (float)(tid + j) * 1e-3f;
+    const float c1 = 0.999f, c2 = 1e-4f;
+    __syncthreads();
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            if (MF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc0) : "v"(a), "v"(b));
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                float& xr = x[(m * NF + f) & 7];
+                if (MF == 2 && (f & 7) == 7) asm volatile("v_exp_f32 %0, %0" : "+v"(xr));
+                else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(xr) : "v"(c1), "v"(c2));
+            }
+        }
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += x[j];
+    s += acc0[tid & 15];
+    if (s == 12345.678f) sink[0] = s;
+    if ((tid & 63) == 0) cycles[blockIdx.x * 8 + (tid >> 6)] = t1 - t0;
+}
 }  // namespace
+
+// cycles[blocks * 8]; threads = 256 (one wave per SIMD) or 512 (two); mf: 0 = no MFMA, 1 = one MFMA per slot, 2 = MFMA + every 8th filler a v_exp
+extern "C" int alive_debug_valu_pairs(const void* rnd, int blocks, int threads, int iters, int nf, int mf, long long* cycles, float* sink, void* stream) {
+    ALIVE_CHECK_ARG(rnd && sink && cycles && blocks > 0 && iters > 0 && (threads == 256 || threads == 512), "alive_debug_valu_pairs: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned short* r = (const unsigned short*)rnd;
+#define ALIVE_VP_CASE(N, M) if (nf == N && mf == M) valu_pair_kernel<N, M><<<blocks, threads, 0, s>>>(r, iters, cycles, sink);
+    ALIVE_VP_CASE(4, 0) ALIVE_VP_CASE(8, 0) ALIVE_VP_CASE(16, 0)
+    ALIVE_VP_CASE(0, 1) ALIVE_VP_CASE(4, 1) ALIVE_VP_CASE(8, 1) ALIVE_VP_CASE(16, 1) ALIVE_VP_CASE(24, 1)
+    ALIVE_VP_CASE(8, 2) ALIVE_VP_CASE(16, 2) ALIVE_VP_CASE(24, 2)
+#undef ALIVE_VP_CASE
+    ALIVE_CHECK_LAUNCH("alive_debug_valu_pairs");
+    return ALIVE_OK;
+}
 
 // launches `blocks` blocks of the loop above; 8 * iters MFMAs per wave.  rnd: 64 KB of random bf16.
 extern "C" int alive_debug_mfma_rate(const void* rnd, int blocks, int iters, int mode, float* sink, void* stream) {

@@ -2436,17 +2436,20 @@ extern "C" int alive_library_pack_fp6(const void* lib_bf16, int64_t M, void* lib
     return ALIVE_OK;
 }
 
-extern "C" size_t alive_knn_workspace_bytes(int64_t Tt, int64_t M) {
+// alive_knn_search_strict with a lo-plane library (lib_lo != NULL) additionally needs both bf16 planes of the frames (they come last in
+// the layout).  alive_knn_workspace_bytes is the bound that is safe for EVERY search entry point (a caller built against an older header
+// sizes one buffer with it and may hand it to the strict search, which takes no size argument); the searches without a lo plane need
+// only alive_knn_workspace_bytes_fast (3 KB per frame less).
+extern "C" size_t alive_knn_workspace_bytes_fast(int64_t Tt, int64_t M) {
     // sized for any k the entry points accept (the exact tier's partial lists grow with ceil(Tt / G(k)))
     const size_t a = ws_layout(nullptr, Tt, M, 4).bytes, b = ws_layout(nullptr, Tt, M, ALIVE_MAX_K).bytes;
     return a > b ? a : b;
 }
-
-// alive_knn_search_strict with a lo-plane library (lib_lo != NULL) additionally needs both bf16 planes of the frames
 extern "C" size_t alive_knn_workspace_bytes_strict(int64_t Tt, int64_t M) {
     const size_t a = ws_layout(nullptr, Tt, M, 4, true).bytes, b = ws_layout(nullptr, Tt, M, ALIVE_MAX_K, true).bytes;
     return a > b ? a : b;
 }
+extern "C" size_t alive_knn_workspace_bytes(int64_t Tt, int64_t M) { return alive_knn_workspace_bytes_strict(Tt, M); }
 
 // The collect tier: the frames whose bf16 certificate failed (list1, with the thresholds thr1 the rescoring kernel recorded
 // for them) go through the bf16 scoring kernel once more, in its COLLECT form -- every row whose stage score reaches the

@@ -812,6 +812,18 @@ extern "C" int alive_f16_saturations(int reset) {
     return (int)(t > 0x7fffffff ? 0x7fffffff : t);
 }
 
+int alive_f16_sat_conv_split_clear(void*), alive_f16_sat_gemm_clear(void*), alive_f16_sat_blocks_clear(void*), alive_f16_sat_conv_clear(void*),
+    alive_f16_sat_filter_mid_clear(void*);
+extern "C" int alive_f16_saturations_clear(void* stream) {
+    const int r = alive_f16_sat_conv_split_clear(stream) | alive_f16_sat_gemm_clear(stream) | alive_f16_sat_blocks_clear(stream) |
+                  alive_f16_sat_conv_clear(stream) | alive_f16_sat_filter_mid_clear(stream);
+    if (r != 0) {
+        alive_set_error("alive_f16_saturations_clear: the runtime refused the asynchronous clear of a counter");
+        return ALIVE_ERR_LAUNCH;
+    }
+    return ALIVE_OK;
+}
+
 extern "C" int alive_encoder_precision(int mode) {
     if (mode == 1 || mode == 2) g_encoder_precision = mode;
     return encoder_precision();

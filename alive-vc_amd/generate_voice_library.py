@@ -18,7 +18,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-from module import audio_io                                     # noqa: E402
+from module import audio_io, ops                                # noqa: E402
 from module.content_encoder import ContentEncoder                # noqa: E402
 from module.spectrogram import spectrogram                       # noqa: E402
 from module.voice_library import VoiceLibrary                    # noqa: E402
@@ -97,7 +97,9 @@ def main(argv=None):
     clips = collect_clips(args.dataset, need, rng)
     filled = 0
     for s in range(0, clips.shape[0], 256):
-        feats = CE(spectrogram(clips[s:s + 256].to(device))).cpu()          # [B, 768, 24]
+        # under the fp16 range guard: a batch whose activations leave fp16's range is encoded again on bf16 planes BEFORE any of
+        # its frames enters the bank (module/ops.py::Fp16Guard)
+        feats = ops.Fp16Guard().run(lambda: CE(spectrogram(clips[s:s + 256].to(device)))).cpu()          # [B, 768, 24]
         for b in range(feats.shape[0]):
             # the reference draws frame randint(0, 7) of each clip (generate_voice_library.py:37)
             frames = rng.sample(range(0, 8), min(args.frames_per_clip, 8))
@@ -105,8 +107,6 @@ def main(argv=None):
                 if filled < args.num_tokens:
                     VL.tokens[0, :, filled] = feats[b, :, fr]
                     filled += 1
-    from module.pipeline import Converter
-    Converter.check_fp16_range()          # the encoder's fp16 split planes count saturated activations: none may have occurred
     if args.dedup is not None and filled > 1:
         keep = dedup_mask(VL.tokens[0, :, :filled].to(device), args.dedup)
         kept = VL.tokens[0, :, :filled][:, keep.cpu()]

@@ -52,6 +52,7 @@ PROTOTYPES = {
     "alive_library_pack": (_I, [_VP, _I64, _I, _VP, _VP, _VP, _VP]),
     "alive_knn_workspace_bytes": (_SZ, [_I64, _I64]),
     "alive_knn_workspace_bytes_strict": (_SZ, [_I64, _I64]),
+    "alive_knn_workspace_bytes_fast": (_SZ, [_I64, _I64]),
     "alive_knn_search": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP]),
     "alive_library_fp8_bytes": (_SZ, [_I64]),
     "alive_library_rounding_bound": (_I, [_VP, _VP, _VP, _I64, _VP, _VP]),
@@ -71,6 +72,7 @@ PROTOTYPES = {
     "alive_decoder_precision": (_I, [_I]),
     "alive_encoder_precision": (_I, [_I]),
     "alive_f16_saturations": (_I, [_I]),
+    "alive_f16_saturations_clear": (_I, [_VP]),
     "alive_gelu_film": (_I, [_VP, _I, _I, _I, _VP, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "alive_planes_bytes": (_SZ, [_I64, _I, _I]),
     "alive_to_planes": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),

@@ -115,7 +115,7 @@ class PackedLibrary:
         val = torch.empty(n * t, k, dtype=torch.float32, device=source.device)
         idx = torch.empty(n * t, k, dtype=torch.int32, device=source.device)
         split = self.strict and self.lib_lo is not None          # the split-bf16 collect tier needs the frames' two planes as well
-        ws = self._ws.get((L.alive_knn_workspace_bytes_strict if split else L.alive_knn_workspace_bytes)(n * t, self.M), source.device)
+        ws = self._ws.get((L.alive_knn_workspace_bytes_strict if split else L.alive_knn_workspace_bytes_fast)(n * t, self.M), source.device)
         ev = (None, None) if events is None else (events[0].cuda_event, events[1].cuda_event)
         if self.strict:
             nat.check(L.alive_knn_search_strict(nat.ptr(source), n, t, nat.ptr(self.lib_bf16), nat.ptr(self.lib_lo), nat.ptr(self.rows), nat.ptr(self.norms),

@@ -335,5 +335,57 @@ def encoder_precision(mode=0):
 
 
 def f16_saturations(reset=False):
-    """values saturated at +-65504 while an fp16 plane was written (alive_f16_saturations); synchronises the device"""
-    return int(nat.lib().alive_f16_saturations(1 if reset else 0))
+    """values saturated at +-65504 while an fp16 plane was written (alive_f16_saturations) on the current device since the last clear;
+    SYNCHRONISES the device before it reads.  A read error raises (it must never pass for "no saturation")."""
+    n = int(nat.lib().alive_f16_saturations(1 if reset else 0))
+    if n < 0:
+        raise RuntimeError("alive_f16_saturations: the device-side saturation counters could not be read (HIP runtime error)")
+    return n
+
+
+def f16_clear():
+    """zeroes the saturation counters asynchronously, in the order of the current stream (alive_f16_saturations_clear)"""
+    nat.check(nat.lib().alive_f16_saturations_clear(nat.stream()), "alive_f16_saturations_clear")
+
+
+class Fp16Guard:
+    """Range guard of the fp16 forms (alive_encoder_precision / alive_decoder_precision, modes 1) around one batch of work:
+
+        out = Fp16Guard().run(lambda: work())
+
+    clears the counters in stream order, runs `work`, reads the counters (one device synchronisation) and -- when a value left fp16's
+    range -- REPEATS `work` with both precision modes at 2 (bf16 planes: fp32's range; the result is then the split-bf16 / bf16x6
+    arithmetic of rounds 1-4, inside the same parity bars) instead of handing a saturated result on.  `fallbacks` counts the repeats;
+    the modes in force before are restored.  Skipped altogether (no synchronisation) when both modes are already 2."""
+    fallbacks = 0                       # process-wide tally, reported by bench.py / the CLIs
+
+    def __init__(self, agree=None):
+        # agree(n) -> n: under a sharded library every rank must take the same decision (the repeat runs collectives):
+        # module/sharded.py passes the max over the ranks
+        self.agree = agree
+
+    def run(self, work):
+        enc, dec = encoder_precision(0), decoder_precision(0)
+        if enc == 2 and dec == 2:
+            return work()
+        f16_clear()
+        out = work()
+        n = f16_saturations(reset=True)
+        if self.agree is not None:
+            n = self.agree(n)
+        if n == 0:
+            return out
+        import warnings
+        warnings.warn(f"{n} activation value(s) left fp16's range in the fp16 forms of the encoder / decoder GEMMs: repeating this batch on "
+                      "bf16 planes (ALIVE_ENCODER_PRECISION=2 ALIVE_DECODER_PRECISION=2 avoids the first attempt)", RuntimeWarning)
+        Fp16Guard.fallbacks += 1
+        try:
+            encoder_precision(2)
+            decoder_precision(2)
+            out = work()
+            if f16_saturations(reset=True) != 0:          # cannot happen: no fp16 plane is written in modes 2
+                raise RuntimeError("fp16 saturations reported with both precision modes at 2")
+        finally:
+            encoder_precision(enc)
+            decoder_precision(dec)
+        return out

@@ -53,6 +53,19 @@ NET_MARGIN = 16
 SPEC_MARGIN = 2
 
 
+def _edge_chunks(n, size):
+    """[i0, i1) bounds of the edge-block launches over n windows, `size` windows at a time.  An edge block is EDGE + NET_MARGIN = 30
+    frame columns per window, and below 96 columns the library switches to its fp32 streaming kernels, which round differently from
+    the plane GEMMs every other window's edge blocks run on: a tail of fewer than 4 windows is folded into the chunk before it, so
+    that the stitched output stays bitwise that of the per-window path for every window count."""
+    need = -(-96 // (EDGE + NET_MARGIN))
+    bounds = [(i, min(n, i + size)) for i in range(0, n, size)]
+    if len(bounds) > 1 and bounds[-1][1] - bounds[-1][0] < need:
+        last = bounds.pop()
+        bounds[-1] = (bounds[-1][0], last[1])
+    return bounds
+
+
 class Converter:
     def __init__(self, content_encoder: ContentEncoder, f0_estimator: F0Estimator, decoder: Decoder, device="cuda"):
         self.device = torch.device(device)
@@ -112,14 +125,14 @@ class Converter:
         nl = EDGE + NET_MARGIN
         fe = torch.empty(n, 768, 2 * EDGE, device=dev)         # edge frames of every window: [0, EDGE) and [lf - EDGE, lf)
         pe_ = torch.empty(n, 1, 2 * EDGE, device=dev)
-        for i in range(0, n, 8 * utt_batch):
-            w = windows[i:i + 8 * utt_batch]
+        for i, j in _edge_chunks(n, 8 * utt_batch):
+            w = windows[i:j]
             sl = spectrogram(w[:, :(nl + SPEC_MARGIN) * 320].contiguous())[:, :, :nl].contiguous()
             sr = spectrogram(w[:, L - (nl + SPEC_MARGIN) * 320:].contiguous())[:, :, SPEC_MARGIN:].contiguous()
-            fe[i:i + 8 * utt_batch, :, :EDGE] = self.ce(sl)[:, :, :EDGE]
-            fe[i:i + 8 * utt_batch, :, EDGE:] = self.ce(sr)[:, :, NET_MARGIN:]
-            pe_[i:i + 8 * utt_batch, :, :EDGE] = self.pe.estimate(sl)[:, :, :EDGE]
-            pe_[i:i + 8 * utt_batch, :, EDGE:] = self.pe.estimate(sr)[:, :, NET_MARGIN:]
+            fe[i:j, :, :EDGE] = self.ce(sl)[:, :, :EDGE]
+            fe[i:j, :, EDGE:] = self.ce(sr)[:, :, NET_MARGIN:]
+            pe_[i:j, :, :EDGE] = self.pe.estimate(sl)[:, :, :EDGE]
+            pe_[i:j, :, EDGE:] = self.pe.estimate(sr)[:, :, NET_MARGIN:]
         # the match: once per distinct frame, and ONE search for the signals' frames and the windows' edge frames together
         # (a search of its own for the 28 edge frames per window would run the scoring kernel at a fraction of its rate)
         tu = fu.shape[2]
@@ -159,12 +172,12 @@ class Converter:
             fu[i:i + utt_batch] = self.ce(spec[:, :, a:b].contiguous())[:, :, u0 - a:u1 - a]
         nl = EDGE + NET_MARGIN
         f0 = torch.empty(n, 1, lf, device=dev)
-        for i in range(0, n, 8 * utt_batch):                    # f0 of the edge frames of every window
-            w = windows[i:i + 8 * utt_batch]
+        for i, j in _edge_chunks(n, 8 * utt_batch):            # f0 of the edge frames of every window
+            w = windows[i:j]
             sl = spectrogram(w[:, :(nl + SPEC_MARGIN) * 320].contiguous())[:, :, :nl].contiguous()
             sr = spectrogram(w[:, L - (nl + SPEC_MARGIN) * 320:].contiguous())[:, :, SPEC_MARGIN:].contiguous()
-            f0[i:i + 8 * utt_batch, :, :EDGE] = self.pe.estimate(sl)[:, :, :EDGE]
-            f0[i:i + 8 * utt_batch, :, lf - EDGE:] = self.pe.estimate(sr)[:, :, NET_MARGIN:]
+            f0[i:j, :, :EDGE] = self.pe.estimate(sl)[:, :, :EDGE]
+            f0[i:j, :, lf - EDGE:] = self.pe.estimate(sr)[:, :, NET_MARGIN:]
         nu = u1 - u0
         matched = self.match(fu.permute(1, 0, 2).reshape(1, 768, m * nu).contiguous(), k, alpha)[0].view(768, m, nu).permute(1, 0, 2)
         feat = torch.empty(n, 768, nr, device=dev)
@@ -179,8 +192,18 @@ class Converter:
         val, idx = self.library.search(feat, k)
         return merge_gather(val, idx, 1, k, alpha, self.library.rows, feat)
 
-    def convert_windows(self, windows, k=4, alpha=0.0, pitch_shift=0.0, intonation=1.0, f0_rate=1.0, window_batch=64,
-                        keep_frames=None, share_overlap=None):
+    def convert_windows(self, windows, *a, **kw):
+        """`_convert_windows` (below: same arguments) under the fp16 range guard (ops.Fp16Guard): the saturation counters of the fp16
+        forms are cleared in stream order when the batch starts and read when it ends (one device synchronisation per call); a batch
+        that drove an activation out of fp16's range is REPEATED on bf16 planes instead of being returned saturated -- every public
+        batch entry point (this one, `convert`, `generate_voice_library.py`, `RealtimeConverter` above 96 columns) is covered."""
+        return ops.Fp16Guard(self._agree_on_saturations()).run(lambda: self._convert_windows(windows, *a, **kw))
+
+    def _agree_on_saturations(self):
+        return None                       # one process, one decision (ShardedConverter: max over the ranks)
+
+    def _convert_windows(self, windows, k=4, alpha=0.0, pitch_shift=0.0, intonation=1.0, f0_rate=1.0, window_batch=64,
+                         keep_frames=None, share_overlap=None):
         """windows [n, L] on the device -> waveforms [n, L]; L a multiple of 320.
         Networks run in batches of `window_batch` windows (bounded scratch); the kNN match runs ONCE over the frames
         of all windows, so every library tile streamed from L2 is used by as many frames as possible.
@@ -296,15 +319,13 @@ class Converter:
             if share == "auto" and self.library is not None:
                 ok = ok and n * (1.0 + self.library.M / 5e5) >= 45.0
             kw["share_overlap"] = n if ok else None
-        out = stitch(self.convert_windows(windows, keep_frames=keep, **kw), total, chunk)
-        self.check_fp16_range()
-        return out
+        return stitch(self.convert_windows(windows, keep_frames=keep, **kw), total, chunk)       # (the guard sits in convert_windows)
 
     @staticmethod
     def check_fp16_range():
-        """The encoders' fp16 split planes and the decoder's plain fp16 planes (alive_encoder_precision / alive_decoder_precision, modes 1)
-        saturate at +-65504 and count it: a checkpoint or an input that drives an activation out of fp16's range must not pass for the
-        reference's result.  One 4-byte device read per kernel file (synchronises)."""
+        """For callers of the LOW-LEVEL ops (ContentEncoder / Decoder objects called directly): raises when a value left fp16's range
+        since the counters were last cleared, and clears them.  `convert_windows` / `convert` do not need it: they run under
+        ops.Fp16Guard, which repeats a saturated batch on bf16 planes.  Synchronises the device."""
         from . import ops
         n = ops.f16_saturations(reset=True)
         if n > 0:

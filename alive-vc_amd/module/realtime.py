@@ -84,6 +84,8 @@ class RealtimeConverter:
         self.reuse = bool(fits and reuse_interior in (True, "auto"))
         self._rows = reuse_rows(frames)
         self._cache_valid = False
+        if self._fp16_guarded():
+            ops.f16_clear()                # stale counts of earlier work in this process are not this stream's
         if self.reuse:
             self._c_feat = torch.zeros(1, 768, frames, device=self.device)      # matched features of the ring's frames
             self._c_f0 = torch.zeros(1, 1, frames, device=self.device)          # transformed f0
@@ -237,6 +239,31 @@ class RealtimeConverter:
         self.phi = phi_next
         return wave
 
+    def _fp16_guarded(self):
+        """Rings of 96 frames or more run the batch kernels and with them the fp16 forms of the encoder / decoder GEMMs (modes 1):
+        `step()` then reads the saturation counters after every chunk (it has just synchronised for the PCM copy).  Shorter rings --
+        the reference's defaults -- run the fp32-activation streaming kernels, which write no fp16 plane: nothing to guard."""
+        return self.frames >= PLANES_MIN_COLS and (ops.encoder_precision(0) != 2 or ops.decoder_precision(0) != 2)
+
+    def _repeat_on_bf16(self, data, saved_phi):
+        """a chunk drove an activation out of fp16's range: switch the process to precision modes 2 (bf16 planes, fp32's range -- a
+        stream that saturates once will do so again, so the modes stay), restore the phase the chunk started from, drop the frame
+        caches, re-capture the step if it was a hipGraph, and convert the chunk again"""
+        import warnings
+        warnings.warn("an activation left fp16's range in the streaming step: switching to ALIVE_ENCODER_PRECISION=2 / "
+                      "ALIVE_DECODER_PRECISION=2 (bf16 planes) and converting the chunk again", RuntimeWarning)
+        ops.Fp16Guard.fallbacks += 1
+        ops.encoder_precision(2)
+        ops.decoder_precision(2)
+        self._cache_valid = False
+        if getattr(self, "_graph", None) is not None:
+            self.enable_graph()
+            self._g_phi.copy_(saved_phi)
+        else:
+            self.phi = saved_phi
+        wave = self.step_device(data, continues=False)
+        return audio_io.float_to_pcm16(wave).cpu().numpy()
+
     def step(self, data_int16: np.ndarray):
         """one chunk of int16 samples -> converted centre chunk (int16), or None while the ring fills
         (the reference's loop emits nothing until it holds more than `buffersize` chunks: :133-137)."""
@@ -247,7 +274,12 @@ class RealtimeConverter:
             return None
         data = torch.from_numpy(np.concatenate(self.ring, 0)).to(self.device)
         data = audio_io.pcm16_to_float(data).unsqueeze(0)            # / 32768 on the device (:139-140)
+        guarded = self._fp16_guarded()
+        if guarded:
+            saved_phi = self._g_phi.clone() if getattr(self, "_graph", None) is not None else self.phi
         wave = self.step_device(data, continues=True)                # this ring is the previous one advanced by one chunk
         out = audio_io.float_to_pcm16(wave).cpu().numpy()            # C cast of numpy's astype, no clipping (:180-183)
+        if guarded and ops.f16_saturations(reset=True) > 0:          # (the copy above has synchronised: five 4-byte reads)
+            out = self._repeat_on_bf16(data, saved_phi)
         center = self.buffersize * self.chunk // 2
         return out[center - self.chunk // 2: center + self.chunk // 2]

@@ -159,6 +159,15 @@ class ShardedConverter(Converter):
                              "share_overlap=None")
         return super().convert_windows(windows, *a, share_overlap=None, **kw)
 
+    def _agree_on_saturations(self):
+        # the fp16 range guard (ops.Fp16Guard) repeats a saturated batch -- through the exchange collectives: all ranks or none
+        def agree(n):
+            grp = self.sharded.group
+            t = torch.tensor([float(n)], dtype=torch.float64, device=self.device if dist.get_backend(grp) == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
+            return int(t.item())
+        return agree
+
 
 def _fence(dev):
     torch.cuda.synchronize(dev)

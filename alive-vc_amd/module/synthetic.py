@@ -119,3 +119,49 @@ def make_waveform(n_samples: int, seed: int, name: str = "wave") -> torch.Tensor
         # steps: parity inputs are always compared as data, never re-derived.
         x += 0.2 * np.round(np.sin(2 * np.pi * f * t / 16000.0) * 1048576.0) / 1048576.0
     return torch.from_numpy(x.astype(np.float32).reshape(1, n_samples))
+
+
+def make_voiced(n_samples: int, seed: int, f_mid: float = 140.0):
+    """A voiced-speech-like test signal (round 6: parity fixtures beyond `make_waveform`'s noise + three partials): a stack of 24
+    harmonics (amplitude 1/h, a fixed phase per harmonic) on a gliding fundamental f_mid +- 30 % with a syllable-rate amplitude
+    envelope, plus 0.01 * N(0,1) breath noise.  Returns (wave [1, n] float32, f0 contour [n] float64 in Hz).  Like `make_waveform`
+    the sines are quantised to 2^-20 (numpy's libm is not a bit-level contract); fixtures store the signal as data."""
+    t = np.arange(n_samples, dtype=np.float64) / 16000.0
+    f0 = f_mid * (1.0 + 0.3 * np.sin(2 * np.pi * 0.7 * t + 0.1 * seed))
+    ph = 2 * np.pi * np.cumsum(f0) / 16000.0
+    env = 0.15 + 0.85 * (0.5 * (1.0 + np.sin(2 * np.pi * 2.3 * t))) ** 2
+    x = np.zeros(n_samples, dtype=np.float64)
+    for h in range(1, 25):
+        x += (0.5 / h) * np.round(np.sin(h * ph + 0.37 * h) * 1048576.0) / 1048576.0
+    x = 0.25 * env * x + 0.01 * normalish("voiced.noise", seed, n_samples)
+    return torch.from_numpy(x.astype(np.float32).reshape(1, n_samples)), f0
+
+
+SCALED_KEYS = ("to_scale.weight", "to_shift.weight", "pw_conv1.weight", "pw_conv2.weight")
+
+
+def scale_weights(sd, factor: float, keys=SCALED_KEYS):
+    """A copy of `sd` with every FiLM projection (decoder.py:109-110) and ConvNeXt pointwise weight (common.py:50-51, 70-71) multiplied
+    by `factor`: the Filter has no normalisation layer and its FiLM gains multiply activations, so this is the cheap stand-in for a
+    trained checkpoint whose activations are an order of magnitude above a fresh initialisation's (round 6 fixtures `full_T450_x4`)."""
+    out = OrderedDict()
+    for k, v in sd.items():
+        out[k] = v * factor if k.endswith(keys) else v.clone()
+    return out
+
+
+# weight sets of the round-6 reference fixtures tests/golden/full_T450_<tag>.npz: tag -> (weight seed, factor of scale_weights, input seed)
+FIXTURE_SETS = {"s3": (3, 1.0, 7), "s5": (5, 1.0, 8), "x4": (2, 4.0, 9)}
+
+
+def fixture_state_dicts(tag: str, schema=None):
+    """(content_encoder, f0_estimator, decoder) state_dicts of fixture set `tag` (FIXTURE_SETS), as oracle/gen_golden.py loaded them
+    into the reference."""
+    if schema is None:
+        from . import schema
+    seed, fac, _ = FIXTURE_SETS[tag]
+    sds = [make_state_dict(s, seed, p) for s, p in ((schema.content_encoder_schema(), "ce."), (schema.f0_estimator_schema(), "pe."),
+                                                    (schema.decoder_schema(), "dec."))]
+    if fac != 1.0:
+        sds = [scale_weights(sd, fac) for sd in sds]
+    return sds

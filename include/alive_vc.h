@@ -72,12 +72,16 @@ int alive_library_pack(const float* tokens_DxM, int64_t M, int D,
  *   again by the exact tier inside the same call: a brute-force fp32 scan of the whole shard with the rescoring
  *   arithmetic (launched up front, sized on the device, no sync).  k > 8: the exact scan for every frame.
  *   out_val[Tt][k] fp32 cosine, descending; out_idx[Tt][k] = idx_base + row.
- *   ws: alive_knn_workspace_bytes(Tt, M) bytes.
+ *   ws: alive_knn_workspace_bytes(Tt, M) bytes -- the bound that is sufficient for EVERY search entry point of this header, the strict
+ *   search with a lo-plane library included (that entry point takes no size argument, so the general query must cover it).
  */
 size_t alive_knn_workspace_bytes(int64_t Tt, int64_t M);
-/* workspace of alive_knn_search_strict when it is given a lo-plane library (lib_lo != NULL): the size above plus both bf16 planes of
- * the frames (2 x 1.5 KB per frame), which only the split-bf16 collect tier of that search uses */
+/* the same bound under its explicit name: alive_knn_search_strict with lib_lo != NULL keeps both bf16 planes of the frames
+ * (2 x 1.5 KB per frame) for its split-bf16 collect tier */
 size_t alive_knn_workspace_bytes_strict(int64_t Tt, int64_t M);
+/* the smaller workspace of every search WITHOUT a lo-plane library (alive_knn_search, _fp8, _fp6, alive_knn_search_strict with
+ * lib_lo == NULL): 3 KB per frame less.  Never hand a buffer of this size to alive_knn_search_strict with lib_lo != NULL. */
+size_t alive_knn_workspace_bytes_fast(int64_t Tt, int64_t M);
 int alive_knn_search(const float* src, int N, int T,
                      const void* lib_bf16, const float* rows_f32, const float* norms,
                      int64_t M, int64_t idx_base, int k,
@@ -483,14 +487,20 @@ int alive_decoder_precision(int mode);
  *          significand bits per operand);
  *   mode 2 (ALIVE_ENCODER_PRECISION=2): three bf16 planes, six MFMAs per product (24 bits; rounds 1 - 4);
  *   mode 0: query.  Both are fp32-grade: content features agree with the reference fixture to < 1e-5 of their RMS in either mode and
- * the f0 classes outside the 1e-4 margin are identical (tests/test_gpu_models.py).  The DFT, the input / output layers and the
- * classifier stay on three bf16 planes (their inputs are not range-limited by a normalisation). */
+ * the f0 classes outside the 1e-4 margin are identical (tests/test_gpu_models.py).  In mode 1 the F0Estimator's classifier runs on
+ * fp16 split planes too (its input is what last_norm leaves); the DFT and the input / output layers of both encoders stay on three
+ * bf16 planes in either mode (their inputs are not range-limited by a normalisation). */
 int alive_encoder_precision(int mode);
 /* Values that left fp16's range (|scaled value| > 65504) while an fp16 plane was written by any kernel of modes 1 above since the last
- * reset -- they were saturated, not turned into infinities, but the result is then not the reference's.  Synchronises the device (a
- * 4-byte read per kernel file); 0 on every tested checkpoint and input.  reset != 0 clears the counters.  -1: read error.
- * module/pipeline.py::Converter.convert checks it once per conversion and raises. */
+ * clear -- they were saturated, not turned into infinities, but the result is then not the reference's.  0 on every tested checkpoint
+ * and input.  SYNCHRONISES THE DEVICE (hipDeviceSynchronize, then a 4-byte read per kernel file of the CURRENT device's counters: the
+ * caller's streams may be non-blocking, so the null stream alone orders nothing); reset != 0 clears the counters after the read.
+ * Returns -1 when a runtime call fails -- callers must treat that as an error, not as "no saturation".
+ * module/pipeline.py::Converter.convert_windows clears the counters when a batch starts (alive_f16_saturations_clear), reads them when
+ * it ends and repeats the batch in modes 2 when they are not zero. */
 int alive_f16_saturations(int reset);
+/* Zeroes the counters asynchronously, in the order of `stream` (five 4-byte memsets; no synchronisation, graph-capturable). */
+int alive_f16_saturations_clear(void* stream);
 
 /* Decoder.forward (decoder.py:205-210) at harmonics_scale == 1:
  *   x[N][768][Lf], f0[N][Lf], phi_in[N][64] or NULL (phi = 0), crop0,

@@ -205,6 +205,35 @@ def main():
         npz(f"full_T{T}", **d)
         report[f"full_T{T}_wave_rms"] = float(wv.pow(2).mean().sqrt())
 
+    # ---- 4b. round 6: 450 frames on more than one weight set -----------------------------------
+    # Every default-size parity test of rounds 1-5 (and the sensitivity study that chose the fp16 layer groups) ran on weight seed 2 and
+    # the noise-like input above.  Two more seeds and one set whose FiLM / pointwise weights are 4 x a fresh initialisation's (the Filter
+    # has no normalisation, decoder.py:153-195; FiLM gains multiply activations, :112-117), on a voiced-speech-like input (harmonic
+    # stack + noise) and the smooth f0 contour that goes with it (frames 100-109 unvoiced).
+    T = 450
+    for tag, (wseed, fac, iseed) in syn.FIXTURE_SETS.items():
+        sce, spe, sdec = syn.fixture_state_dicts(tag, schema)
+        m_ce, m_pe, m_dec = rce.ContentEncoder(), rpe.F0Estimator(), rdec.Decoder()
+        m_ce.load_state_dict(sce); m_pe.load_state_dict(spe); m_dec.load_state_dict(sdec)
+        wav, contour = syn.make_voiced(320 * T, iseed)
+        spec = rsp.spectrogram(wav)
+        assert torch.equal(O.spectrogram(wav), spec)
+        feat = m_ce(spec)
+        f0 = m_pe.estimate(spec)
+        lg = m_pe(spec)
+        assert torch.equal(O.content_encoder(sce, spec), feat)
+        assert torch.equal(O.f0_estimate(spe, spec), f0)
+        top2 = torch.topk(lg, 2, dim=1).values
+        f0d = torch.from_numpy(contour[160::320].astype(np.float32)).reshape(1, 1, T).clone()
+        f0d[:, :, 100:110] = 0.0
+        wv, ph = m_dec(feat, f0d)
+        owv, oph = O.decoder(sdec, feat, f0d)
+        assert torch.equal(owv, wv) and torch.equal(oph, ph), "oracle != reference (decoder, set %s)" % tag
+        npz(f"full_T450_{tag}", wav=wav, f0=f0, f0_margin=(top2[:, 0] - top2[:, 1]), f0_dec=f0d, wave=wv,
+            phi_last=ph[:, :, -1], feat=feat[:, ::8, :], weight_seed=wseed, weight_factor=fac, input_seed=iseed)
+        report[f"full_T450_{tag}_wave_rms"] = float(wv.pow(2).mean().sqrt())
+        report[f"full_T450_{tag}_wave_max"] = float(wv.abs().max())
+
     # ---- 5. windowing + one converted utterance --------------------------------------------
     wins = {}
     for L in (1, 15999, 16000, 48000, 100001):

@@ -153,3 +153,21 @@ def test_shared_and_trimmed_conversion_of_one_utterance(rig):
     assert conv.last_front_end_frames is not None                   # shared (62 windows against 200 k vectors) ...
     assert conv.last_front_end_frames < 0.4 * 62 * 150              # ... and trimmed: about a third of the per-window frames
     assert torch.equal(out, conv.convert(long, chunk=16000, k=4))
+
+
+def test_a_short_tail_of_edge_blocks_stays_on_the_batch_kernels(rig):
+    """the shared front end runs the windows' edge blocks 256 windows at a time; 257 - 259 windows used to leave a tail of
+    1 - 3 windows = 30 - 90 frame columns, below the 96 from which the plane GEMMs run -- those windows' f0 / features then came from
+    the fp32 streaming kernels, which round differently, and the stitched file was no longer bitwise the per-window path's.  The tail
+    is folded into the chunk before it (module/pipeline.py::_edge_chunks): one utterance of 257 windows, shared + trimmed and shared
+    alone, against the plain path."""
+    from module.pipeline import _edge_chunks
+    assert _edge_chunks(257, 256) == [(0, 257)] and _edge_chunks(260, 256) == [(0, 256), (256, 260)]
+    conv, _, _ = rig
+    chunk = 46 * 320                                                # 138-frame windows: the shortest whose trimmed range is interior frames
+    wf = (0.3 * synthetic.make_waveform(chunk * 255 - 77, 43)).to(DEV)           # 257 windows (make_windows pads by two chunks)
+    from module.pipeline import make_windows
+    assert make_windows(wf, chunk)[0].shape[0] == 257
+    ref = conv.convert(wf, chunk=chunk, k=4)
+    assert torch.equal(conv.convert(wf, chunk=chunk, k=4, share_overlap=True), ref)
+    assert torch.equal(conv.convert(wf, chunk=chunk, k=4, share_overlap=True, trim_context=True), ref)

@@ -456,7 +456,8 @@ def test_knn_search_stays_inside_its_workspace_and_outputs(prefilter, n, t, m, k
     lib = PackedLibrary(torch.randn(768, m, device=DEV, generator=g), prefilter=prefilter)
     src = torch.randn(n, 768, t, device=DEV, generator=g)
     tt = n * t
-    need = L.alive_knn_workspace_bytes(tt, m)
+    need = L.alive_knn_workspace_bytes_fast(tt, m)               # the tight size of the searches without a lo plane
+    assert L.alive_knn_workspace_bytes(tt, m) == L.alive_knn_workspace_bytes_strict(tt, m) >= need + 2 * 2 * 768 * tt
     guard = 8 << 20
     ws = torch.full((need + guard,), 0xAB, dtype=torch.uint8, device=DEV)
     outv = torch.full((tt * k + 2048,), 12345.0, device=DEV)

@@ -45,6 +45,16 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert rc == -1 and b"at least 5 frames" in L.alive_last_error()
 
 
+def test_knn_workspace_query_covers_every_search_entry_point():
+    """alive_knn_search_strict takes no workspace size, so the general query must be the bound that covers its layout (a C
+    caller built against an older header sizes ONE buffer with alive_knn_workspace_bytes); the tight size has a name of its own"""
+    L = nat.lib()
+    for tt, m in ((8, 1000), (450, 50000), (172800, 1000000)):
+        gen, strict, fast = (int(f(tt, m)) for f in (L.alive_knn_workspace_bytes, L.alive_knn_workspace_bytes_strict,
+                                                     L.alive_knn_workspace_bytes_fast))
+        assert gen == strict and strict >= fast + 2 * 2 * 768 * tt > fast > 0
+
+
 def test_product_path_refuses_cpu_tensors():
     from module.common import match_features
     from module.content_encoder import ContentEncoder
