@@ -566,3 +566,30 @@ def test_fp6_stage_at_and_beyond_the_end_of_its_operand_range(prefilter, height,
         assert st["frames_failed_fp8_certificate"] >= 1200, st
         bv, bi = _brute_force_topk(src.permute(0, 2, 1).reshape(-1, 768), plain, 4)
         _assert_equals_brute_force(val, idx, bv, bi, 4, min_safe=3000)
+
+
+def test_block_scaled_scoring_kernels_soak_under_a_concurrent_matrix_load(prefilter):
+    """Round 6: both block-scaled scoring kernels carry the accumulation-chain gap of DESIGN 3.2b' (a tile's
+    accumulators are read beside the next tile's MFMAs); 200 searches of 21 600 frames against 200 000 rows while a side stream runs
+    large bf16 GEMMs (clock / power perturbation): every search's lists bitwise the first one's -- values AND indices."""
+    if prefilter not in LOW:
+        pytest.skip("the bf16 scoring kernel reads its accumulators at the end of the tile that produced them")
+    from module.common import PackedLibrary
+    g = torch.Generator(device=DEV).manual_seed(31)
+    lib = PackedLibrary(torch.randn(768, 200_000, device=DEV, generator=g), prefilter=prefilter)
+    src = torch.randn(48, 768, 450, device=DEV, generator=g)
+    side = torch.cuda.Stream()
+    ga = torch.randn(8192, 8192, device=DEV, dtype=torch.bfloat16)
+    gb = torch.randn(8192, 8192, device=DEV, dtype=torch.bfloat16)
+    gc_ = torch.empty(8192, 8192, device=DEV, dtype=torch.bfloat16)
+    v0, i0 = lib.search(src, 4)
+    v0, i0 = v0.clone(), i0.clone()
+    bad = torch.zeros((), dtype=torch.int64, device=DEV)
+    side.wait_stream(torch.cuda.current_stream())
+    for rep in range(200):
+        with torch.cuda.stream(side):
+            torch.mm(ga, gb, out=gc_)
+        v, i = lib.search(src, 4)
+        bad += (v != v0).any() | (i != i0).any()
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0, f"{int(bad.item())} of 200 searches differ from the first"

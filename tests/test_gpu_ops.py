@@ -719,6 +719,62 @@ def test_fused_filter_blocks_are_deterministic_at_batch_scale(c, l):
             assert torch.equal(out, first), f"launch {rep} differs from the first"
 
 
+@pytest.mark.parametrize("c", [64, -64, 16, 8])
+def test_guarded_mfma_kernels_soak_under_a_concurrent_matrix_load(c):
+    """Round 6: the accumulation-chain hazard of DESIGN 3.2b' has no root cause -- the stand-alone probe does not
+    reproduce it -- so the conservative fence (ALIVE_CHAIN_GAP, enforced on the listings at build time) gets a second, independent
+    check at run time: every fused FilterBlock that rests on it runs 1000 launches at a window batch that fills a fraction of the chip
+    (24 windows) and 400 at the bench's (128), while a side stream keeps the matrix pipes and the power budget busy with large bf16
+    GEMMs (the clock the chip holds under load moves by 20 %: MI355X_MICROARCH.md, DVFS give-back) -- every launch bitwise the first.
+    Mismatches are counted on the device; one synchronisation per shape."""
+    plain, c = c < 0, abs(c)
+    from module import _native as nat
+    L_ = nat.lib()
+    lf, l = 450, {64: 36000, 16: 72000, 8: 144000}[c]
+    side = torch.cuda.Stream()
+    ga = torch.randn(8192, 8192, device=DEV, dtype=torch.bfloat16)
+    gb = torch.randn(8192, 8192, device=DEV, dtype=torch.bfloat16)
+    gc_ = torch.empty(8192, 8192, device=DEV, dtype=torch.bfloat16)
+    for N, reps in ((24, 1000), (128, 400)):
+        gen = torch.Generator(device=DEV).manual_seed(3 + N)
+        film = torch.randn(N, 4128, lf, device=DEV, generator=gen)
+        x = torch.randn(N, c, l, device=DEV, generator=gen)
+        skip = torch.randn(N, c, l, device=DEV, generator=gen)
+        out = torch.empty_like(x)
+        st = torch.cuda.current_stream().cuda_stream
+        if c == 64:
+            w = (torch.randn(L_.alive_filter_block64_weights(), device=DEV, generator=gen) * 0.05).to(torch.bfloat16)
+            b = torch.randn(7, 64, device=DEV, generator=gen) * 0.1
+            fn = L_.alive_filter_block64_range_fp16 if plain else L_.alive_filter_block64_range
+
+            def run():
+                nat.check(fn(x.data_ptr(), N, l, w.data_ptr(), b.data_ptr(), film.data_ptr(), 4128, lf, 3072, 0, 0, lf, skip.data_ptr(),
+                             out.data_ptr(), st))
+        else:
+            nw = L_.alive_filter_block_small_weights(c)
+            w = (torch.cat([torch.randn(224, device=DEV, generator=gen) * 0.1,
+                           (torch.randn(2 * (nw - 224), device=DEV, generator=gen) * 0.1).to(torch.bfloat16).view(torch.int16).view(torch.float32)]).contiguous())
+
+            def run():
+                nat.check(L_.alive_filter_block_small(x.data_ptr(), N, c, l, w.data_ptr(), film.data_ptr(), 4128, lf, 100, skip.data_ptr(),
+                                                      out.data_ptr(), st))
+        run()
+        first = out.clone()
+        assert torch.isfinite(first).all()
+        bad = torch.zeros((), dtype=torch.int64, device=DEV)
+        side.wait_stream(torch.cuda.current_stream())
+        for rep in range(reps):
+            if rep % 2 == 0:                                       # (one 1.1-TFLOP GEMM ~ 1 ms: a steady load beside every launch)
+                with torch.cuda.stream(side):
+                    torch.mm(ga, gb, out=gc_)
+            out.zero_()
+            run()
+            bad += (out != first).any()
+        torch.cuda.synchronize()
+        assert int(bad.item()) == 0, f"C = {c}{' (fp16 form)' if plain else ''}, {N} windows: {int(bad.item())} of {reps} launches differ from the first"
+        del film, x, skip, out, first
+
+
 def test_operators_write_only_their_outputs(monkeypatch):
     """every tensor an operator wrapper allocates for the C ABI (module/ops.py: outputs and plane buffers) is placed between
     two guard bands; after a battery of ragged shapes through alive_conv1d (fp32 / split / transposed / strided / skinny),
