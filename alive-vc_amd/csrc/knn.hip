@@ -37,6 +37,72 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// x / n for the operands the exact tiers divide -- the rows and norms of a packed library: finite, normal range, n > 0 (zero-norm rows
+// are refused when a library is packed).  This IS the fp32 division hipcc expands `x / n` into (v_rcp_f32, one Newton step on the
+// reciprocal, the quotient with two residual corrections) WITHOUT its v_div_scale / v_div_fmas / v_div_fixup steps, which only act on
+// operands near the ends of the exponent range: bit for bit the IEEE quotient for every operand pair these kernels see, at 5 fused
+// operations per element and 3 per divisor instead of 11 + a quarter-rate reciprocal per element (round 6: the rescoring kernel spent
+// 2 400 of its ~7 000 vector instructions per frame in divisions).  ONE helper for knn_rescore_kernel, knn_exact_kernel and
+// knn_scan_kernel: their values must agree bitwise with each other.
+struct NormDiv {
+    float n, y;
+};
+__device__ __forceinline__ NormDiv norm_div(float n) {
+    float y = __builtin_amdgcn_rcpf(n);
+    const float e = fmaf(-n, y, 1.0f);
+    y = fmaf(e, y, y);
+    return NormDiv{n, y};
+}
+__device__ __forceinline__ float div_by(float x, const NormDiv& d) {
+    float q = x * d.y;
+    float r = fmaf(-d.n, q, x);
+    q = fmaf(r, d.y, q);
+    r = fmaf(-d.n, q, x);
+    return fmaf(r, d.y, q);
+}
+
+// DPP forms of the order-independent wave reductions (max / min): no LDS permutes (a __shfl_xor is a ds_bpermute_b32: the rescoring
+// kernel issued ~650 of them per frame).  row = 16 consecutive lanes.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+// min over aligned groups of 8 (LEN8) or 16 lanes, in every lane of the group
+template <bool LEN16>
+__device__ __forceinline__ float group_min(float v) {
+    v = fminf(v, dpp_f<DPP_XOR1>(v));
+    v = fminf(v, dpp_f<DPP_XOR2>(v));
+    v = fminf(v, dpp_f<DPP_HALF_MIRROR>(v));
+    if (LEN16) v = fminf(v, dpp_f<DPP_MIRROR>(v));
+    return v;
+}
+__device__ __forceinline__ float wave_max_u(float v) {          // wave-uniform maximum
+    v = fmaxf(v, dpp_f<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f<DPP_MIRROR>(v));
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+__device__ __forceinline__ unsigned wave_min_u(unsigned v) {    // wave-uniform minimum of unsigned values
+    unsigned o;
+    o = dpp_u<DPP_XOR1>(v); v = o < v ? o : v;
+    o = dpp_u<DPP_XOR2>(v); v = o < v ? o : v;
+    o = dpp_u<DPP_HALF_MIRROR>(v); v = o < v ? o : v;
+    o = dpp_u<DPP_MIRROR>(v); v = o < v ? o : v;
+    const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    const unsigned a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+    return a < b ? a : b;
+}
+
 // ----------------------------------------------------------------------------------------------
 // packing
 // ----------------------------------------------------------------------------------------------
@@ -320,6 +386,7 @@ constexpr int SCORE_LDS = 2 * ABUF + FT * KP * 8;   // 143360 B
 
 // Fallback kernels of the fp8 search are launched unconditionally (no host sync) and decide on the device whether they
 // have work: active iff lo < *cnt <= hi (cnt = number of frames whose fp8 candidate set could not be certified).
+constexpr int GATE_BOOL = -2;             // knn_rescore_kernel: gate_lo value that makes gate_cnt an on / off word
 __device__ __forceinline__ bool gate_open(const int* cnt, int lo, int hi, int& c) {
     c = 0x7fffffff;
     if (cnt == nullptr) return true;
@@ -1358,8 +1425,8 @@ __global__ __launch_bounds__(256, 1) void knn_score8_kernel(const unsigned char*
 }
 __global__ __launch_bounds__(256, 1) void knn_probe8_kernel(const unsigned char* __restrict__ s_f8, const unsigned char* __restrict__ lib,
                                                             int64_t M, int tiles_total, int tiles_per_split, int P,
-                                                            float* __restrict__ cand_val, int* __restrict__ cand_idx) {
-    knn_score8_body<0, 2>(s_f8, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, nullptr, 0, 0, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr});
+                                                            float* __restrict__ cand_val, int* __restrict__ cand_idx, const int* __restrict__ gate) {
+    knn_score8_body<0, 2>(s_f8, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, gate, 0, 1, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr});
 }
 // the fp6 stage (round 5): e2m3 operands on both sides, three column tiles per wave
 __global__ __launch_bounds__(256, 1) void knn_score6_kernel(const unsigned char* __restrict__ s_f6, const unsigned char* __restrict__ lib,
@@ -1370,13 +1437,47 @@ __global__ __launch_bounds__(256, 1) void knn_score6_kernel(const unsigned char*
 }
 __global__ __launch_bounds__(256, 1) void knn_probe6_kernel(const unsigned char* __restrict__ s_f6, const unsigned char* __restrict__ lib,
                                                             int64_t M, int tiles_total, int tiles_per_split, int P,
-                                                            float* __restrict__ cand_val, int* __restrict__ cand_idx) {
-    knn_score8_body<2, 3>(s_f6, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, nullptr, 0, 0, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr});
+                                                            float* __restrict__ cand_val, int* __restrict__ cand_idx, const int* __restrict__ gate) {
+    knn_score8_body<2, 3>(s_f6, lib, M, tiles_total, tiles_per_split, P, cand_val, cand_idx, gate, 0, 1, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr});
 }
 
 // ----------------------------------------------------------------------------------------------
 // exact fp32 rescoring + top-k  (one wave per frame)
 // ----------------------------------------------------------------------------------------------
+// Wave sums of G per-lane partials at once, bitwise equal to G calls of wave_sum (the xor tree 32, 16, 8, 4, 2, 1):
+// in the first log2(G) levels a lane keeps half of its values and hands the other half to its partner (own + partner's,
+// the operands of wave_sum's add at that level), so G values cost G - 1 + (6 - log2 G) shuffles instead of 6 G.
+// Returns the total of frame t = lane / (64 / G) (the 64 / G lanes of that group all hold it).
+template <int G>
+__device__ __forceinline__ float wave_sum_frames(float (&d)[G], int lane) {
+    if constexpr (G >= 16) {
+        const bool up = lane & 32;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = (up ? d[8 + j] : d[j]) + __shfl_xor(up ? d[j] : d[8 + j], 32);
+    }
+    if constexpr (G >= 8) {
+        constexpr int o = G >= 16 ? 16 : 32;
+        const bool up = lane & o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = (up ? d[4 + j] : d[j]) + __shfl_xor(up ? d[j] : d[4 + j], o);
+    }
+    if constexpr (G >= 4) {
+        constexpr int o = G >= 16 ? 8 : (G >= 8 ? 16 : 32);
+        const bool up = lane & o;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) d[j] = (up ? d[2 + j] : d[j]) + __shfl_xor(up ? d[j] : d[2 + j], o);
+    }
+    if constexpr (G >= 2) {
+        constexpr int o = G >= 16 ? 4 : (G >= 8 ? 8 : (G >= 4 ? 16 : 32));
+        const bool up = lane & o;
+        d[0] = (up ? d[1] : d[0]) + __shfl_xor(up ? d[0] : d[1], o);
+    }
+    float v = d[0];
+#pragma unroll
+    for (int o = 32 / G; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
 // (value desc, index asc) ordering, wave-wide argmax; returns the winning lane
 __device__ __forceinline__ int wave_argbest(float v, int idx) {
     float bv = v;
@@ -1393,6 +1494,19 @@ __device__ __forceinline__ int wave_argbest(float v, int idx) {
     return bl;
 }
 
+// Round 6: the kernel was the sum of three costs of about equal size that one wave per frame could not overlap -- ~7 000 vector
+// instructions per frame (4 000 of them in a 64-step argmax selection over sixteen-wide register arrays of which a 160-candidate frame
+// fills three, 2 400 in IEEE divisions), ~650 LDS permutes (every __shfl is a ds_bpermute_b32) and the 3-KB row gathers: 6.2 ms per
+// 172 800 frames where the gathers alone are worth ~2.  Now:
+//   * PER (template): candidates per lane, the size of the register arrays (R = P * kp <= 64 PER lanes);
+//   * the selection is a THRESHOLD, not a ranking: 16 removal steps over the lanes' running maxima (DPP reductions, no LDS) give the
+//     k-th and the 16th best stage score, everything at or above min(k-th - prune, 16th) is kept (the same set the ranking kept, plus
+//     ties), compacted to one candidate per lane through 512 B of LDS per wave; only a frame with more than 64 such rows takes the old
+//     ranking loop;
+//   * divisions by the norm through div_by (see there), four candidates' wave sums through wave_sum_frames (7 permutes instead of 24,
+//     bitwise the same sums), candidate broadcasts through v_readlane, the final top-k through DPP max / min.
+// Results are bit for bit what they were (same products, same summation trees, same tie-breaks).
+template <int PER>
 __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
                                                           int P, int kp, const float* __restrict__ s_f32,
                                                           const float* __restrict__ rows, const float* __restrict__ norms,
@@ -1406,10 +1520,17 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
                                                           const unsigned char* __restrict__ force_fail = nullptr) {
     // force_fail (fp6 stage): frames whose fp6 image clipped an element (|x| 2^5 > 7.5) -- their stage scores are off by more than
     // any error statistic of their candidates can show, so they go to the next tier whatever the certificate says
-    const int lane = threadIdx.x & 63;
-    const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // candidate lists are indexed by slot
+    __shared__ float cs_v[4][64];          // compaction of the selected candidates, one row per wave
+    __shared__ int cs_i[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t slot = (int64_t)blockIdx.x * 4 + wv;     // candidate lists are indexed by slot
     int gc;
-    if (!gate_open(gate_cnt, gate_lo, gate_hi, gc)) return;
+    if (gate_lo == GATE_BOOL) {            // an on / off word (the probe's history gate), not a count of listed frames
+        if (*gate_cnt == 0) return;
+        gc = 0x7fffffff;
+    } else if (!gate_open(gate_cnt, gate_lo, gate_hi, gc)) {
+        return;
+    }
     if (slot >= Tt || (frame_list != nullptr && slot >= gc)) return;
     const int64_t ft = frame_list != nullptr ? frame_list[slot] : slot;     // frame: source row and output row
     const int R = P * kp;                  // kp candidates per frame and split: KP (bf16 scoring) or KP8 (fp8 scoring)
@@ -1425,14 +1546,9 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
 
     // ---- candidate selection: this lane ends up with (at most) one candidate ----
     int my_idx = -1;
-    // smallest entry of each FULL partial list (16 consecutive entries; an empty slot holds -inf): rows that never entered
-    // (list_len consecutive entries: 16 behind the fp8 stage, 8 behind the bf16 stage)
-    auto list_floor = [&](float v) {
-        v = fminf(v, __shfl_xor(v, 1)); v = fminf(v, __shfl_xor(v, 2));
-        v = fminf(v, __shfl_xor(v, 4));
-        if (list_len > 8) v = fminf(v, __shfl_xor(v, 8));
-        return v;
-    };
+    // smallest entry of each FULL partial list (list_len consecutive entries = an aligned group of lanes: 16 behind the fp8 / fp6 stage,
+    // 8 behind the bf16 stage; an empty slot holds -inf, or the seed of a seeded list): rows that never entered
+    auto list_floor = [&](float v) { return list_len > 8 ? group_min<true>(v) : group_min<false>(v); };
     // Pruning (certified searches only): a candidate whose prefilter score lies more than 2 z sigma below the k-th best
     // prefilter score cannot reach the exact top-k unless two score errors beyond z sigma coincide; it is not rescored (a
     // 3-KB row gather saved: the kernel is bound by them) and counts, like every row that was never a candidate, into c_cut --
@@ -1446,7 +1562,7 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
     const float det_bound = det_q != nullptr ? det_q[ft] + 1.004f * det_lib[0] + 1.0e-4f : 0.0f;
     const float prune = !certify ? INFINITY
                                  : (det_q != nullptr ? 2.0f * det_bound : 2.0f * zsig * sd_prior) / pre_scale;     // in prefilter-score units
-    if (R <= 64) {
+    if constexpr (PER == 0) {              // R <= 64: one candidate per lane as it stands
         if (lane < R) my_idx = ci[lane];
         if (collect) {
             overflow = __builtin_amdgcn_ballot_w64(my_idx == -2) != 0;
@@ -1460,9 +1576,7 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
             // k-th and MIN_RESCORE-th largest prefilter score of the frame (wave-wide, by removal)
             float rest = my_pre, sk = -INFINITY, s16 = -INFINITY;
             for (int j = 0; j < MIN_RESCORE; ++j) {
-                float m = rest;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+                const float m = wave_max_u(rest);
                 if (j == k - 1) sk = m;
                 s16 = m;
                 const unsigned long long hit = __builtin_amdgcn_ballot_w64(rest == m && m > -INFINITY);
@@ -1476,54 +1590,112 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
             }
         }
     } else {
-        // keep the 64 best bf16 scores: R/64 candidates per lane in registers (R <= 1024)
-        float v[16];
-        int id[16];
-        const int per = (R + 63) / 64;
+        // R = P * kp <= 64 PER candidates, PER per lane in registers
+        float v[PER];
+        int id[PER];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            int e = j * 64 + lane;
-            bool in = (j < per) && (e < R);
+        for (int j = 0; j < PER; ++j) {
+            const int e = j * 64 + lane;
+            const bool in = e < R;
             v[j] = in ? cv[e] : -INFINITY;
             id[j] = in ? ci[e] : -1;
             if (collect && id[j] == -2) overflow = true;
             if (certify) c_cut = fmaxf(c_cut, list_floor(v[j]));       // empty entries included: -inf, or the seed of a seeded list
             if (id[j] < 0) v[j] = -INFINITY;
         }
-        float sk = -INFINITY;              // k-th best prefilter score of the frame
-        for (int sel = 0; sel < 64; ++sel) {
-            float bv = v[0];
-            int bj = 0;
+        // k-th and MIN_RESCORE-th best stage score of the frame, by removal from a working copy (one instance per step)
+        float t[PER];
 #pragma unroll
-            for (int j = 1; j < 16; ++j)
-                if (v[j] > bv) { bv = v[j]; bj = j; }
-            int bid = -1;
+        for (int j = 0; j < PER; ++j) t[j] = v[j];
+        float sk = -INFINITY, s16 = -INFINITY;
+        for (int it = 0; it < MIN_RESCORE; ++it) {
+            float lm = t[0];
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (j == bj) bid = id[j];
-            int win = wave_argbest(bv, bid);
-            int widx = __shfl(bid, win);
-            float wval = __shfl(bv, win);
-            if (sel == k - 1) sk = wval;
-            if (!(wval > -INFINITY)) break;                            // wave-uniform: no candidate left
-            if (sel >= MIN_RESCORE && wval < sk - prune) break;        // wave-uniform: the rest stays in v[] and counts into c_cut
-            if (lane == sel) { my_idx = (wval > -INFINITY) ? widx : -1; my_pre = wval; }
-            if (lane == win) {
+            for (int j = 1; j < PER; ++j) lm = fmaxf(lm, t[j]);
+            const float m = wave_max_u(lm);
+            if (it == k - 1) sk = m;
+            s16 = m;
+            if (!(m > -INFINITY)) break;                               // wave-uniform: fewer candidates than that
+            const unsigned long long hit = __builtin_amdgcn_ballot_w64(lm == m);
+            if (lane == (int)__builtin_ctzll(hit)) {
+                bool done = false;
 #pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    if (j == bj) v[j] = -INFINITY;
+                for (int j = 0; j < PER; ++j) {
+                    const bool here = !done && t[j] == m;
+                    t[j] = here ? -INFINITY : t[j];
+                    done = done || here;
+                }
             }
         }
-        if (certify) {                     // candidates the selection of 64 left behind
+        const float cut = fminf(sk - prune, s16);                      // (-inf when fewer than MIN_RESCORE candidates exist, or nothing is pruned)
+        bool sel[PER];
+        int total = 0;
+        unsigned long long msk[PER];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) c_cut = fmaxf(c_cut, v[j]);
+        for (int j = 0; j < PER; ++j) {
+            sel[j] = id[j] >= 0 && v[j] >= cut;
+            msk[j] = __builtin_amdgcn_ballot_w64(sel[j]);
+            total += (int)__builtin_popcountll(msk[j]);
         }
-        if (collect) {                     // collected rows that did not fit the 64 lanes: the frame goes to the exact scan
-            float left = -INFINITY;
+        if (total <= 64) {                                             // wave-uniform
+            int base = 0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) left = fmaxf(left, v[j]);
-            overflow = __builtin_amdgcn_ballot_w64(overflow || left > -INFINITY) != 0;
+            for (int j = 0; j < PER; ++j) {
+                const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(msk[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)msk[j], 0u));
+                if (sel[j]) {
+                    cs_v[wv][pos] = v[j];
+                    cs_i[wv][pos] = id[j];
+                } else if (certify) {
+                    c_cut = fmaxf(c_cut, v[j]);                        // a candidate the cut left behind
+                }
+                base += (int)__builtin_popcountll(msk[j]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // (one wave writes and reads its own row: LDS operations of a wave complete in order)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (lane < total) {
+                my_idx = cs_i[wv][lane];
+                my_pre = cs_v[wv][lane];
+            }
+        } else {
+            // more than 64 rows at or above the cut (clusters of near-copies; every collect launch of a crowded frame): the 64 best by
+            // stage score, one argmax per step
+            float skr = -INFINITY;
+            for (int selr = 0; selr < 64; ++selr) {
+                float bv = v[0];
+                int bj = 0;
+#pragma unroll
+                for (int j = 1; j < PER; ++j)
+                    if (v[j] > bv) { bv = v[j]; bj = j; }
+                int bid = -1;
+#pragma unroll
+                for (int j = 0; j < PER; ++j)
+                    if (j == bj) bid = id[j];
+                const int win = wave_argbest(bv, bid);
+                const int widx = __shfl(bid, win);
+                const float wval = __shfl(bv, win);
+                if (selr == k - 1) skr = wval;
+                if (!(wval > -INFINITY)) break;                        // wave-uniform: no candidate left
+                if (selr >= MIN_RESCORE && wval < skr - prune) break;  // wave-uniform: the rest stays in v[] and counts into c_cut
+                if (lane == selr) { my_idx = (wval > -INFINITY) ? widx : -1; my_pre = wval; }
+                if (lane == win) {
+#pragma unroll
+                    for (int j = 0; j < PER; ++j)
+                        if (j == bj) v[j] = -INFINITY;
+                }
+            }
+            if (certify) {                 // candidates the selection of 64 left behind
+#pragma unroll
+                for (int j = 0; j < PER; ++j) c_cut = fmaxf(c_cut, v[j]);
+            }
+            if (collect) {                 // collected rows that did not fit the 64 lanes: the frame goes to the exact scan
+                float left = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < PER; ++j) left = fmaxf(left, v[j]);
+                overflow = __builtin_amdgcn_ballot_w64(overflow || left > -INFINITY) != 0;
+            }
         }
+        if (collect) overflow = __builtin_amdgcn_ballot_w64(overflow) != 0;
     }
     if (collect) {
         // the frame's current exact top-k joins the candidates (its rows lie at or above the threshold and are collected again
@@ -1546,13 +1718,15 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
     f32x4 s0 = sp[lane], s1 = sp[lane + 64], s2 = sp[lane + 128];
     float my_score = -INFINITY;
     // four candidates per trip: their 3-KB rows are requested together (one wave per frame: a serial walk pays one
-    // gather latency per candidate)
-    for (int c0 = 0; c0 < 64; c0 += 4) {
+    // gather latency per candidate); lanes past the last candidate are not visited
+    const unsigned long long have = __builtin_amdgcn_ballot_w64(my_idx >= 0);
+    const int hi = have == 0 ? 0 : 64 - (int)__builtin_clzll(have);
+    for (int c0 = 0; c0 < hi; c0 += 4) {
         int idx[4];
         bool any = false;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            idx[u] = __shfl(my_idx, c0 + u);
+            idx[u] = __builtin_amdgcn_readlane(my_idx, c0 + u);
             any |= idx[u] >= 0;
         }
         if (!any) continue;                              // wave-uniform
@@ -1567,18 +1741,24 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
             r2[u] = rp[lane + 128];
             nn[u] = norms[ii];
         }
+        float d4[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (idx[u] < 0) continue;                    // wave-uniform
+            const NormDiv nd = norm_div(nn[u]);
             float p = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) p = fmaf(s0[j], r0[u][j] / nn[u], p);
+            for (int j = 0; j < 4; ++j) p = fmaf(s0[j], div_by(r0[u][j], nd), p);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) p = fmaf(s1[j], r1[u][j] / nn[u], p);
+            for (int j = 0; j < 4; ++j) p = fmaf(s1[j], div_by(r1[u][j], nd), p);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) p = fmaf(s2[j], r2[u][j] / nn[u], p);
-            p = wave_sum(p);
-            if (lane == c0 + u) my_score = p;
+            for (int j = 0; j < 4; ++j) p = fmaf(s2[j], div_by(r2[u][j], nd), p);
+            d4[u] = p;
+        }
+        const int tot = __builtin_bit_cast(int, wave_sum_frames<4>(d4, lane));     // candidate u's sum in lanes 16 u .. 16 u + 15
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float p = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tot, 16 * u));
+            if (idx[u] >= 0 && lane == c0 + u) my_score = p;
         }
     }
 
@@ -1593,30 +1773,33 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
     if (certify) {
         const bool okc = my_idx >= 0 && my_score > -INFINITY;
         const float e = okc ? my_pre * pre_scale - my_score : 0.0f;
-        const float n = wave_sum(okc ? 1.0f : 0.0f);
-        err_mu = fminf(wave_sum(e) / fmaxf(n, 1.0f), 0.0f);
-        err_sd = fmaxf(sqrtf(wave_sum(e * e) / fmaxf(n, 1.0f)), sd_prior);      // never below the stage's typical error
-        err_max = fabsf(e);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) err_max = fmaxf(err_max, __shfl_xor(err_max, o));
-        c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 16));
-        c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 32));
-        c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 1)); c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 2));
-        c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 4)); c_cut = fmaxf(c_cut, __shfl_xor(c_cut, 8));
+        float st3[4] = {okc ? 1.0f : 0.0f, e, e * e, 0.0f};
+        // (three wave sums at once; each group of 16 lanes ends up with one of them)
+        const int tot = __builtin_bit_cast(int, wave_sum_frames<4>(st3, lane));
+        const float n = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tot, 0));
+        const float se = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tot, 16));
+        const float see = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tot, 32));
+        err_mu = fminf(se / fmaxf(n, 1.0f), 0.0f);
+        err_sd = fmaxf(sqrtf(see / fmaxf(n, 1.0f)), sd_prior);      // never below the stage's typical error
+        err_max = wave_max_u(fabsf(e));
+        c_cut = wave_max_u(c_cut);
     }
 
-    // ---- exact top-k, descending, ties to the lower library index ----
+    // ---- exact top-k, descending, ties to the lower library index (then to the lower lane) ----
     float vk = -INFINITY;
     for (int j = 0; j < k; ++j) {
-        int win = wave_argbest(my_score, my_idx < 0 ? 0x7fffffff : my_idx);
-        float wv = __shfl(my_score, win);
-        int wi = __shfl(my_idx, win);
+        const float wv_ = wave_max_u(my_score);
+        const unsigned key = (my_score == wv_) ? (unsigned)(my_idx < 0 ? 0x7fffffff : my_idx) : 0xffffffffu;
+        const unsigned wi_u = wave_min_u(key);
+        const unsigned long long winm = __builtin_amdgcn_ballot_w64(key == wi_u && my_score == wv_);
+        const int win = winm != 0 ? (int)__builtin_ctzll(winm) : 0;
+        const int wi = (wi_u == 0x7fffffffu || wi_u == 0xffffffffu) ? -1 : (int)wi_u;
         if (lane == 0) {
-            out_val[(size_t)ft * k + j] = wv;
-            out_idx[(size_t)ft * k + j] = (wi < 0 || !(wv > -INFINITY)) ? -1 : (int)(idx_base + wi);
+            out_val[(size_t)ft * k + j] = wv_;
+            out_idx[(size_t)ft * k + j] = (wi < 0 || !(wv_ > -INFINITY)) ? -1 : (int)(idx_base + wi);
         }
         if (lane == win) my_score = -INFINITY;
-        vk = wv;
+        vk = wv_;
     }
     // A row outside the rescored set has prefilter score <= c_cut, hence (prefilter = exact + error, error ~ (mu, sd) as
     // measured on this frame's own candidates) an exact score below c_cut - mu + z sd except in the z-sigma tail.  If the
@@ -1643,6 +1826,17 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
         flag_list[pos] = (int)ft;
         if (thr_list != nullptr) thr_list[pos] = vk - overflow_slack;
     }
+}
+
+// PER from the candidate count of a launch: R = P * kp <= 64 PER
+template <typename... A>
+static void rescore_launch(unsigned grid, hipStream_t s, const float* cv, const int* ci, int P, int kp, A... rest) {
+    const int R = P * kp;
+    if (R <= 64) knn_rescore_kernel<0><<<grid, 256, 0, s>>>(cv, ci, P, kp, rest...);
+    else if (R <= 192) knn_rescore_kernel<3><<<grid, 256, 0, s>>>(cv, ci, P, kp, rest...);
+    else if (R <= 256) knn_rescore_kernel<4><<<grid, 256, 0, s>>>(cv, ci, P, kp, rest...);
+    else if (R <= 512) knn_rescore_kernel<8><<<grid, 256, 0, s>>>(cv, ci, P, kp, rest...);
+    else knn_rescore_kernel<16><<<grid, 256, 0, s>>>(cv, ci, P, kp, rest...);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1694,8 +1888,9 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void knn_scan_kernel(const float* 
             nn = norms[r];
             q0 = rp[lane]; q1 = rp[lane + 64]; q2 = rp[lane + 128];
         }
+        const NormDiv nd = norm_div(nn);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { q0[j] = q0[j] / nn; q1[j] = q1[j] / nn; q2[j] = q2[j] / nn; }
+        for (int j = 0; j < 4; ++j) { q0[j] = div_by(q0[j], nd); q1[j] = div_by(q1[j], nd); q2[j] = div_by(q2[j], nd); }
         float p = -INFINITY;                             // the score of this lane's frame (the wave sum is lane-uniform)
         for (int t = 0; t < Tt; ++t) {
             const f32x4* sp = (const f32x4*)(s_f32 + (size_t)t * D);
@@ -1932,40 +2127,6 @@ static size_t exact_lists(int64_t frames, int k) {
     return (size_t)(a > b ? a : b) + 4;
 }
 
-// Wave sums of G per-lane partials at once, bitwise equal to G calls of wave_sum (the xor tree 32, 16, 8, 4, 2, 1):
-// in the first log2(G) levels a lane keeps half of its values and hands the other half to its partner (own + partner's,
-// the operands of wave_sum's add at that level), so G values cost G - 1 + (6 - log2 G) shuffles instead of 6 G.
-// Returns the total of frame t = lane / (64 / G) (the 64 / G lanes of that group all hold it).
-template <int G>
-__device__ __forceinline__ float wave_sum_frames(float (&d)[G], int lane) {
-    if constexpr (G >= 16) {
-        const bool up = lane & 32;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) d[j] = (up ? d[8 + j] : d[j]) + __shfl_xor(up ? d[j] : d[8 + j], 32);
-    }
-    if constexpr (G >= 8) {
-        constexpr int o = G >= 16 ? 16 : 32;
-        const bool up = lane & o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) d[j] = (up ? d[4 + j] : d[j]) + __shfl_xor(up ? d[j] : d[4 + j], o);
-    }
-    if constexpr (G >= 4) {
-        constexpr int o = G >= 16 ? 8 : (G >= 8 ? 16 : 32);
-        const bool up = lane & o;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) d[j] = (up ? d[2 + j] : d[j]) + __shfl_xor(up ? d[j] : d[2 + j], o);
-    }
-    if constexpr (G >= 2) {
-        constexpr int o = G >= 16 ? 4 : (G >= 8 ? 8 : (G >= 4 ? 16 : 32));
-        const bool up = lane & o;
-        d[0] = (up ? d[1] : d[0]) + __shfl_xor(up ? d[0] : d[1], o);
-    }
-    float v = d[0];
-#pragma unroll
-    for (int o = 32 / G; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
 template <int G>
 __global__ __launch_bounds__(256, 2) void knn_exact_kernel(const float* __restrict__ s_f32, const float* __restrict__ rows,
                                                         const float* __restrict__ norms, int64_t M, int64_t Tt, int k,
@@ -2010,8 +2171,9 @@ __global__ __launch_bounds__(256, 2) void knn_exact_kernel(const float* __restri
                 n0 = rp[lane]; n1 = rp[lane + 64]; n2 = rp[lane + 128];
                 nnn = norms[r + nw];
             }
+            const NormDiv nd = norm_div(nn);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { q0[j] = q0[j] / nn; q1[j] = q1[j] / nn; q2[j] = q2[j] / nn; }
+            for (int j = 0; j < 4; ++j) { q0[j] = div_by(q0[j], nd); q1[j] = div_by(q1[j], nd); q2[j] = div_by(q2[j], nd); }
             float d[G];
 #pragma unroll
             for (int t = 0; t < G; ++t) {
@@ -2115,20 +2277,44 @@ constexpr int RESEARCH_MIN = 64;          // frames failing the fp8 certificate:
                                           // against ~0.75 ms per group of 64 / k frames of exact scan.  256 was tried: at k = 8 the 178
                                           // frames of the bench batch then cost 111.5 instead of 104.9 ms per search)
 enum { ST_FLAG8 = 0, ST_FLAG16 = 1, ST_PROBE_N = 2, ST_PROBE_FAIL = 3, ST_MODE = 4, ST_FIRST = 5, ST_PROBE_CNT = 6, ST_TIER = 7, ST_FLAGC = 8, ST_SEEDED = 9, ST_SEEDED16 = 10, ST_RESEARCH_MIN = 11, ST_COLLECT_MIN = 12,
-       ST_WORDS = 16 };
+       ST_PROBE_SKIPPED = 13,
+       // Probe history (round 6), kept in the CALLER'S workspace across calls and never reset by a search: the probe costs 1.8 ms per
+       // 172 800-frame search and says the same thing every time a library is searched with frames of one kind.  After two consecutive
+       // searches on this workspace (same library size, same frame count: ST_HIST_TAG) in which the probe chose the low-precision stage
+       // and fewer than 5 % of the batch then failed its certificate, the probe runs on every 16th search only; any search that breaks
+       // the pattern re-arms it.  A fresh or foreign workspace (tag mismatch) always probes.  The history changes which tier a frame
+       // is answered by, never the answer.
+       ST_HIST_TAG = 16, ST_HIST_STREAK = 17, ST_HIST_CALLS = 18, ST_PROBE_GATE = 19,
+       ST_WORDS = 32 };
+constexpr int PROBE_EVERY = 16, PROBE_STREAK = 2;
 // ST_TIER: which path the last search on this workspace took (written by every path, so that the host never has to
 // re-derive the dispatch): 1 = streaming scan, 2 = exact scan of every frame (k > 8), 3 = bf16 first, 4 = fp8 first
 enum { TIER_SCAN = 1, TIER_EXACT_ALL = 2, TIER_BF16 = 3, TIER_FP8 = 4, TIER_FP6 = 5 };
-__global__ void stats_init_kernel(int* __restrict__ stats, int tier) {
+__global__ void stats_init_kernel(int* __restrict__ stats, int tier, int hist_tag = 0) {
     // (the two tier limits are written out with the counters, so that a reader never repeats the constants)
-    if (threadIdx.x < ST_WORDS)
+    if (threadIdx.x < ST_HIST_TAG)
         stats[threadIdx.x] = threadIdx.x == ST_TIER ? tier
                            : threadIdx.x == ST_RESEARCH_MIN ? RESEARCH_MIN : threadIdx.x == ST_COLLECT_MIN ? COLLECT_MIN : 0;
+    if (threadIdx.x == ST_HIST_TAG) {                 // one thread owns the history words (see the enum)
+        const bool valid = hist_tag != 0 && stats[ST_HIST_TAG] == hist_tag;
+        const int streak = valid ? stats[ST_HIST_STREAK] : 0, calls = valid ? stats[ST_HIST_CALLS] : 0;
+        const bool skip = streak >= PROBE_STREAK && (calls % PROBE_EVERY) != 0;
+        stats[ST_HIST_TAG] = hist_tag;
+        stats[ST_HIST_STREAK] = streak;
+        stats[ST_HIST_CALLS] = calls + 1;
+        stats[ST_PROBE_GATE] = skip ? 0 : 1;
+        stats[ST_PROBE_SKIPPED] = skip ? 1 : 0;
+    }
 }
-
-// the sample of the probe: n frames at a fixed stride through the batch (rows of s_f8 copied, padded to a block of 256)
+// end of a low-precision-first search: did it go the way the probe (or the history) said it would?
+__global__ void probe_history_kernel(int* __restrict__ stats, int64_t Tt) {
+    const bool clean = stats[ST_MODE] == 0 && (int64_t)stats[ST_FLAG8] * 20 <= Tt &&
+                       (stats[ST_PROBE_GATE] == 0 || (int64_t)stats[ST_PROBE_FAIL] * 4 <= (int64_t)stats[ST_PROBE_N]);
+    stats[ST_HIST_STREAK] = clean ? stats[ST_HIST_STREAK] + 1 : 0;
+}
 __global__ __launch_bounds__(64) void probe_gather_kernel(const unsigned char* __restrict__ s_f8, int64_t Tt, int n, int n_pad,
-                                                          unsigned char* __restrict__ out, int* __restrict__ plist) {
+                                                          unsigned char* __restrict__ out, int* __restrict__ plist, const int* __restrict__ gate) {
+    if (*gate == 0) return;                            // the history says this search needs no probe
     const int slot = blockIdx.x;
     if (slot >= n_pad) return;
     u32x4 v = {0u, 0u, 0u, 0u};
@@ -2142,6 +2328,7 @@ __global__ __launch_bounds__(64) void probe_gather_kernel(const unsigned char* _
 
 // mode = 1 (bf16 first) iff the fp8 certificate failed on more than `num / den` of the probe sample
 __global__ void probe_decide_kernel(int* __restrict__ stats, int n, int num, int den) {
+    if (stats[ST_PROBE_GATE] == 0) return;             // no probe ran: ST_MODE stays 0 (the low-precision stage first), ST_PROBE_N 0
     const int fail = stats[ST_PROBE_CNT];
     stats[ST_PROBE_N] = n;
     stats[ST_PROBE_FAIL] = fail;
@@ -2475,7 +2662,7 @@ static void collect_tier_launch(const SearchWs& w, const void* lib_bf16, const f
         knn_collect_split_kernel<<<dim3(Tp / FT2, w.p16.split), 256, SPLIT_LDS, s>>>(
             w.s_c2h, w.s_c2l, (const unsigned short*)lib_bf16, w.lib_lo, M, w.p16.tiles_total, w.p16.tiles_per_split, w.p16.P, caps,
             w.c2v, w.c2i, cnt1, COLLECT_MIN, w.thr1);
-        knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.c2v, w.c2i, w.p16.P, caps, w.s_f32, rows_f32, norms, Tt, idx_base, k,
+        rescore_launch((unsigned)((Tt + 3) / 4), s, w.c2v, w.c2i, w.p16.P, caps, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                    out_val, out_idx, w.list1, cnt1, COLLECT_MIN, 0x7fffffff, w.list2, cnt2,
                                                                    CERT_Z, KH, 1.0f, SD_PRIOR16, nullptr, nullptr, nullptr, 1, 0.0f);
         knn_exact_launch(w, rows_f32, norms, M, Tt, idx_base, k, w.list2, cnt2, out_val, out_idx, s);
@@ -2489,7 +2676,7 @@ static void collect_tier_launch(const SearchWs& w, const void* lib_bf16, const f
     knn_score_kernel<true><<<dim3((unsigned)(fcap / FT), w.pt.split), 256, SCORE_LDS, s>>>(
         w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.c2v, w.c2i, cnt1, COLLECT_MIN, fcap, 1,
         w.thr1, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr}, caps_t);
-    knn_rescore_kernel<<<(unsigned)((fcap + 3) / 4), 256, 0, s>>>(w.c2v, w.c2i, w.pt.P, caps_t, w.s_f32, rows_f32, norms, fcap, idx_base, k,
+    rescore_launch((unsigned)((fcap + 3) / 4), s, w.c2v, w.c2i, w.pt.P, caps_t, w.s_f32, rows_f32, norms, fcap, idx_base, k,
                                                                  out_val, out_idx, w.list1, cnt1, COLLECT_MIN, fcap, w.list2, cnt2, CERT_Z,
                                                                  KH, 1.0f, SD_PRIOR16, nullptr, nullptr, nullptr, 1, 0.0f);
     if (w.p16.Tt_pad > fcap) {
@@ -2497,7 +2684,7 @@ static void collect_tier_launch(const SearchWs& w, const void* lib_bf16, const f
         knn_score_kernel<true><<<dim3((unsigned)(w.p16.Tt_pad / FT), w.p16.split), 256, SCORE_LDS, s>>>(
             w.s_c, (const unsigned short*)lib_bf16, M, w.p16.tiles_total, w.p16.tiles_per_split, w.p16.P, w.c2v, w.c2i, cnt1, fcap,
             0x7fffffff, 1, w.thr1, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr}, caps_b);
-        knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.c2v, w.c2i, w.p16.P, caps_b, w.s_f32, rows_f32, norms, Tt, idx_base, k,
+        rescore_launch((unsigned)((Tt + 3) / 4), s, w.c2v, w.c2i, w.p16.P, caps_b, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                    out_val, out_idx, w.list1, cnt1, fcap, 0x7fffffff, w.list2, cnt2,
                                                                    CERT_Z, KH, 1.0f, SD_PRIOR16, nullptr, nullptr, nullptr, 1, 0.0f);
     }
@@ -2524,13 +2711,13 @@ static void bf16_tiers_launch(const SearchWs& w, const void* lib_bf16, const flo
     gather_frames_kernel<<<(unsigned)t1a, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, RESEARCH_MIN, t1a, w.s_c);
     knn_score_kernel<false><<<dim3(1, w.pa.split), 256, SCORE_LDS, s>>>(
         w.s_c, (const unsigned short*)lib_bf16, M, w.pa.tiles_total, w.pa.tiles_per_split, w.pa.P, w.cv1, w.ci1, cnt0, RESEARCH_MIN, t1a, 1, nullptr, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr}, 0);
-    knn_rescore_kernel<<<(unsigned)((t1a + 3) / 4), 256, 0, s>>>(w.cv1, w.ci1, w.pa.P, KP, w.s_f32, rows_f32, norms, t1a, idx_base, k,
+    rescore_launch((unsigned)((t1a + 3) / 4), s, w.cv1, w.ci1, w.pa.P, KP, w.s_f32, rows_f32, norms, t1a, idx_base, k,
                                                                 out_val, out_idx, w.list0, cnt0, RESEARCH_MIN, t1a, w.list1, cnt1, CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0, w.lib_lo != nullptr ? SPLIT_BOUND : 0.0f);
     if (fcap > t1a) {
     gather_frames_kernel<<<(unsigned)fcap, 128, 0, s>>>(w.s_bf16, w.list0, cnt0, t1a, fcap, w.s_c);
     knn_score_kernel<false><<<dim3((unsigned)(fcap / FT), w.pt.split), 256, SCORE_LDS, s>>>(
         w.s_c, (const unsigned short*)lib_bf16, M, w.pt.tiles_total, w.pt.tiles_per_split, w.pt.P, w.cv1, w.ci1, cnt0, t1a, fcap, 1, nullptr, SeedArgs{nullptr, nullptr, 0, 0.0f, nullptr}, 0);
-    knn_rescore_kernel<<<(unsigned)((fcap + 3) / 4), 256, 0, s>>>(w.cv1, w.ci1, w.pt.P, KP, w.s_f32, rows_f32, norms, fcap, idx_base, k,
+    rescore_launch((unsigned)((fcap + 3) / 4), s, w.cv1, w.ci1, w.pt.P, KP, w.s_f32, rows_f32, norms, fcap, idx_base, k,
                                                                  out_val, out_idx, w.list0, cnt0, t1a, fcap, w.list1, cnt1, CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0, w.lib_lo != nullptr ? SPLIT_BOUND : 0.0f);
     }
     if (w.p16.Tt_pad > fcap) {
@@ -2541,7 +2728,7 @@ static void bf16_tiers_launch(const SearchWs& w, const void* lib_bf16, const flo
         knn_score_kernel<false><<<dim3((unsigned)(w.p16.Tt_pad / FT), w.p16.split), 256, SCORE_LDS, s>>>(
             w.s_c, (const unsigned short*)lib_bf16, M, w.p16.tiles_total, w.p16.tiles_per_split, w.p16.P, w.cv, w.ci, cnt0, fcap,
             0x7fffffff, 1, nullptr, sa, 0);
-        knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, w.p16.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
+        rescore_launch((unsigned)((Tt + 3) / 4), s, w.cv, w.ci, w.p16.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                    out_val, out_idx, w.list0, cnt0, fcap, 0x7fffffff, w.list1, cnt1,
                                                                    CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0, w.lib_lo != nullptr ? SPLIT_BOUND : 0.0f);
     }
@@ -2583,7 +2770,7 @@ static int knn_search_impl(const float* src, int N, int T, const void* lib_bf16,
     knn_score_kernel<false><<<dim3((unsigned)(p.Tt_pad / FT), p.split), 256, SCORE_LDS, s>>>(
         w.s_bf16, (const unsigned short*)lib_bf16, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, nullptr, 0, 0, 0, nullptr, sa, 0);
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
-    knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, p.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
+    rescore_launch((unsigned)((Tt + 3) / 4), s, w.cv, w.ci, p.P, KP, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                out_val, out_idx, nullptr, nullptr, 0, 0, w.list1, w.stats + ST_FLAG16,
                                                                CERT_Z, KH, 1.0f, SD_PRIOR16, w.det_q, w.det_lib, w.thr1, 0, w.lib_lo != nullptr ? SPLIT_BOUND : 0.0f);
     collect_tier_launch(w, lib_bf16, rows_f32, norms, M, Tt, idx_base, k, out_val, out_idx, s);
@@ -2662,7 +2849,9 @@ static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f
     if (Tt * k <= 64 && M <= SCAN_ROWS_MAX)            // streaming ring: the exact scan, no candidate stage at all
         return knn_scan_launch(src, T, Tt, rows_f32, norms, M, idx_base, k, w.s_f32, w.s_bf16, w.pv, w.pi, out_val, out_idx, w.stats, s, g_ev_start, g_ev_stop);
     if (int rc = lds_optin("alive_knn_search_fp8")) return rc;
-    stats_init_kernel<<<1, 64, 0, s>>>(w.stats, f6 ? TIER_FP6 : TIER_FP8);
+    // (history tag: library size, frame count and stage -- a workspace that was last used for another search starts over)
+    const int hist_tag = (int)(((uint64_t)M * 0x9E3779B1u) ^ ((uint64_t)Tt * 0x85EBCA77u) ^ (f6 ? 0x6u : 0x8u)) | 1;
+    stats_init_kernel<<<1, 64, 0, s>>>(w.stats, f6 ? TIER_FP6 : TIER_FP8, w.probe_n > 0 ? hist_tag : 0);
     src_prep_launch(w, src, T, Tt, s);
     if (f6) {
         const int64_t n32 = p.Tt_pad * D / 32;
@@ -2674,18 +2863,19 @@ static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f
     }
     int* mode = w.stats + ST_MODE;
     if (w.probe_n > 0) {
-        probe_gather_kernel<<<(unsigned)probe_pad, 64, 0, s>>>(w.s_f8, Tt, w.probe_n, probe_pad, w.s_p8, w.p_list);
+        const int* pgate = w.stats + ST_PROBE_GATE;      // 0: the history of this workspace says no probe is needed (all five launches return at once)
+        probe_gather_kernel<<<(unsigned)probe_pad, 64, 0, s>>>(w.s_f8, Tt, w.probe_n, probe_pad, w.s_p8, w.p_list, pgate);
         if (f6)
             knn_probe6_kernel<<<dim3((unsigned)(probe_pad / ft), pp.split), 256, lds, s>>>(
-                w.s_p8, (const unsigned char*)lib_f8, M, pp.tiles_total, pp.tiles_per_split, pp.P, w.cvp, w.cip);
+                w.s_p8, (const unsigned char*)lib_f8, M, pp.tiles_total, pp.tiles_per_split, pp.P, w.cvp, w.cip, pgate);
         else
             knn_probe8_kernel<<<dim3((unsigned)(probe_pad / ft), pp.split), 256, lds, s>>>(
-                w.s_p8, (const unsigned char*)lib_f8, M, pp.tiles_total, pp.tiles_per_split, pp.P, w.cvp, w.cip);
+                w.s_p8, (const unsigned char*)lib_f8, M, pp.tiles_total, pp.tiles_per_split, pp.P, w.cvp, w.cip, pgate);
         // the sample's own rescoring.  The kernel writes a frame's result to the frame's own output rows (out[frame]), so
         // the sample's exact lists land in the caller's outputs and are overwritten by the pass over the batch; its flagged
         // frames (second half of p_list) are only counted
-        knn_rescore_kernel<<<(unsigned)((w.probe_n + 3) / 4), 256, 0, s>>>(w.cvp, w.cip, pp.P, KP8, w.s_f32, rows_f32, norms, w.probe_n,
-                                                                          idx_base, k, out_val, out_idx, w.p_list, nullptr, 0, 0,
+        rescore_launch((unsigned)((w.probe_n + 3) / 4), s, w.cvp, w.cip, pp.P, KP8, w.s_f32, rows_f32, norms, w.probe_n,
+                                                                          idx_base, k, out_val, out_idx, w.p_list, pgate, GATE_BOOL, 0,
                                                                           w.p_list + probe_pad, w.stats + ST_PROBE_CNT, CERT_Z, KH8,
                                                                           pre, prior, nullptr, nullptr, nullptr, 0, 0.0f, f6 ? w.clip6 : nullptr);
         probe_decide_kernel<<<1, 1, 0, s>>>(w.stats, w.probe_n, PROBE_NUM, PROBE_DEN);
@@ -2700,11 +2890,12 @@ static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f
         knn_score8_kernel<<<dim3((unsigned)(p.Tt_pad / ft), p.split), 256, lds, s>>>(
             w.s_f8, (const unsigned char*)lib_f8, M, p.tiles_total, p.tiles_per_split, p.P, w.cv, w.ci, mode, -1, 0, sa8);
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
-    knn_rescore_kernel<<<(unsigned)((Tt + 3) / 4), 256, 0, s>>>(w.cv, w.ci, p.P, KP8, w.s_f32, rows_f32, norms, Tt, idx_base, k,
+    rescore_launch((unsigned)((Tt + 3) / 4), s, w.cv, w.ci, p.P, KP8, w.s_f32, rows_f32, norms, Tt, idx_base, k,
                                                                out_val, out_idx, nullptr, mode, -1, 0, w.list0, w.stats + ST_FLAG8,
                                                                CERT_Z, KH8, pre, prior, nullptr, nullptr, nullptr, 0, 0.0f, f6 ? w.clip6 : nullptr);
     // ---- mode 1: bf16 first (every frame into list0) ----
     if (w.probe_n > 0) flag_all_kernel<<<(unsigned)((Tt + 255) / 256), 256, 0, s>>>(w.list0, w.stats + ST_FLAG8, Tt, mode, 0, 1);
+    if (w.probe_n > 0) probe_history_kernel<<<1, 1, 0, s>>>(w.stats, Tt);        // (ST_FLAG8 is final here: the tiers below only read it)
     bf16_tiers_launch(w, lib_bf16, rows_f32, norms, M, Tt, idx_base, k, out_val, out_idx, s);
     ALIVE_CHECK_LAUNCH("alive_knn_search_fp8");
     return ALIVE_OK;

@@ -46,30 +46,47 @@ def collect_clips(root, max_clips, rng):
     return clips[order[:max_clips]]
 
 
-def dedup_mask(tokens_DxM, threshold, k=8, chunk=65536):
+def dedup_mask(tokens_DxM, threshold, k=8, chunk=65536, stats=None):
     """keep[m] = False when some KEPT frame m' < m has cos(m, m') > threshold (greedy in index order).  Neighbours come
     from the HIP kNN search of the library against itself (k nearest, the frame itself included), in chunks of frames;
     the greedy recursion is resolved on the device by passes (alive_dedup_pass): a frame is decided once all of its
-    earlier near neighbours are -- as many passes as the longest chain of near-duplicates, no per-row host loop."""
+    earlier near neighbours are -- as many passes as the longest chain of near-duplicates, no per-row host loop (the
+    undecided count is read back once per 8 passes).  stats: a dict that receives the time of the self-search, the number
+    of passes and what the search's tiers did with the last chunk."""
+    import time
     from module import _native as nat
     from module.common import PackedLibrary
     m = tokens_DxM.shape[1]
     k = min(k, m)
     dev = tokens_DxM.device
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
     lib = PackedLibrary(tokens_DxM.contiguous())
     val = torch.empty(m, k, dtype=torch.float32, device=dev)
     idx = torch.empty(m, k, dtype=torch.int32, device=dev)
+    exact = 0
     for s in range(0, m, chunk):
         v, i = lib.search(tokens_DxM[:, s:s + chunk].unsqueeze(0).contiguous(), k)
         val[s:s + chunk], idx[s:s + chunk] = v, i
+        if stats is not None:
+            exact += int(lib.search_stats().get("frames_searched_exactly", 0))
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
     state = torch.zeros(m, dtype=torch.int32, device=dev)
     undecided = torch.zeros(1, dtype=torch.int32, device=dev)
-    for _ in range(m + 1):
-        undecided.zero_()
-        nat.check(nat.lib().alive_dedup_pass(nat.ptr(val), nat.ptr(idx), m, k, float(threshold), nat.ptr(state), nat.ptr(undecided),
-                                             nat.stream()), "alive_dedup_pass")
+    passes = 0
+    while passes <= m:
+        for _ in range(8):
+            undecided.zero_()
+            nat.check(nat.lib().alive_dedup_pass(nat.ptr(val), nat.ptr(idx), m, k, float(threshold), nat.ptr(state), nat.ptr(undecided),
+                                                 nat.stream()), "alive_dedup_pass")
+        passes += 8
         if int(undecided.item()) == 0:
             break
+    if stats is not None:
+        torch.cuda.synchronize(dev)
+        stats.update(self_search_s=round(t1 - t0, 3), passes_s=round(time.perf_counter() - t1, 3), passes=passes,
+                     frames_searched_exactly=exact, prefilter=lib.prefilter, last_chunk_tiers=lib.search_stats())
     return (state == 1).cpu()
 
 

@@ -183,7 +183,8 @@ class PackedLibrary:
             # [0] frames that failed the fp8 certificate: up to [11] of them go straight to the exact scan (knn.hip RESEARCH_MIN)
             few = c[0] if c[0] <= c[11] else 0
             st.update(frames_failed_fp8_certificate=c[0], frames_researched_on_bf16=0 if few else c[0], probe_sample=c[2],
-                      probe_failed_fp8_certificate=c[3], probe_chose_bf16_first=bool(c[4]), fp8_blocks_seeded=c[9])
+                      probe_failed_fp8_certificate=c[3], probe_chose_bf16_first=bool(c[4]), fp8_blocks_seeded=c[9],
+                      probe_skipped_on_history=bool(c[13]))      # knn.hip ST_PROBE_SKIPPED: the workspace's last searches all went one way
         # [1] frames that failed the bf16 certificate: up to [12] of them go straight to the exact scan (knn.hip COLLECT_MIN),
         # more go through the collect tier and only its overflow ([8]) is scanned exactly
         direct = c[1] <= c[12]

@@ -73,6 +73,8 @@ class Converter:
         self.library = None
         for net in (self.ce, self.pe, self.dec):       # pack the weight tables now, on the caller's stream (not lazily
             net.table()                                # inside the first window batch, which runs on a side stream)
+        if self.device.type == "cuda":
+            self.dec._split_for_this_checkpoint()      # ... and calibrate the decoder's precision mode for this checkpoint (module/decoder.py)
 
     def set_library(self, tokens):
         """tokens [1, 768, M] (voice_library.pt layout) or an already packed PackedLibrary."""

@@ -53,6 +53,7 @@ class RealtimeConverter:
         self.ce, self.pe, self.dec = content_encoder.to(device), f0_estimator.to(device), decoder.to(device)
         for net in (self.ce, self.pe, self.dec):
             net.table()                                # weight tables packed up front (never inside a captured step)
+        self.dec._split_for_this_checkpoint()          # precision calibration of this checkpoint, also never inside a capture
         self.lib = library_tokens if isinstance(library_tokens, PackedLibrary) else PackedLibrary(library_tokens[0].to(device))
         self.chunk, self.buffersize = chunk, buffersize
         self.input_sr, self.output_sr = input_sr, output_sr

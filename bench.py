@@ -367,7 +367,7 @@ def main():
         # product, and so do the norm-FiLM projection (4.19), the two coarse down convs (2.62 + 1.31) and the mid conv (0.66): 60.68 MFLOP
         # priced at 2.5 PF; the other 35.91 MFLOP run three.  The family's peak is the blend: its FLOP / its ideal time.
         from module import ops as _ops
-        dec_mode = _ops.decoder_precision(0)
+        dec_mode = 2 if conv.dec._split_for_this_checkpoint() else _ops.decoder_precision(0)
         # ... and the six k5 convs of the fused 64-channel FilterBlock (6 x 2*64*64*5 x 80 columns = 19.66)
         fl_dec_plain = (12.58 + 39.32 + 4.19 + 2.62 + 1.31 + 0.66 + 19.66) * 1e6 * frames_per_step if dec_mode == 1 else 0.0
         dec_ideal_s = fl_dec_plain / (PEAK_BF16_TFLOPS * 1e12) + (fl_dec - fl_dec_plain) / (PEAK_BF16_TFLOPS / 3 * 1e12)
@@ -640,7 +640,7 @@ def main():
     # SURVEY 8 f3 at scale (never `value`): generate_voice_library.py's device work for a 200 000-vector bank -- the content encoder
     # over a synthetic corpus of 25 000 clips of 7 680 samples (the reference's clip length: 24 frames each), eight frames per clip
     # (the reference draws from frames 0..7), then --dedup 0.98 (the library's own kNN kernel against itself + alive_dedup_pass)
-    def library_build_leg(n_clips):
+    def library_build_leg(n_clips, noise=0.05):
         import generate_voice_library as G
         fpc = 8
         gl = torch.Generator(device=dev).manual_seed(77)
@@ -654,25 +654,32 @@ def main():
             nb = min(1000, n_clips - s0)
             f = 80.0 + 400.0 * torch.rand(nb, 1, device=dev, generator=gl)
             clips = 0.4 * torch.sin(2 * math.pi * f * t) + 0.2 * torch.sin(2 * math.pi * 2.7 * f * t + 1.0) \
-                + 0.05 * torch.randn(nb, G.CLIP, device=dev, generator=gl)
+                + noise * torch.randn(nb, G.CLIP, device=dev, generator=gl)
             feats = conv.ce(G.spectrogram(clips))                           # [nb, 768, 24]
             toks[:, s0 * fpc:(s0 + nb) * fpc] = feats[:, :, :fpc].permute(1, 0, 2).reshape(768, nb * fpc)
         torch.cuda.synchronize()
         t_enc = time.perf_counter() - t0
-        keep = G.dedup_mask(toks, 0.98)
+        dstats = {}
+        keep = G.dedup_mask(toks, 0.98, stats=dstats)
         torch.cuda.synchronize()
         t_all = time.perf_counter() - t0
         n = toks.shape[1]
         return {"vectors": n, "kept_after_dedup": int(keep.sum()), "encode_s": round(t_enc, 3), "dedup_s": round(t_all - t_enc, 3),
-                "vectors_per_s": round(n / t_all, 1), "frames_encoded": n_clips * 24,
-                "peak_device_bytes_above_resident": int(torch.cuda.max_memory_allocated(dev) - mem0),
+                "vectors_per_s": round(n / t_all, 1), "frames_encoded": n_clips * 24, "corpus_noise": noise,
+                "dedup": dstats,
+                "peak_device_bytes_above_resident": int(torch.cuda.max_memory_allocated(dev) - mem0), "resident_bytes_before": int(mem0),
                 "note": "content encoder in batches of 1000 clips (24 frames each, 8 kept), greedy --dedup 0.98 through the k = 8 self-search of the bank "
                         "(a dense CE-derived bank: the search runs its bf16 / collect tiers)"}
     if "library_build" in legs:
         extra["library_build"] = guarded(lambda: library_build_leg(25_000))
     # ... and at BASELINE config 4's size: 1 000 000 vectors (125 000 clips), the bank generate_voice_library.py exists for
+    # Two corpora: breathy clips (noise 0.3: about the share of near-duplicates a speech corpus has) in the default set, and the 200 k
+    # leg's clean two-partial clips (74 % of the frames are near-duplicates of an earlier one: three quarters of the self-search fall
+    # through to the exact scan, 52 s in round 6 -- `--legs library_build_1m_dense`, not part of "all")
     if "library_build_1m" in legs:
-        extra["library_build_1m"] = guarded(lambda: library_build_leg(125_000))
+        extra["library_build_1m"] = guarded(lambda: library_build_leg(125_000, noise=0.3))
+    if "library_build_1m_dense" in legs:
+        extra["library_build_1m_dense"] = guarded(lambda: library_build_leg(125_000))
 
     # PCIe-inclusive rate (never `value`): the same step with the windows arriving from pinned host memory and the
     # waveforms returned to it, as the CLI edge does (inference.py:88-94,134)
@@ -812,7 +819,7 @@ def main():
         ms_step = dt / args.steps * 1e3
         audio_s = world * args.utterances * args.seconds
         from module import ops as _ops
-        decoder_mode = _ops.decoder_precision(0)
+        decoder_mode = 2 if conv.dec._split_for_this_checkpoint() else _ops.decoder_precision(0)     # (the checkpoint's calibrated mode)
         encoder_mode = _ops.encoder_precision(0)
         dtype_detail = ({"fp6": "fp6 (e2m3)", "fp8": "fp8 (e4m3)"}[library.prefilter] + " MFMA candidate scoring + exact f32 rescoring, every frame "
                       "certified at 7 sigma of its measured stage error (statistical: audited against brute force on every frame of this "
@@ -842,6 +849,7 @@ def main():
             "rtf": round((dt / args.steps) / audio_s, 6),
             "roofline": roofline,
             "decoder_precision_mode": decoder_mode, "encoder_precision_mode": encoder_mode,
+            "decoder_precision_calibration": conv.dec.calibration,      # module/decoder.py: fp16 forms kept only within 1.5e-4 of split bf16 on a probe
             "fp16_saturations": _ops.f16_saturations(),      # values left saturated at the end of the run (every batch entry point clears and checks: 0)
             "fp16_fallbacks": _ops.Fp16Guard.fallbacks,      # batches the range guard repeated on bf16 planes (module/ops.py::Fp16Guard): 0
             "roofline_nets": roofline_nets,

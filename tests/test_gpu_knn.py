@@ -593,3 +593,34 @@ def test_block_scaled_scoring_kernels_soak_under_a_concurrent_matrix_load(prefil
         bad += (v != v0).any() | (i != i0).any()
     torch.cuda.synchronize()
     assert int(bad.item()) == 0, f"{int(bad.item())} of 200 searches differ from the first"
+
+
+def test_probe_is_skipped_on_a_clean_history_and_rearmed_by_a_dirty_one(prefilter):
+    """Round 6: the 1 024-frame probe of a big low-precision-first search (1.8 ms per 172 800 x 1 M search) keeps its verdict in the
+    caller's workspace: after two consecutive clean searches of the same shape it runs on every 16th search only; a search whose batch
+    fails its certificates re-arms it.  Which tier answers a frame changes, the answer does not: every search bitwise the first."""
+    if prefilter not in LOW:
+        pytest.skip("the probe belongs to the fp8 / fp6 stages")
+    from module.common import PackedLibrary
+    g = torch.Generator(device=DEV).manual_seed(77)
+    lib = PackedLibrary(torch.randn(768, 60_000, device=DEV, generator=g), prefilter=prefilter)
+    src = torch.randn(40, 768, 450, device=DEV, generator=g)                        # 18 000 frames: probed
+    v0, i0 = lib.search(src, 4)
+    v0, i0 = v0.clone(), i0.clone()
+    skipped = [lib.search_stats()["probe_skipped_on_history"]]
+    for _ in range(5):
+        v, i = lib.search(src, 4)
+        assert torch.equal(v, v0) and torch.equal(i, i0)
+        skipped.append(lib.search_stats()["probe_skipped_on_history"])
+    assert skipped == [False, False, True, True, True, True], skipped
+    # a batch of the same shape that the low-precision stage cannot certify (frames = near-copies of one direction against a library
+    # shifted the same way would need another library; here: frames that ARE dense combinations of many rows)
+    base = lib.rows[:4096].mean(0, keepdim=True)
+    hard = (base.t().unsqueeze(0) + 0.02 * torch.randn(40, 768, 450, device=DEV, generator=g)).contiguous()
+    vh, ih = lib.search(hard, 4)
+    st = lib.search_stats()
+    ref = PackedLibrary(lib.rows.t().contiguous(), prefilter="bf16").search(hard, 4)
+    assert torch.equal(vh, ref[0]) and torch.equal(ih, ref[1])
+    if st["frames_failed_fp8_certificate"] * 20 > 18_000:                              # the pattern broke: the next search probes again
+        lib.search(src, 4)
+        assert lib.search_stats()["probe_skipped_on_history"] is False
