@@ -256,6 +256,90 @@ __global__ __launch_bounds__(256) void src_to_fp8_kernel(const unsigned short* _
     out[i] = make_uint2(to_fp8x4(f[0], f[1], f[2], f[3]), to_fp8x4(f[4], f[5], f[6], f[7]));
 }
 
+// ---- the ROTATED form of the fp8 stage operands (round 6) -------------------------------------------------------------
+// A dense bank (one speaker: every row shares a large common component) defeats an 8-bit candidate stage: thousands of rows sit inside
+// the stage's score error of a frame's k-th neighbour, and 172 800 of 172 800 bench frames fell through to the bf16 stage.  Measured
+// before anything was built (tools/knn_pca_probe.py, profiles/r06_knn_pca_probe.json): with the bank's leading principal directions
+// carried at 8 significant bits instead of 4 the stage error falls from 1.6e-3 to 3.7e-4 and 93 % of the frames certify.  No kernel
+// change is needed for that on e4m3, whose range makes every code `value x 2^8` as before:
+//   * the bank lives in a subspace (the reference's ContentEncoder ends in Conv1d(512 -> 768): rank <= 513); unit vectors are expressed
+//     in a basis W = [U_0..63 | U_64..575 R] -- the 64 leading eigenvectors of the rows' second moment, then the next 512 mixed by a
+//     fixed random rotation R (eigen-coordinates concentrate the residual's energy in a few blocks, which averages the rounding errors
+//     over fewer terms: sigma 5.9e-4 unmixed against 3.7e-4) -- the 192 directions behind them carry no energy and are dropped;
+//   * the 64 alpha coordinates travel as TWO e4m3 digits each (hi = e4m3(a), lo = e4m3(a - hi)), laid out so that the plain dot product
+//     of the two code vectors IS (hi + lo)(hi + lo) + rho . rho:   rows   [hi | lo | hi | lo | rho x 512]
+//                                                                  frames [hi | hi | lo | lo | rho x 512]      (64 codes per group)
+// y: the rotated coordinates, `side` 0 = library rows, row-major [n][RC]; side 1 = frames, as alive_conv1d leaves them: [N][RC][T]
+// (frame f = n T + t), NOT normalised -- the kernel divides by the frame's norm (|W^T x| = |x| for a frame inside the bank's subspace;
+// a frame with energy outside it gets scores that are too high by one factor for all rows: the ranking stands, the certificate sees
+// the mismatch with the exact cosines and sends the frame to the next tier).  out: [n_pad][768] codes, zero rows beyond n.
+constexpr int ROT_A = 64, ROT_RHO = 512, ROT_C = ROT_A + ROT_RHO;      // 576 coordinates -> 4 x 64 + 512 = 768 codes
+__device__ __forceinline__ float fp8_value(unsigned code) {             // e4m3 byte -> the value it stands for (x 2^-8 applied by the caller)
+    return __builtin_amdgcn_cvt_f32_fp8((int)code, 0);
+}
+__global__ __launch_bounds__(256) void rot_codes_kernel(const float* __restrict__ y, int64_t n, int64_t n_pad, int T, int side,
+                                                        unsigned char* __restrict__ out) {
+    __shared__ float tile[ROT_C][33];          // [coordinate][frame of the block], 76 KB
+    __shared__ float ssq[8][32];
+    const int fl = threadIdx.x & 31, cg = threadIdx.x >> 5;
+    const int64_t f = (int64_t)blockIdx.x * 32 + fl;
+    const bool live = f < n;
+    const float* base;
+    int64_t sc;
+    if (T > 0) {                               // frames: [N][RC][T]
+        const int64_t ni = live ? f / T : 0, ti = live ? f - ni * T : 0;
+        base = y + (size_t)ni * ROT_C * T + ti;
+        sc = T;
+    } else {                                   // rows: [n][RC]
+        base = y + (size_t)(live ? f : 0) * ROT_C;
+        sc = 1;
+    }
+    float s2 = 0.0f;
+    for (int c = cg; c < ROT_C; c += 8) {
+        const float v = live ? base[(size_t)c * sc] : 0.0f;
+        tile[c][fl] = v;
+        s2 = fmaf(v, v, s2);
+    }
+    ssq[cg][fl] = s2;
+    __syncthreads();
+    float nrm = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) nrm += ssq[g][fl];
+    const float inv = (T > 0 && nrm > 0.0f) ? 1.0f / sqrtf(nrm) : (T > 0 ? 0.0f : 1.0f);     // rows arrive as coordinates of unit vectors
+    if (f >= n_pad) return;
+    // 24 groups of 32 codes per vector: groups 0 .. 7 are the four alpha blocks (64 codes each), 8 .. 23 rho
+    for (int g = cg; g < 24; g += 8) {
+        unsigned w[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 4 * q + e;                       // code j of group g
+                float x;
+                if (g < 8) {
+                    const int blk = g >> 1, a = 32 * (g & 1) + j;                  // alpha coordinate a of digit block blk
+                    const float al = tile[a][fl] * inv;
+                    const bool lo = side == 0 ? (blk & 1) != 0 : blk >= 2;         // rows [hi lo hi lo], frames [hi hi lo lo]
+                    if (lo) {
+                        const unsigned ch = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(al * F8_SCALE, 0.0f, 0, false) & 0xffu;
+                        x = al - fp8_value(ch) * (1.0f / F8_SCALE);
+                    } else {
+                        x = al;
+                    }
+                } else {
+                    x = tile[ROT_A + 32 * (g - 8) + j][fl] * inv;
+                }
+                v[e] = live ? x : 0.0f;
+            }
+            w[q] = to_fp8x4(v[0], v[1], v[2], v[3]);
+        }
+        u32x4* o = (u32x4*)(out + (size_t)f * D + 32 * g);
+        o[0] = u32x4{w[0], w[1], w[2], w[3]};
+        o[1] = u32x4{w[4], w[5], w[6], w[7]};
+    }
+}
+
 // src[N][D][T] -> s_f32[Tt][D] (normalised, fp32), s_bf16[Tt_pad][D]
 // dq (optional): || q^ - bf16(q^) ||_2 per frame, rounded up -- the frame's share of the strict certificate's bound
 __global__ __launch_bounds__(256) void src_prep_kernel(const float* __restrict__ src, int T, int64_t Tt, int64_t Tt_pad,
@@ -2416,6 +2500,7 @@ constexpr int TIER1A = 256;               // tier 1a: up to one frame block of f
 constexpr int FPLAN = 4096;               // ... with the library split chosen for this many (blocks past the count exit at once)
 constexpr float CERT_Z = 7.0f;            // sigmas of candidate-score error the certificates allow for
 constexpr float SD_PRIOR6 = 2.0e-3f;      // fp6 stage: 1.8e-3 simulated / measured on unit vectors of Gaussian elements
+constexpr float SD_PRIOR8R = 4.0e-4f;     // the fp8 stage on ROTATED operands (rot_codes_kernel): 3.7e-4 measured on the dense bank (profiles/r06_knn_pca_probe.json)
 constexpr float SD_PRIOR8 = 1.5e-3f;      // typical error (cosine units) of an fp8 / a bf16 candidate score: floor of the per-frame estimate
 constexpr float SD_PRIOR16 = 8.0e-5f;
 constexpr int PROBE_N = 1024;             // frames of the adaptive probe (fp8 searches of >= PROBE_MIN_T frames)
@@ -2833,7 +2918,11 @@ extern "C" int alive_knn_search_timed(const float* src, int N, int T, const void
 
 static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f8, const void* lib_bf16, const float* rows_f32,
                                const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
-                               void* ws, void* stream, hipEvent_t g_ev_start, hipEvent_t g_ev_stop, int fmt = 0) {
+                               void* ws, void* stream, hipEvent_t g_ev_start, hipEvent_t g_ev_stop, int fmt = 0,
+                               const float* y_rot = nullptr) {
+    // y_rot != NULL (fp8 only): lib_f8 holds the ROTATED codes of the rows (alive_library_pack_fp8_rot) and y_rot the frames' rotated
+    // coordinates [N][576][T]: the frames' codes come from rot_codes_kernel, the stage's error prior is SD_PRIOR8R; everything else --
+    // exact rescoring on the original rows, certificates, the bf16 tiers on lib_bf16 -- is the plain search's
     ALIVE_CHECK_ARG(src && lib_f8 && lib_bf16 && rows_f32 && norms && out_val && out_idx && ws, "alive_knn_search_fp8: null pointer");
     if (int rc = check_search_args("alive_knn_search_fp8", src, ws, N, T, k, M)) return rc;
     const int64_t Tt = (int64_t)N * T;
@@ -2844,19 +2933,22 @@ static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f
     const SearchPlan& p = f6 ? w.p6 : w.p8;
     const SearchPlan& pp = f6 ? w.pp6 : w.pp;
     const int ft = f6 ? FT6 : FT, probe_pad = f6 ? w.probe_pad6 : w.probe_pad, lds = f6 ? SCORE6_LDS : SCORE8_LDS;
-    const float pre = f6 ? 1.0f / (F6_SCALE * F6_SCALE) : 1.0f / (F8_SCALE * F8_SCALE), prior = f6 ? SD_PRIOR6 : SD_PRIOR8;
+    const float pre = f6 ? 1.0f / (F6_SCALE * F6_SCALE) : 1.0f / (F8_SCALE * F8_SCALE),
+                prior = f6 ? SD_PRIOR6 : (y_rot != nullptr ? SD_PRIOR8R : SD_PRIOR8);
     hipStream_t s = (hipStream_t)stream;
     if (Tt * k <= 64 && M <= SCAN_ROWS_MAX)            // streaming ring: the exact scan, no candidate stage at all
         return knn_scan_launch(src, T, Tt, rows_f32, norms, M, idx_base, k, w.s_f32, w.s_bf16, w.pv, w.pi, out_val, out_idx, w.stats, s, g_ev_start, g_ev_stop);
     if (int rc = lds_optin("alive_knn_search_fp8")) return rc;
     // (history tag: library size, frame count and stage -- a workspace that was last used for another search starts over)
-    const int hist_tag = (int)(((uint64_t)M * 0x9E3779B1u) ^ ((uint64_t)Tt * 0x85EBCA77u) ^ (f6 ? 0x6u : 0x8u)) | 1;
+    const int hist_tag = (int)(((uint64_t)M * 0x9E3779B1u) ^ ((uint64_t)Tt * 0x85EBCA77u) ^ (f6 ? 0x6u : (y_rot != nullptr ? 0x18u : 0x8u))) | 1;
     stats_init_kernel<<<1, 64, 0, s>>>(w.stats, f6 ? TIER_FP6 : TIER_FP8, w.probe_n > 0 ? hist_tag : 0);
     src_prep_launch(w, src, T, Tt, s);
     if (f6) {
         const int64_t n32 = p.Tt_pad * D / 32;
         (void)hipMemsetAsync(w.clip6, 0, (size_t)p.Tt_pad, s);
         to_fp6_kernel<<<(unsigned)((n32 + 255) / 256), 256, 0, s>>>(w.s_bf16, n32, w.p16.Tt_pad * D / 32, (u32x4*)w.s_f8, w.clip6);
+    } else if (y_rot != nullptr) {
+        rot_codes_kernel<<<(unsigned)(p.Tt_pad / 32), 256, 0, s>>>(y_rot, Tt, p.Tt_pad, T, 1, w.s_f8);
     } else {
         const int64_t n8 = p.Tt_pad * D / 8;
         src_to_fp8_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>(w.s_bf16, n8, (uint2*)w.s_f8);
@@ -2911,6 +3003,28 @@ extern "C" int alive_knn_search_fp8_timed(const float* src, int N, int T, const 
                                           void* ws, void* stream, void* ev_start, void* ev_stop) {
     return knn_search_fp8_impl(src, N, T, lib_f8, lib_bf16, rows_f32, norms, M, idx_base, k, out_val, out_idx, ws, stream,
                                (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
+}
+
+// The fp8 search on ROTATED operands (dense banks; rot_codes_kernel above).  y_rows: [count][576] fp32 coordinates of the unit rows
+// m0 .. m0 + count - 1 in the bank's basis (the caller may pack a big bank in chunks); lib_f8: alive_library_fp8_bytes(M) bytes.
+extern "C" int alive_knn_rot_coordinates(void) { return ROT_C; }
+extern "C" int alive_knn_rot_leading(void) { return ROT_A; }
+extern "C" int alive_library_pack_fp8_rot(const float* y_rows, int64_t m0, int64_t count, int64_t M, void* lib_f8, void* stream) {
+    ALIVE_CHECK_ARG(y_rows && lib_f8 && M >= 1 && m0 >= 0 && count >= 1 && m0 + count <= M && (m0 % 32) == 0,
+                    "alive_library_pack_fp8_rot: bad args (m0 must be a multiple of 32)");
+    const int64_t m_pad = alive_library_padded_rows(M);
+    const int64_t span = m0 + count == M ? m_pad - m0 : count;          // the last chunk also zeroes the padding rows
+    ALIVE_CHECK_ARG(span % 32 == 0, "alive_library_pack_fp8_rot: a chunk that is not the last must hold a multiple of 32 rows");
+    rot_codes_kernel<<<(unsigned)(span / 32), 256, 0, (hipStream_t)stream>>>(y_rows, count, span, 0, 0, (unsigned char*)lib_f8 + (size_t)m0 * D);
+    ALIVE_CHECK_LAUNCH("alive_library_pack_fp8_rot");
+    return ALIVE_OK;
+}
+extern "C" int alive_knn_search_fp8_rot_timed(const float* src, const float* y_rot, int N, int T, const void* lib_f8_rot, const void* lib_bf16,
+                                              const float* rows_f32, const float* norms, int64_t M, int64_t idx_base, int k, float* out_val,
+                                              int32_t* out_idx, void* ws, void* stream, void* ev_start, void* ev_stop) {
+    ALIVE_CHECK_ARG(y_rot != nullptr, "alive_knn_search_fp8_rot: null rotated frames");
+    return knn_search_fp8_impl(src, N, T, lib_f8_rot, lib_bf16, rows_f32, norms, M, idx_base, k, out_val, out_idx, ws, stream,
+                               (hipEvent_t)ev_start, (hipEvent_t)ev_stop, 0, y_rot);
 }
 
 // The same search with the candidate stage on the fp6 MFMA (knn_score6_kernel); lib_f6 from alive_library_pack_fp6.

@@ -26,6 +26,18 @@ def _prefilter():
     return os.environ.get("ALIVE_KNN_PREFILTER", DEFAULT_PREFILTER)
 
 
+def _rotate_allowed():
+    """ALIVE_KNN_ROTATE=0 switches the rotated form of the fp8 stage off (dense banks then go through the bf16 stage as in round 5)"""
+    return os.environ.get("ALIVE_KNN_ROTATE", "1") not in ("0", "false", "False")
+
+
+# A bank is searched on ROTATED fp8 operands (csrc/knn.hip rot_codes_kernel, include/alive_vc.h) when it is DENSE -- its rows share a
+# common component: the leading eigenvalue of the unit rows' second moment carries at least ROT_MIN_LEAD of the trace -- and lives in a
+# subspace of at most 576 dimensions (the reference's ContentEncoder ends in Conv1d(512 -> 768): every bank it produces does).
+ROT_MIN_LEAD = 0.10
+ROT_MAX_TAIL = 1.0e-9
+
+
 def _strict():
     """ALIVE_KNN_STRICT=1: every search through the bf16 stage with the DETERMINISTIC certificate (no statistical
     assumption; include/alive_vc.h: alive_knn_search_strict).  The default certificates are statistical (7 sigma of the
@@ -67,14 +79,17 @@ class PackedLibrary:
                              f"remove them (the reference would match every frame to them through NaN cosines)")
         self.lib_f8 = None                 # the fp8 OR the fp6 image of the rows (same size and tile layout), per self.prefilter
         self.fp6_declined = False
-        if self.prefilter == "fp6" and self.M > 0:
+        self.rot = None                    # rotated fp8 stage: {"W": packed 1x1 conv weights of the basis, "spectrum": ...}
+        if self.prefilter in ("fp6", "fp8") and self.M >= 4096 and _rotate_allowed():
+            self._try_rotated()            # a dense bank: the fp8 stage on rotated operands (sets self.rot, self.lib_f8, prefilter "fp8")
+        if self.rot is None and self.prefilter == "fp6" and self.M > 0:
             # e2m3 x 2^5 ends at 7.5 / 32 = 0.234: a row of a unit-norm library with a larger element (a few dominant coordinates:
             # "spiky" banks, never a dense content-encoder bank, whose elements are ~0.036 +- a few sigma) would be CLIPPED, and a clipped
             # row's score is low by more than any per-frame error statistic shows -- such a library is searched through the fp8 stage
             # (e4m3 x 2^8 reaches 1.75).  One reduction + sync per pack.  (A frame that clips is caught per search: knn.hip force_fail.)
             if self._fp6_would_clip():
                 self.prefilter, self.fp6_declined = "fp8", True
-        if self.prefilter in ("fp8", "fp6"):
+        if self.rot is None and self.prefilter in ("fp8", "fp6"):
             self.lib_f8 = self._pack_stage(self.prefilter)
         self.bound = None
         self.lib_lo = None
@@ -94,6 +109,55 @@ class PackedLibrary:
         fn = L.alive_library_pack_fp6 if prefilter == "fp6" else L.alive_library_pack_fp8
         nat.check(fn(nat.ptr(self.lib_bf16), self.M, nat.ptr(buf), nat.stream()), "alive_library_pack_" + prefilter)
         return buf
+
+    def _try_rotated(self, chunk=131072):
+        """Decide whether this bank is searched on rotated fp8 operands and, if so, build the basis and the rows' codes (once per bank:
+        torch is used for the 768 x 768 second moment, its eigen-decomposition and the rows' change of basis -- pack-time plumbing; the
+        codes, the frames' change of basis (alive_conv1d) and the search are the library's own kernels)."""
+        from ._pack import pack_conv_split
+        L = nat.lib()
+        rc, ra = L.alive_knn_rot_coordinates(), L.alive_knn_rot_leading()
+        dev = self.rows.device
+        C = torch.zeros(DIM, DIM, dtype=torch.float64, device=dev)
+        for s0 in range(0, self.M, chunk):
+            ln = self.rows[s0:s0 + chunk] / self.norms[s0:s0 + chunk, None]
+            C += (ln.t() @ ln).double()
+        evals, evecs = torch.linalg.eigh((C / self.M).cpu())
+        order = torch.argsort(evals, descending=True)
+        evals, U = evals[order].clamp(min=0.0), evecs[:, order]
+        total = float(evals.sum())
+        lead, tail = float(evals[0]) / total, float(evals[rc:].sum()) / total
+        self.rot_spectrum = {"leading_eigenvalue_share": lead, "energy_beyond_576_directions": tail}
+        if not (lead >= ROT_MIN_LEAD and tail <= ROT_MAX_TAIL):
+            return
+        g = torch.Generator().manual_seed(20261004)
+        R = torch.linalg.qr(torch.randn(rc - ra, rc - ra, generator=g, dtype=torch.float64))[0]
+        W = torch.cat([U[:, :ra], U[:, ra:rc] @ R], 1).float().to(dev)                    # [768, 576]: orthonormal columns
+        buf = torch.empty(L.alive_library_fp8_bytes(self.M), dtype=torch.uint8, device=dev)
+        for s0 in range(0, self.M, chunk):                                                    # (chunk is a multiple of 32)
+            ln = self.rows[s0:s0 + chunk] / self.norms[s0:s0 + chunk, None]
+            y = (ln @ W).contiguous()
+            nat.check(L.alive_library_pack_fp8_rot(nat.ptr(y), s0, y.shape[0], self.M, nat.ptr(buf), nat.stream()), "alive_library_pack_fp8_rot")
+        self.lib_f8 = buf
+        self.prefilter = "fp8"
+        # the frames' change of basis is a 1x1 conv 768 -> 576 on two bf16 planes (2^-16: far below the stage's 8-bit digits)
+        self.rot = {"W": pack_conv_split(W.t().contiguous().unsqueeze(2), 2), "co": rc, "basis": W}
+
+    def _rotate_frames(self, source):
+        """source [n, 768, t] -> W^T source [n, 576, t] through alive_conv1d (split bf16)"""
+        import ctypes as C
+        n, d, t = source.shape
+        y = torch.empty(n, self.rot["co"], t, device=source.device)
+        W = self.rot["W"]
+        dsc = nat.AliveConv()
+        dsc.W, dsc.bias, dsc.X = nat.ptr(W), None, nat.ptr(source)
+        dsc.N, dsc.Ci, dsc.Tin, dsc.Co, dsc.K_pad = n, d, t, self.rot["co"], W.shape[1] * 32
+        dsc.precision, dsc.Ci_pad = 1, d
+        dsc.KW, dsc.stride, dsc.dil, dsc.pad_left, dsc.pad_mode = 1, 1, 1, 0, 0
+        dsc.Tout, dsc.up, dsc.act = t, 1, 0
+        dsc.Y = nat.ptr(y)
+        nat.check(nat.lib().alive_conv1d(C.byref(dsc), nat.stream()), "alive_conv1d (frames -> the bank's basis)")
+        return y
 
     def _make_bound(self):
         """max_R || r^ - bf16(r^) ||: the library's share of the strict certificate's deterministic bound -- and the library's lo
@@ -121,6 +185,11 @@ class PackedLibrary:
             nat.check(L.alive_knn_search_strict(nat.ptr(source), n, t, nat.ptr(self.lib_bf16), nat.ptr(self.lib_lo), nat.ptr(self.rows), nat.ptr(self.norms),
                                                 nat.ptr(self.bound), self.M, self.idx_base, k, nat.ptr(val), nat.ptr(idx),
                                                 nat.ptr(ws), nat.stream(), *ev), "alive_knn_search_strict")
+        elif self.rot is not None:
+            y = self._rotate_frames(source)
+            nat.check(L.alive_knn_search_fp8_rot_timed(nat.ptr(source), nat.ptr(y), n, t, nat.ptr(self.lib_f8), nat.ptr(self.lib_bf16),
+                                                       nat.ptr(self.rows), nat.ptr(self.norms), self.M, self.idx_base, k,
+                                                       nat.ptr(val), nat.ptr(idx), nat.ptr(ws), nat.stream(), *ev), "alive_knn_search_fp8_rot")
         elif self.lib_f8 is not None:
             fn = L.alive_knn_search_fp6_timed if self.prefilter == "fp6" else L.alive_knn_search_fp8_timed
             nat.check(fn(nat.ptr(source), n, t, nat.ptr(self.lib_f8), nat.ptr(self.lib_bf16),
@@ -134,13 +203,19 @@ class PackedLibrary:
         return val, idx
 
 
-    def with_prefilter(self, prefilter):
-        """the same resident library searched through the other candidate stage (shares every tensor)"""
+    def with_prefilter(self, prefilter, rotated=False):
+        """the same resident library searched through the other candidate stage (shares every tensor); the PLAIN form of that stage
+        unless rotated=True and this library has a rotated fp8 image"""
         import copy
         if prefilter not in _STAGES:
             raise ValueError(prefilter)
         other = copy.copy(self)
         other.__dict__.pop("search", None)             # an instrumented search (bench.py) stays with the original
+        if rotated and self.rot is not None and prefilter == "fp8":
+            other._ws, other._last = nat.Workspace(), None
+            other.strict, other.bound, other.lib_lo = False, None, None
+            return other
+        was_rot, other.rot = self.rot is not None, None
         other.fp6_declined = prefilter == "fp6" and self._fp6_would_clip()
         if other.fp6_declined:
             prefilter = "fp8"
@@ -150,7 +225,7 @@ class PackedLibrary:
         other._last = None
         if prefilter == "bf16":
             other.lib_f8 = None
-        elif self.lib_f8 is None or self.prefilter != prefilter:
+        elif self.lib_f8 is None or self.prefilter != prefilter or was_rot:
             other.lib_f8 = self._pack_stage(prefilter)
         return other
 
@@ -169,6 +244,8 @@ class PackedLibrary:
         n, t, k, ws = last
         torch.cuda.synchronize()
         st = {"prefilter": self.prefilter, "certificate": "deterministic" if self.strict else "statistical"}
+        if getattr(self, "rot", None) is not None:
+            st["rotated_operands"] = True          # dense bank: the fp8 stage on the bank's own basis (csrc/knn.hip rot_codes_kernel)
         off = nat.lib().alive_knn_search_stats(n, t, self.M, nat.ptr(ws)) - ws.data_ptr()
         c = ws[off:off + 64].view(torch.int32).tolist()       # int[16]: knn.hip ST_*
         tier = c[7]                                     # written by the C side on every path (knn.hip: ST_TIER)

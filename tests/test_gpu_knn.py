@@ -624,3 +624,93 @@ def test_probe_is_skipped_on_a_clean_history_and_rearmed_by_a_dirty_one(prefilte
     if st["frames_failed_fp8_certificate"] * 20 > 18_000:                              # the pattern broke: the next search probes again
         lib.search(src, 4)
         assert lib.search_stats()["probe_skipped_on_history"] is False
+
+
+def _dense_bank(m, n_frames, seed):
+    """rows and frames that share a large common component inside a 300-dimensional subspace (what a single-speaker content-encoder bank
+    looks like to the search: rank <= 513 by construction of the reference's encoder, leading eigenvalue ~0.4 of the trace)"""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    A = torch.randn(768, 300, device=DEV, generator=g) / 300 ** 0.5
+    decay = torch.linspace(0, 4, 300, device=DEV).neg().exp()                        # a decaying spectrum inside the subspace
+    c = A @ torch.randn(300, device=DEV, generator=g)
+    rows = c[:, None] * 1.2 + A @ (decay[:, None] * torch.randn(300, m, device=DEV, generator=g))
+    fr = c[:, None] * 1.2 + A @ (decay[:, None] * torch.randn(300, n_frames, device=DEV, generator=g))
+    return rows.contiguous(), fr
+
+
+def test_dense_banks_are_searched_on_rotated_fp8_operands(prefilter, monkeypatch):
+    """Round 6 (profiles/r06_knn_pca_probe.json): a bank whose rows share a large common component is packed in the
+    bank's own basis -- 64 leading principal directions as two e4m3 digits each, 512 further coordinates mixed by a fixed rotation --
+    and searched by the UNCHANGED fp8 scoring kernel; exact rescoring, certificates and the bf16 tiers are the plain search's, so the
+    lists are bitwise those of the bf16-first search and of brute force, and far fewer frames fall through to the bf16 stage than with
+    plain operands.  An isotropic bank (torch.randn) keeps the plain stage."""
+    if prefilter not in LOW:
+        pytest.skip("the rotated form replaces the fp6 / fp8 first stage")
+    from module.common import PackedLibrary
+    rows, fr = _dense_bank(60_000, 40 * 450, 5)
+    src = fr.t().reshape(40, 450, 768).permute(0, 2, 1).contiguous()
+    lib = PackedLibrary(rows, prefilter=prefilter)
+    assert lib.rot is not None and lib.prefilter == "fp8", lib.rot_spectrum
+    v, i = lib.search(src, 4)
+    st = lib.search_stats()
+    assert st["rotated_operands"] and not st["probe_chose_bf16_first"], st
+    ref = PackedLibrary(rows, prefilter="bf16")
+    assert ref.rot is None
+    vr, ir = ref.search(src, 4)
+    assert torch.equal(v, vr) and torch.equal(i, ir)
+    # brute force on a sample of the frames
+    qn = fr[:, :2000].t() / fr[:, :2000].t().norm(dim=1, keepdim=True)
+    ln = rows.t() / rows.t().norm(dim=1, keepdim=True)
+    top = torch.topk(qn @ ln.t(), 5, dim=1)
+    safe = (top.values[:, 3] - top.values[:, 4]) > 1e-5
+    got = torch.sort(i[:2000].long(), 1).values
+    assert torch.equal(got[safe], torch.sort(top.indices[:, :4], 1).values[safe]) and int(safe.sum()) > 1500
+    # the plain stage on the same bank: (nearly) every frame fails its certificate
+    monkeypatch.setenv("ALIVE_KNN_ROTATE", "0")
+    plain = PackedLibrary(rows, prefilter=prefilter)
+    assert plain.rot is None
+    vp, ip = plain.search(src, 4)
+    assert torch.equal(vp, v) and torch.equal(ip, i)
+    stp = plain.search_stats()
+    failed_plain = 18_000 if stp["probe_chose_bf16_first"] else stp["frames_failed_fp8_certificate"]
+    print(f"dense bank, 18 000 frames: plain {prefilter} stage -> {failed_plain} frames to the bf16 stage, rotated fp8 stage -> {st['frames_failed_fp8_certificate']}; "
+          f"spectrum {lib.rot_spectrum}")
+    assert st["frames_failed_fp8_certificate"] < 0.5 * failed_plain and failed_plain > 0.9 * 18_000
+    monkeypatch.delenv("ALIVE_KNN_ROTATE")
+    iso = PackedLibrary(torch.randn(768, 20_000, device=DEV), prefilter=prefilter)
+    assert iso.rot is None and iso.rot_spectrum["energy_beyond_576_directions"] > 0.1
+
+
+def test_rotated_codes_are_the_two_digit_e4m3_form_of_the_coordinates():
+    """alive_library_pack_fp8_rot (rows, row-major coordinates of unit vectors) and the frames' form inside the search ([N][576][T],
+    normalised by the kernel): 768 codes per vector = [hi | lo | hi | lo | rho] / [hi | hi | lo | lo | rho], hi = e4m3(256 a),
+    lo = e4m3(256 (a - hi / 256)), rho = e4m3(256 r) -- bit for bit torch.float8_e4m3fn"""
+    from module import _native as nat
+    L = nat.lib()
+    rc, ra = L.alive_knn_rot_coordinates(), L.alive_knn_rot_leading()
+    assert (rc, ra) == (576, 64)
+    g = torch.Generator(device=DEV).manual_seed(8)
+    m = 1000
+    y = torch.randn(m, rc, device=DEV, generator=g)
+    y[:, :ra] *= 3.0
+    y = (y / y.norm(dim=1, keepdim=True)).contiguous()
+    buf = torch.full((L.alive_library_fp8_bytes(m),), 0xEE, dtype=torch.uint8, device=DEV)
+    nat.check(L.alive_library_pack_fp8_rot(nat.ptr(y), 0, m, m, nat.ptr(buf), nat.stream()), "pack")
+    codes = buf.view(-1, 768)
+    assert codes.shape[0] == L.alive_library_padded_rows(m) and bool((codes[m:] == 0).all())
+
+    def e4(x):
+        return (x * 256.0).to(torch.float8_e4m3fn)
+    a, r = y[:, :ra], y[:, ra:]
+    hi = e4(a)
+    lo = e4(a - hi.float() / 256.0)
+    want = torch.cat([hi, lo, hi, lo, e4(r)], 1).view(torch.uint8)
+    assert torch.equal(codes[:m], want)
+    # the dot product of two code vectors in the two layouts is the cosine to the stage's accuracy
+    yq = torch.randn(64, rc, device=DEV, generator=g)
+    yq[:, :ra] *= 3.0
+    yq = yq / yq.norm(dim=1, keepdim=True)
+    hq = e4(yq[:, :ra]); lq = e4(yq[:, :ra] - hq.float() / 256.0)
+    cq = torch.cat([hq, hq, lq, lq, e4(yq[:, ra:])], 1).float() / 256.0
+    stage = cq @ (codes[:m].view(torch.float8_e4m3fn).float() / 256.0).t()
+    assert float((stage - yq @ y.t()).abs().max()) < 6e-3 and float((stage - yq @ y.t()).std()) < 1.5e-3      # (isotropic rho: the plain stage's error)
