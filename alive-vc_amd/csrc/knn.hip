@@ -2500,7 +2500,7 @@ constexpr int TIER1A = 256;               // tier 1a: up to one frame block of f
 constexpr int FPLAN = 4096;               // ... with the library split chosen for this many (blocks past the count exit at once)
 constexpr float CERT_Z = 7.0f;            // sigmas of candidate-score error the certificates allow for
 constexpr float SD_PRIOR6 = 2.0e-3f;      // fp6 stage: 1.8e-3 simulated / measured on unit vectors of Gaussian elements
-constexpr float SD_PRIOR8R = 4.0e-4f;     // the fp8 stage on ROTATED operands (rot_codes_kernel): 3.7e-4 measured on the dense bank (profiles/r06_knn_pca_probe.json)
+constexpr float SD_PRIOR8R = 3.5e-4f;     // the fp8 stage on ROTATED operands (rot_codes_kernel): 3.3e-4 on a frame's true neighbours, 3.7e-4 over all pairs of the dense bank (profiles/r06_knn_pca_probe.json); a floor of the per-frame estimate, as for the other stages
 constexpr float SD_PRIOR8 = 1.5e-3f;      // typical error (cosine units) of an fp8 / a bf16 candidate score: floor of the per-frame estimate
 constexpr float SD_PRIOR16 = 8.0e-5f;
 constexpr int PROBE_N = 1024;             // frames of the adaptive probe (fp8 searches of >= PROBE_MIN_T frames)

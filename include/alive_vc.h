@@ -161,7 +161,7 @@ int alive_knn_search_fp8_timed(const float* src, int N, int T,
  *   alive_library_pack_fp8_rot: y_rows[count][576] = coordinates of the UNIT rows m0 .. m0 + count - 1 -> their codes in lib_f8
  *       (alive_library_fp8_bytes(M) bytes; chunks in ascending order, m0 a multiple of 32, the last chunk ends at M);
  *   alive_knn_search_fp8_rot_timed: alive_knn_search_fp8_timed with y_rot[N][576][T] = W^T src (not normalised) beside src.
- * Results are those of every other search: exact fp32 rescoring on the original rows, the same certificates (stage prior 4.0e-4),
+ * Results are those of every other search: exact fp32 rescoring on the original rows, the same certificates (stage prior 3.5e-4),
  * the bf16 tiers on lib_bf16 behind them. */
 int alive_knn_rot_coordinates(void);
 int alive_knn_rot_leading(void);
