@@ -751,9 +751,11 @@ def main():
                         lat.append((time.perf_counter() - t1) * 1e3)
                     return lat, o_
                 first, _ = calls(4)                                  # warm-up: workspaces, side streams, allocator pools
-                # round 5 reported max 40.1 ms against p50 4.19 (per-window mode, 10 calls) without a cause.  The leg now times 50 calls with
-                # the cyclic garbage collector held off and 50 with it on, and reports both maxima and the collector's own count of passes
-                # during the second loop: a collector pass over the bench's object graph lands inside whichever call trips its threshold
+                # round 5 reported max 40.1 ms against p50 4.19 (per-window mode, 10 calls after 2 warm-up calls) without a cause.  The leg
+                # now drops four warm-up calls (the first call of a fresh Converter grows its workspaces and creates its side streams:
+                # 5 - 12 ms, reported as first_four_calls_ms) and times 50 calls with the cyclic garbage collector held off and 50 with it
+                # on, with the collector's own count of passes in the second loop.  Round 6: no call above 4.8 ms in either loop and no
+                # collector pass inside them -- the outlier belonged to the warm-up, not to the steady state
                 gc.collect()
                 gc.disable()
                 try:
