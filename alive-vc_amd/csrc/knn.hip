@@ -267,17 +267,23 @@ __global__ __launch_bounds__(256) void src_to_fp8_kernel(const unsigned short* _
 //     fixed random rotation R (eigen-coordinates concentrate the residual's energy in a few blocks, which averages the rounding errors
 //     over fewer terms: sigma 5.9e-4 unmixed against 3.7e-4) -- the 192 directions behind them carry no energy and are dropped;
 //   * the 64 alpha coordinates travel as TWO e4m3 digits each (hi = e4m3(a), lo = e4m3(a - hi)), laid out so that the plain dot product
-//     of the two code vectors IS (hi + lo)(hi + lo) + rho . rho:   rows   [hi | lo | hi | lo | rho x 512]
-//                                                                  frames [hi | hi | lo | lo | rho x 512]      (64 codes per group)
-// y: the rotated coordinates, `side` 0 = library rows, row-major [n][RC]; side 1 = frames, as alive_conv1d leaves them: [N][RC][T]
+//     of the two code vectors IS (hi + lo)(hi + lo) + rho . rho:   rows   [hi | lo | hi | lo | rho x 507 | 5 codes]
+//                                                                  frames [hi | hi | lo | lo | rho x 507 | 5 codes]      (64 codes per group)
+//   * the LEADING coordinate alpha_0 is ~0.65 for every row and every frame (it IS the common component), and two e4m3 digits of 0.65 are
+//     good to ~2^-9 of it: that one coordinate carried two thirds of the stage's remaining error (sigma 3.7e-4 -> 2.4e-4 with it exact,
+//     certified frames 92.9 % -> 99.6 %: tools/knn_pca_probe.py "A0").  It is CENTRED: alpha_0 = c0 + a with c0 an e4m3-exact constant of
+//     the bank (the mean of its rows' alpha_0), a in two digits in alpha_0's four slots, and
+//     (c0 + a_q)(c0 + a_r) = a_q a_r + [c0 c0 + a_r c0 + c0 a_q] through the vector's last five codes:
+//                                                                  rows   [c0, a_hi, a_lo, c0, c0]      frames [c0, c0, c0, a_hi, a_lo]
+// y: the rotated coordinates (576 per vector; the last 5 are not read), `side` 0 = library rows, row-major [n][RC]; side 1 = frames, as alive_conv1d leaves them: [N][RC][T]
 // (frame f = n T + t), NOT normalised -- the kernel divides by the frame's norm (|W^T x| = |x| for a frame inside the bank's subspace;
 // a frame with energy outside it gets scores that are too high by one factor for all rows: the ranking stands, the certificate sees
 // the mismatch with the exact cosines and sends the frame to the next tier).  out: [n_pad][768] codes, zero rows beyond n.
-constexpr int ROT_A = 64, ROT_RHO = 512, ROT_C = ROT_A + ROT_RHO;      // 576 coordinates -> 4 x 64 + 512 = 768 codes
+constexpr int ROT_A = 64, ROT_RHO = 507, ROT_C = 576;      // 64 + 507 coordinates read (of 576 passed) -> 4 x 64 + 507 + 5 = 768 codes
 __device__ __forceinline__ float fp8_value(unsigned code) {             // e4m3 byte -> the value it stands for (x 2^-8 applied by the caller)
     return __builtin_amdgcn_cvt_f32_fp8((int)code, 0);
 }
-__global__ __launch_bounds__(256) void rot_codes_kernel(const float* __restrict__ y, int64_t n, int64_t n_pad, int T, int side,
+__global__ __launch_bounds__(256) void rot_codes_kernel(const float* __restrict__ y, int64_t n, int64_t n_pad, int T, int side, float c0,
                                                         unsigned char* __restrict__ out) {
     __shared__ float tile[ROT_C][33];          // [coordinate][frame of the block], 76 KB
     __shared__ float ssq[8][32];
@@ -317,18 +323,25 @@ __global__ __launch_bounds__(256) void rot_codes_kernel(const float* __restrict_
             for (int e = 0; e < 4; ++e) {
                 const int j = 4 * q + e;                       // code j of group g
                 float x;
+                auto lo_digit = [](float al) {                                    // al - e4m3(al): what the second digit carries
+                    const unsigned ch = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(al * F8_SCALE, 0.0f, 0, false) & 0xffu;
+                    return al - fp8_value(ch) * (1.0f / F8_SCALE);
+                };
                 if (g < 8) {
                     const int blk = g >> 1, a = 32 * (g & 1) + j;                  // alpha coordinate a of digit block blk
-                    const float al = tile[a][fl] * inv;
+                    const float al = tile[a][fl] * inv - (a == 0 ? c0 : 0.0f);     // (the leading coordinate is centred)
                     const bool lo = side == 0 ? (blk & 1) != 0 : blk >= 2;         // rows [hi lo hi lo], frames [hi hi lo lo]
-                    if (lo) {
-                        const unsigned ch = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(al * F8_SCALE, 0.0f, 0, false) & 0xffu;
-                        x = al - fp8_value(ch) * (1.0f / F8_SCALE);
-                    } else {
-                        x = al;
-                    }
+                    x = lo ? lo_digit(al) : al;
                 } else {
-                    x = tile[ROT_A + 32 * (g - 8) + j][fl] * inv;
+                    const int r = 32 * (g - 8) + j;                                // rho position 0 .. 511
+                    if (r < ROT_RHO) {
+                        x = tile[ROT_A + r][fl] * inv;
+                    } else {                                                       // the five codes of the centred leading coordinate
+                        const int q = r - ROT_RHO;
+                        const float a0 = tile[0][fl] * inv - c0;
+                        const int role = side == 0 ? (q == 1 ? 1 : (q == 2 ? 2 : 0)) : (q == 3 ? 1 : (q == 4 ? 2 : 0));       // 0: c0, 1: a_hi, 2: a_lo
+                        x = role == 0 ? c0 : (role == 1 ? a0 : lo_digit(a0));
+                    }
                 }
                 v[e] = live ? x : 0.0f;
             }
@@ -2500,7 +2513,7 @@ constexpr int TIER1A = 256;               // tier 1a: up to one frame block of f
 constexpr int FPLAN = 4096;               // ... with the library split chosen for this many (blocks past the count exit at once)
 constexpr float CERT_Z = 7.0f;            // sigmas of candidate-score error the certificates allow for
 constexpr float SD_PRIOR6 = 2.0e-3f;      // fp6 stage: 1.8e-3 simulated / measured on unit vectors of Gaussian elements
-constexpr float SD_PRIOR8R = 3.5e-4f;     // the fp8 stage on ROTATED operands (rot_codes_kernel): 3.3e-4 on a frame's true neighbours, 3.7e-4 over all pairs of the dense bank (profiles/r06_knn_pca_probe.json); a floor of the per-frame estimate, as for the other stages
+constexpr float SD_PRIOR8R = 2.5e-4f;     // the fp8 stage on ROTATED operands (rot_codes_kernel): 2.2e-4 on a frame's true neighbours, 2.4e-4 over all pairs of the dense bank with the leading coordinate centred (profiles/r06_knn_pca_probe.json); a floor of the per-frame estimate, as for the other stages
 constexpr float SD_PRIOR8 = 1.5e-3f;      // typical error (cosine units) of an fp8 / a bf16 candidate score: floor of the per-frame estimate
 constexpr float SD_PRIOR16 = 8.0e-5f;
 constexpr int PROBE_N = 1024;             // frames of the adaptive probe (fp8 searches of >= PROBE_MIN_T frames)
@@ -2919,7 +2932,7 @@ extern "C" int alive_knn_search_timed(const float* src, int N, int T, const void
 static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f8, const void* lib_bf16, const float* rows_f32,
                                const float* norms, int64_t M, int64_t idx_base, int k, float* out_val, int32_t* out_idx,
                                void* ws, void* stream, hipEvent_t g_ev_start, hipEvent_t g_ev_stop, int fmt = 0,
-                               const float* y_rot = nullptr) {
+                               const float* y_rot = nullptr, float rot_c0 = 0.0f) {
     // y_rot != NULL (fp8 only): lib_f8 holds the ROTATED codes of the rows (alive_library_pack_fp8_rot) and y_rot the frames' rotated
     // coordinates [N][576][T]: the frames' codes come from rot_codes_kernel, the stage's error prior is SD_PRIOR8R; everything else --
     // exact rescoring on the original rows, certificates, the bf16 tiers on lib_bf16 -- is the plain search's
@@ -2948,7 +2961,7 @@ static int knn_search_fp8_impl(const float* src, int N, int T, const void* lib_f
         (void)hipMemsetAsync(w.clip6, 0, (size_t)p.Tt_pad, s);
         to_fp6_kernel<<<(unsigned)((n32 + 255) / 256), 256, 0, s>>>(w.s_bf16, n32, w.p16.Tt_pad * D / 32, (u32x4*)w.s_f8, w.clip6);
     } else if (y_rot != nullptr) {
-        rot_codes_kernel<<<(unsigned)(p.Tt_pad / 32), 256, 0, s>>>(y_rot, Tt, p.Tt_pad, T, 1, w.s_f8);
+        rot_codes_kernel<<<(unsigned)(p.Tt_pad / 32), 256, 0, s>>>(y_rot, Tt, p.Tt_pad, T, 1, rot_c0, w.s_f8);
     } else {
         const int64_t n8 = p.Tt_pad * D / 8;
         src_to_fp8_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>(w.s_bf16, n8, (uint2*)w.s_f8);
@@ -3009,22 +3022,23 @@ extern "C" int alive_knn_search_fp8_timed(const float* src, int N, int T, const 
 // m0 .. m0 + count - 1 in the bank's basis (the caller may pack a big bank in chunks); lib_f8: alive_library_fp8_bytes(M) bytes.
 extern "C" int alive_knn_rot_coordinates(void) { return ROT_C; }
 extern "C" int alive_knn_rot_leading(void) { return ROT_A; }
-extern "C" int alive_library_pack_fp8_rot(const float* y_rows, int64_t m0, int64_t count, int64_t M, void* lib_f8, void* stream) {
+extern "C" int alive_knn_rot_mixed(void) { return ROT_RHO; }
+extern "C" int alive_library_pack_fp8_rot(const float* y_rows, int64_t m0, int64_t count, int64_t M, float c0, void* lib_f8, void* stream) {
     ALIVE_CHECK_ARG(y_rows && lib_f8 && M >= 1 && m0 >= 0 && count >= 1 && m0 + count <= M && (m0 % 32) == 0,
                     "alive_library_pack_fp8_rot: bad args (m0 must be a multiple of 32)");
     const int64_t m_pad = alive_library_padded_rows(M);
     const int64_t span = m0 + count == M ? m_pad - m0 : count;          // the last chunk also zeroes the padding rows
     ALIVE_CHECK_ARG(span % 32 == 0, "alive_library_pack_fp8_rot: a chunk that is not the last must hold a multiple of 32 rows");
-    rot_codes_kernel<<<(unsigned)(span / 32), 256, 0, (hipStream_t)stream>>>(y_rows, count, span, 0, 0, (unsigned char*)lib_f8 + (size_t)m0 * D);
+    rot_codes_kernel<<<(unsigned)(span / 32), 256, 0, (hipStream_t)stream>>>(y_rows, count, span, 0, 0, c0, (unsigned char*)lib_f8 + (size_t)m0 * D);
     ALIVE_CHECK_LAUNCH("alive_library_pack_fp8_rot");
     return ALIVE_OK;
 }
-extern "C" int alive_knn_search_fp8_rot_timed(const float* src, const float* y_rot, int N, int T, const void* lib_f8_rot, const void* lib_bf16,
+extern "C" int alive_knn_search_fp8_rot_timed(const float* src, const float* y_rot, float c0, int N, int T, const void* lib_f8_rot, const void* lib_bf16,
                                               const float* rows_f32, const float* norms, int64_t M, int64_t idx_base, int k, float* out_val,
                                               int32_t* out_idx, void* ws, void* stream, void* ev_start, void* ev_stop) {
     ALIVE_CHECK_ARG(y_rot != nullptr, "alive_knn_search_fp8_rot: null rotated frames");
     return knn_search_fp8_impl(src, N, T, lib_f8_rot, lib_bf16, rows_f32, norms, M, idx_base, k, out_val, out_idx, ws, stream,
-                               (hipEvent_t)ev_start, (hipEvent_t)ev_stop, 0, y_rot);
+                               (hipEvent_t)ev_start, (hipEvent_t)ev_stop, 0, y_rot, c0);
 }
 
 // The same search with the candidate stage on the fp6 MFMA (knn_score6_kernel); lib_f6 from alive_library_pack_fp6.

@@ -66,8 +66,9 @@ PROTOTYPES = {
     "alive_library_pack_fp6": (_I, [_VP, _I64, _VP, _VP]),
     "alive_knn_rot_coordinates": (_I, []),
     "alive_knn_rot_leading": (_I, []),
-    "alive_library_pack_fp8_rot": (_I, [_VP, _I64, _I64, _I64, _VP, _VP]),
-    "alive_knn_search_fp8_rot_timed": (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "alive_knn_rot_mixed": (_I, []),
+    "alive_library_pack_fp8_rot": (_I, [_VP, _I64, _I64, _I64, _F, _VP, _VP]),
+    "alive_knn_search_fp8_rot_timed": (_I, [_VP, _VP, _F, _I, _I, _VP, _VP, _VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "alive_knn_search_fp6": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP]),
     "alive_knn_search_fp6_timed": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _I64, _I64, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "alive_dedup_pass": (_I, [_VP, _VP, _I64, _I, _D, _VP, _VP, _VP]),

@@ -33,7 +33,7 @@ def _rotate_allowed():
 
 # A bank is searched on ROTATED fp8 operands (csrc/knn.hip rot_codes_kernel, include/alive_vc.h) when it is DENSE -- its rows share a
 # common component: the leading eigenvalue of the unit rows' second moment carries at least ROT_MIN_LEAD of the trace -- and lives in a
-# subspace of at most 576 dimensions (the reference's ContentEncoder ends in Conv1d(512 -> 768): every bank it produces does).
+# subspace of at most 571 dimensions (the reference's ContentEncoder ends in Conv1d(512 -> 768): every bank it produces does).
 ROT_MIN_LEAD = 0.10
 ROT_MAX_TAIL = 1.0e-9
 
@@ -116,32 +116,42 @@ class PackedLibrary:
         codes, the frames' change of basis (alive_conv1d) and the search are the library's own kernels)."""
         from ._pack import pack_conv_split
         L = nat.lib()
-        rc, ra = L.alive_knn_rot_coordinates(), L.alive_knn_rot_leading()
+        rc, ra, rm = L.alive_knn_rot_coordinates(), L.alive_knn_rot_leading(), L.alive_knn_rot_mixed()
+        used = ra + rm                                          # 571 directions carry the bank; the 5 coordinates behind them are not read
         dev = self.rows.device
         C = torch.zeros(DIM, DIM, dtype=torch.float64, device=dev)
+        mean = torch.zeros(DIM, dtype=torch.float64, device=dev)
         for s0 in range(0, self.M, chunk):
             ln = self.rows[s0:s0 + chunk] / self.norms[s0:s0 + chunk, None]
             C += (ln.t() @ ln).double()
+            mean += ln.double().sum(0)
         evals, evecs = torch.linalg.eigh((C / self.M).cpu())
         order = torch.argsort(evals, descending=True)
         evals, U = evals[order].clamp(min=0.0), evecs[:, order]
         total = float(evals.sum())
-        lead, tail = float(evals[0]) / total, float(evals[rc:].sum()) / total
-        self.rot_spectrum = {"leading_eigenvalue_share": lead, "energy_beyond_576_directions": tail}
+        lead, tail = float(evals[0]) / total, float(evals[used:].sum()) / total
+        self.rot_spectrum = {"leading_eigenvalue_share": lead, "energy_beyond_571_directions": tail}
         if not (lead >= ROT_MIN_LEAD and tail <= ROT_MAX_TAIL):
             return
+        a0 = float((mean.cpu() / self.M) @ U[:, 0])             # mean of the rows' leading coordinate: make it positive
+        if a0 < 0:
+            U[:, 0], a0 = -U[:, 0], -a0
+        c0 = float((torch.tensor([a0 * 256.0]).to(torch.float8_e4m3fn).float() / 256.0)[0])      # e4m3-exact centring constant
         g = torch.Generator().manual_seed(20261004)
-        R = torch.linalg.qr(torch.randn(rc - ra, rc - ra, generator=g, dtype=torch.float64))[0]
-        W = torch.cat([U[:, :ra], U[:, ra:rc] @ R], 1).float().to(dev)                    # [768, 576]: orthonormal columns
+        R = torch.linalg.qr(torch.randn(rm, rm, generator=g, dtype=torch.float64))[0]
+        W = torch.zeros(DIM, rc, dtype=torch.float64)
+        W[:, :ra] = U[:, :ra]
+        W[:, ra:used] = U[:, ra:used] @ R
+        W = W.float().to(dev)                                   # [768, 576]: 571 orthonormal columns, 5 zero ones
         buf = torch.empty(L.alive_library_fp8_bytes(self.M), dtype=torch.uint8, device=dev)
         for s0 in range(0, self.M, chunk):                                                    # (chunk is a multiple of 32)
             ln = self.rows[s0:s0 + chunk] / self.norms[s0:s0 + chunk, None]
             y = (ln @ W).contiguous()
-            nat.check(L.alive_library_pack_fp8_rot(nat.ptr(y), s0, y.shape[0], self.M, nat.ptr(buf), nat.stream()), "alive_library_pack_fp8_rot")
+            nat.check(L.alive_library_pack_fp8_rot(nat.ptr(y), s0, y.shape[0], self.M, c0, nat.ptr(buf), nat.stream()), "alive_library_pack_fp8_rot")
         self.lib_f8 = buf
         self.prefilter = "fp8"
         # the frames' change of basis is a 1x1 conv 768 -> 576 on two bf16 planes (2^-16: far below the stage's 8-bit digits)
-        self.rot = {"W": pack_conv_split(W.t().contiguous().unsqueeze(2), 2), "co": rc, "basis": W}
+        self.rot = {"W": pack_conv_split(W.t().contiguous().unsqueeze(2), 2), "co": rc, "basis": W, "c0": c0}
 
     def _rotate_frames(self, source):
         """source [n, 768, t] -> W^T source [n, 576, t] through alive_conv1d (split bf16)"""
@@ -187,7 +197,7 @@ class PackedLibrary:
                                                 nat.ptr(ws), nat.stream(), *ev), "alive_knn_search_strict")
         elif self.rot is not None:
             y = self._rotate_frames(source)
-            nat.check(L.alive_knn_search_fp8_rot_timed(nat.ptr(source), nat.ptr(y), n, t, nat.ptr(self.lib_f8), nat.ptr(self.lib_bf16),
+            nat.check(L.alive_knn_search_fp8_rot_timed(nat.ptr(source), nat.ptr(y), self.rot["c0"], n, t, nat.ptr(self.lib_f8), nat.ptr(self.lib_bf16),
                                                        nat.ptr(self.rows), nat.ptr(self.norms), self.M, self.idx_base, k,
                                                        nat.ptr(val), nat.ptr(idx), nat.ptr(ws), nat.stream(), *ev), "alive_knn_search_fp8_rot")
         elif self.lib_f8 is not None:

@@ -155,18 +155,22 @@ int alive_knn_search_fp8_timed(const float* src, int N, int T,
  * unit vectors are expressed in a basis of the bank's own subspace -- 64 leading principal directions, carried as two e4m3 digits each,
  * and 512 further coordinates mixed by a fixed rotation; /root/reference/module/content_encoder.py ends in Conv1d(512 -> 768), so a bank
  * has rank <= 513 and nothing is lost -- and laid out so that the unchanged scoring kernel's dot product of the two 768-code vectors is
- * the cosine at a stage error of 3.7e-4 instead of 1.6e-3 (profiles/r06_knn_pca_probe.json; csrc/knn.hip rot_codes_kernel).  The
+ * the cosine at a stage error of 2.4e-4 instead of 1.6e-3 (profiles/r06_knn_pca_probe.json; csrc/knn.hip rot_codes_kernel).  The
  * caller owns the basis (module/common.py::PackedLibrary builds it when a bank is packed and rotates the frames with alive_conv1d):
- *   alive_knn_rot_coordinates() = 576 coordinates per vector, the first alive_knn_rot_leading() = 64 of them the leading directions;
+ *   alive_knn_rot_coordinates() = 576 coordinates per vector are passed: the first alive_knn_rot_leading() = 64 the leading directions,
+ *       the next alive_knn_rot_mixed() = 507 the mixed ones, the last 5 unread;
+ *   c0: the bank's centring constant of the leading coordinate (an e4m3-exact value near the mean of the rows' first coordinate: that
+ *       coordinate is ~0.65 for every vector of a dense bank and is carried as c0 + two digits of the difference);
  *   alive_library_pack_fp8_rot: y_rows[count][576] = coordinates of the UNIT rows m0 .. m0 + count - 1 -> their codes in lib_f8
  *       (alive_library_fp8_bytes(M) bytes; chunks in ascending order, m0 a multiple of 32, the last chunk ends at M);
  *   alive_knn_search_fp8_rot_timed: alive_knn_search_fp8_timed with y_rot[N][576][T] = W^T src (not normalised) beside src.
- * Results are those of every other search: exact fp32 rescoring on the original rows, the same certificates (stage prior 3.5e-4),
+ * Results are those of every other search: exact fp32 rescoring on the original rows, the same certificates (stage prior 2.5e-4),
  * the bf16 tiers on lib_bf16 behind them. */
 int alive_knn_rot_coordinates(void);
 int alive_knn_rot_leading(void);
-int alive_library_pack_fp8_rot(const float* y_rows, int64_t m0, int64_t count, int64_t M, void* lib_f8, void* stream);
-int alive_knn_search_fp8_rot_timed(const float* src, const float* y_rot, int N, int T,
+int alive_knn_rot_mixed(void);
+int alive_library_pack_fp8_rot(const float* y_rows, int64_t m0, int64_t count, int64_t M, float c0, void* lib_f8, void* stream);
+int alive_knn_search_fp8_rot_timed(const float* src, const float* y_rot, float c0, int N, int T,
                                    const void* lib_f8_rot, const void* lib_bf16, const float* rows_f32, const float* norms,
                                    int64_t M, int64_t idx_base, int k,
                                    float* out_val, int32_t* out_idx, void* ws, void* stream, void* ev_start, void* ev_stop);
