@@ -93,13 +93,21 @@ __device__ __forceinline__ int swz(int r) { return (r >> 1) & 7; }
 // H16 (round 5, decoder precision mode 1 with ALIVE_DECODER_BF16_MASK bit 16): the six k5 convs multiply ONE fp16 plane of the modulated
 // tensor by ONE fp16 plane of the weights -- a third of the MFMAs, no lo plane in LDS, half the weight registers.  The 1x1 input conv
 // keeps the split form (its operand is the raw residual stream).
-template <bool FIRST, int NTT = 4, bool H16 = false>
+// SWEEP (round 6; H16 only, batch path): a block walks a SEGMENT of a window left to right, 256 NEW columns per tile, and hands every
+// conv's causal context -- the last 16 columns of that conv's input, 2 KB -- to the next tile through LDS instead of recomputing a
+// 56-column halo per 200 outputs (22 % of the kernel's work).  A segment starts with one warm-up tile whose output is not stored (its
+// own first 56 columns are computed from nothing; the context it leaves is clean).  Same columns from the same operands in the same order:
+// bit for bit the tiled form's output.  c_first: first column of segment 0 (the window's first 200 columns stay with the FIRST form,
+// which reflects at t = 0); seg_cols: columns per segment, a multiple of 256.
+template <bool FIRST, int NTT = 4, bool H16 = false, bool SWEEP = false>
 __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __restrict__ U, int L,
                                                                 const unsigned short* __restrict__ W16,
                                                                 const float* __restrict__ biases,
                                                                 const float* __restrict__ film, int film_rows, int Lf,
                                                                 int film_off, float ratio, int t_off, int f_off, int film_ld,
-                                                                const float* __restrict__ skip, float* __restrict__ out, long long* stamps) {
+                                                                const float* __restrict__ skip, float* __restrict__ out, long long* stamps,
+                                                                int c_first = 0, int seg_cols = 0) {
+    static_assert(!SWEEP || (H16 && !FIRST && NTT == 4), "the sweep form exists for the fp16 batch tiles only (it parks the context in the unused lo plane)");
 #ifdef ALIVE_STAMPS                 // diagnostic build only (tools/ab_build.sh x.so filter_mid.hip -DALIVE_STAMPS; tools/stamp_fb64.py)
     long long ts3[12];
     int nts = 0;
@@ -108,7 +116,8 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
 #define STAMP3()
 #endif
     STAMP3();
-    constexpr int NT = NTT, BL = 64 * NT, TT = BL - HALO, PLANE = BL * ROWB, BUF = 2 * PLANE;      // (shadow the batch constants above)
+    constexpr int HALO_ = SWEEP ? 0 : HALO;            // columns of a tile that are recomputed context
+    constexpr int NT = NTT, BL = 64 * NT, TT = BL - HALO_, PLANE = BL * ROWB, BUF = 2 * PLANE;      // (shadow the batch constants above)
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     unsigned char* bufZ = sm + GUARD;
     unsigned char* bufY = bufZ + BUF;
@@ -120,9 +129,40 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
     const int rg = w & 1, chalf = w >> 1;
     const int n32 = lane & 31, lh = lane >> 5;
     const int n = blockIdx.y;
-    const int t0 = FIRST ? blockIdx.x * TT : (blockIdx.x + 1) * TT;      // FIRST: the host launches it for tile 0 (or for every tile of a small problem)
-    const int tbase = t0 - HALO;
     const float* Un = U + (size_t)n * C * L;
+    // sweep form: this block's segment, the context slots (one per conv, in the lo plane of bufY, which the fp16 form never touches) and
+    // the 16 rows in front of either buffer that a tile's leftmost fragments read (bufY's: the tail of bufZ's lo plane, free once the
+    // input conv has read the raw tile)
+    const int seg_begin = SWEEP ? c_first + (int)blockIdx.x * seg_cols : 0;
+    const int seg_end = SWEEP ? (seg_begin + seg_cols < L ? seg_begin + seg_cols : L) : 0;
+    unsigned char* const hist = bufY + PLANE;
+    unsigned char* const guardZ = bufZ - GUARD;
+    unsigned char* const guardY = bufY - GUARD;
+    auto copy2k = [&](unsigned char* dst, const unsigned char* src) {          // one wave: 2 KB = 16 rows of 128 B, swizzle preserved (256 = 0 mod 16)
+        *(u32x4*)(dst + lane * 16) = *(const u32x4*)(src + lane * 16);
+        *(u32x4*)(dst + 1024 + lane * 16) = *(const u32x4*)(src + 1024 + lane * 16);
+    };
+    if constexpr (SWEEP) {
+        if (seg_begin >= L) return;
+        for (int i = tid; i < (NCONV * GUARD) / 16; i += 256) ((u32x4*)hist)[i] = u32x4{0u, 0u, 0u, 0u};
+        for (int i = tid; i < GUARD / 16; i += 256) ((u32x4*)guardZ)[i] = u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+    }
+#pragma unroll 1
+    for (int it = SWEEP ? -1 : 0;; ++it) {
+    const bool warm = SWEEP && it < 0;                 // the segment's warm-up tile: computed for its context, not stored
+    const float* biases_i = biases;
+    const unsigned short* W16_i = W16;
+    int n32 = lane & 31, lh = lane >> 5, rg = w & 1, chalf = w >> 1;        // (shadow the kernel-scope values: opaque per tile in the sweep form)
+    if constexpr (SWEEP) {
+        asm volatile("" : "+s"(biases_i));
+        asm volatile("" : "+s"(W16_i));
+        asm volatile("" : "+v"(n32), "+v"(lh));
+        asm volatile("" : "+s"(rg), "+s"(chalf));
+    }
+    const int t0 = SWEEP ? seg_begin + it * BL : (FIRST ? blockIdx.x * TT : (blockIdx.x + 1) * TT);      // FIRST: the host launches it for tile 0 (or for every tile of a small problem)
+    if (SWEEP && it >= 0 && t0 >= seg_end) break;
+    const int tbase = t0 - HALO_;
 
     // ---- stage the raw input tile (split into planes; thread = column) and the FiLM rows of the tile: every global load of the
     //      prologue is issued before the first LDS write, so one memory latency covers all of them ----
@@ -178,6 +218,9 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
             // the scale rows are stored halved (exact): gelu(x) * sc + sh = (x + |x| erf|x / sqrt 2|) * (sc / 2) + sh saves the 0.5 x
             ((float*)Fs)[((q * C + c) * NFS + f) * 2 + sel] = sel == 0 ? 0.5f * fv[k] : fv[k];
         }
+        if constexpr (SWEEP) {
+            if (w == 0) copy2k(guardZ, hist);                    // conv 0's context: the last 16 columns of the previous tile's z0
+        }
     }
     __syncthreads();
     STAMP3();
@@ -186,7 +229,10 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
     f32x16 h[NT];
 
     // lane-constant pieces of the per-tile addresses: tile i of this wave adds the immediate i * TSTEP
-    const int colw = chalf * 32 + n32;                                             // column of tile i: colw + 64 i
+    int colw = chalf * 32 + n32;                                                   // column of tile i: colw + 64 i
+    if constexpr (SWEEP) asm volatile("" : "+v"(colw));       // (a loop body now: without the opaque uses below hipcc hoists every lane-constant
+                                                              //  address, bias tuple and weight pointer of all seven stages out of the tile loop
+                                                              //  -- 512 registers and 132 spilled)
     int st_off[4];                                                                 // modulated planes: channels 32 rg + 8 g + 4 lh .. +3
 #pragma unroll
     for (int g = 0; g < 4; ++g) st_off[g] = colw * ROWB + (((4 * rg + g) ^ swz(colw)) << 4) + 8 * lh;
@@ -276,7 +322,7 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
             if constexpr (H16) {
                 // one fp16 plane, saturating; saturations are counted in the tile's OUTPUT columns only: the halo columns are its
                 // neighbour's outputs, and left of their dependency cone they hold arbitrary values
-                const bool cnt = colw + 64 * t >= HALO;
+                const bool cnt = SWEEP ? !warm : colw + 64 * t >= HALO;
                 *(uint2*)p = make_uint2(pack_f16x2(z[0], z[1], cnt), pack_f16x2(z[2], z[3], cnt));
             } else {
                 const unsigned h01 = pack2(z[0], z[1]), h23 = pack2(z[2], z[3]);
@@ -292,10 +338,10 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
     bf16x8 a[20][2];
     auto load_weights_step = [&](int q, int s) {
         if constexpr (H16) {
-            const unsigned short* Wq = W16 + W_IN + (size_t)NCONV * W_K5 + (size_t)q * W_K5H + (size_t)(32 * rg + n32) * (5 * C) + 8 * lh;
+            const unsigned short* Wq = W16_i + W_IN + (size_t)NCONV * W_K5 + (size_t)q * W_K5H + (size_t)(32 * rg + n32) * (5 * C) + 8 * lh;
             a[s][0] = *(const bf16x8*)(Wq + s * 16);
         } else {
-            const unsigned short* Wq = W16 + W_IN + (size_t)q * W_K5 + (size_t)(32 * rg + n32) * (5 * C) + 8 * lh;
+            const unsigned short* Wq = W16_i + W_IN + (size_t)q * W_K5 + (size_t)(32 * rg + n32) * (5 * C) + 8 * lh;
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) a[s][pl] = *(const bf16x8*)(Wq + (size_t)pl * C * 5 * C + s * 16);
         }
@@ -308,12 +354,12 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
-                ai[s][pl] = *(const bf16x8*)(W16 + (size_t)pl * C * C + (size_t)(32 * rg + n32) * C + s * 16 + 8 * lh);
+                ai[s][pl] = *(const bf16x8*)(W16_i + (size_t)pl * C * C + (size_t)(32 * rg + n32) * C + s * 16 + 8 * lh);
         f32x16 b16;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) b16[4 * g + e] = biases[32 * rg + 8 * g + 4 * lh + e];
+            for (int e = 0; e < 4; ++e) b16[4 * g + e] = biases_i[32 * rg + 8 * g + 4 * lh + e];
         const int bw = colw * ROWB + ((lh ^ swz(colw)) << 4);
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -368,7 +414,7 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) b16[4 * g + e] = biases[(1 + q) * C + 32 * rg + 8 * g + 4 * lh + e];
+            for (int e = 0; e < 4; ++e) b16[4 * g + e] = biases_i[(1 + q) * C + 32 * rg + 8 * g + 4 * lh + e];
         const int d = 1 << (q >> 1);
         // B fragment of k-step s = 4 j + cb of tile i: row r = colw + 64 i + (j - 4) d, 16 B at r * 128 + ((2 cb + lh) ^ swz(r)) * 16
         // = base[s] + i * TSTEP (swz does not depend on i): twenty lane-constant registers per conv, immediates per tile -- an XOR
@@ -410,6 +456,13 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
 #ifndef ALIVE_FB64_NO_CHAIN_GAP
             ALIVE_CHAIN_GAP(15);                              // see the header: distance between two accumulation chains
 #endif
+            if constexpr (SWEEP) {
+                // this conv's input is complete since the barrier of step 0 (its last tile was the pending item): keep its last 16
+                // columns for the next tile; one step later hand the NEXT conv its context (it reads the other buffer, whose front
+                // rows nobody reads before that conv starts)
+                if (i == 1 && w == 0) copy2k(hist + q * GUARD, in + (BL - 16) * ROWB);
+                if (i == 2 && w == 0 && q + 1 < NCONV) copy2k(SECOND ? guardZ : guardY, hist + (q + 1) * GUARD);
+            }
             Epi E;
             if (it_emit) epi_begin(E, it_qf, it_t);
             // Two tiles per wave, window start: the reflected fragments of tile 0 (columns up to HALO + 47) lie in the columns of the
@@ -474,7 +527,8 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
 #pragma unroll
             for (int e = 0; e < 4; ++e) Ht[(32 * rg + 8 * g + 4 * lh + e) * HP + colw + 64 * i] = h[i][4 * g + e];
     __syncthreads();
-    constexpr int NV = (C * (TT / 4) + 255) / 256;          // 13 vectors of 4 columns per thread
+    constexpr int NV = (C * (TT / 4) + 255) / 256;          // 13 (sweep: 16) vectors of 4 columns per thread
+    if (!warm) {                                            // (block-uniform)
     f32x4 sk[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -491,13 +545,17 @@ __global__ __launch_bounds__(256, 1) void filter_block64_kernel(const float* __r
         const int t = t0 + c4;
         if (g >= C * (TT / 4) || t >= L) continue;
         const size_t o = ((size_t)n * C + co) * L + t;
-        const f32x4 v = *(const f32x4*)&Ht[co * HP + HALO + c4];
+        const f32x4 v = *(const f32x4*)&Ht[co * HP + HALO_ + c4];
         if (t + 3 < L) {
             *(f32x4*)(out + o) = v + sk[i];
         } else {
             for (int e = 0; e < 4 && t + e < L; ++e) out[o + e] = v[e] + (skip != nullptr ? skip[o + e] : 0.0f);
         }
     }
+    }
+    if (!SWEEP) break;
+    __syncthreads();                                        // the next tile's staging overwrites the buffers Ht lies over
+    }      // tiles of the segment
 #ifdef ALIVE_STAMPS
     // per block 32 words: wave 0 -> [0..8] phase durations (staging, input conv, six convs, store); wave 2 -> [16..]
     if (stamps != nullptr && (tid == 0 || tid == 128)) {
@@ -532,8 +590,10 @@ int filter_block64_impl(const float* U, int N, int L, const void* W16, const flo
     ALIVE_CHECK_ARG((double)BL * film_ld / L + 3.0 <= NFP, "alive_filter_block64: tile spans more than %d frames (L %d, frames %d)", NFP, L, film_ld);
     {
         static LdsOptIn optin;
-        hipError_t e = optin.ensure({(const void*)filter_block64_kernel<false, 4, H16>, (const void*)filter_block64_kernel<true, 4, H16>,
-                                     (const void*)filter_block64_kernel<true, 2, H16>}, LDS_BYTES);
+        hipError_t e = H16 ? optin.ensure({(const void*)filter_block64_kernel<false, 4, H16>, (const void*)filter_block64_kernel<true, 4, H16>,
+                                           (const void*)filter_block64_kernel<true, 2, H16>, (const void*)filter_block64_kernel<false, 4, true, true>}, LDS_BYTES)
+                           : optin.ensure({(const void*)filter_block64_kernel<false, 4, H16>, (const void*)filter_block64_kernel<true, 4, H16>,
+                                           (const void*)filter_block64_kernel<true, 2, H16>}, LDS_BYTES);
         if (e != hipSuccess) {
             alive_set_error("alive_filter_block64: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(e));
             return ALIVE_ERR_LAUNCH;
@@ -557,6 +617,25 @@ int filter_block64_impl(const float* U, int N, int L, const void* W16, const flo
     const bool small = (int64_t)tiles * N <= 256;
     filter_block64_kernel<true, 4, H16><<<dim3(small ? tiles : 1, N), 256, LDS_BYTES, (hipStream_t)stream>>>(
         U, L, (const unsigned short*)W16, biases, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld, skip, out, g_stamps64);
+    if constexpr (H16) {
+        // the sweep form (see the kernel): columns [TT, L) in segments walked left to right; ALIVE_FB64_SWEEP=0 keeps the tiled form (A/B)
+        static const bool sweep = !(getenv("ALIVE_FB64_SWEEP") && atoi(getenv("ALIVE_FB64_SWEEP")) == 0);
+        if (sweep && tiles > 1 && !small) {
+            const int rem = L - TT, t256 = cdiv(rem, BL);
+            // segments per window: the fewest chip rounds x (tiles per segment + the warm-up tile)
+            int best_s = 1;
+            int64_t best_cost = -1;
+            for (int sg = 1; sg <= (t256 < 64 ? t256 : 64); ++sg) {
+                const int64_t cost = (int64_t)cdiv((int64_t)N * sg, 256) * (cdiv(t256, sg) + 1);
+                if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_s = sg; }
+            }
+            const int seg_cols = cdiv(t256, best_s) * BL;
+            filter_block64_kernel<false, 4, true, true><<<dim3(cdiv(rem, seg_cols), N), 256, LDS_BYTES, (hipStream_t)stream>>>(
+                U, L, (const unsigned short*)W16, biases, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld, skip, out, g_stamps64, TT, seg_cols);
+            ALIVE_CHECK_LAUNCH("alive_filter_block64");
+            return ALIVE_OK;
+        }
+    }
     if (tiles > 1 && !small)
         filter_block64_kernel<false, 4, H16><<<dim3(tiles - 1, N), 256, LDS_BYTES, (hipStream_t)stream>>>(
             U, L, (const unsigned short*)W16, biases, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld, skip, out, g_stamps64);
