@@ -1,0 +1,426 @@
+// FilterBlock.forward for the 256-channel scale of the decoder's U-Net (/root/reference/module/decoder.py:105-150; its 1x1 input conv is
+// composed into the transposed conv in front of it, module/_pack.py), fused into ONE kernel on plain fp16 operands (decoder precision
+// mode 1): round 6.
+//
+// Conv by conv (conv_split_kernel<128, 1, true, true>, six launches + alive_gelu_film per window batch) every k5 conv reads one fp16
+// plane and writes one, every second one also streams the fp32 residual in and out, and each launch runs at ~0.2 of the matrix pipe.
+// Here a block keeps a tile of 128 columns x 256 channels on chip through all six GELU -> FiLM -> reflect-left causal k5 convs
+// (dilations 1, 1, 2, 2, 4, 4):
+//   * the modulated conv input lives in two LDS buffers as ONE fp16 plane, [column][256 channels] = 512-byte rows, 16-byte chunks
+//     XOR-swizzled by (row & 15): a 32x32x16 B fragment is one conflict-free ds_read_b128 at any tap shift;
+//   * wave w owns output channels 64 w .. 64 w + 63 (two 32-row groups) of ALL 128 columns: a k-step (one tap x 16 channels) is two A
+//     fragments of the weights, streamed from L2 in the k-blocked fp16 slab of module/_pack.py::pack_conv_split_h, four B fragments
+//     from LDS and eight MFMAs into eight 32 x 32 accumulators -- 32 B per clock and CU from the L1, 64 from LDS, half of what each
+//     delivers (with 64 columns per wave the weight stream alone was measured at 1.9 of 8.7 ms);
+//   * the fp32 residual stream of the wave's 64 x 128 outputs stays in 128 registers from the tile's load to its store (+ U-Net skip);
+//   * the SWEEP of filter_mid.hip: a block walks a segment of a window left to right, every tile is 128 NEW columns, and each conv's
+//     causal context -- the last 16 columns of its input, 8 KB -- travels to the next tile in REGISTERS (32 bytes per thread and conv);
+//     a segment starts with a warm-up tile that is not stored; at the window's first tile the context is the reflection of the tile's
+//     own columns 1 .. 16 (ReflectionPad1d, common.py:88);
+//   * bufY has no context rows of its own: its rows -16 .. -1 ARE bufZ's rows 112 .. 127 (the buffers are adjacent), which are dead
+//     whenever bufY is read -- their content (the tail of the previous conv's input) has been taken into the context registers by then;
+//   * the FiLM rows a wave applies are those of its own 64 channels: each wave stages them (per 64-column half: <= 10 frames) in a
+//     private LDS table, loaded under the MFMA loop -- no block barrier for them.
+// HBM traffic: the residual stream in, the skip in, the output out (12 B per element instead of ~48).
+#include "conv_epilogue.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int C = 256;
+constexpr int NCONV = 6;
+constexpr int BL = 128;                  // columns per tile
+constexpr int ROWB = 2 * C;              // 512 bytes per LDS row
+constexpr int CTX = 16;                  // context rows in front of a buffer (4 taps back x dilation 4)
+constexpr int GUARD = CTX * ROWB;        // 8 KB
+constexpr int BUFB = BL * ROWB;          // 64 KB
+constexpr int NFS = 16;                  // staged FiLM frames per tile (128 columns span <= 12.8 frames at >= 10 samples per frame, + 1, + slack)
+constexpr int FS_WAVE = 64 * NFS;        // (scale / 2, shift) pairs of one wave's table
+constexpr int FS_BYTES = 4 * FS_WAVE * 8;                             // 32 KB
+// One 32-KB region in front of bufZ serves three tenants in turn, conv by conv: the four waves' bias lines (its first KB: from a conv's
+// start to the accumulators' initialisation), bufZ's 16 context rows (its last 8 KB: from there to the end of the k-loop, even convs), the
+// waves' FiLM tables (all of it: from the barrier behind the k-loop to the end of the epilogue).  With bufZ and bufY: all 160 KB.
+constexpr int LDS_BYTES = FS_BYTES + 2 * BUFB;                        // 163 840 B
+constexpr int KW = 5, NKS = KW * (C / 16);                            // 80 k-steps per conv
+constexpr int PF = 4;                    // k-steps of weights in flight
+
+__device__ __forceinline__ int swz(int row) { return row & 15; }
+__device__ unsigned long long fb256_prof[16];
+#ifdef ALIVE_FB256_PROF        // (phase clocks of one block, printed per call: make EXTRA=-DALIVE_FB256_PROF)
+#define PROF(i) do { const long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define PROF(i) do {} while (0)
+#endif
+
+
+struct Fb256Weights {
+    const unsigned short* w[NCONV];      // fp16 slab of each conv, k-blocked [K / 32][256][32], K = 5 x 256 tap-major
+    const float* b[NCONV];
+};
+
+__global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __restrict__ U, int L, Fb256Weights wts, const float* __restrict__ film,
+                                                                 int film_rows, int Lf, int film_off, float ratio, int t_off, int f_off,
+                                                                 int film_ld, const float* __restrict__ skip, float* __restrict__ out,
+                                                                 int seg_cols, unsigned char* __restrict__ ws, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    unsigned char* const bufZ = sm + FS_BYTES;
+    unsigned char* const bufY = bufZ + BUFB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    f32x2* const Fs = (f32x2*)(bufZ - FS_BYTES) + w * FS_WAVE;                 // this wave's [64 channels][NFS] (scale / 2, shift)
+    float* const Bs = (float*)(bufZ - FS_BYTES) + 64 * w;                      // this wave's 64 biases of the current conv
+    const int n = blockIdx.y;
+    const int seg_begin = (int)blockIdx.x * seg_cols;
+    if (seg_begin >= L) return;
+    const int seg_end = seg_begin + seg_cols < L ? seg_begin + seg_cols : L;
+    const float* Un = U + (size_t)n * C * L;
+    const bool prof = (dbg & 8) && blockIdx.x == 1 && blockIdx.y == 7;
+    long long pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+    // the FiLM rows of this wave's channels 64 w .., conv 0: scale; + 256 rows: shift; + 512 rows: the next conv
+    const float* film_w = film + ((size_t)n * film_rows + film_off + 64 * w) * film_ld;
+
+    // each conv's causal context (its input's last 16 columns, 8 KB) waits for the next tile in the block's slice of the workspace: 32 bytes
+    // per thread and conv, written and read back by the same thread (L2-resident; in registers they cost the k-loop its schedule)
+    unsigned char* const ctx_ws = ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NCONV * GUARD) + tid * 16;
+    const int it_begin = seg_begin > 0 ? -1 : 0;
+
+#pragma unroll 1
+    for (int it = it_begin;; ++it) {
+        const bool warm = it < 0;                       // a segment inside the window starts with a warm-up tile: computed for its context only
+        const int tbase = seg_begin + it * BL;
+        if (it >= 0 && tbase >= seg_end) break;
+        const bool first = tbase == 0;                  // the window's first tile: the context is the reflection of its own columns
+        int n32 = lane & 31, lh = lane >> 5;
+        asm volatile("" : "+v"(n32), "+v"(lh));         // (opaque per tile: keeps hipcc from hoisting every lane-constant address out of the tile loop)
+        const unsigned short* wrow = wts.w[0] + (size_t)(64 * w + n32) * 32 + 8 * lh;
+
+        // weights: A fragment of k-step ks = 16 j + cb for row group rg: rows 64 w + 32 rg + n32, k = 256 j + 16 cb + 8 lh .. + 7
+        auto a_ptr = [&](const unsigned short* Wc, int ks, int rg) {
+            if (dbg & 4) ks &= 3;
+            const int kb = 8 * (ks >> 4) + ((ks & 15) >> 1);
+            return (const bf16x8*)(Wc + (wrow - wts.w[0]) + ((size_t)kb * C + 32 * rg) * 32 + (ks & 1) * 16);
+        };
+        bf16x8 a[PF][2];
+        auto prime = [&](int q) {                       // the first PF k-steps of conv q
+#pragma unroll
+            for (int s = 0; s < PF; ++s) { a[s][0] = *a_ptr(wts.w[q], s, 0); a[s][1] = *a_ptr(wts.w[q], s, 1); }
+        };
+        prime(0);
+
+        // F.interpolate coordinates of this lane's four columns (window frames: t_off in range mode), and the first frame of each half's table
+        int ci0[4]; float cw1[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const int t = tbase + 32 * ct + n32;
+            const Lerp lp = lerp_coord((t < L ? t : L - 1) + t_off, ratio, Lf);
+            ci0[ct] = lp.i0;
+            cw1[ct] = lp.w1;
+        }
+        const int f_lo = lerp_coord((tbase < L ? tbase : L - 1) + t_off, ratio, Lf).i0;
+        // FiLM rows qf (the modulation in front of conv qf) of the wave's 64 channels, frames f_lo .. f_lo + 15: loads, then the table.
+        // A load instruction takes four rows x 16 consecutive frames (a lane per frame: one or two cache lines per row -- a lane per
+        // ROW touches 64 lines per instruction, and the CU's address unit takes them one per clock: 15 k cycles per conv, measured).
+        float fr[32];
+        const int f_lane = lane & 15, r_lane = lane >> 4;
+        auto film_load = [&](int qf) {
+            int fa = f_lo + f_lane;
+            fa = fa < Lf ? fa : Lf - 1;
+            int fc = fa - f_off;                                 // frame of the window -> column of the film tensor
+            fc = fc < 0 ? 0 : (fc < film_ld ? fc : film_ld - 1);
+            const float* p = film_w + ((size_t)qf * 2 * C + r_lane) * film_ld + fc;
+#pragma unroll
+            for (int i = 0; i < 32; ++i)                          // row 4 i + r_lane of the wave's 128: scale rows of 64 channels, then shift rows
+                fr[i] = p[((size_t)(i >> 4) * C + 4 * (i & 15)) * film_ld];
+        };
+        auto film_put = [&]() {
+#pragma unroll
+            for (int i = 0; i < 32; ++i)                          // scale rows halved (exact): see filter_mid.hip
+                ((float*)Fs)[((2 * (i & 15) + (r_lane >> 1)) * NFS + f_lane) * 4 + 2 * (i >> 4) + (r_lane & 1)] = i < 16 ? 0.5f * fr[i] : fr[i];
+        };
+        film_load(0);
+
+        // ---- residual stream of this wave's 64 channels x 128 columns, in the MFMA C layout: h[rg][ct][4 g + e] = channel
+        //      64 w + 32 rg + 8 g + 4 lh + e of column 32 ct + n32 ----
+        float h[2][4][16];
+        auto h_get = [&](int rg, int ct, int r) { return h[rg][ct][r]; };
+        auto h_set = [&](int rg, int ct, int r, float x) { h[rg][ct][r] = x; };
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const int t = tbase + 32 * ct + n32;
+                const float* up = Un + (size_t)(64 * w + 32 * rg + 4 * lh) * L + (t < L ? t : L - 1);      // (columns past the end: finite, never stored)
+                float x[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[r] = up[(size_t)(8 * (r >> 2) + (r & 3)) * L];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h_set(rg, ct, r, x[r]);
+            }
+
+        // GELU -> FiLM -> fp16 -> LDS of one 32 x 32 accumulator tile (channel group rg, column tile ct), FiLM rows from the wave's table
+        auto emit_tile = [&](const f32x16& v, int rg, int ct, unsigned char* dstp) {
+            int col = 32 * ct + n32;
+            int i0 = ci0[ct] - f_lo;
+            i0 = i0 < NFS - 2 ? i0 : NFS - 2;
+            asm volatile("" : "+v"(col), "+v"(i0));         // (opaque per call: the 32 LDS addresses derived from them are three instructions each,
+                                                            // hoisted out of the tile loop they are 100+ registers and the kernel spills)
+            const float w1 = cw1[ct], w0 = 1.0f - w1;
+            const f32x2 W0 = {w0, w0}, W1 = {w1, w1};
+            const bool cnt = !warm && tbase + col < L;      // (saturations of stored columns only)
+            float zmax = 0.0f;
+            // Two adjacent channels at a time on the packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32: two IEEE operations per issue
+            // slot -- the epilogue runs with the matrix pipe idle and is bound by vector issue).  Same operations per value as the scalar
+            // form of filter_mid.hip.  The table holds (scale / 2 of both channels, shift of both) per frame: one ds_read_b128 each.
+            auto fma2 = [](f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); };
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned zz[2];
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const f32x4* fp = (const f32x4*)Fs + (16 * rg + 4 * g + 2 * lh + pr) * NFS + i0;
+                    const f32x4 a0 = fp[0], a1 = fp[1];
+                    const f32x2 sc = fma2(W0, f32x2{a0[0], a0[1]}, W1 * f32x2{a1[0], a1[1]});      // ATen's linear interpolation
+                    const f32x2 sh = fma2(W0, f32x2{a0[2], a0[3]}, W1 * f32x2{a1[2], a1[3]});
+                    const f32x2 x = {v[4 * g + 2 * pr], v[4 * g + 2 * pr + 1]};
+                    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+                    const f32x2 tq = fma2(ax, f32x2{0.3275911f * 0.70710678118654752440f, 0.3275911f * 0.70710678118654752440f}, f32x2{1.0f, 1.0f});
+                    const f32x2 t = {__builtin_amdgcn_rcpf(tq[0]), __builtin_amdgcn_rcpf(tq[1])};
+                    const f32x2 xs = x * f32x2{0.84932180028801904272f, 0.84932180028801904272f};
+                    const f32x2 qq = xs * xs;
+                    const f32x2 ex = {__builtin_amdgcn_exp2f(-qq[0]), __builtin_amdgcn_exp2f(-qq[1])};
+                    f32x2 p = fma2(f32x2{1.061405429f, 1.061405429f}, t, f32x2{-1.453152027f, -1.453152027f});
+                    p = fma2(p, t, f32x2{1.421413741f, 1.421413741f});
+                    p = fma2(p, t, f32x2{-0.284496736f, -0.284496736f});
+                    p = fma2(p, t, f32x2{0.254829592f, 0.254829592f});
+                    const f32x2 erf_abs = fma2(-(p * t), ex, f32x2{1.0f, 1.0f});
+                    const f32x2 z = fma2(fma2(ax, erf_abs, x), sc, sh);          // 2 gelu(x) * (scale / 2) + shift
+                    zmax = fmaxf(zmax, fmaxf(fabsf(z[0]), fabsf(z[1])));
+                    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+                    const f16x2_t hz = {(_Float16)__builtin_amdgcn_fmed3f(z[0], -65504.0f, 65504.0f), (_Float16)__builtin_amdgcn_fmed3f(z[1], -65504.0f, 65504.0f)};
+                    zz[pr] = __builtin_bit_cast(unsigned, hz);
+                }
+                const int chunk = 8 * w + 4 * rg + g;
+                unsigned char* p = dstp + col * ROWB + ((chunk ^ swz(col)) << 4) + 8 * lh;
+                *(uint2*)p = make_uint2(zz[0], zz[1]);
+            }
+            // (one count per lane and 16 values, not per converted pair: the guards read "any")
+            if (__builtin_expect(cnt && zmax > 65504.0f, 0)) atomicAdd(&alive_f16_sat_count, 1u);
+        };
+        // the context in front of a buffer: the previous tile's (registers) or, at the window's first tile, rows 1 .. 16 reflected
+        auto put_context = [&](unsigned char* buf, int q) {
+            if (first) {
+                const int j = 1 + (tid >> 4);                   // rows 1 .. 16, 32 chunks each: two chunks per thread
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int p = (tid & 15) + 16 * u;          // stored chunk position in row j
+                    const int c = p ^ swz(j);                   // the channel chunk it holds
+                    *(u32x4*)(buf - j * ROWB + ((c ^ swz(-j)) << 4)) = *(const u32x4*)(buf + j * ROWB + (p << 4));
+                }
+            } else {
+                u32x4 c0 = {0u, 0u, 0u, 0u}, c1 = c0;            // (a warm-up tile has no context: its stored columns' cone does not reach it)
+                if (it != it_begin) {
+                    c0 = *(const u32x4*)(ctx_ws + q * GUARD);
+                    c1 = *(const u32x4*)(ctx_ws + q * GUARD + 4096);
+                }
+                *(u32x4*)(buf - GUARD + tid * 16) = c0;
+                *(u32x4*)(buf - GUARD + 4096 + tid * 16) = c1;
+            }
+        };
+        auto take_context = [&](const unsigned char* buf, int q) {          // rows 112 .. 127 of a conv's complete input
+            *(u32x4*)(ctx_ws + q * GUARD) = *(const u32x4*)(buf + (BL - CTX) * ROWB + tid * 16);
+            *(u32x4*)(ctx_ws + q * GUARD + 4096) = *(const u32x4*)(buf + (BL - CTX) * ROWB + 4096 + tid * 16);
+        };
+
+        PROF(0);
+        __syncthreads();                                  // the previous tile is done with the buffers
+        PROF(1);
+        // ---- z0 = mod_0(h) ----
+        film_put();
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                f32x16 v;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = h_get(rg, ct, r);
+                emit_tile(v, rg, ct, bufZ);
+            }
+        __syncthreads();
+        PROF(2);
+
+        // ---- six convs: q = 2 j (c1), 2 j + 1 (c2), dilation 2^j   (decoder.py:128-134) ----
+#pragma unroll 1
+        for (int q = 0; q < NCONV; ++q) {
+            const bool second = (q & 1) != 0;
+            const bool last = q + 1 == NCONV;
+            unsigned char* in = second ? bufY : bufZ;
+            unsigned char* dst = second ? bufZ : bufY;
+            const int d = 1 << (q >> 1);
+            const unsigned short* Wc = wts.w[q];
+            const float* bc = wts.b[q];
+            // `in` is complete (barrier behind the previous stage).  Its own context goes in front of it -- the previous tile's, from the
+            // registers, or the reflection -- and its tail becomes the next tile's context.  The two touch different rows: for bufY the
+            // context rows are bufZ's rows 112 .. 127, which the conv before this one has finished reading (and taken).
+            put_context(in, q);
+            take_context(in, q);
+            __syncthreads();
+            PROF(3);
+            f32x16 acc[2][4];
+            Bs[lane] = bc[64 * w + lane];                  // (one coalesced load, then the C layout's 32 values per lane as 8 LDS reads)
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg) {
+                f32x16 b16;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = *(const f32x4*)(Bs + 32 * rg + 8 * g + 4 * lh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b16[4 * g + e] = v[e];
+                }
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[rg][ct] = b16;
+            }
+            // One k-step = 8 MFMAs, 4 B fragments of the NEXT k-step (LDS, into the other buffer), 2 A fragments of k-step ks + PF (L2, into
+            // the ring slot this k-step has just read).  ONE memory instruction per MFMA: with a wave per SIMD a memory instruction that
+            // waits for its queue (four waves in step behind the same barrier) holds up the wave's next MFMA, and four or two of them in a
+            // row cost a k-step 170 of 426 cycles (measured against the loop without them); behind an MFMA the wait runs under its 32
+            // cycles.  (The scheduling fences keep hipcc from regrouping them; no value outlives its register's next definition, so ring
+            // and buffers stay in place.)  Each accumulator still takes one MFMA per k-step in k order: the sums are the same bits.
+            auto b_frag = [&](int ks, int ct) {
+                const int j = ks >> 4, cb = ks & 15;
+                const int row = 32 * ct + n32 + (j - 4) * d;           // >= -16: the context rows
+                return *(const bf16x8*)(in + row * ROWB + (((2 * cb + lh) ^ swz(row)) << 4));
+            };
+            bf16x8 bfr[2][4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) bfr[0][ct] = b_frag(0, ct);
+#pragma unroll 4
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int k1 = ks + 1 < NKS ? ks + 1 : NKS - 1;                                // (past the end: the last k-step again, no branch)
+                const int kn = (dbg & 16) ? 0 : (ks + PF < NKS ? ks + PF : NKS - 1);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    acc[0][ct] = mfma_f16(a[ks % PF][0], bfr[ks & 1][ct], acc[0][ct]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    bfr[(ks + 1) & 1][ct] = b_frag(k1, ct);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc[1][0] = mfma_f16(a[ks % PF][1], bfr[ks & 1][0], acc[1][0]);
+                __builtin_amdgcn_sched_barrier(0);
+                a[ks % PF][0] = *a_ptr(Wc, kn, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ct = 1; ct < 4; ++ct) acc[1][ct] = mfma_f16(a[ks % PF][1], bfr[ks & 1][ct], acc[1][ct]);
+                __builtin_amdgcn_sched_barrier(0);
+                a[ks % PF][1] = *a_ptr(Wc, kn, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            PROF(4);
+            if (!last) {
+                film_load(q + 1);                           // (behind the k-loop: 32 registers that the loop's schedule does not have)
+                prime(q + 1);                               // (in flight under the epilogue)
+            }
+            __syncthreads();                               // every wave is done reading `in` (and bufZ's context rows, which the tables replace)
+            PROF(5);
+            if (!last) film_put();
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    f32x16 v = acc[rg][ct];
+                    if (second) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { v[r] = v[r] + h_get(rg, ct, r); h_set(rg, ct, r, v[r]); }
+                    }
+                    if (!last && !(dbg & 2)) emit_tile(v, rg, ct, dst);
+                }
+            __syncthreads();                               // dst complete
+            PROF(6);
+        }
+
+        // ---- store (+ U-Net skip, decoder.py:191), straight from the residual registers ----
+        if (!warm) {
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    const int t = tbase + 32 * ct + n32;
+                    if (t >= L) continue;
+                    const size_t o = ((size_t)n * C + 64 * w + 32 * rg + 4 * lh) * L + t;
+                    if (skip != nullptr) {
+                        float sk[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sk[r] = skip[o + (size_t)(8 * (r >> 2) + (r & 3)) * L];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) out[o + (size_t)(8 * (r >> 2) + (r & 3)) * L] = h_get(rg, ct, r) + sk[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) out[o + (size_t)(8 * (r >> 2) + (r & 3)) * L] = h_get(rg, ct, r);
+                    }
+                }
+        }
+        PROF(7);
+    }
+    if (prof && tid == 0)
+        for (int i = 0; i < 10; ++i) atomicAdd(&fb256_prof[i], (unsigned long long)pacc[i]);
+}
+
+}  // namespace
+
+// U[N][256][L] (the block's residual stream: the output of the composed transposed conv) -> out = FilterBlock(U) + skip, fp32.
+// w16[q] / bias[q], q = 0 .. 5: blocks[q / 2].c1 / .c2 -- the fp16 slab of module/_pack.py::pack_conv_split_h and the fp32 bias.
+// film[N][film_rows][film_ld]: rows film_off + q * 512 + (0 .. 255 scale | 256 .. 511 shift) for conv q; frame range as alive_filter_block64_range.
+// bytes of workspace alive_filter_block256_fp16 needs at most: six 8-KB contexts per block, one block per segment of a window
+extern "C" int64_t alive_filter_block256_workspace_bytes(int N, int L) {
+    return N > 0 && L > 0 ? (int64_t)N * cdiv(L, BL) * NCONV * GUARD : 0;
+}
+
+extern "C" int alive_filter_block256_fp16(const float* U, int N, int L, const void* const* w16, const float* const* bias, const float* film,
+                                          int film_rows, int Lf, int film_off, int t0, int f0, int film_ld, const float* skip, float* out,
+                                          void* ws, int64_t ws_bytes, void* stream) {
+    ALIVE_CHECK_ARG(U && w16 && bias && film && out, "alive_filter_block256_fp16: null pointer");
+    ALIVE_CHECK_ARG(N > 0 && L > 2 * CTX && Lf > 0, "alive_filter_block256_fp16: bad sizes (L must exceed 32)");
+    ALIVE_CHECK_ARG(U != out, "alive_filter_block256_fp16: in-place not supported (a segment's warm-up tile reads its left neighbour's input)");
+    ALIVE_CHECK_ARG(film_ld > 0 && t0 >= 0 && f0 >= 0, "alive_filter_block256_fp16: bad frame range");
+    ALIVE_CHECK_ARG((double)BL * film_ld / L + 3.0 <= NFS, "alive_filter_block256_fp16: 128 columns span more than %d frames (L %d, frames %d)", NFS - 3, L, film_ld);
+    Fb256Weights wts;
+    for (int q = 0; q < NCONV; ++q) {
+        ALIVE_CHECK_ARG(w16[q] && bias[q], "alive_filter_block256_fp16: null weights");
+        wts.w[q] = (const unsigned short*)w16[q];
+        wts.b[q] = bias[q];
+    }
+    {
+        static LdsOptIn optin;
+        hipError_t e = optin.ensure({(const void*)filter_block256_kernel}, LDS_BYTES);
+        if (e != hipSuccess) {
+            alive_set_error("alive_filter_block256_fp16: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(e));
+            return ALIVE_ERR_LAUNCH;
+        }
+    }
+    const float ratio = (float)film_ld / (float)L;
+    const int tiles = cdiv(L, BL);
+    // segments per window: the fewest chip rounds x (tiles per segment + the warm-up tile of a segment inside the window)
+    int best_s = 1;
+    int64_t best_cost = -1;
+    for (int sg = 1; sg <= (tiles < 64 ? tiles : 64); ++sg) {
+        const int64_t cost = (int64_t)cdiv((int64_t)N * sg, 256) * (cdiv(tiles, sg) + (sg > 1 ? 1 : 0));
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_s = sg; }
+    }
+    const int seg_cols = cdiv(tiles, best_s) * BL;
+    ALIVE_CHECK_ARG(ws != nullptr && ws_bytes >= (int64_t)N * cdiv(L, seg_cols) * NCONV * GUARD,
+                    "alive_filter_block256_fp16: workspace too small (alive_filter_block256_workspace_bytes)");
+    filter_block256_kernel<<<dim3(cdiv(L, seg_cols), N), 256, LDS_BYTES, (hipStream_t)stream>>>(
+        U, L, wts, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld, skip, out, seg_cols, (unsigned char*)ws, getenv("ALIVE_FB256_DBG") ? atoi(getenv("ALIVE_FB256_DBG")) : 0);
+    ALIVE_CHECK_LAUNCH("alive_filter_block256_fp16");
+    if (getenv("ALIVE_FB256_DBG") && (atoi(getenv("ALIVE_FB256_DBG")) & 8)) {
+        unsigned long long v[16], z[16] = {0};
+        hipDeviceSynchronize();
+        hipMemcpyFromSymbol(v, HIP_SYMBOL(fb256_prof), sizeof(v));
+        hipMemcpyToSymbol(HIP_SYMBOL(fb256_prof), z, sizeof(z));
+        fprintf(stderr, "fb256 cycles: start->loads issued %llu | barrier %llu | z0 %llu | ctx+B1 %llu | k-loop %llu | B2 %llu | epilogue+B3 %llu | store %llu | (k-loop head: bias, stores, first loads) %llu\n", v[0], v[1], v[2],
+                v[3], v[4], v[5], v[6], v[7], v[8]);
+    }
+    return ALIVE_OK;
+}
+
+ALIVE_F16_SAT_GETTER(alive_f16_sat_filter_big)

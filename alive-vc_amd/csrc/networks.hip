@@ -151,6 +151,11 @@ int decoder_bf16_mask() {
     return decoder_precision() == 1 ? m : 0;
 }
 
+bool fb256_enabled() {          // ALIVE_FB256=0: the 256-channel block conv by conv, as in round 5
+    static const bool on = !(getenv("ALIVE_FB256") && atoi(getenv("ALIVE_FB256")) == 0);
+    return on;
+}
+
 // the plain (fp16) image of a weight tensor packed by module/_pack.py::pack_conv_split_h: the third slab behind the two bf16 planes
 const float* plain_w(const float* W, int rows_pad16, int K) {
     return (const float*)((const unsigned short*)W + (size_t)2 * rows_pad16 * K);
@@ -715,9 +720,12 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
     int cin = 256, L = Lf, film_off = 0;
     for (int s = 0; s < 4; ++s) {
         const int C = F_CH[s], r = F_UP[s];
+        // (a) in decoder precision mode 1, batch path: the 256-channel block in one kernel (filter_big.hip), U -> Hh like the finer scales.
+        // (The rule reads the signal's length only: a window's samples do not depend on how many windows share the call.)
+        const bool fused256 = F_MODE[s] == 0 && (decoder_bf16_mask() & 1) != 0 && b.Pa != nullptr && fb256_enabled() && L * r >= 128;
         {   // ConvTranspose1d(cin, C, r, r): rows = (co, j).  Unfused scale: the weights are ups[s] x input_conv (module/_pack.py), the
             // output is the block's residual stream itself
-            AliveConv d = conv_desc(upW[s], upb[s], cur, N, cin, L, C * r, 1, 1, 1, 0, 0, L, F_MODE[s] == 0 ? b.Hh : b.U);
+            AliveConv d = conv_desc(upW[s], upb[s], cur, N, cin, L, C * r, 1, 1, 1, 0, 0, L, F_MODE[s] == 0 && !fused256 ? b.Hh : b.U);
             d.up = r;
             if (F_SPLIT[s]) d = split(d);
             // (experiment, mask bit 8, off: the two transposed convs are bound by their stores -- 170.1 +- 0.3 ms per step either way, and the
@@ -741,6 +749,20 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
                     RUN(alive_filter_block64_range(b.U, N, L, w16, bias, b.film, FILM_ROWS, Lw_frames, film_off, f_begin * (L / Lf), f_begin, Lf,
                                                    skips[s], b.Hh, stream));
             }
+            film_off += 6 * 2 * C;
+            cur = b.Hh;
+            cin = C;
+            continue;
+        }
+        if (fused256) {
+            const void* w16[6]; const float* bias[6];
+            for (int q = 0; q < 6; ++q) {
+                w16[q] = plain_w(t.next(), C, 5 * C);
+                bias[q] = t.next();
+            }
+            // (workspace: Zz, idle on this path -- N x 5120 Lf floats against N x (10 Lf / 128 + 1) x 48 KB)
+            RUN(alive_filter_block256_fp16(b.U, N, L, w16, bias, b.film, FILM_ROWS, Lw_frames, film_off, f_begin * (L / Lf), f_begin, Lf, skips[s],
+                                           b.Hh, b.Zz, (int64_t)N * 64 * (Lw / 4) * 4, stream));
             film_off += 6 * 2 * C;
             cur = b.Hh;
             cin = C;
@@ -803,20 +825,21 @@ extern "C" int alive_decoder_precision(int mode) {
     return decoder_precision();
 }
 
-int alive_f16_sat_conv_split(int), alive_f16_sat_gemm(int), alive_f16_sat_blocks(int), alive_f16_sat_conv(int), alive_f16_sat_filter_mid(int);
+int alive_f16_sat_conv_split(int), alive_f16_sat_gemm(int), alive_f16_sat_blocks(int), alive_f16_sat_conv(int), alive_f16_sat_filter_mid(int),
+    alive_f16_sat_filter_big(int);
 extern "C" int alive_f16_saturations(int reset) {
     const int a = alive_f16_sat_conv_split(reset), b = alive_f16_sat_gemm(reset), c = alive_f16_sat_blocks(reset), d = alive_f16_sat_conv(reset);
-    const int e = alive_f16_sat_filter_mid(reset);
-    if (a < 0 || b < 0 || c < 0 || d < 0 || e < 0) return -1;
-    const long long t = (long long)a + b + c + d + e;
+    const int e = alive_f16_sat_filter_mid(reset), f = alive_f16_sat_filter_big(reset);
+    if (a < 0 || b < 0 || c < 0 || d < 0 || e < 0 || f < 0) return -1;
+    const long long t = (long long)a + b + c + d + e + f;
     return (int)(t > 0x7fffffff ? 0x7fffffff : t);
 }
 
 int alive_f16_sat_conv_split_clear(void*), alive_f16_sat_gemm_clear(void*), alive_f16_sat_blocks_clear(void*), alive_f16_sat_conv_clear(void*),
-    alive_f16_sat_filter_mid_clear(void*);
+    alive_f16_sat_filter_mid_clear(void*), alive_f16_sat_filter_big_clear(void*);
 extern "C" int alive_f16_saturations_clear(void* stream) {
     const int r = alive_f16_sat_conv_split_clear(stream) | alive_f16_sat_gemm_clear(stream) | alive_f16_sat_blocks_clear(stream) |
-                  alive_f16_sat_conv_clear(stream) | alive_f16_sat_filter_mid_clear(stream);
+                  alive_f16_sat_conv_clear(stream) | alive_f16_sat_filter_mid_clear(stream) | alive_f16_sat_filter_big_clear(stream);
     if (r != 0) {
         alive_set_error("alive_f16_saturations_clear: the runtime refused the asynchronous clear of a counter");
         return ALIVE_ERR_LAUNCH;

@@ -247,6 +247,33 @@ def filter_block64(x, sd, prefix, film, film_off, skip=None, plain=False):
     return out
 
 
+def filter_block256(x, sd, prefix, film, film_off, skip=None, t0=0, f0=0, frames=None):
+    """fused FilterBlock for C = 256 on plain fp16 operands WITHOUT its 1x1 input conv (the decoder composes that into the transposed conv
+    that produces x; csrc/filter_big.hip, decoder precision mode 1): x[N,256,L] = the block's residual stream, reference-layout weights
+    sd[prefix + '.blocks.j.c1 / c2 ...'].  t0 / f0 / frames: the window's place in a longer signal (alive_filter_block64_range)."""
+    import ctypes
+    from ._pack import pack_conv_split_h
+    x, film, skip = _f(x), _f(film), _f(skip)
+    n, c, l = x.shape
+    assert c == 256
+    keep, ws, bs = [], [], []
+    for j in range(3):
+        for cc in ("c1", "c2"):
+            w = pack_conv_split_h(sd[f"{prefix}.blocks.{j}.{cc}.conv.conv.weight"].to(x.device))       # [3, K / 32, 256, 32]: slab 2 = fp16
+            b = _f(sd[f"{prefix}.blocks.{j}.{cc}.conv.conv.bias"]).to(x.device)
+            keep += [w, b]
+            ws.append(nat.ptr(w[2]))
+            bs.append(nat.ptr(b))
+    nbytes = nat.lib().alive_filter_block256_workspace_bytes(n, l)
+    ws_buf = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    out = torch.empty_like(x)
+    nat.check(nat.lib().alive_filter_block256_fp16(nat.ptr(x), n, l, (ctypes.c_void_p * 6)(*ws), (ctypes.c_void_p * 6)(*bs), nat.ptr(film),
+                                                   film.shape[1], film.shape[2] if frames is None else frames, film_off, t0, f0,
+                                                   film.shape[2], nat.ptr(skip), nat.ptr(out), nat.ptr(ws_buf), nbytes, nat.stream()),
+              "alive_filter_block256_fp16")
+    return out
+
+
 def filter_source_in(src, w_in, b_in, w_d, b_d):
     """downs[0](source_in(src)) in one streaming kernel: src[N,1,Lw] -> [N,16,Lw/2] (reference-layout weights)"""
     src = _f(src)

@@ -380,6 +380,18 @@ int alive_filter_block64_range_fp16(const float* U, int N, int L, const void* W1
                                int film_rows, int Lf, int film_off, int t0, int f0, int film_ld, const float* skip,
                                float* out, void* stream);
 
+/* FilterBlock.forward (decoder.py:137-150) for C = 256 fused into one kernel on plain fp16 operands (filter_big.hip; decoder precision
+ * mode 1, batch path): a block sweeps a segment of a window in tiles of 128 columns, the six modulated k5 convs' inputs stay in LDS as one
+ * fp16 plane, the residual stream in registers.  The 1x1 input conv is part of the transposed conv that produces U (module/_pack.py).
+ *   w16[q], bias[q], q = 0..5: blocks[q / 2].c1 / .c2 -- the fp16 slab [K / 32][256][32] (K = 5 x 256, tap-major) of
+ *        module/_pack.py::pack_conv_split_h (third slab of the pack) and the fp32 bias [256];  w16 and bias are HOST arrays of device pointers.
+ *   film / film_off / t0 / f0 / film_ld / skip / out as alive_filter_block64_range;  L > 32;  not in place;
+ *   ws: alive_filter_block256_workspace_bytes(N, L) bytes of device scratch (the convs' causal contexts between a block's tiles). */
+int64_t alive_filter_block256_workspace_bytes(int N, int L);
+int alive_filter_block256_fp16(const float* U, int N, int L, const void* const* w16, const float* const* bias, const float* film,
+                               int film_rows, int Lf, int film_off, int t0, int f0, int film_ld, const float* skip, float* out,
+                               void* ws, int64_t ws_bytes, void* stream);
+
 /* The waveform-rate edges of Filter.forward (decoder.py:164,182,186-188,194) as streaming kernels:
  *   alive_filter_source_in : downs[0](source_in(src)):  src[N][Lw] -> d0[N][16][Lw/2]
  *                            Win[8][7], bin[8] = source_in (pad 3); Wd[16][8][2], bd[16] = downs[0] (stride 2); fp32,

@@ -301,6 +301,74 @@ def test_modulated_chain_split_bf16(golden_dir):
     assert relerr(h, ref) < 1e-4, relerr(h, ref)
 
 
+@pytest.mark.parametrize("l,lf,n", [(4500, 450, 2), (370, 37, 3), (1280, 128, 1), (130, 13, 2), (4490, 449, 9)])
+def test_fused_filter_block_256(l, lf, n):
+    """the 256-channel FilterBlock in one kernel (round 6, csrc/filter_big.hip: plain fp16 operands, a block sweeps a segment of a window in
+    128-column tiles, contexts handed over through the workspace, warm-up tile per inner segment, reflection at a window's start) against
+    the oracle's conv-by-conv evaluation (decoder.py:105-150) with an identity input conv: fp16 operand rounding (2^-12 per operand) is
+    the whole difference.  Lengths that are no multiple of the tile or of 4, one tile, many segments per window (n = 1) and few (n = 9)."""
+    from module import ops
+    c, cond_ch = 256, 24
+    x = g(f"fb256x{l}", (n, c, l))
+    cnd = g(f"fb256c{l}", (n, cond_ch, lf))
+    skip = g(f"fb256s{l}", (n, c, l))
+    sd = {"n.input_conv.weight": torch.eye(c).unsqueeze(-1).contiguous(), "n.input_conv.bias": torch.zeros(c)}
+    ws, bs, post = [], [], []
+    for j in range(3):
+        for cc in ("c1", "c2"):
+            p = f"n.blocks.{j}.{cc}"
+            sd[p + ".conv.conv.weight"] = g(p + "w256", (c, c, 5), scale=0.5 / np.sqrt(c))
+            sd[p + ".conv.conv.bias"] = g(p + "b256", (c,), scale=0.1)
+            sd[p + ".to_scale.weight"] = g(p + "sw256", (c, cond_ch, 1), scale=0.1)
+            sd[p + ".to_scale.bias"] = g(p + "sb256", (c,), scale=0.1)
+            sd[p + ".to_shift.weight"] = g(p + "hw256", (c, cond_ch, 1), scale=0.1)
+            sd[p + ".to_shift.bias"] = g(p + "hb256", (c,), scale=0.1)
+            ws += [sd[p + ".to_scale.weight"], sd[p + ".to_shift.weight"]]
+            bs += [sd[p + ".to_scale.bias"], sd[p + ".to_shift.bias"]]
+            post += [torch.ones(c), torch.zeros(c)]
+    ref = O.filter_block(sd, "n", x, cnd) + skip
+    pad_rows = 5                                     # FiLM rows start at an offset inside a larger table, as in the decoder
+    film, _ = ops.conv1d(cnd.to(DEV), torch.cat([torch.zeros(pad_rows, cond_ch, 1)] + ws, 0).to(DEV),
+                         torch.cat([torch.zeros(pad_rows)] + bs, 0).to(DEV), post_add=torch.cat([torch.zeros(pad_rows)] + post).to(DEV))
+    ops.f16_saturations(reset=True)
+    out = ops.filter_block256(x.to(DEV), sd, "n", film, pad_rows, skip=skip.to(DEV))
+    e = relerr(out, ref)
+    assert e < 6e-4, e                               # (the 64-channel block's fp16 form: < 6e-4 on the same construction)
+    assert ops.f16_saturations(reset=True) == 0
+    for _ in range(2):                               # run to run, and window by window: a window's samples do not depend on how many
+        assert torch.equal(ops.filter_block256(x.to(DEV), sd, "n", film, pad_rows, skip=skip.to(DEV)), out)       # windows share the call
+    one = ops.filter_block256(x[:1].to(DEV), sd, "n", film[:1].contiguous(), pad_rows, skip=skip[:1].to(DEV))      # (other segmentation)
+    assert torch.equal(one, out[:1])
+
+
+def test_fused_filter_block_256_in_a_frame_range():
+    """range mode (alive_filter_block64_range's t0 / f0 / film_ld): frames 40 .. 89 of a 128-frame signal with the FiLM rows of those frames
+    only.  Past the reach of the window's start (its first 5 columns interpolate towards frame 39, which the table does not hold, and
+    the reflected context reaches 4 (1 + 1 + 2 + 2 + 4 + 4) = 56 columns further) and short of its last frame (whose interpolation
+    partner lies outside the table) the samples are those of the whole signal's run, bit for bit -- the interpolation
+    coordinates are the signal's, and a column's sums do not depend on the tile it falls into."""
+    from module import ops
+    c, cond_ch, lf, f0, nf = 256, 24, 128, 40, 50
+    x = g("fb256rx", (1, c, 10 * lf))
+    cnd = g("fb256rc", (1, cond_ch, lf))
+    sd = {}
+    ws, bs, post = [], [], []
+    for j in range(3):
+        for cc in ("c1", "c2"):
+            p = f"n.blocks.{j}.{cc}"
+            sd[p + ".conv.conv.weight"] = g(p + "w256", (c, c, 5), scale=0.5 / np.sqrt(c))
+            sd[p + ".conv.conv.bias"] = g(p + "b256", (c,), scale=0.1)
+            ws += [g(p + "sw256", (c, cond_ch, 1), scale=0.1), g(p + "hw256", (c, cond_ch, 1), scale=0.1)]
+            bs += [g(p + "sb256", (c,), scale=0.1), g(p + "hb256", (c,), scale=0.1)]
+            post += [torch.ones(c), torch.zeros(c)]
+    film, _ = ops.conv1d(cnd.to(DEV), torch.cat(ws, 0).to(DEV), torch.cat(bs, 0).to(DEV), post_add=torch.cat(post).to(DEV))
+    whole = ops.filter_block256(x.to(DEV), sd, "n", film, 0)
+    part = ops.filter_block256(x[:, :, 10 * f0:10 * (f0 + nf)].contiguous().to(DEV), sd, "n", film[:, :, f0:f0 + nf].contiguous(), 0,
+                               t0=10 * f0, f0=f0, frames=lf)
+    assert torch.equal(part[:, :, 61:10 * nf - 16], whole[:, :, 10 * f0 + 61:10 * (f0 + nf) - 16])
+    assert not torch.equal(part[:, :, :16], whole[:, :, 10 * f0:10 * f0 + 16])             # (the reflected start is the window's own)
+
+
 @pytest.mark.parametrize("c,l,lf", [(8, 4800, 15), (16, 2400, 15), (8, 144000, 450), (16, 1000, 5),
                                     (64, 1200, 15), (64, 36000, 450), (64, 400, 5), (64, 408, 5)])
 def test_fused_filter_block_small(c, l, lf):
