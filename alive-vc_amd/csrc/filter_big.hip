@@ -45,8 +45,25 @@ constexpr int KW = 5, NKS = KW * (C / 16);                            // 80 k-st
 constexpr int PF = 4;                    // k-steps of weights in flight
 
 __device__ __forceinline__ int swz(int row) { return row & 15; }
+
+// LDS by byte offset, through pointers of the LDS address space only.  (As generic pointers -- selected between the two buffers, captured
+// by the lambdas -- hipcc 7.2 at times leaves one as a flat pointer with a null test it cannot select: "Illegal instruction detected:
+// V_CMP_NE_U32_e32 0, $src_shared_base", on and off with unrelated edits.)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"      // (the host pass sees 64-bit pointers; LDS pointers are 32 bits)
+// (`off`: a compile-time constant where there is one -- added in the pointer domain it folds into the instruction's offset field)
+template <class T>
+__device__ __forceinline__ T lds_get(int base, int off = 0) {
+    return *(const __attribute__((address_space(3))) T*)((const __attribute__((address_space(3))) unsigned char*)(unsigned)base + off);
+}
+template <class T>
+__device__ __forceinline__ void lds_put(int base, int off, T v) {
+    *(__attribute__((address_space(3))) T*)((__attribute__((address_space(3))) unsigned char*)(unsigned)base + off) = v;
+}
+#pragma clang diagnostic pop
+#ifdef ALIVE_FB256_PROF        // (phase clocks of block 7, printed per call: make EXTRA=-DALIVE_FB256_PROF; tools/bench_fb256.py)
 __device__ unsigned long long fb256_prof[16];
-#ifdef ALIVE_FB256_PROF        // (phase clocks of one block, printed per call: make EXTRA=-DALIVE_FB256_PROF)
 #define PROF(i) do { const long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - tprev; tprev = t_; } while (0)
 #else
 #define PROF(i) do {} while (0)
@@ -61,43 +78,42 @@ struct Fb256Weights {
 __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __restrict__ U, int L, Fb256Weights wts, const float* __restrict__ film,
                                                                  int film_rows, int Lf, int film_off, float ratio, int t_off, int f_off,
                                                                  int film_ld, const float* __restrict__ skip, float* __restrict__ out,
-                                                                 int seg_cols, unsigned char* __restrict__ ws, int dbg) {
+                                                                 int tiles, int per_block, int total, unsigned char* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-    unsigned char* const bufZ = sm + FS_BYTES;
-    unsigned char* const bufY = bufZ + BUFB;
+    const int sm0 = (int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)sm;      // (0: the kernel has no static LDS)
+    const int bufZ = sm0 + FS_BYTES;
+    const int bufY = bufZ + BUFB;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    f32x2* const Fs = (f32x2*)(bufZ - FS_BYTES) + w * FS_WAVE;                 // this wave's [64 channels][NFS] (scale / 2, shift)
-    float* const Bs = (float*)(bufZ - FS_BYTES) + 64 * w;                      // this wave's 64 biases of the current conv
-    const int n = blockIdx.y;
-    const int seg_begin = (int)blockIdx.x * seg_cols;
-    if (seg_begin >= L) return;
-    const int seg_end = seg_begin + seg_cols < L ? seg_begin + seg_cols : L;
-    const float* Un = U + (size_t)n * C * L;
-    const bool prof = (dbg & 8) && blockIdx.x == 1 && blockIdx.y == 7;
+    const int Fs = sm0 + w * FS_WAVE * 8;                       // this wave's [32 channel pairs][NFS] x (scale / 2 of both, shift of both)
+    const int Bs = sm0 + 256 * w;                               // this wave's 64 biases of the current conv
+    // The batch is one sequence of tiles, window after window; a block takes per_block consecutive ones (any number of windows, any
+    // place inside one) -- every CU gets the same count whatever the batch size, and one warm-up tile per block is all the redundancy.
+    const int g0 = (int)blockIdx.x * per_block;
+    const int g1 = g0 + per_block < total ? g0 + per_block : total;
+#ifdef ALIVE_FB256_PROF
     long long pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
-    // the FiLM rows of this wave's channels 64 w .., conv 0: scale; + 256 rows: shift; + 512 rows: the next conv
-    const float* film_w = film + ((size_t)n * film_rows + film_off + 64 * w) * film_ld;
-
+#endif
     // each conv's causal context (its input's last 16 columns, 8 KB) waits for the next tile in the block's slice of the workspace: 32 bytes
     // per thread and conv, written and read back by the same thread (L2-resident; in registers they cost the k-loop its schedule)
-    unsigned char* const ctx_ws = ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NCONV * GUARD) + tid * 16;
-    const int it_begin = seg_begin > 0 ? -1 : 0;
+    unsigned char* const ctx_ws = ws + (size_t)blockIdx.x * (NCONV * GUARD) + tid * 16;
 
 #pragma unroll 1
-    for (int it = it_begin;; ++it) {
-        const bool warm = it < 0;                       // a segment inside the window starts with a warm-up tile: computed for its context only
-        const int tbase = seg_begin + it * BL;
-        if (it >= 0 && tbase >= seg_end) break;
+    for (int g = g0 % tiles ? g0 - 1 : g0; g < g1; ++g) {
+        const bool warm = g < g0;                       // a block that starts inside a window computes the tile before for its contexts only
+        const int n = g / tiles;
+        const int tbase = (g - n * tiles) * BL;
         const bool first = tbase == 0;                  // the window's first tile: the context is the reflection of its own columns
+        const float* Un = U + (size_t)n * C * L;
+        // the FiLM rows of this wave's channels 64 w .., conv 0: scale; + 256 rows: shift; + 512 rows: the next conv
+        const float* film_w = film + ((size_t)n * film_rows + film_off + 64 * w) * film_ld;
         int n32 = lane & 31, lh = lane >> 5;
         asm volatile("" : "+v"(n32), "+v"(lh));         // (opaque per tile: keeps hipcc from hoisting every lane-constant address out of the tile loop)
         const unsigned short* wrow = wts.w[0] + (size_t)(64 * w + n32) * 32 + 8 * lh;
 
         // weights: A fragment of k-step ks = 16 j + cb for row group rg: rows 64 w + 32 rg + n32, k = 256 j + 16 cb + 8 lh .. + 7
         auto a_ptr = [&](const unsigned short* Wc, int ks, int rg) {
-            if (dbg & 4) ks &= 3;
             const int kb = 8 * (ks >> 4) + ((ks & 15) >> 1);
             return (const bf16x8*)(Wc + (wrow - wts.w[0]) + ((size_t)kb * C + 32 * rg) * 32 + (ks & 1) * 16);
         };
@@ -131,12 +147,12 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
             const float* p = film_w + ((size_t)qf * 2 * C + r_lane) * film_ld + fc;
 #pragma unroll
             for (int i = 0; i < 32; ++i)                          // row 4 i + r_lane of the wave's 128: scale rows of 64 channels, then shift rows
-                fr[i] = p[((size_t)(i >> 4) * C + 4 * (i & 15)) * film_ld];
+                fr[i] = __builtin_nontemporal_load(p + ((size_t)(i >> 4) * C + 4 * (i & 15)) * film_ld);
         };
         auto film_put = [&]() {
 #pragma unroll
             for (int i = 0; i < 32; ++i)                          // scale rows halved (exact): see filter_mid.hip
-                ((float*)Fs)[((2 * (i & 15) + (r_lane >> 1)) * NFS + f_lane) * 4 + 2 * (i >> 4) + (r_lane & 1)] = i < 16 ? 0.5f * fr[i] : fr[i];
+                lds_put<float>(Fs + 4 * (((r_lane >> 1) * NFS + f_lane) * 4 + (r_lane & 1)), 4 * (2 * (i & 15) * NFS * 4 + 2 * (i >> 4)), i < 16 ? 0.5f * fr[i] : fr[i]);
         };
         film_load(0);
 
@@ -153,83 +169,81 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
                 const float* up = Un + (size_t)(64 * w + 32 * rg + 4 * lh) * L + (t < L ? t : L - 1);      // (columns past the end: finite, never stored)
                 float x[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) x[r] = up[(size_t)(8 * (r >> 2) + (r & 3)) * L];
+                for (int r = 0; r < 16; ++r) x[r] = __builtin_nontemporal_load(up + (size_t)(8 * (r >> 2) + (r & 3)) * L);      // (read once: not to evict the weights from L2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h_set(rg, ct, r, x[r]);
             }
 
         // GELU -> FiLM -> fp16 -> LDS of one 32 x 32 accumulator tile (channel group rg, column tile ct), FiLM rows from the wave's table
-        auto emit_tile = [&](const f32x16& v, int rg, int ct, unsigned char* dstp) {
+        auto emit_tile = [&](const f32x16& v, int rg, int ct, int dstp) {
             int col = 32 * ct + n32;
             int i0 = ci0[ct] - f_lo;
             i0 = i0 < NFS - 2 ? i0 : NFS - 2;
             asm volatile("" : "+v"(col), "+v"(i0));         // (opaque per call: the 32 LDS addresses derived from them are three instructions each,
                                                             // hoisted out of the tile loop they are 100+ registers and the kernel spills)
             const float w1 = cw1[ct], w0 = 1.0f - w1;
-            const f32x2 W0 = {w0, w0}, W1 = {w1, w1};
             const bool cnt = !warm && tbase + col < L;      // (saturations of stored columns only)
             float zmax = 0.0f;
             // Two adjacent channels at a time on the packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32: two IEEE operations per issue
             // slot -- the epilogue runs with the matrix pipe idle and is bound by vector issue).  Same operations per value as the scalar
             // form of filter_mid.hip.  The table holds (scale / 2 of both channels, shift of both) per frame: one ds_read_b128 each.
-            auto fma2 = [](f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); };
+            // (Four values -- two packed pairs -- per source statement: hipcc then alternates the two pairs' instructions; one pair at a
+            // time it emits a dependent chain with a wait state between every two packed operations, 58 s_nop per 16 values.)
+            auto fma4 = [](f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); };
+            auto splat = [](float c) { return f32x4{c, c, c, c}; };
+            const f32x4 W0 = splat(w0), W1 = splat(w1);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                unsigned zz[2];
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const f32x4* fp = (const f32x4*)Fs + (16 * rg + 4 * g + 2 * lh + pr) * NFS + i0;
-                    const f32x4 a0 = fp[0], a1 = fp[1];
-                    const f32x2 sc = fma2(W0, f32x2{a0[0], a0[1]}, W1 * f32x2{a1[0], a1[1]});      // ATen's linear interpolation
-                    const f32x2 sh = fma2(W0, f32x2{a0[2], a0[3]}, W1 * f32x2{a1[2], a1[3]});
-                    const f32x2 x = {v[4 * g + 2 * pr], v[4 * g + 2 * pr + 1]};
-                    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
-                    const f32x2 tq = fma2(ax, f32x2{0.3275911f * 0.70710678118654752440f, 0.3275911f * 0.70710678118654752440f}, f32x2{1.0f, 1.0f});
-                    const f32x2 t = {__builtin_amdgcn_rcpf(tq[0]), __builtin_amdgcn_rcpf(tq[1])};
-                    const f32x2 xs = x * f32x2{0.84932180028801904272f, 0.84932180028801904272f};
-                    const f32x2 qq = xs * xs;
-                    const f32x2 ex = {__builtin_amdgcn_exp2f(-qq[0]), __builtin_amdgcn_exp2f(-qq[1])};
-                    f32x2 p = fma2(f32x2{1.061405429f, 1.061405429f}, t, f32x2{-1.453152027f, -1.453152027f});
-                    p = fma2(p, t, f32x2{1.421413741f, 1.421413741f});
-                    p = fma2(p, t, f32x2{-0.284496736f, -0.284496736f});
-                    p = fma2(p, t, f32x2{0.254829592f, 0.254829592f});
-                    const f32x2 erf_abs = fma2(-(p * t), ex, f32x2{1.0f, 1.0f});
-                    const f32x2 z = fma2(fma2(ax, erf_abs, x), sc, sh);          // 2 gelu(x) * (scale / 2) + shift
-                    zmax = fmaxf(zmax, fmaxf(fabsf(z[0]), fabsf(z[1])));
-                    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-                    const f16x2_t hz = {(_Float16)__builtin_amdgcn_fmed3f(z[0], -65504.0f, 65504.0f), (_Float16)__builtin_amdgcn_fmed3f(z[1], -65504.0f, 65504.0f)};
-                    zz[pr] = __builtin_bit_cast(unsigned, hz);
-                }
+                const int fp = Fs + 16 * (2 * lh * NFS + i0), fo = 16 * (16 * rg + 4 * g) * NFS;      // channel pair 0 of the four; pair 1: + NFS
+                const f32x4 a0 = lds_get<f32x4>(fp, fo), a1 = lds_get<f32x4>(fp, fo + 16), b0 = lds_get<f32x4>(fp, fo + 16 * NFS), b1 = lds_get<f32x4>(fp, fo + 16 * NFS + 16);
+                const f32x4 sc = fma4(W0, f32x4{a0[0], a0[1], b0[0], b0[1]}, W1 * f32x4{a1[0], a1[1], b1[0], b1[1]});      // ATen's linear interpolation
+                const f32x4 sh = fma4(W0, f32x4{a0[2], a0[3], b0[2], b0[3]}, W1 * f32x4{a1[2], a1[3], b1[2], b1[3]});
+                const f32x4 x = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+                const f32x4 ax = {fabsf(x[0]), fabsf(x[1]), fabsf(x[2]), fabsf(x[3])};
+                const f32x4 tq = fma4(ax, splat(0.3275911f * 0.70710678118654752440f), splat(1.0f));
+                const f32x4 t = {__builtin_amdgcn_rcpf(tq[0]), __builtin_amdgcn_rcpf(tq[1]), __builtin_amdgcn_rcpf(tq[2]), __builtin_amdgcn_rcpf(tq[3])};
+                const f32x4 xs = x * splat(0.84932180028801904272f);
+                const f32x4 qq = xs * xs;
+                const f32x4 ex = {__builtin_amdgcn_exp2f(-qq[0]), __builtin_amdgcn_exp2f(-qq[1]), __builtin_amdgcn_exp2f(-qq[2]), __builtin_amdgcn_exp2f(-qq[3])};
+                f32x4 p = fma4(splat(1.061405429f), t, splat(-1.453152027f));
+                p = fma4(p, t, splat(1.421413741f));
+                p = fma4(p, t, splat(-0.284496736f));
+                p = fma4(p, t, splat(0.254829592f));
+                const f32x4 erf_abs = fma4(-(p * t), ex, splat(1.0f));
+                const f32x4 z = fma4(fma4(ax, erf_abs, x), sc, sh);             // 2 gelu(x) * (scale / 2) + shift
+                zmax = fmaxf(fmaxf(zmax, fmaxf(fabsf(z[0]), fabsf(z[1]))), fmaxf(fabsf(z[2]), fabsf(z[3])));
+                typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+                const f16x2_t h0 = {(_Float16)__builtin_amdgcn_fmed3f(z[0], -65504.0f, 65504.0f), (_Float16)__builtin_amdgcn_fmed3f(z[1], -65504.0f, 65504.0f)};
+                const f16x2_t h1 = {(_Float16)__builtin_amdgcn_fmed3f(z[2], -65504.0f, 65504.0f), (_Float16)__builtin_amdgcn_fmed3f(z[3], -65504.0f, 65504.0f)};
                 const int chunk = 8 * w + 4 * rg + g;
-                unsigned char* p = dstp + col * ROWB + ((chunk ^ swz(col)) << 4) + 8 * lh;
-                *(uint2*)p = make_uint2(zz[0], zz[1]);
+                lds_put<u32x2>(dstp + col * ROWB + ((chunk ^ swz(col)) << 4) + 8 * lh, 0, u32x2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)});
             }
             // (one count per lane and 16 values, not per converted pair: the guards read "any")
             if (__builtin_expect(cnt && zmax > 65504.0f, 0)) atomicAdd(&alive_f16_sat_count, 1u);
         };
         // the context in front of a buffer: the previous tile's (registers) or, at the window's first tile, rows 1 .. 16 reflected
-        auto put_context = [&](unsigned char* buf, int q) {
+        auto put_context = [&](int buf, int q) {
             if (first) {
                 const int j = 1 + (tid >> 4);                   // rows 1 .. 16, 32 chunks each: two chunks per thread
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int p = (tid & 15) + 16 * u;          // stored chunk position in row j
                     const int c = p ^ swz(j);                   // the channel chunk it holds
-                    *(u32x4*)(buf - j * ROWB + ((c ^ swz(-j)) << 4)) = *(const u32x4*)(buf + j * ROWB + (p << 4));
+                    lds_put<u32x4>(buf - j * ROWB + ((c ^ swz(-j)) << 4), 0, lds_get<u32x4>(buf + j * ROWB + (p << 4)));
                 }
             } else {
                 u32x4 c0 = {0u, 0u, 0u, 0u}, c1 = c0;            // (a warm-up tile has no context: its stored columns' cone does not reach it)
-                if (it != it_begin) {
+                if (!warm) {
                     c0 = *(const u32x4*)(ctx_ws + q * GUARD);
                     c1 = *(const u32x4*)(ctx_ws + q * GUARD + 4096);
                 }
-                *(u32x4*)(buf - GUARD + tid * 16) = c0;
-                *(u32x4*)(buf - GUARD + 4096 + tid * 16) = c1;
+                lds_put<u32x4>(buf - GUARD + tid * 16, 0, c0);
+                lds_put<u32x4>(buf - GUARD + tid * 16, 4096, c1);
             }
         };
-        auto take_context = [&](const unsigned char* buf, int q) {          // rows 112 .. 127 of a conv's complete input
-            *(u32x4*)(ctx_ws + q * GUARD) = *(const u32x4*)(buf + (BL - CTX) * ROWB + tid * 16);
-            *(u32x4*)(ctx_ws + q * GUARD + 4096) = *(const u32x4*)(buf + (BL - CTX) * ROWB + 4096 + tid * 16);
+        auto take_context = [&](int buf, int q) {          // rows 112 .. 127 of a conv's complete input
+            *(u32x4*)(ctx_ws + q * GUARD) = lds_get<u32x4>(buf + (BL - CTX) * ROWB + tid * 16);
+            *(u32x4*)(ctx_ws + q * GUARD + 4096) = lds_get<u32x4>(buf + (BL - CTX) * ROWB + tid * 16, 4096);
         };
 
         PROF(0);
@@ -254,8 +268,8 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
         for (int q = 0; q < NCONV; ++q) {
             const bool second = (q & 1) != 0;
             const bool last = q + 1 == NCONV;
-            unsigned char* in = second ? bufY : bufZ;
-            unsigned char* dst = second ? bufZ : bufY;
+            const int in = second ? bufY : bufZ;
+            const int dst = second ? bufZ : bufY;
             const int d = 1 << (q >> 1);
             const unsigned short* Wc = wts.w[q];
             const float* bc = wts.b[q];
@@ -264,16 +278,17 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
             // context rows are bufZ's rows 112 .. 127, which the conv before this one has finished reading (and taken).
             put_context(in, q);
             take_context(in, q);
+            if (warm && last) break;                       // (a warm-up tile is computed for the contexts only: the last conv's output is nobody's)
             __syncthreads();
             PROF(3);
             f32x16 acc[2][4];
-            Bs[lane] = bc[64 * w + lane];                  // (one coalesced load, then the C layout's 32 values per lane as 8 LDS reads)
+            lds_put<float>(Bs + 4 * lane, 0, bc[64 * w + lane]);                  // (one coalesced load, then the C layout's 32 values per lane as 8 LDS reads)
 #pragma unroll
             for (int rg = 0; rg < 2; ++rg) {
                 f32x16 b16;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 v = *(const f32x4*)(Bs + 32 * rg + 8 * g + 4 * lh);
+                    const f32x4 v = lds_get<f32x4>(Bs + 16 * lh, 4 * (32 * rg + 8 * g));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) b16[4 * g + e] = v[e];
                 }
@@ -288,8 +303,8 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
             // and buffers stay in place.)  Each accumulator still takes one MFMA per k-step in k order: the sums are the same bits.
             auto b_frag = [&](int ks, int ct) {
                 const int j = ks >> 4, cb = ks & 15;
-                const int row = 32 * ct + n32 + (j - 4) * d;           // >= -16: the context rows
-                return *(const bf16x8*)(in + row * ROWB + (((2 * cb + lh) ^ swz(row)) << 4));
+                const int row = n32 + (j - 4) * d;                     // of column tile 0: >= -16, the context rows (32 rows on: the same swizzle)
+                return lds_get<bf16x8>(in + row * ROWB + (((2 * cb + lh) ^ swz(row)) << 4), 32 * ROWB * ct);
             };
             bf16x8 bfr[2][4];
 #pragma unroll
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
 #pragma unroll 4
             for (int ks = 0; ks < NKS; ++ks) {
                 const int k1 = ks + 1 < NKS ? ks + 1 : NKS - 1;                                // (past the end: the last k-step again, no branch)
-                const int kn = (dbg & 16) ? 0 : (ks + PF < NKS ? ks + PF : NKS - 1);
+                const int kn = ks + PF < NKS ? ks + PF : NKS - 1;
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) {
                     acc[0][ct] = mfma_f16(a[ks % PF][0], bfr[ks & 1][ct], acc[0][ct]);
@@ -332,7 +347,7 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
 #pragma unroll
                         for (int r = 0; r < 16; ++r) { v[r] = v[r] + h_get(rg, ct, r); h_set(rg, ct, r, v[r]); }
                     }
-                    if (!last && !(dbg & 2)) emit_tile(v, rg, ct, dst);
+                    if (!last) emit_tile(v, rg, ct, dst);
                 }
             __syncthreads();                               // dst complete
             PROF(6);
@@ -350,19 +365,21 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
                     if (skip != nullptr) {
                         float sk[16];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) sk[r] = skip[o + (size_t)(8 * (r >> 2) + (r & 3)) * L];
+                        for (int r = 0; r < 16; ++r) sk[r] = __builtin_nontemporal_load(skip + o + (size_t)(8 * (r >> 2) + (r & 3)) * L);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) out[o + (size_t)(8 * (r >> 2) + (r & 3)) * L] = h_get(rg, ct, r) + sk[r];
+                        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(h_get(rg, ct, r) + sk[r], out + o + (size_t)(8 * (r >> 2) + (r & 3)) * L);
                     } else {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) out[o + (size_t)(8 * (r >> 2) + (r & 3)) * L] = h_get(rg, ct, r);
+                        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(h_get(rg, ct, r), out + o + (size_t)(8 * (r >> 2) + (r & 3)) * L);
                     }
                 }
         }
         PROF(7);
     }
-    if (prof && tid == 0)
+#ifdef ALIVE_FB256_PROF
+    if (blockIdx.x == 7 && tid == 0)
         for (int i = 0; i < 10; ++i) atomicAdd(&fb256_prof[i], (unsigned long long)pacc[i]);
+#endif
 }
 
 }  // namespace
@@ -370,7 +387,7 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
 // U[N][256][L] (the block's residual stream: the output of the composed transposed conv) -> out = FilterBlock(U) + skip, fp32.
 // w16[q] / bias[q], q = 0 .. 5: blocks[q / 2].c1 / .c2 -- the fp16 slab of module/_pack.py::pack_conv_split_h and the fp32 bias.
 // film[N][film_rows][film_ld]: rows film_off + q * 512 + (0 .. 255 scale | 256 .. 511 shift) for conv q; frame range as alive_filter_block64_range.
-// bytes of workspace alive_filter_block256_fp16 needs at most: six 8-KB contexts per block, one block per segment of a window
+// bytes of workspace alive_filter_block256_fp16 needs at most: six 8-KB contexts per block, at most one block per tile
 extern "C" int64_t alive_filter_block256_workspace_bytes(int N, int L) {
     return N > 0 && L > 0 ? (int64_t)N * cdiv(L, BL) * NCONV * GUARD : 0;
 }
@@ -399,27 +416,25 @@ extern "C" int alive_filter_block256_fp16(const float* U, int N, int L, const vo
     }
     const float ratio = (float)film_ld / (float)L;
     const int tiles = cdiv(L, BL);
-    // segments per window: the fewest chip rounds x (tiles per segment + the warm-up tile of a segment inside the window)
-    int best_s = 1;
-    int64_t best_cost = -1;
-    for (int sg = 1; sg <= (tiles < 64 ? tiles : 64); ++sg) {
-        const int64_t cost = (int64_t)cdiv((int64_t)N * sg, 256) * (cdiv(tiles, sg) + (sg > 1 ? 1 : 0));
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_s = sg; }
-    }
-    const int seg_cols = cdiv(tiles, best_s) * BL;
-    ALIVE_CHECK_ARG(ws != nullptr && ws_bytes >= (int64_t)N * cdiv(L, seg_cols) * NCONV * GUARD,
+    ALIVE_CHECK_ARG((int64_t)N * tiles < (1ll << 31), "alive_filter_block256_fp16: too many tiles");
+    static int cus = 0;
+    if (cus == 0 && (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess || cus <= 0)) cus = 256;
+    const int total = N * tiles, per_block = cdiv(total, cus), blocks = cdiv(total, per_block);
+    ALIVE_CHECK_ARG(ws != nullptr && ws_bytes >= (int64_t)blocks * NCONV * GUARD,
                     "alive_filter_block256_fp16: workspace too small (alive_filter_block256_workspace_bytes)");
-    filter_block256_kernel<<<dim3(cdiv(L, seg_cols), N), 256, LDS_BYTES, (hipStream_t)stream>>>(
-        U, L, wts, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld, skip, out, seg_cols, (unsigned char*)ws, getenv("ALIVE_FB256_DBG") ? atoi(getenv("ALIVE_FB256_DBG")) : 0);
+    filter_block256_kernel<<<blocks, 256, LDS_BYTES, (hipStream_t)stream>>>(U, L, wts, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld,
+                                                                               skip, out, tiles, per_block, total, (unsigned char*)ws);
     ALIVE_CHECK_LAUNCH("alive_filter_block256_fp16");
-    if (getenv("ALIVE_FB256_DBG") && (atoi(getenv("ALIVE_FB256_DBG")) & 8)) {
+#ifdef ALIVE_FB256_PROF
+    {
         unsigned long long v[16], z[16] = {0};
-        hipDeviceSynchronize();
-        hipMemcpyFromSymbol(v, HIP_SYMBOL(fb256_prof), sizeof(v));
-        hipMemcpyToSymbol(HIP_SYMBOL(fb256_prof), z, sizeof(z));
-        fprintf(stderr, "fb256 cycles: start->loads issued %llu | barrier %llu | z0 %llu | ctx+B1 %llu | k-loop %llu | B2 %llu | epilogue+B3 %llu | store %llu | (k-loop head: bias, stores, first loads) %llu\n", v[0], v[1], v[2],
-                v[3], v[4], v[5], v[6], v[7], v[8]);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(fb256_prof), sizeof(v));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(fb256_prof), z, sizeof(z));
+        fprintf(stderr, "fb256 cycles: start->loads issued %llu | barrier %llu | z0 %llu | ctx+B1 %llu | k-loop %llu | B2 %llu | epilogue+B3 %llu | store %llu | (k-loop head) %llu\n",
+                v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]);
     }
+#endif
     return ALIVE_OK;
 }
 

@@ -1,4 +1,5 @@
-"""time of the fused 256-channel FilterBlock alone (csrc/filter_big.hip): python tools/bench_fb256.py [N] [L]"""
+"""time of the fused 256-channel FilterBlock alone (csrc/filter_big.hip): python tools/bench_fb256.py [N] [L]
+(a library built with `make EXTRA=-DALIVE_FB256_PROF` also prints one block's phase clocks per call)"""
 import ctypes, hashlib, os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "alive-vc_amd"))
 from module import _native as nat
@@ -22,4 +23,4 @@ a.record()
 for _ in range(5): run()
 e.record(); torch.cuda.synchronize()
 ms = a.elapsed_time(e) / 5
-print(f"dbg {os.environ.get('ALIVE_FB256_DBG', '0')}: {ms:.3f} ms per {N} x {L}; {6 * 2 * 256 * 1280 * N * L / ms / 1e9:.0f} TFLOP/s; finite {bool(torch.isfinite(out).all())} sat {L_.alive_f16_saturations(1)} digest {hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:16]}")
+print(f"{ms:.3f} ms per {N} x {L}; {6 * 2 * 256 * 1280 * N * L / ms / 1e9:.0f} TFLOP/s; finite {bool(torch.isfinite(out).all())} sat {L_.alive_f16_saturations(1)} digest {hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:16]}")

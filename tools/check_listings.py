@@ -1,5 +1,5 @@
 """Build-time guard (csrc/Makefile runs it as part of `make all`): two properties the results depend on are enforced by
-nothing but the shape of the code hipcc emits, so the BUILD -- not only pytest -- compiles the three guarded sources to gfx950 listings
+nothing but the shape of the code hipcc emits, so the BUILD -- not only pytest -- compiles the four guarded sources to gfx950 listings
 and fails when either is violated:
   * every MFMA accumulation chain that starts beside a finished, still unread accumulator keeps >= 8 idle wait states to it
     (common.h ALIVE_CHAIN_GAP; DESIGN.md 3.2b': fused FilterBlocks, block-scaled scoring kernels);
@@ -24,7 +24,9 @@ def main():
             "--cuda-device-only", "-S"]
     mk = open(os.path.join(csrc, "Makefile")).read()
     mid = [ln for ln in mk.splitlines() if ln.startswith("FLAGS_filter_mid")][0].split(":=")[1].split()
-    jobs = {"knn": ("knn.hip", []), "filter_mid": ("filter_mid.hip", mid), "filter_small": ("filter_small.hip", mid)}
+    jobs = {"knn": ("knn.hip", []), "filter_mid": ("filter_mid.hip", mid), "filter_small": ("filter_small.hip", mid),
+            "filter_big": ("filter_big.hip", [])}
+    least = {"filter_big": 32}                      # MFMAs a listing must show at least (else the scan looked at the wrong thing): 100 elsewhere
     bad = []
     with tempfile.TemporaryDirectory() as tmp:
         def build(item):
@@ -32,13 +34,13 @@ def main():
             out = os.path.join(tmp, tag + ".s")
             subprocess.run([hipcc] + base + extra + [os.path.join(csrc, src), "-o", out], check=True, capture_output=True, timeout=1800)
             return tag, out
-        with ThreadPoolExecutor(3) as ex:
+        with ThreadPoolExecutor(4) as ex:
             lst = dict(ex.map(build, jobs.items()))
         for tag, path in lst.items():
             r = hz.chain_gap_scan(path)
             short = [s for s in r["switches"] if s[4] < hz.CHAIN_GAP_MIN]
             print(f"check_listings: {tag}: {r['mfma']} MFMAs, {len(r['switches'])} chain switches beside an unread accumulator, {len(short)} without the gap")
-            if r["mfma"] < 100 or short:
+            if r["mfma"] < least.get(tag, 100) or short:
                 bad.append((tag, "chain gap", short[:3]))
         for kern in ("knn_score6_kernel", "knn_probe6_kernel"):
             n_asm, unwaited = hz.asm_lds_reads_are_waited_for(lst["knn"], kern)
