@@ -42,7 +42,7 @@ constexpr int FS_BYTES = 4 * FS_WAVE * 8;                             // 32 KB
 // waves' FiLM tables (all of it: from the barrier behind the k-loop to the end of the epilogue).  With bufZ and bufY: all 160 KB.
 constexpr int LDS_BYTES = FS_BYTES + 2 * BUFB;                        // 163 840 B
 constexpr int KW = 5, NKS = KW * (C / 16);                            // 80 k-steps per conv
-constexpr int PF = 4;                    // k-steps of weights in flight
+constexpr int PF1 = 4, PF2 = 4;           // k-steps of weights in flight per wave (one / two waves per SIMD)
 
 __device__ __forceinline__ int swz(int row) { return row & 15; }
 
@@ -75,7 +75,13 @@ struct Fb256Weights {
     const float* b[NCONV];
 };
 
-__global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __restrict__ U, int L, Fb256Weights wts, const float* __restrict__ film,
+// RG: 32-channel row groups per wave.  2: four waves of 64 channels x 128 columns (one per SIMD, 512 registers).  1: eight waves of 32
+// channels x 128 columns (two per SIMD, 256 registers): every weight fragment is still loaded once per block (eight waves of 64 channels
+// x 64 columns load each twice -- the second read hits the L1, whose 64 B per clock then bound the k-loop: 505 cycles per k-step
+// against 318, measured), the B fragments are read from LDS by twice as many waves (half of what it delivers), the epilogue's vector
+// work issues from two waves per SIMD.
+template <int RG>
+__global__ __launch_bounds__(512 / RG, 1) void filter_block256_kernel(const float* __restrict__ U, int L, Fb256Weights wts, const float* __restrict__ film,
                                                                  int film_rows, int Lf, int film_off, float ratio, int t_off, int f_off,
                                                                  int film_ld, const float* __restrict__ skip, float* __restrict__ out,
                                                                  int tiles, int per_block, int total, unsigned char* __restrict__ ws) {
@@ -84,10 +90,11 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
     const int bufZ = sm0 + FS_BYTES;
     const int bufY = bufZ + BUFB;
 
+    constexpr int NT = 512 / RG, CTW = 4, CW = 32 * RG, PF = RG == 1 ? PF2 : PF1;      // CW: channels per wave
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int Fs = sm0 + w * FS_WAVE * 8;                       // this wave's [32 channel pairs][NFS] x (scale / 2 of both, shift of both)
-    const int Bs = sm0 + 256 * w;                               // this wave's 64 biases of the current conv
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);    // channels CW w .. CW w + CW - 1
+    const int Fs = sm0 + w * (CW / 2 * NFS * 16);               // this wave's [CW / 2 channel pairs][NFS] x (scale / 2 of both, shift of both)
+    const int Bs = sm0 + 4 * CW * w;                            // its biases of the current conv
     // The batch is one sequence of tiles, window after window; a block takes per_block consecutive ones (any number of windows, any
     // place inside one) -- every CU gets the same count whatever the batch size, and one warm-up tile per block is all the redundancy.
     const int g0 = (int)blockIdx.x * per_block;
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
 #endif
     // each conv's causal context (its input's last 16 columns, 8 KB) waits for the next tile in the block's slice of the workspace: 32 bytes
     // per thread and conv, written and read back by the same thread (L2-resident; in registers they cost the k-loop its schedule)
-    unsigned char* const ctx_ws = ws + (size_t)blockIdx.x * (NCONV * GUARD) + tid * 16;
+    unsigned char* const ctx_ws = ws + (size_t)blockIdx.x * (NCONV * GUARD) + tid * 16;      // (+ NT * 16 for a thread's second piece)
 
 #pragma unroll 1
     for (int g = g0 % tiles ? g0 - 1 : g0; g < g1; ++g) {
@@ -107,37 +114,40 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
         const bool first = tbase == 0;                  // the window's first tile: the context is the reflection of its own columns
         const float* Un = U + (size_t)n * C * L;
         // the FiLM rows of this wave's channels 64 w .., conv 0: scale; + 256 rows: shift; + 512 rows: the next conv
-        const float* film_w = film + ((size_t)n * film_rows + film_off + 64 * w) * film_ld;
+        const float* film_w = film + ((size_t)n * film_rows + film_off + CW * w) * film_ld;
         int n32 = lane & 31, lh = lane >> 5;
         asm volatile("" : "+v"(n32), "+v"(lh));         // (opaque per tile: keeps hipcc from hoisting every lane-constant address out of the tile loop)
-        const unsigned short* wrow = wts.w[0] + (size_t)(64 * w + n32) * 32 + 8 * lh;
+        const unsigned short* wrow = wts.w[0] + (size_t)(CW * w + n32) * 32 + 8 * lh;
 
         // weights: A fragment of k-step ks = 16 j + cb for row group rg: rows 64 w + 32 rg + n32, k = 256 j + 16 cb + 8 lh .. + 7
         auto a_ptr = [&](const unsigned short* Wc, int ks, int rg) {
             const int kb = 8 * (ks >> 4) + ((ks & 15) >> 1);
             return (const bf16x8*)(Wc + (wrow - wts.w[0]) + ((size_t)kb * C + 32 * rg) * 32 + (ks & 1) * 16);
         };
-        bf16x8 a[PF][2];
+        bf16x8 a[PF][RG];
         auto prime = [&](int q) {                       // the first PF k-steps of conv q
 #pragma unroll
-            for (int s = 0; s < PF; ++s) { a[s][0] = *a_ptr(wts.w[q], s, 0); a[s][1] = *a_ptr(wts.w[q], s, 1); }
+            for (int s = 0; s < PF; ++s)
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg) a[s][rg] = *a_ptr(wts.w[q], s, rg);
         };
         prime(0);
 
         // F.interpolate coordinates of this lane's four columns (window frames: t_off in range mode), and the first frame of each half's table
-        int ci0[4]; float cw1[4];
+        int ci0[CTW]; float cw1[CTW];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
+        for (int c = 0; c < CTW; ++c) {
+            const int ct = c;
             const int t = tbase + 32 * ct + n32;
             const Lerp lp = lerp_coord((t < L ? t : L - 1) + t_off, ratio, Lf);
-            ci0[ct] = lp.i0;
-            cw1[ct] = lp.w1;
+            ci0[c] = lp.i0;
+            cw1[c] = lp.w1;
         }
         const int f_lo = lerp_coord((tbase < L ? tbase : L - 1) + t_off, ratio, Lf).i0;
         // FiLM rows qf (the modulation in front of conv qf) of the wave's 64 channels, frames f_lo .. f_lo + 15: loads, then the table.
         // A load instruction takes four rows x 16 consecutive frames (a lane per frame: one or two cache lines per row -- a lane per
         // ROW touches 64 lines per instruction, and the CU's address unit takes them one per clock: 15 k cycles per conv, measured).
-        float fr[32];
+        float fr[16 * RG];
         const int f_lane = lane & 15, r_lane = lane >> 4;
         auto film_load = [&](int qf) {
             int fa = f_lo + f_lane;
@@ -146,42 +156,43 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
             fc = fc < 0 ? 0 : (fc < film_ld ? fc : film_ld - 1);
             const float* p = film_w + ((size_t)qf * 2 * C + r_lane) * film_ld + fc;
 #pragma unroll
-            for (int i = 0; i < 32; ++i)                          // row 4 i + r_lane of the wave's 128: scale rows of 64 channels, then shift rows
-                fr[i] = __builtin_nontemporal_load(p + ((size_t)(i >> 4) * C + 4 * (i & 15)) * film_ld);
+            for (int i = 0; i < 16 * RG; ++i)                     // rows 4 (i % (8 RG)) + r_lane of the wave's channels: their scale rows, then their shift rows
+                fr[i] = __builtin_nontemporal_load(p + ((size_t)(i / (8 * RG)) * C + 4 * (i % (8 * RG))) * film_ld);
         };
         auto film_put = [&]() {
 #pragma unroll
-            for (int i = 0; i < 32; ++i)                          // scale rows halved (exact): see filter_mid.hip
-                lds_put<float>(Fs + 4 * (((r_lane >> 1) * NFS + f_lane) * 4 + (r_lane & 1)), 4 * (2 * (i & 15) * NFS * 4 + 2 * (i >> 4)), i < 16 ? 0.5f * fr[i] : fr[i]);
+            for (int i = 0; i < 16 * RG; ++i)                     // scale rows halved (exact): see filter_mid.hip
+                lds_put<float>(Fs + 4 * (((r_lane >> 1) * NFS + f_lane) * 4 + (r_lane & 1)), 4 * (2 * (i % (8 * RG)) * NFS * 4 + 2 * (i / (8 * RG))),
+                               i < 8 * RG ? 0.5f * fr[i] : fr[i]);
         };
         film_load(0);
 
         // ---- residual stream of this wave's 64 channels x 128 columns, in the MFMA C layout: h[rg][ct][4 g + e] = channel
         //      64 w + 32 rg + 8 g + 4 lh + e of column 32 ct + n32 ----
-        float h[2][4][16];
+        float h[RG][CTW][16];
         auto h_get = [&](int rg, int ct, int r) { return h[rg][ct][r]; };
         auto h_set = [&](int rg, int ct, int r, float x) { h[rg][ct][r] = x; };
 #pragma unroll
-        for (int rg = 0; rg < 2; ++rg)
+        for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                const int t = tbase + 32 * ct + n32;
-                const float* up = Un + (size_t)(64 * w + 32 * rg + 4 * lh) * L + (t < L ? t : L - 1);      // (columns past the end: finite, never stored)
+            for (int c = 0; c < CTW; ++c) {
+                const int t = tbase + 32 * c + n32;
+                const float* up = Un + (size_t)(CW * w + 32 * rg + 4 * lh) * L + (t < L ? t : L - 1);      // (columns past the end: finite, never stored)
                 float x[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) x[r] = __builtin_nontemporal_load(up + (size_t)(8 * (r >> 2) + (r & 3)) * L);      // (read once: not to evict the weights from L2)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) h_set(rg, ct, r, x[r]);
+                for (int r = 0; r < 16; ++r) h_set(rg, c, r, x[r]);
             }
 
         // GELU -> FiLM -> fp16 -> LDS of one 32 x 32 accumulator tile (channel group rg, column tile ct), FiLM rows from the wave's table
-        auto emit_tile = [&](const f32x16& v, int rg, int ct, int dstp) {
-            int col = 32 * ct + n32;
-            int i0 = ci0[ct] - f_lo;
+        auto emit_tile = [&](const f32x16& v, int rg, int c, int dstp) {
+            int col = 32 * c + n32;
+            int i0 = ci0[c] - f_lo;
             i0 = i0 < NFS - 2 ? i0 : NFS - 2;
             asm volatile("" : "+v"(col), "+v"(i0));         // (opaque per call: the 32 LDS addresses derived from them are three instructions each,
                                                             // hoisted out of the tile loop they are 100+ registers and the kernel spills)
-            const float w1 = cw1[ct], w0 = 1.0f - w1;
+            const float w1 = cw1[c], w0 = 1.0f - w1;
             const bool cnt = !warm && tbase + col < L;      // (saturations of stored columns only)
             float zmax = 0.0f;
             // Two adjacent channels at a time on the packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32: two IEEE operations per issue
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
                 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
                 const f16x2_t h0 = {(_Float16)__builtin_amdgcn_fmed3f(z[0], -65504.0f, 65504.0f), (_Float16)__builtin_amdgcn_fmed3f(z[1], -65504.0f, 65504.0f)};
                 const f16x2_t h1 = {(_Float16)__builtin_amdgcn_fmed3f(z[2], -65504.0f, 65504.0f), (_Float16)__builtin_amdgcn_fmed3f(z[3], -65504.0f, 65504.0f)};
-                const int chunk = 8 * w + 4 * rg + g;
+                const int chunk = CW / 8 * w + 4 * rg + g;
                 lds_put<u32x2>(dstp + col * ROWB + ((chunk ^ swz(col)) << 4) + 8 * lh, 0, u32x2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)});
             }
             // (one count per lane and 16 values, not per converted pair: the guards read "any")
@@ -224,26 +235,26 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
         // the context in front of a buffer: the previous tile's (registers) or, at the window's first tile, rows 1 .. 16 reflected
         auto put_context = [&](int buf, int q) {
             if (first) {
-                const int j = 1 + (tid >> 4);                   // rows 1 .. 16, 32 chunks each: two chunks per thread
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int p = (tid & 15) + 16 * u;          // stored chunk position in row j
+                for (int u = 0; u < 512 / NT; ++u) {            // rows 1 .. 16, 32 chunks each
+                    const int e = tid + NT * u;
+                    const int j = 1 + (e >> 5), p = e & 31;     // stored chunk position p in row j
                     const int c = p ^ swz(j);                   // the channel chunk it holds
                     lds_put<u32x4>(buf - j * ROWB + ((c ^ swz(-j)) << 4), 0, lds_get<u32x4>(buf + j * ROWB + (p << 4)));
                 }
             } else {
-                u32x4 c0 = {0u, 0u, 0u, 0u}, c1 = c0;            // (a warm-up tile has no context: its stored columns' cone does not reach it)
-                if (!warm) {
-                    c0 = *(const u32x4*)(ctx_ws + q * GUARD);
-                    c1 = *(const u32x4*)(ctx_ws + q * GUARD + 4096);
+#pragma unroll
+                for (int u = 0; u < 512 / NT; ++u) {
+                    u32x4 c0 = {0u, 0u, 0u, 0u};                 // (a warm-up tile has no context: its stored columns' cone does not reach it)
+                    if (!warm) c0 = *(const u32x4*)(ctx_ws + q * GUARD + NT * 16 * u);
+                    lds_put<u32x4>(buf - GUARD + tid * 16, NT * 16 * u, c0);
                 }
-                lds_put<u32x4>(buf - GUARD + tid * 16, 0, c0);
-                lds_put<u32x4>(buf - GUARD + tid * 16, 4096, c1);
             }
         };
         auto take_context = [&](int buf, int q) {          // rows 112 .. 127 of a conv's complete input
-            *(u32x4*)(ctx_ws + q * GUARD) = lds_get<u32x4>(buf + (BL - CTX) * ROWB + tid * 16);
-            *(u32x4*)(ctx_ws + q * GUARD + 4096) = lds_get<u32x4>(buf + (BL - CTX) * ROWB + tid * 16, 4096);
+#pragma unroll
+            for (int u = 0; u < 512 / NT; ++u)
+                *(u32x4*)(ctx_ws + q * GUARD + NT * 16 * u) = lds_get<u32x4>(buf + (BL - CTX) * ROWB + tid * 16, NT * 16 * u);
         };
 
         PROF(0);
@@ -252,13 +263,13 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
         // ---- z0 = mod_0(h) ----
         film_put();
 #pragma unroll
-        for (int rg = 0; rg < 2; ++rg)
+        for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
+            for (int c = 0; c < CTW; ++c) {
                 f32x16 v;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = h_get(rg, ct, r);
-                emit_tile(v, rg, ct, bufZ);
+                for (int r = 0; r < 16; ++r) v[r] = h_get(rg, c, r);
+                emit_tile(v, rg, c, bufZ);
             }
         __syncthreads();
         PROF(2);
@@ -281,10 +292,10 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
             if (warm && last) break;                       // (a warm-up tile is computed for the contexts only: the last conv's output is nobody's)
             __syncthreads();
             PROF(3);
-            f32x16 acc[2][4];
-            lds_put<float>(Bs + 4 * lane, 0, bc[64 * w + lane]);                  // (one coalesced load, then the C layout's 32 values per lane as 8 LDS reads)
+            f32x16 acc[RG][CTW];
+            if (lane < CW) lds_put<float>(Bs + 4 * lane, 0, bc[CW * w + lane]);                  // (one coalesced load, then the C layout's 32 values per lane as 8 LDS reads)
 #pragma unroll
-            for (int rg = 0; rg < 2; ++rg) {
+            for (int rg = 0; rg < RG; ++rg) {
                 f32x16 b16;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -293,7 +304,7 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
                     for (int e = 0; e < 4; ++e) b16[4 * g + e] = v[e];
                 }
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[rg][ct] = b16;
+                for (int c = 0; c < CTW; ++c) acc[rg][c] = b16;
             }
             // One k-step = 8 MFMAs, 4 B fragments of the NEXT k-step (LDS, into the other buffer), 2 A fragments of k-step ks + PF (L2, into
             // the ring slot this k-step has just read).  ONE memory instruction per MFMA: with a wave per SIMD a memory instruction that
@@ -301,34 +312,38 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
             // row cost a k-step 170 of 426 cycles (measured against the loop without them); behind an MFMA the wait runs under its 32
             // cycles.  (The scheduling fences keep hipcc from regrouping them; no value outlives its register's next definition, so ring
             // and buffers stay in place.)  Each accumulator still takes one MFMA per k-step in k order: the sums are the same bits.
-            auto b_frag = [&](int ks, int ct) {
+            auto b_frag = [&](int ks, int c) {
                 const int j = ks >> 4, cb = ks & 15;
                 const int row = n32 + (j - 4) * d;                     // of column tile 0: >= -16, the context rows (32 rows on: the same swizzle)
-                return lds_get<bf16x8>(in + row * ROWB + (((2 * cb + lh) ^ swz(row)) << 4), 32 * ROWB * ct);
+                return lds_get<bf16x8>(in + row * ROWB + (((2 * cb + lh) ^ swz(row)) << 4), 32 * ROWB * c);
             };
-            bf16x8 bfr[2][4];
+            bf16x8 bfr[2][CTW];
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) bfr[0][ct] = b_frag(0, ct);
+            for (int c = 0; c < CTW; ++c) bfr[0][c] = b_frag(0, c);
 #pragma unroll 4
             for (int ks = 0; ks < NKS; ++ks) {
                 const int k1 = ks + 1 < NKS ? ks + 1 : NKS - 1;                                // (past the end: the last k-step again, no branch)
                 const int kn = ks + PF < NKS ? ks + PF : NKS - 1;
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    acc[0][ct] = mfma_f16(a[ks % PF][0], bfr[ks & 1][ct], acc[0][ct]);
+                for (int c = 0; c < CTW; ++c) {
+                    acc[0][c] = mfma_f16(a[ks % PF][0], bfr[ks & 1][c], acc[0][c]);
                     __builtin_amdgcn_sched_barrier(0);
-                    bfr[(ks + 1) & 1][ct] = b_frag(k1, ct);
+                    bfr[(ks + 1) & 1][c] = b_frag(k1, c);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                acc[1][0] = mfma_f16(a[ks % PF][1], bfr[ks & 1][0], acc[1][0]);
-                __builtin_amdgcn_sched_barrier(0);
+                if (RG == 2) {
+                    acc[RG - 1][0] = mfma_f16(a[ks % PF][RG - 1], bfr[ks & 1][0], acc[RG - 1][0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 a[ks % PF][0] = *a_ptr(Wc, kn, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (RG == 2) {
 #pragma unroll
-                for (int ct = 1; ct < 4; ++ct) acc[1][ct] = mfma_f16(a[ks % PF][1], bfr[ks & 1][ct], acc[1][ct]);
-                __builtin_amdgcn_sched_barrier(0);
-                a[ks % PF][1] = *a_ptr(Wc, kn, 1);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int c = 1; c < CTW; ++c) acc[RG - 1][c] = mfma_f16(a[ks % PF][RG - 1], bfr[ks & 1][c], acc[RG - 1][c]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    a[ks % PF][RG - 1] = *a_ptr(Wc, kn, RG - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             PROF(4);
             if (!last) {
@@ -337,17 +352,19 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
             }
             __syncthreads();                               // every wave is done reading `in` (and bufZ's context rows, which the tables replace)
             PROF(5);
-            if (!last) film_put();
+            if (!last) {
+                film_put();
+            }
 #pragma unroll
-            for (int rg = 0; rg < 2; ++rg)
+            for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    f32x16 v = acc[rg][ct];
+                for (int c = 0; c < CTW; ++c) {
+                    f32x16 v = acc[rg][c];
                     if (second) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) { v[r] = v[r] + h_get(rg, ct, r); h_set(rg, ct, r, v[r]); }
+                        for (int r = 0; r < 16; ++r) { v[r] = v[r] + h_get(rg, c, r); h_set(rg, c, r, v[r]); }
                     }
-                    if (!last) emit_tile(v, rg, ct, dst);
+                    if (!last) emit_tile(v, rg, c, dst);
                 }
             __syncthreads();                               // dst complete
             PROF(6);
@@ -356,21 +373,21 @@ __global__ __launch_bounds__(256, 1) void filter_block256_kernel(const float* __
         // ---- store (+ U-Net skip, decoder.py:191), straight from the residual registers ----
         if (!warm) {
 #pragma unroll
-            for (int rg = 0; rg < 2; ++rg)
+            for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    const int t = tbase + 32 * ct + n32;
+                for (int c = 0; c < CTW; ++c) {
+                    const int t = tbase + 32 * c + n32;
                     if (t >= L) continue;
-                    const size_t o = ((size_t)n * C + 64 * w + 32 * rg + 4 * lh) * L + t;
+                    const size_t o = ((size_t)n * C + CW * w + 32 * rg + 4 * lh) * L + t;
                     if (skip != nullptr) {
                         float sk[16];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) sk[r] = __builtin_nontemporal_load(skip + o + (size_t)(8 * (r >> 2) + (r & 3)) * L);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(h_get(rg, ct, r) + sk[r], out + o + (size_t)(8 * (r >> 2) + (r & 3)) * L);
+                        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(h_get(rg, c, r) + sk[r], out + o + (size_t)(8 * (r >> 2) + (r & 3)) * L);
                     } else {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(h_get(rg, ct, r), out + o + (size_t)(8 * (r >> 2) + (r & 3)) * L);
+                        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(h_get(rg, c, r), out + o + (size_t)(8 * (r >> 2) + (r & 3)) * L);
                     }
                 }
         }
@@ -408,7 +425,7 @@ extern "C" int alive_filter_block256_fp16(const float* U, int N, int L, const vo
     }
     {
         static LdsOptIn optin;
-        hipError_t e = optin.ensure({(const void*)filter_block256_kernel}, LDS_BYTES);
+        hipError_t e = optin.ensure({(const void*)filter_block256_kernel<2>, (const void*)filter_block256_kernel<1>}, LDS_BYTES);
         if (e != hipSuccess) {
             alive_set_error("alive_filter_block256_fp16: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(e));
             return ALIVE_ERR_LAUNCH;
@@ -422,8 +439,13 @@ extern "C" int alive_filter_block256_fp16(const float* U, int N, int L, const vo
     const int total = N * tiles, per_block = cdiv(total, cus), blocks = cdiv(total, per_block);
     ALIVE_CHECK_ARG(ws != nullptr && ws_bytes >= (int64_t)blocks * NCONV * GUARD,
                     "alive_filter_block256_fp16: workspace too small (alive_filter_block256_workspace_bytes)");
-    filter_block256_kernel<<<blocks, 256, LDS_BYTES, (hipStream_t)stream>>>(U, L, wts, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld,
-                                                                               skip, out, tiles, per_block, total, (unsigned char*)ws);
+    static const bool eight = !(getenv("ALIVE_FB256_WAVES") && atoi(getenv("ALIVE_FB256_WAVES")) == 4);
+    if (eight)
+        filter_block256_kernel<1><<<blocks, 512, LDS_BYTES, (hipStream_t)stream>>>(U, L, wts, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld,
+                                                                                      skip, out, tiles, per_block, total, (unsigned char*)ws);
+    else
+        filter_block256_kernel<2><<<blocks, 256, LDS_BYTES, (hipStream_t)stream>>>(U, L, wts, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld,
+                                                                                      skip, out, tiles, per_block, total, (unsigned char*)ws);
     ALIVE_CHECK_LAUNCH("alive_filter_block256_fp16");
 #ifdef ALIVE_FB256_PROF
     {
