@@ -317,6 +317,7 @@ __global__ __launch_bounds__(512 / RG, 1) void filter_block256_kernel(const floa
                 const int row = n32 + (j - 4) * d;                     // of column tile 0: >= -16, the context rows (32 rows on: the same swizzle)
                 return lds_get<bf16x8>(in + row * ROWB + (((2 * cb + lh) ^ swz(row)) << 4), 32 * ROWB * c);
             };
+            if (RG == 1 && !last) film_load(q + 1);
             bf16x8 bfr[2][CTW];
 #pragma unroll
             for (int c = 0; c < CTW; ++c) bfr[0][c] = b_frag(0, c);
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(512 / RG, 1) void filter_block256_kernel(const floa
             }
             PROF(4);
             if (!last) {
-                film_load(q + 1);                           // (behind the k-loop: 32 registers that the loop's schedule does not have)
+                if (RG == 2) film_load(q + 1);              // (behind the k-loop: 32 registers that the loop's schedule does not have)
                 prime(q + 1);                               // (in flight under the epilogue)
             }
             __syncthreads();                               // every wave is done reading `in` (and bufZ's context rows, which the tables replace)
