@@ -27,24 +27,41 @@
 
 namespace {
 
-constexpr int C = 256;
 constexpr int NCONV = 6;
-constexpr int BL = 128;                  // columns per tile
-constexpr int ROWB = 2 * C;              // 512 bytes per LDS row
 constexpr int CTX = 16;                  // context rows in front of a buffer (4 taps back x dilation 4)
-constexpr int GUARD = CTX * ROWB;        // 8 KB
-constexpr int BUFB = BL * ROWB;          // 64 KB
-constexpr int NFS = 16;                  // staged FiLM frames per tile (128 columns span <= 12.8 frames at >= 10 samples per frame, + 1, + slack)
-constexpr int FS_WAVE = 64 * NFS;        // (scale / 2, shift) pairs of one wave's table
-constexpr int FS_BYTES = 4 * FS_WAVE * 8;                             // 32 KB
-// One 32-KB region in front of bufZ serves three tenants in turn, conv by conv: the four waves' bias lines (its first KB: from a conv's
-// start to the accumulators' initialisation), bufZ's 16 context rows (its last 8 KB: from there to the end of the k-loop, even convs), the
-// waves' FiLM tables (all of it: from the barrier behind the k-loop to the end of the epilogue).  With bufZ and bufY: all 160 KB.
-constexpr int LDS_BYTES = FS_BYTES + 2 * BUFB;                        // 163 840 B
-constexpr int KW = 5, NKS = KW * (C / 16);                            // 80 k-steps per conv
-constexpr int PF1 = 4, PF2 = 4;           // k-steps of weights in flight per wave (one / two waves per SIMD)
+constexpr int KW = 5;
+constexpr int PF1 = 4, PF2 = 4;          // k-steps of weights in flight per wave (one / two waves per SIMD)
 
-__device__ __forceinline__ int swz(int row) { return row & 15; }
+// The geometry of a block for C channels (256: decoder scale 0; 64: scale 1) and RG 32-channel row groups per wave.  A wave owns
+// 32 RG channels x 128 columns; at C = 256 the waves tile the channels and a tile is 128 columns, at C = 64 they tile the channels (RG = 1:
+// two waves) and four column groups: a tile is 512 columns.  Either way a buffer is 64 KB.
+template <int C, int RG>
+struct Geo {
+    static constexpr int CW = 32 * RG;                       // channels per wave
+    static constexpr int NWR = C / CW;                       // waves along the channels
+    static constexpr int NWC = C == 256 ? 1 : 4;             // column groups of waves
+    static constexpr int NW = NWR * NWC, NT = 64 * NW;
+    static constexpr int BL = 128 * NWC;                     // columns per tile
+    static constexpr int ROWB = 2 * C;                       // bytes per LDS row: one column, all channels, fp16
+    static constexpr int CPR = ROWB / 16;                    // 16-byte chunks (8 channels) per row
+    static constexpr int GUARD = CTX * ROWB;                 // a conv's context: 8 KB / 2 KB
+    static constexpr int BUFB = BL * ROWB;                   // 64 KB
+    static constexpr int LG = C == 256 ? 16 : 8;             // lanes (= frames) per FiLM row in a staging load; the frames a wave's table holds
+    static constexpr int NFS = LG;                           //   (128 columns span <= 12.8 frames at 10 samples per frame, 1.6 at 80; + 1, + slack)
+    static constexpr int FS_WAVE = CW / 2 * NFS * 16;        // bytes of a wave's table: [CW / 2 channel pairs][NFS] x (scale / 2 of both, shift of both)
+    // One region in front of bufZ serves three tenants in turn, conv by conv: the waves' bias lines (its start: from a conv's start to the
+    // accumulators' initialisation), bufZ's 16 context rows (its end: from there to the end of the k-loop, even convs), the waves' FiLM
+    // tables (all of it: from the barrier behind the k-loop to the end of the epilogue).  At C = 256 with bufZ and bufY: all 160 KB.
+    static constexpr int FS_BYTES = NW * FS_WAVE;            // 32 KB / 16 KB
+    static constexpr int LDS_BYTES = FS_BYTES + 2 * BUFB;
+    static constexpr int NKC = C / 16;                       // k-steps per tap
+    static constexpr int NKS = KW * NKC;                     // 80 / 20 k-steps per conv
+    static_assert(FS_BYTES >= GUARD && FS_BYTES >= NW * CW * 4 && NKC % 2 == 0, "region in front of bufZ");
+    // the 16-byte chunk c of row r sits at position c ^ swz(r): 16 lanes of a ds_read_b128 group (16 rows, one chunk index) then hit 16
+    // different bank quads -- rows 512 B apart share their banks (swizzle on the row's low 4 bits), rows 128 B apart alternate between
+    // two halves of them (swizzle on bits 1 .. 3)
+    static __device__ __forceinline__ int swz(int row) { return C == 256 ? (row & 15) : ((row >> 1) & 7); }
+};
 
 // LDS by byte offset, through pointers of the LDS address space only.  (As generic pointers -- selected between the two buffers, captured
 // by the lambdas -- hipcc 7.2 at times leaves one as a flat pointer with a null test it cannot select: "Illegal instruction detected:
@@ -71,7 +88,7 @@ __device__ unsigned long long fb256_prof[16];
 
 
 struct Fb256Weights {
-    const unsigned short* w[NCONV];      // fp16 slab of each conv, k-blocked [K / 32][256][32], K = 5 x 256 tap-major
+    const unsigned short* w[NCONV];      // fp16 slab of each conv, k-blocked [K / 32][C][32], K = 5 x C tap-major
     const float* b[NCONV];
 };
 
@@ -80,21 +97,26 @@ struct Fb256Weights {
 // x 64 columns load each twice -- the second read hits the L1, whose 64 B per clock then bound the k-loop: 505 cycles per k-step
 // against 318, measured), the B fragments are read from LDS by twice as many waves (half of what it delivers), the epilogue's vector
 // work issues from two waves per SIMD.
-template <int RG>
-__global__ __launch_bounds__(512 / RG, 1) void filter_block256_kernel(const float* __restrict__ U, int L, Fb256Weights wts, const float* __restrict__ film,
+template <int C, int RG>
+__global__ __launch_bounds__((Geo<C, RG>::NT), 1) void filter_block256_kernel(const float* __restrict__ U, int L, Fb256Weights wts, const float* __restrict__ film,
                                                                  int film_rows, int Lf, int film_off, float ratio, int t_off, int f_off,
                                                                  int film_ld, const float* __restrict__ skip, float* __restrict__ out,
                                                                  int tiles, int per_block, int total, unsigned char* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int sm0 = (int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)sm;      // (0: the kernel has no static LDS)
-    const int bufZ = sm0 + FS_BYTES;
+    typedef Geo<C, RG> G;
+    constexpr int NT = G::NT, CTW = 4, CW = G::CW, PF = RG == 1 ? PF2 : PF1, BL = G::BL, ROWB = G::ROWB, GUARD = G::GUARD, BUFB = G::BUFB,
+                  NFS = G::NFS, LG = G::LG, NKS = G::NKS, NKC = G::NKC, CPR = G::CPR;
+    auto swz = [](int row) { return G::swz(row); };
+    const int bufZ = sm0 + G::FS_BYTES;
     const int bufY = bufZ + BUFB;
 
-    constexpr int NT = 512 / RG, CTW = 4, CW = 32 * RG, PF = RG == 1 ? PF2 : PF1;      // CW: channels per wave
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);    // channels CW w .. CW w + CW - 1
-    const int Fs = sm0 + w * (CW / 2 * NFS * 16);               // this wave's [CW / 2 channel pairs][NFS] x (scale / 2 of both, shift of both)
-    const int Bs = sm0 + 4 * CW * w;                            // its biases of the current conv
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wv % G::NWR;                                  // channels CW w .. CW w + CW - 1
+    const int col0 = 128 * (wv / G::NWR);                       // columns col0 .. col0 + 127 of the tile
+    const int Fs = sm0 + wv * G::FS_WAVE;                       // this wave's FiLM table
+    const int Bs = sm0 + 4 * CW * wv;                           // its biases of the current conv
     // The batch is one sequence of tiles, window after window; a block takes per_block consecutive ones (any number of windows, any
     // place inside one) -- every CU gets the same count whatever the batch size, and one warm-up tile per block is all the redundancy.
     const int g0 = (int)blockIdx.x * per_block;
@@ -121,7 +143,7 @@ __global__ __launch_bounds__(512 / RG, 1) void filter_block256_kernel(const floa
 
         // weights: A fragment of k-step ks = 16 j + cb for row group rg: rows 64 w + 32 rg + n32, k = 256 j + 16 cb + 8 lh .. + 7
         auto a_ptr = [&](const unsigned short* Wc, int ks, int rg) {
-            const int kb = 8 * (ks >> 4) + ((ks & 15) >> 1);
+            const int kb = C / 32 * (ks / NKC) + ((ks % NKC) >> 1);
             return (const bf16x8*)(Wc + (wrow - wts.w[0]) + ((size_t)kb * C + 32 * rg) * 32 + (ks & 1) * 16);
         };
         bf16x8 a[PF][RG];
@@ -138,17 +160,18 @@ __global__ __launch_bounds__(512 / RG, 1) void filter_block256_kernel(const floa
 #pragma unroll
         for (int c = 0; c < CTW; ++c) {
             const int ct = c;
-            const int t = tbase + 32 * ct + n32;
+            const int t = tbase + col0 + 32 * ct + n32;
             const Lerp lp = lerp_coord((t < L ? t : L - 1) + t_off, ratio, Lf);
             ci0[c] = lp.i0;
             cw1[c] = lp.w1;
         }
-        const int f_lo = lerp_coord((tbase < L ? tbase : L - 1) + t_off, ratio, Lf).i0;
+        const int f_lo = lerp_coord((tbase + col0 < L ? tbase + col0 : L - 1) + t_off, ratio, Lf).i0;      // of the wave's columns
         // FiLM rows qf (the modulation in front of conv qf) of the wave's 64 channels, frames f_lo .. f_lo + 15: loads, then the table.
         // A load instruction takes four rows x 16 consecutive frames (a lane per frame: one or two cache lines per row -- a lane per
         // ROW touches 64 lines per instruction, and the CU's address unit takes them one per clock: 15 k cycles per conv, measured).
-        float fr[16 * RG];
-        const int f_lane = lane & 15, r_lane = lane >> 4;
+        constexpr int RPI = 64 / LG, NI = 2 * CW / RPI;           // rows per staging load, loads per table
+        float fr[NI];
+        const int f_lane = lane % LG, r_lane = lane / LG;
         auto film_load = [&](int qf) {
             int fa = f_lo + f_lane;
             fa = fa < Lf ? fa : Lf - 1;
@@ -156,14 +179,14 @@ __global__ __launch_bounds__(512 / RG, 1) void filter_block256_kernel(const floa
             fc = fc < 0 ? 0 : (fc < film_ld ? fc : film_ld - 1);
             const float* p = film_w + ((size_t)qf * 2 * C + r_lane) * film_ld + fc;
 #pragma unroll
-            for (int i = 0; i < 16 * RG; ++i)                     // rows 4 (i % (8 RG)) + r_lane of the wave's channels: their scale rows, then their shift rows
-                fr[i] = __builtin_nontemporal_load(p + ((size_t)(i / (8 * RG)) * C + 4 * (i % (8 * RG))) * film_ld);
+            for (int i = 0; i < NI; ++i)                          // rows RPI i + r_lane of the wave's 2 CW: its channels' scale rows, then their shift rows
+                fr[i] = __builtin_nontemporal_load(p + ((size_t)(RPI * i / CW) * C + RPI * i % CW) * film_ld);
         };
         auto film_put = [&]() {
 #pragma unroll
-            for (int i = 0; i < 16 * RG; ++i)                     // scale rows halved (exact): see filter_mid.hip
-                lds_put<float>(Fs + 4 * (((r_lane >> 1) * NFS + f_lane) * 4 + (r_lane & 1)), 4 * (2 * (i % (8 * RG)) * NFS * 4 + 2 * (i / (8 * RG))),
-                               i < 8 * RG ? 0.5f * fr[i] : fr[i]);
+            for (int i = 0; i < NI; ++i)                          // scale rows halved (exact): see filter_mid.hip
+                lds_put<float>(Fs + 4 * (((r_lane >> 1) * NFS + f_lane) * 4 + (r_lane & 1)), 4 * ((RPI * i % CW / 2) * NFS * 4 + 2 * (RPI * i / CW)),
+                               RPI * i < CW ? 0.5f * fr[i] : fr[i]);
         };
         film_load(0);
 
@@ -176,7 +199,7 @@ __global__ __launch_bounds__(512 / RG, 1) void filter_block256_kernel(const floa
         for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
             for (int c = 0; c < CTW; ++c) {
-                const int t = tbase + 32 * c + n32;
+                const int t = tbase + col0 + 32 * c + n32;
                 const float* up = Un + (size_t)(CW * w + 32 * rg + 4 * lh) * L + (t < L ? t : L - 1);      // (columns past the end: finite, never stored)
                 float x[16];
 #pragma unroll
@@ -187,7 +210,7 @@ __global__ __launch_bounds__(512 / RG, 1) void filter_block256_kernel(const floa
 
         // GELU -> FiLM -> fp16 -> LDS of one 32 x 32 accumulator tile (channel group rg, column tile ct), FiLM rows from the wave's table
         auto emit_tile = [&](const f32x16& v, int rg, int c, int dstp) {
-            int col = 32 * c + n32;
+            int col = col0 + 32 * c + n32;
             int i0 = ci0[c] - f_lo;
             i0 = i0 < NFS - 2 ? i0 : NFS - 2;
             asm volatile("" : "+v"(col), "+v"(i0));         // (opaque per call: the 32 LDS addresses derived from them are three instructions each,
@@ -233,28 +256,32 @@ __global__ __launch_bounds__(512 / RG, 1) void filter_block256_kernel(const floa
             if (__builtin_expect(cnt && zmax > 65504.0f, 0)) atomicAdd(&alive_f16_sat_count, 1u);
         };
         // the context in front of a buffer: the previous tile's (registers) or, at the window's first tile, rows 1 .. 16 reflected
+        constexpr int NCH = GUARD / 16, NP = (NCH + NT - 1) / NT;      // a context's 16-byte pieces; per thread
         auto put_context = [&](int buf, int q) {
             if (first) {
 #pragma unroll
-                for (int u = 0; u < 512 / NT; ++u) {            // rows 1 .. 16, 32 chunks each
+                for (int u = 0; u < NP; ++u) {                  // rows 1 .. 16, CPR chunks each
                     const int e = tid + NT * u;
-                    const int j = 1 + (e >> 5), p = e & 31;     // stored chunk position p in row j
+                    const int j = 1 + e / CPR, p = e % CPR;     // stored chunk position p in row j
                     const int c = p ^ swz(j);                   // the channel chunk it holds
-                    lds_put<u32x4>(buf - j * ROWB + ((c ^ swz(-j)) << 4), 0, lds_get<u32x4>(buf + j * ROWB + (p << 4)));
+                    if (NCH % NT == 0 || e < NCH) lds_put<u32x4>(buf - j * ROWB + ((c ^ swz(-j)) << 4), 0, lds_get<u32x4>(buf + j * ROWB + (p << 4)));
                 }
             } else {
 #pragma unroll
-                for (int u = 0; u < 512 / NT; ++u) {
+                for (int u = 0; u < NP; ++u) {
                     u32x4 c0 = {0u, 0u, 0u, 0u};                 // (a warm-up tile has no context: its stored columns' cone does not reach it)
-                    if (!warm) c0 = *(const u32x4*)(ctx_ws + q * GUARD + NT * 16 * u);
-                    lds_put<u32x4>(buf - GUARD + tid * 16, NT * 16 * u, c0);
+                    if (NCH % NT == 0 || tid + NT * u < NCH) {
+                        if (!warm) c0 = *(const u32x4*)(ctx_ws + q * GUARD + NT * 16 * u);
+                        lds_put<u32x4>(buf - GUARD + tid * 16, NT * 16 * u, c0);
+                    }
                 }
             }
         };
-        auto take_context = [&](int buf, int q) {          // rows 112 .. 127 of a conv's complete input
+        auto take_context = [&](int buf, int q) {          // rows BL - 16 .. BL - 1 of a conv's complete input
 #pragma unroll
-            for (int u = 0; u < 512 / NT; ++u)
-                *(u32x4*)(ctx_ws + q * GUARD + NT * 16 * u) = lds_get<u32x4>(buf + (BL - CTX) * ROWB + tid * 16, NT * 16 * u);
+            for (int u = 0; u < NP; ++u)
+                if (NCH % NT == 0 || tid + NT * u < NCH)
+                    *(u32x4*)(ctx_ws + q * GUARD + NT * 16 * u) = lds_get<u32x4>(buf + (BL - CTX) * ROWB + tid * 16, NT * 16 * u);
         };
 
         PROF(0);
@@ -313,8 +340,8 @@ __global__ __launch_bounds__(512 / RG, 1) void filter_block256_kernel(const floa
             // cycles.  (The scheduling fences keep hipcc from regrouping them; no value outlives its register's next definition, so ring
             // and buffers stay in place.)  Each accumulator still takes one MFMA per k-step in k order: the sums are the same bits.
             auto b_frag = [&](int ks, int c) {
-                const int j = ks >> 4, cb = ks & 15;
-                const int row = n32 + (j - 4) * d;                     // of column tile 0: >= -16, the context rows (32 rows on: the same swizzle)
+                const int j = ks / NKC, cb = ks % NKC;
+                const int row = col0 + n32 + (j - 4) * d;                     // of column tile 0: >= -16, the context rows (32 rows on: the same swizzle)
                 return lds_get<bf16x8>(in + row * ROWB + (((2 * cb + lh) ^ swz(row)) << 4), 32 * ROWB * c);
             };
             if (RG == 1 && !last) film_load(q + 1);
@@ -377,7 +404,7 @@ __global__ __launch_bounds__(512 / RG, 1) void filter_block256_kernel(const floa
             for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
                 for (int c = 0; c < CTW; ++c) {
-                    const int t = tbase + 32 * c + n32;
+                    const int t = tbase + col0 + 32 * c + n32;
                     if (t >= L) continue;
                     const size_t o = ((size_t)n * C + CW * w + 32 * rg + 4 * lh) * L + t;
                     if (skip != nullptr) {
@@ -400,65 +427,78 @@ __global__ __launch_bounds__(512 / RG, 1) void filter_block256_kernel(const floa
 #endif
 }
 
-}  // namespace
-
-// U[N][256][L] (the block's residual stream: the output of the composed transposed conv) -> out = FilterBlock(U) + skip, fp32.
-// w16[q] / bias[q], q = 0 .. 5: blocks[q / 2].c1 / .c2 -- the fp16 slab of module/_pack.py::pack_conv_split_h and the fp32 bias.
-// film[N][film_rows][film_ld]: rows film_off + q * 512 + (0 .. 255 scale | 256 .. 511 shift) for conv q; frame range as alive_filter_block64_range.
-// bytes of workspace alive_filter_block256_fp16 needs at most: six 8-KB contexts per block, at most one block per tile
-extern "C" int64_t alive_filter_block256_workspace_bytes(int N, int L) {
-    return N > 0 && L > 0 ? (int64_t)N * cdiv(L, BL) * NCONV * GUARD : 0;
-}
-
-extern "C" int alive_filter_block256_fp16(const float* U, int N, int L, const void* const* w16, const float* const* bias, const float* film,
-                                          int film_rows, int Lf, int film_off, int t0, int f0, int film_ld, const float* skip, float* out,
-                                          void* ws, int64_t ws_bytes, void* stream) {
-    ALIVE_CHECK_ARG(U && w16 && bias && film && out, "alive_filter_block256_fp16: null pointer");
-    ALIVE_CHECK_ARG(N > 0 && L > 2 * CTX && Lf > 0, "alive_filter_block256_fp16: bad sizes (L must exceed 32)");
-    ALIVE_CHECK_ARG(U != out, "alive_filter_block256_fp16: in-place not supported (a segment's warm-up tile reads its left neighbour's input)");
-    ALIVE_CHECK_ARG(film_ld > 0 && t0 >= 0 && f0 >= 0, "alive_filter_block256_fp16: bad frame range");
-    ALIVE_CHECK_ARG((double)BL * film_ld / L + 3.0 <= NFS, "alive_filter_block256_fp16: 128 columns span more than %d frames (L %d, frames %d)", NFS - 3, L, film_ld);
+template <int C>
+int fb_launch(const char* name, const float* U, int N, int L, const void* const* w16, const float* const* bias, const float* film, int film_rows,
+              int Lf, int film_off, int t0, int f0, int film_ld, const float* skip, float* out, void* ws, int64_t ws_bytes, void* stream) {
+    typedef Geo<C, 1> G;                      // (tile, context and table sizes do not depend on RG)
+    ALIVE_CHECK_ARG(U && w16 && bias && film && out, "%s: null pointer", name);
+    ALIVE_CHECK_ARG(N > 0 && L > 2 * CTX && Lf > 0, "%s: bad sizes (L must exceed 32)", name);
+    ALIVE_CHECK_ARG(U != out, "%s: in-place not supported (a block's warm-up tile reads columns another block has stored)", name);
+    ALIVE_CHECK_ARG(film_ld > 0 && t0 >= 0 && f0 >= 0, "%s: bad frame range", name);
+    ALIVE_CHECK_ARG(128.0 * film_ld / L + 3.0 <= G::NFS, "%s: 128 columns span more than %d frames (L %d, frames %d)", name, G::NFS - 3, L, film_ld);
     Fb256Weights wts;
     for (int q = 0; q < NCONV; ++q) {
-        ALIVE_CHECK_ARG(w16[q] && bias[q], "alive_filter_block256_fp16: null weights");
+        ALIVE_CHECK_ARG(w16[q] && bias[q], "%s: null weights", name);
         wts.w[q] = (const unsigned short*)w16[q];
         wts.b[q] = bias[q];
     }
     {
         static LdsOptIn optin;
-        hipError_t e = optin.ensure({(const void*)filter_block256_kernel<2>, (const void*)filter_block256_kernel<1>}, LDS_BYTES);
+        hipError_t e = optin.ensure({(const void*)filter_block256_kernel<C, 2>, (const void*)filter_block256_kernel<C, 1>}, G::LDS_BYTES);
         if (e != hipSuccess) {
-            alive_set_error("alive_filter_block256_fp16: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(e));
+            alive_set_error("%s: cannot reserve %d B of LDS: %s", name, G::LDS_BYTES, hipGetErrorString(e));
             return ALIVE_ERR_LAUNCH;
         }
     }
     const float ratio = (float)film_ld / (float)L;
-    const int tiles = cdiv(L, BL);
-    ALIVE_CHECK_ARG((int64_t)N * tiles < (1ll << 31), "alive_filter_block256_fp16: too many tiles");
+    const int tiles = cdiv(L, G::BL);
+    ALIVE_CHECK_ARG((int64_t)N * tiles < (1ll << 31), "%s: too many tiles", name);
     static int cus = 0;
     if (cus == 0 && (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess || cus <= 0)) cus = 256;
     const int total = N * tiles, per_block = cdiv(total, cus), blocks = cdiv(total, per_block);
-    ALIVE_CHECK_ARG(ws != nullptr && ws_bytes >= (int64_t)blocks * NCONV * GUARD,
-                    "alive_filter_block256_fp16: workspace too small (alive_filter_block256_workspace_bytes)");
-    static const bool eight = !(getenv("ALIVE_FB256_WAVES") && atoi(getenv("ALIVE_FB256_WAVES")) == 4);
-    if (eight)
-        filter_block256_kernel<1><<<blocks, 512, LDS_BYTES, (hipStream_t)stream>>>(U, L, wts, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld,
-                                                                                      skip, out, tiles, per_block, total, (unsigned char*)ws);
+    ALIVE_CHECK_ARG(ws != nullptr && ws_bytes >= (int64_t)blocks * NCONV * G::GUARD, "%s: workspace too small (see the _workspace_bytes query)", name);
+    // ALIVE_FB256_WAVES = 4: one wave per SIMD (64 channels x 128 columns each); default: two (32 channels x 128 columns each)
+    static const bool two = !(getenv("ALIVE_FB256_WAVES") && atoi(getenv("ALIVE_FB256_WAVES")) == 4);
+    if (two)
+        filter_block256_kernel<C, 1><<<blocks, Geo<C, 1>::NT, G::LDS_BYTES, (hipStream_t)stream>>>(U, L, wts, film, film_rows, Lf, film_off, ratio, t0, f0,
+                                                                                                   film_ld, skip, out, tiles, per_block, total, (unsigned char*)ws);
     else
-        filter_block256_kernel<2><<<blocks, 256, LDS_BYTES, (hipStream_t)stream>>>(U, L, wts, film, film_rows, Lf, film_off, ratio, t0, f0, film_ld,
-                                                                                      skip, out, tiles, per_block, total, (unsigned char*)ws);
-    ALIVE_CHECK_LAUNCH("alive_filter_block256_fp16");
+        filter_block256_kernel<C, 2><<<blocks, Geo<C, 2>::NT, G::LDS_BYTES, (hipStream_t)stream>>>(U, L, wts, film, film_rows, Lf, film_off, ratio, t0, f0,
+                                                                                                   film_ld, skip, out, tiles, per_block, total, (unsigned char*)ws);
+    ALIVE_CHECK_LAUNCH(name);
 #ifdef ALIVE_FB256_PROF
     {
         unsigned long long v[16], z[16] = {0};
         (void)hipDeviceSynchronize();
         (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(fb256_prof), sizeof(v));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(fb256_prof), z, sizeof(z));
-        fprintf(stderr, "fb256 cycles: start->loads issued %llu | barrier %llu | z0 %llu | ctx+B1 %llu | k-loop %llu | B2 %llu | epilogue+B3 %llu | store %llu | (k-loop head) %llu\n",
-                v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]);
+        fprintf(stderr, "%s cycles: start->loads issued %llu | barrier %llu | z0 %llu | ctx+B1 %llu | k-loop %llu | B2 %llu | epilogue+B3 %llu | store %llu\n",
+                name, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
     }
 #endif
     return ALIVE_OK;
+}
+}  // namespace
+
+// U[N][C][L] (the block's residual stream: the output of the composed transposed conv) -> out = FilterBlock(U) + skip, fp32.
+// w16[q] / bias[q], q = 0 .. 5: blocks[q / 2].c1 / .c2 -- the fp16 slab of module/_pack.py::pack_conv_split_h and the fp32 bias.
+// film[N][film_rows][film_ld]: rows film_off + q * 2 C + (0 .. C - 1 scale | C .. 2 C - 1 shift) for conv q; frame range as alive_filter_block64_range.
+// workspace: six contexts (16 columns x C channels, fp16) per block, at most one block per tile
+extern "C" int64_t alive_filter_block256_workspace_bytes(int N, int L) {
+    return N > 0 && L > 0 ? (int64_t)N * cdiv(L, Geo<256, 1>::BL) * NCONV * Geo<256, 1>::GUARD : 0;
+}
+extern "C" int alive_filter_block256_fp16(const float* U, int N, int L, const void* const* w16, const float* const* bias, const float* film,
+                                          int film_rows, int Lf, int film_off, int t0, int f0, int film_ld, const float* skip, float* out,
+                                          void* ws, int64_t ws_bytes, void* stream) {
+    return fb_launch<256>("alive_filter_block256_fp16", U, N, L, w16, bias, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, ws, ws_bytes, stream);
+}
+extern "C" int64_t alive_filter_block64s_workspace_bytes(int N, int L) {
+    return N > 0 && L > 0 ? (int64_t)N * cdiv(L, Geo<64, 1>::BL) * NCONV * Geo<64, 1>::GUARD : 0;
+}
+extern "C" int alive_filter_block64s_fp16(const float* U, int N, int L, const void* const* w16, const float* const* bias, const float* film,
+                                          int film_rows, int Lf, int film_off, int t0, int f0, int film_ld, const float* skip, float* out,
+                                          void* ws, int64_t ws_bytes, void* stream) {
+    return fb_launch<64>("alive_filter_block64s_fp16", U, N, L, w16, bias, film, film_rows, Lf, film_off, t0, f0, film_ld, skip, out, ws, ws_bytes, stream);
 }
 
 ALIVE_F16_SAT_GETTER(alive_f16_sat_filter_big)

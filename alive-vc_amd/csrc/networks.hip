@@ -68,12 +68,15 @@ const Names& names_of(int model) {
             if (i >= 2) dec.add("flt.down" + std::to_string(i) + ".Wp");      // the same weights as bf16 planes, tap-major (batch path)
         }
         dec.add("flt.mid.W"); dec.add("flt.mid.b");
-        for (int i = 0; i < 4; ++i) { dec.add("flt.up" + std::to_string(i) + ".W"); dec.add("flt.up" + std::to_string(i) + ".b"); }
+        for (int i = 0; i < 4; ++i) {
+            dec.add("flt.up" + std::to_string(i) + ".W"); dec.add("flt.up" + std::to_string(i) + ".b");
+            if (F_MODE[i] == 1) { dec.add("flt.up" + std::to_string(i) + ".Wc"); dec.add("flt.up" + std::to_string(i) + ".bc"); }      // x input_conv
+        }
         for (int s = 0; s < 4; ++s) {
             std::string b = "flt.blk" + std::to_string(s);
             if (F_MODE[s] == 2) { dec.add(b + ".pack"); continue; }     // fused 16- / 8-channel FilterBlock
-            if (F_MODE[s] == 1) { dec.add(b + ".packW"); dec.add(b + ".packB"); continue; }   // fused 64-channel FilterBlock
-            // (no input_conv: module/_pack.py composes it into the transposed conv in front of the block)
+            if (F_MODE[s] == 1) { dec.add(b + ".packW"); dec.add(b + ".packB"); }   // fused 64-channel FilterBlock (filter_mid.hip), then its
+            // k5 convs one by one (filter_big.hip).  F_MODE 0: no input_conv -- module/_pack.py composes it into the transposed conv
             for (int j = 0; j < 3; ++j)
                 for (int c = 1; c <= 2; ++c) {
                     std::string q = b + "." + std::to_string(j) + ".c" + std::to_string(c);
@@ -151,6 +154,10 @@ int decoder_bf16_mask() {
     return decoder_precision() == 1 ? m : 0;
 }
 
+bool fb64s_enabled() {          // ALIVE_FB64S=0: the 64-channel block on filter_mid.hip's sweep kernel, as before
+    static const bool on = !(getenv("ALIVE_FB64S") && atoi(getenv("ALIVE_FB64S")) == 0);
+    return on;
+}
 bool fb256_enabled() {          // ALIVE_FB256=0: the 256-channel block conv by conv, as in round 5
     static const bool on = !(getenv("ALIVE_FB256") && atoi(getenv("ALIVE_FB256")) == 0);
     return on;
@@ -714,7 +721,11 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
         RUN(alive_conv1d(&d, stream));
     }
     const float* upW[4]; const float* upb[4];
-    for (int i = 0; i < 4; ++i) { upW[i] = t.next(); upb[i] = t.next(); }
+    const float* upWc = nullptr; const float* upbc = nullptr;
+    for (int i = 0; i < 4; ++i) {
+        upW[i] = t.next(); upb[i] = t.next();
+        if (F_MODE[i] == 1) { upWc = t.next(); upbc = t.next(); }
+    }
     const float* skips[4] = {b.d2, b.d1, b.d0, nullptr};
     const float* cur = b.m;
     int cin = 256, L = Lf, film_off = 0;
@@ -723,9 +734,12 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
         // (a) in decoder precision mode 1, batch path: the 256-channel block in one kernel (filter_big.hip), U -> Hh like the finer scales.
         // (The rule reads the signal's length only: a window's samples do not depend on how many windows share the call.)
         const bool fused256 = F_MODE[s] == 0 && (decoder_bf16_mask() & 1) != 0 && b.Pa != nullptr && fb256_enabled() && L * r >= 128;
+        // (e) the same kernel for the 64-channel block (tiles of 512 columns); its input conv goes into the transposed conv too
+        const bool fused64s = F_MODE[s] == 1 && (decoder_bf16_mask() & 16) != 0 && b.Pa != nullptr && fb64s_enabled() && L * r >= 512;
         {   // ConvTranspose1d(cin, C, r, r): rows = (co, j).  Unfused scale: the weights are ups[s] x input_conv (module/_pack.py), the
             // output is the block's residual stream itself
-            AliveConv d = conv_desc(upW[s], upb[s], cur, N, cin, L, C * r, 1, 1, 1, 0, 0, L, F_MODE[s] == 0 && !fused256 ? b.Hh : b.U);
+            AliveConv d = conv_desc(fused64s ? upWc : upW[s], fused64s ? upbc : upb[s], cur, N, cin, L, C * r, 1, 1, 1, 0, 0, L,
+                                    F_MODE[s] == 0 && !fused256 ? b.Hh : b.U);
             d.up = r;
             if (F_SPLIT[s]) d = split(d);
             // (experiment, mask bit 8, off: the two transposed convs are bound by their stores -- 170.1 +- 0.3 ms per step either way, and the
@@ -741,8 +755,16 @@ int decoder_run(const float* const* w, const float* x_in, const float* f0, const
                                                    skips[s], b.Hh, stream));
             } else {
                 const float* w16 = t.next(); const float* bias = t.next();
+                const void* w6[6]; const float* b6[6];
+                for (int q = 0; q < 6; ++q) {
+                    w6[q] = plain_w(t.next(), C, 5 * C);
+                    b6[q] = t.next();
+                }
                 // (e) decoder precision mode 1: the block's six k5 convs on one fp16 plane
-                if ((decoder_bf16_mask() & 16) && b.Pa != nullptr)          // (batch path only, like the other groups)
+                if (fused64s)
+                    RUN(alive_filter_block64s_fp16(b.U, N, L, w6, b6, b.film, FILM_ROWS, Lw_frames, film_off, f_begin * (L / Lf), f_begin, Lf, skips[s],
+                                                   b.Hh, b.Zz, (int64_t)N * 64 * (Lw / 4) * 4, stream));
+                else if ((decoder_bf16_mask() & 16) && b.Pa != nullptr)          // (batch path only, like the other groups)
                     RUN(alive_filter_block64_range_fp16(b.U, N, L, w16, bias, b.film, FILM_ROWS, Lw_frames, film_off, f_begin * (L / Lf), f_begin, Lf,
                                                         skips[s], b.Hh, stream));
                 else

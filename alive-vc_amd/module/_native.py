@@ -92,6 +92,8 @@ PROTOTYPES = {
     "alive_filter_block64_range_fp16": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "alive_filter_block256_workspace_bytes": (_I64, [_I, _I]),
     "alive_filter_block256_fp16": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _I64, _VP]),
+    "alive_filter_block64s_workspace_bytes": (_I64, [_I, _I]),
+    "alive_filter_block64s_fp16": (_I, [_VP, _I, _I, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _I64, _VP]),
     "alive_filter_source_in": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "alive_filter_source_out": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP]),
     "alive_dwconv_norm": (_I, [_VP, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP]),

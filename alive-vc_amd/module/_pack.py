@@ -265,6 +265,13 @@ def pack_decoder(sd):
             wt = torch.einsum("icj,dc->idj", wt.double(), win).float()
             bt = bc.float()
         out[f"flt.up{i}.W"], out[f"flt.up{i}.b"] = pt(wt, bt)
+        if FILTER_MODE[i] == "mid":
+            # the same composition for the 64-channel scale, used when its FilterBlock runs on csrc/filter_big.hip (decoder precision mode
+            # 1, batch path: alive_filter_block64s_fp16 takes the residual stream like the 256-channel block); filter_mid.hip keeps the
+            # input conv inside and the plain ups[i] above
+            win = sd[f"{f}.blocks.{i}.input_conv.weight"].double()[:, :, 0]
+            bc = win @ bt.double() + sd[f"{f}.blocks.{i}.input_conv.bias"].double()
+            out[f"flt.up{i}.Wc"], out[f"flt.up{i}.bc"] = pt(torch.einsum("icj,dc->idj", wt.double(), win).float(), bc.float())
     for s in range(4):
         b = f"{f}.blocks.{s}"
         if FILTER_MODE[s] == "small":                # 16- / 8-channel scales: one fused kernel per FilterBlock
@@ -272,6 +279,10 @@ def pack_decoder(sd):
             continue
         if FILTER_MODE[s] == "mid":                  # 64-channel scale: fused, split-bf16
             out[f"flt.blk{s}.packW"], out[f"flt.blk{s}.packB"] = pack_filter_mid(sd, b)
+            for j in range(3):                       # (+ the six k5 convs as fp16 slabs of their own: csrc/filter_big.hip)
+                for cc in ("c1", "c2"):
+                    out[f"flt.blk{s}.{j}.{cc}.W"] = pack_conv_split_h(sd[f"{b}.blocks.{j}.{cc}.conv.conv.weight"])
+                    out[f"flt.blk{s}.{j}.{cc}.b"] = _vec(sd[f"{b}.blocks.{j}.{cc}.conv.conv.bias"])
             continue
         for j in range(3):                           # (input_conv: composed into flt.up{s} above)
             for cc in ("c1", "c2"):

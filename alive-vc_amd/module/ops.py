@@ -248,14 +248,17 @@ def filter_block64(x, sd, prefix, film, film_off, skip=None, plain=False):
 
 
 def filter_block256(x, sd, prefix, film, film_off, skip=None, t0=0, f0=0, frames=None):
-    """fused FilterBlock for C = 256 on plain fp16 operands WITHOUT its 1x1 input conv (the decoder composes that into the transposed conv
-    that produces x; csrc/filter_big.hip, decoder precision mode 1): x[N,256,L] = the block's residual stream, reference-layout weights
-    sd[prefix + '.blocks.j.c1 / c2 ...'].  t0 / f0 / frames: the window's place in a longer signal (alive_filter_block64_range)."""
+    """fused FilterBlock for C = 256 (or 64: alive_filter_block64s_fp16) on plain fp16 operands WITHOUT its 1x1 input conv (the decoder
+    composes that into the transposed conv that produces x; csrc/filter_big.hip, decoder precision mode 1): x[N,C,L] = the block's
+    residual stream, reference-layout weights sd[prefix + '.blocks.j.c1 / c2 ...'].  t0 / f0 / frames: the window's place in a longer
+    signal (alive_filter_block64_range)."""
     import ctypes
     from ._pack import pack_conv_split_h
     x, film, skip = _f(x), _f(film), _f(skip)
     n, c, l = x.shape
-    assert c == 256
+    assert c in (256, 64)
+    entry, query = (("alive_filter_block256_fp16", "alive_filter_block256_workspace_bytes") if c == 256 else
+                    ("alive_filter_block64s_fp16", "alive_filter_block64s_workspace_bytes"))
     keep, ws, bs = [], [], []
     for j in range(3):
         for cc in ("c1", "c2"):
@@ -264,13 +267,13 @@ def filter_block256(x, sd, prefix, film, film_off, skip=None, t0=0, f0=0, frames
             keep += [w, b]
             ws.append(nat.ptr(w[2]))
             bs.append(nat.ptr(b))
-    nbytes = nat.lib().alive_filter_block256_workspace_bytes(n, l)
+    nbytes = getattr(nat.lib(), query)(n, l)
     ws_buf = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     out = torch.empty_like(x)
-    nat.check(nat.lib().alive_filter_block256_fp16(nat.ptr(x), n, l, (ctypes.c_void_p * 6)(*ws), (ctypes.c_void_p * 6)(*bs), nat.ptr(film),
+    nat.check(getattr(nat.lib(), entry)(nat.ptr(x), n, l, (ctypes.c_void_p * 6)(*ws), (ctypes.c_void_p * 6)(*bs), nat.ptr(film),
                                                    film.shape[1], film.shape[2] if frames is None else frames, film_off, t0, f0,
                                                    film.shape[2], nat.ptr(skip), nat.ptr(out), nat.ptr(ws_buf), nbytes, nat.stream()),
-              "alive_filter_block256_fp16")
+              entry)
     return out
 
 

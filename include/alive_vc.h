@@ -392,6 +392,15 @@ int alive_filter_block256_fp16(const float* U, int N, int L, const void* const* 
                                int film_rows, int Lf, int film_off, int t0, int f0, int film_ld, const float* skip, float* out,
                                void* ws, int64_t ws_bytes, void* stream);
 
+/* the same kernel for C = 64 (decoder scale 1; round 6): tiles of 512 columns, four column groups of waves, FiLM at <= 1 frame per 25
+ * columns.  Like the 256-channel form it takes the block's residual stream -- the decoder composes blocks[1].input_conv into ups[1]
+ * (module/_pack.py "flt.up1.Wc") -- and six fp16 slabs [K / 32][64][32], K = 5 x 64.  alive_filter_block64_range_fp16 (input conv inside,
+ * one bf16-typed pack) stays for the split-bf16 mode and for short signals. */
+int64_t alive_filter_block64s_workspace_bytes(int N, int L);
+int alive_filter_block64s_fp16(const float* U, int N, int L, const void* const* w16, const float* const* bias, const float* film,
+                               int film_rows, int Lf, int film_off, int t0, int f0, int film_ld, const float* skip, float* out,
+                               void* ws, int64_t ws_bytes, void* stream);
+
 /* The waveform-rate edges of Filter.forward (decoder.py:164,182,186-188,194) as streaming kernels:
  *   alive_filter_source_in : downs[0](source_in(src)):  src[N][Lw] -> d0[N][16][Lw/2]
  *                            Win[8][7], bin[8] = source_in (pad 3); Wd[16][8][2], bd[16] = downs[0] (stride 2); fp32,

@@ -301,14 +301,16 @@ def test_modulated_chain_split_bf16(golden_dir):
     assert relerr(h, ref) < 1e-4, relerr(h, ref)
 
 
-@pytest.mark.parametrize("l,lf,n", [(4500, 450, 2), (370, 37, 3), (1280, 128, 1), (130, 13, 2), (4490, 449, 9)])
-def test_fused_filter_block_256(l, lf, n):
+@pytest.mark.parametrize("l,lf,n,c", [(4500, 450, 2, 256), (370, 37, 3, 256), (1280, 128, 1, 256), (130, 13, 2, 256), (4490, 449, 9, 256),
+                                      (36000, 450, 2, 64), (1200, 15, 3, 64), (408, 5, 2, 64), (5040, 63, 5, 64), (520, 6, 1, 64)])
+def test_fused_filter_block_256(l, lf, n, c):
     """the 256-channel FilterBlock in one kernel (round 6, csrc/filter_big.hip: plain fp16 operands, a block sweeps a segment of a window in
     128-column tiles, contexts handed over through the workspace, warm-up tile per inner segment, reflection at a window's start) against
     the oracle's conv-by-conv evaluation (decoder.py:105-150) with an identity input conv: fp16 operand rounding (2^-12 per operand) is
-    the whole difference.  Lengths that are no multiple of the tile or of 4, one tile, many segments per window (n = 1) and few (n = 9)."""
+    the whole difference.  Lengths that are no multiple of the tile or of 4, one tile, many blocks per window (n = 1) and few (n = 9).
+    c = 64: the same kernel for decoder scale 1 (alive_filter_block64s_fp16: tiles of 512 columns, 80 samples per frame)."""
     from module import ops
-    c, cond_ch = 256, 24
+    cond_ch = 24
     x = g(f"fb256x{l}", (n, c, l))
     cnd = g(f"fb256c{l}", (n, cond_ch, lf))
     skip = g(f"fb256s{l}", (n, c, l))

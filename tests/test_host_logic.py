@@ -78,7 +78,7 @@ def test_weight_tables_cover_the_schema():
                 assert v.shape[0] % 16 == 0 and v.shape[1] % 16 == 0
             if k.endswith(".W") and v.dtype == torch.bfloat16:         # split kernel, k-blocked: [planes][KW * Ci_pad32 / 32][Co_pad16][32]
                 # encoders: 3 bf16 planes; decoder: 2, or 2 + the fp16 slab of the plain kernels (decoder precision mode 1, _pack.pack_conv_split_h)
-                plain = mid == 2 and (k.startswith("flt.blk0.") or k.startswith("flt.up") or k == "flt.mid.W" or k == "fe.normfilm.W"
+                plain = mid == 2 and (k.startswith("flt.blk0.") or k.startswith("flt.blk1.") or k.startswith("flt.up") or k == "flt.mid.W" or k == "fe.normfilm.W"
                                       or (k.startswith("fe.mid") and ".pw" in k))
                 f16s = mid < 2 and (".pw" in k or (mid == 1 and k == "output.W"))      # encoders' pointwise convs, the f0 classifier: 3 bf16 planes + the fp16 (hi, lo) pair (_pack.pack_conv_split_f16s)
                 assert v.dim() == 4 and v.shape[0] == (5 if f16s else 3 if mid < 2 or plain else 2) and v.shape[2] % 16 == 0 and v.shape[3] == 32, k

@@ -1,7 +1,8 @@
 """The fused 256-channel FilterBlock (csrc/filter_big.hip, round 6) against the conv-by-conv form of round 5 (ALIVE_FB256=0), through the
 decoder: waveform RMS error against every reference fixture (tests/golden/full_T450*.npz), the difference between the two forms, fp16
 saturations, and the decoder's time on a batch of windows.  One subprocess per form (the switch is read once per process).
-usage: python tools/cmp_fb256.py [windows] [out.json]"""
+usage: python tools/cmp_fb256.py [windows] [out.json] [switch]      switch: ALIVE_FB256 (default) or ALIVE_FB64S (the 64-channel block on
+the same kernel against filter_mid.hip's sweep kernel)"""
 import json
 import os
 import subprocess
@@ -50,19 +51,20 @@ print("RESULT " + json.dumps(res))
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    switch = sys.argv[3] if len(sys.argv) > 3 else "ALIVE_FB256"
     out = {}
     import numpy as np
     for form in ("0", "1"):
         d = os.path.join(ROOT, "gpurun_out", "cmp_fb256_" + form)
         os.makedirs(d, exist_ok=True)
-        r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "n": n, "out": d}], env=dict(os.environ, ALIVE_FB256=form),
+        r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "n": n, "out": d}], env=dict(os.environ, **{switch: form}),
                            capture_output=True, text=True, timeout=1200)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
         if not line:
             print(r.stdout[-3000:], r.stderr[-3000:])
-            raise SystemExit(f"ALIVE_FB256={form} failed")
+            raise SystemExit(f"{switch}={form} failed")
         out[form] = json.loads(line[0][7:])
-        print(f"ALIVE_FB256={form}: " + json.dumps(out[form]), flush=True)
+        print(f"{switch}={form}: " + json.dumps(out[form]), flush=True)
     diff = {}
     for name in [k for k in out["0"] if k.startswith("full")]:
         a = np.load(os.path.join(ROOT, "gpurun_out", "cmp_fb256_0", name + ".npy")).astype(np.float64)
