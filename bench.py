@@ -391,7 +391,7 @@ def main():
                 "decoder": dict(fam(ms_dec, fl_dec, pk_dec, ("FeatureExtractor + HarmonicOscillator + Filter: plain fp16 (1 MFMA per product) for the ConvNeXt pointwise convs, the k5 convs of the 256- and 64-channel FilterBlocks, the norm-FiLM projection, the two coarse down convs and the mid conv "
                                                               "(80.3 of the 96.6 MFLOP per frame), 2-plane split bf16 (3 MFMAs per product) for the rest; peak = the blend, FLOP / ideal time" if dec_mode == 1 else
                                                               "FeatureExtractor + HarmonicOscillator + Filter: 2-plane split bf16, 3 MFMAs per product") +
-                                                             " (fused FilterBlocks at 64 / 16 / 8 channels on the same MFMA; exact f32 MFMA only for the strided / transposed convs of the two finest scales)"),
+                                                             " (every FilterBlock one fused kernel: 256 / 64 channels csrc/filter_big.hip, 16 / 8 channels csrc/filter_small.hip; exact f32 MFMA only for the strided / transposed convs of the two finest scales)"),
                                 precision_mode=dec_mode, frac_of_split_bf16_peak=round(fl_dec / (ms_dec * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS / 3), 4)),
                 "step": {"ideal_ms": round(ideal_ms, 1), "ms_per_step": round(dt / args.steps * 1e3, 2), "frac": round(ideal_ms / (dt / args.steps * 1e3), 4),
                          "ideal": "kNN 2*768*M*T FLOP at the candidate stage's MFMA peak + decoder at its blended peak (2.5 PF for the plain-fp16 layers, 2.5 PF / 3 for the rest) + front end at its blended peak (2.5 PF / 3 for the fp16-split layers, 2.5 PF / 6 for the rest)"}}
