@@ -845,6 +845,57 @@ def test_guarded_mfma_kernels_soak_under_a_concurrent_matrix_load(c):
         del film, x, skip, out, first
 
 
+@pytest.mark.parametrize("c,l", [(256, 4500), (64, 36000)])
+def test_fused_sweep_blocks_soak_under_a_concurrent_matrix_load(c, l):
+    """the sweep kernel of the 256- and 64-channel FilterBlock (csrc/filter_big.hip) under the same perturbation as the guarded kernels
+    above: x 300 at 24 windows (blocks of few tiles, many warm-up tiles) and x 150 at the bench's 192, a bf16 GEMM load beside every
+    launch, every launch bitwise the first.  (Its hand-overs: contexts through an L2 workspace between a block's tiles, LDS regions with
+    three tenants per conv, two waves per SIMD behind block barriers.)"""
+    import ctypes
+    from module import _native as nat
+    L_ = nat.lib()
+    lf = 450
+    entry, query = ((L_.alive_filter_block256_fp16, L_.alive_filter_block256_workspace_bytes) if c == 256 else
+                    (L_.alive_filter_block64s_fp16, L_.alive_filter_block64s_workspace_bytes))
+    side = torch.cuda.Stream()
+    ga = torch.randn(8192, 8192, device=DEV, dtype=torch.bfloat16)
+    gb = torch.randn(8192, 8192, device=DEV, dtype=torch.bfloat16)
+    gc_ = torch.empty(8192, 8192, device=DEV, dtype=torch.bfloat16)
+    for N, reps in ((24, 300), (192, 150)):
+        gen = torch.Generator(device=DEV).manual_seed(5 + N)
+        film = 0.05 * torch.randn(N, 4128, lf, device=DEV, generator=gen)
+        x = 0.3 * torch.randn(N, c, l, device=DEV, generator=gen)
+        skip = 0.3 * torch.randn(N, c, l, device=DEV, generator=gen)
+        out = torch.empty_like(x)
+        ws = [(torch.randn(c * 5 * c, device=DEV, generator=gen) * (0.32 / c ** 0.5)).to(torch.float16) for _ in range(6)]
+        bs = [torch.randn(c, device=DEV, generator=gen) * 0.1 for _ in range(6)]
+        W = (ctypes.c_void_p * 6)(*[w.data_ptr() for w in ws])
+        B = (ctypes.c_void_p * 6)(*[b.data_ptr() for b in bs])
+        nbytes = query(N, l)
+        wsp = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        st = torch.cuda.current_stream().cuda_stream
+
+        def run():
+            nat.check(entry(x.data_ptr(), N, l, W, B, film.data_ptr(), 4128, lf, 0 if c == 256 else 3072, 0, 0, lf, skip.data_ptr(), out.data_ptr(),
+                            wsp.data_ptr(), nbytes, st))
+        run()
+        first = out.clone()
+        assert torch.isfinite(first).all()
+        bad = torch.zeros((), dtype=torch.int64, device=DEV)
+        side.wait_stream(torch.cuda.current_stream())
+        for rep in range(reps):
+            if rep % 2 == 0:
+                with torch.cuda.stream(side):
+                    torch.mm(ga, gb, out=gc_)
+            out.zero_()
+            wsp.random_(0, 255)                                     # (the workspace's old contents are nobody's input)
+            run()
+            bad += (out != first).any()
+        torch.cuda.synchronize()
+        assert int(bad.item()) == 0, f"C = {c}, {N} windows: {int(bad.item())} of {reps} launches differ from the first"
+        del film, x, skip, out, first, wsp
+
+
 def test_operators_write_only_their_outputs(monkeypatch):
     """every tensor an operator wrapper allocates for the C ABI (module/ops.py: outputs and plane buffers) is placed between
     two guard bands; after a battery of ragged shapes through alive_conv1d (fp32 / split / transposed / strided / skinny),
