@@ -343,15 +343,17 @@ def test_fused_filter_block_256(l, lf, n, c):
     assert torch.equal(one, out[:1])
 
 
-def test_fused_filter_block_256_in_a_frame_range():
+@pytest.mark.parametrize("c", [256, 64])
+def test_fused_filter_block_256_in_a_frame_range(c):
     """range mode (alive_filter_block64_range's t0 / f0 / film_ld): frames 40 .. 89 of a 128-frame signal with the FiLM rows of those frames
     only.  Past the reach of the window's start (its first 5 columns interpolate towards frame 39, which the table does not hold, and
     the reflected context reaches 4 (1 + 1 + 2 + 2 + 4 + 4) = 56 columns further) and short of its last frame (whose interpolation
     partner lies outside the table) the samples are those of the whole signal's run, bit for bit -- the interpolation
     coordinates are the signal's, and a column's sums do not depend on the tile it falls into."""
     from module import ops
-    c, cond_ch, lf, f0, nf = 256, 24, 128, 40, 50
-    x = g("fb256rx", (1, c, 10 * lf))
+    cond_ch, lf, f0, nf = 24, 128, 40, 50
+    up = 10 if c == 256 else 80                      # samples per frame at the block's scale
+    x = g(f"fb256rx{c}", (1, c, up * lf))
     cnd = g("fb256rc", (1, cond_ch, lf))
     sd = {}
     ws, bs, post = [], [], []
@@ -365,10 +367,11 @@ def test_fused_filter_block_256_in_a_frame_range():
             post += [torch.ones(c), torch.zeros(c)]
     film, _ = ops.conv1d(cnd.to(DEV), torch.cat(ws, 0).to(DEV), torch.cat(bs, 0).to(DEV), post_add=torch.cat(post).to(DEV))
     whole = ops.filter_block256(x.to(DEV), sd, "n", film, 0)
-    part = ops.filter_block256(x[:, :, 10 * f0:10 * (f0 + nf)].contiguous().to(DEV), sd, "n", film[:, :, f0:f0 + nf].contiguous(), 0,
-                               t0=10 * f0, f0=f0, frames=lf)
-    assert torch.equal(part[:, :, 61:10 * nf - 16], whole[:, :, 10 * f0 + 61:10 * (f0 + nf) - 16])
-    assert not torch.equal(part[:, :, :16], whole[:, :, 10 * f0:10 * f0 + 16])             # (the reflected start is the window's own)
+    part = ops.filter_block256(x[:, :, up * f0:up * (f0 + nf)].contiguous().to(DEV), sd, "n", film[:, :, f0:f0 + nf].contiguous(), 0,
+                               t0=up * f0, f0=f0, frames=lf)
+    lo, hi = up // 2 + 1 + 56, up * nf - up - up // 2 - 1      # (first columns: towards frame f0 - 1; last: towards frame f0 + nf)
+    assert torch.equal(part[:, :, lo:hi], whole[:, :, up * f0 + lo:up * f0 + hi])
+    assert not torch.equal(part[:, :, :16], whole[:, :, up * f0:up * f0 + 16])             # (the reflected start is the window's own)
 
 
 @pytest.mark.parametrize("c,l,lf", [(8, 4800, 15), (16, 2400, 15), (8, 144000, 450), (16, 1000, 5),
