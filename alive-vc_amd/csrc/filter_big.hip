@@ -454,7 +454,10 @@ int fb_launch(const char* name, const float* U, int N, int L, const void* const*
     const int tiles = cdiv(L, G::BL);
     ALIVE_CHECK_ARG((int64_t)N * tiles < (1ll << 31), "%s: too many tiles", name);
     static int cus = 0;
-    if (cus == 0 && (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess || cus <= 0)) cus = 256;
+    if (cus == 0) {                              // (one process drives one GPU: the count of the current device, once)
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
     const int total = N * tiles, per_block = cdiv(total, cus), blocks = cdiv(total, per_block);
     ALIVE_CHECK_ARG(ws != nullptr && ws_bytes >= (int64_t)blocks * NCONV * G::GUARD, "%s: workspace too small (see the _workspace_bytes query)", name);
     // ALIVE_FB256_WAVES = 4: one wave per SIMD (64 channels x 128 columns each); default: two (32 channels x 128 columns each)
