@@ -1,27 +1,27 @@
-// FilterBlock.forward for the 256-channel scale of the decoder's U-Net (/root/reference/module/decoder.py:105-150; its 1x1 input conv is
-// composed into the transposed conv in front of it, module/_pack.py), fused into ONE kernel on plain fp16 operands (decoder precision
-// mode 1): round 6.
+// FilterBlock.forward for the 256- and the 64-channel scale of the decoder's U-Net (/root/reference/module/decoder.py:105-150; the 1x1
+// input conv is composed into the transposed conv in front of the block, module/_pack.py), fused into ONE kernel on plain fp16 operands
+// (decoder precision mode 1, batch path): round 6.  DESIGN.md 3.2g has the measurements behind every choice below.
 //
-// Conv by conv (conv_split_kernel<128, 1, true, true>, six launches + alive_gelu_film per window batch) every k5 conv reads one fp16
-// plane and writes one, every second one also streams the fp32 residual in and out, and each launch runs at ~0.2 of the matrix pipe.
-// Here a block keeps a tile of 128 columns x 256 channels on chip through all six GELU -> FiLM -> reflect-left causal k5 convs
-// (dilations 1, 1, 2, 2, 4, 4):
-//   * the modulated conv input lives in two LDS buffers as ONE fp16 plane, [column][256 channels] = 512-byte rows, 16-byte chunks
-//     XOR-swizzled by (row & 15): a 32x32x16 B fragment is one conflict-free ds_read_b128 at any tap shift;
-//   * wave w owns output channels 64 w .. 64 w + 63 (two 32-row groups) of ALL 128 columns: a k-step (one tap x 16 channels) is two A
-//     fragments of the weights, streamed from L2 in the k-blocked fp16 slab of module/_pack.py::pack_conv_split_h, four B fragments
-//     from LDS and eight MFMAs into eight 32 x 32 accumulators -- 32 B per clock and CU from the L1, 64 from LDS, half of what each
-//     delivers (with 64 columns per wave the weight stream alone was measured at 1.9 of 8.7 ms);
-//   * the fp32 residual stream of the wave's 64 x 128 outputs stays in 128 registers from the tile's load to its store (+ U-Net skip);
-//   * the SWEEP of filter_mid.hip: a block walks a segment of a window left to right, every tile is 128 NEW columns, and each conv's
-//     causal context -- the last 16 columns of its input, 8 KB -- travels to the next tile in REGISTERS (32 bytes per thread and conv);
-//     a segment starts with a warm-up tile that is not stored; at the window's first tile the context is the reflection of the tile's
-//     own columns 1 .. 16 (ReflectionPad1d, common.py:88);
-//   * bufY has no context rows of its own: its rows -16 .. -1 ARE bufZ's rows 112 .. 127 (the buffers are adjacent), which are dead
-//     whenever bufY is read -- their content (the tail of the previous conv's input) has been taken into the context registers by then;
-//   * the FiLM rows a wave applies are those of its own 64 channels: each wave stages them (per 64-column half: <= 10 frames) in a
-//     private LDS table, loaded under the MFMA loop -- no block barrier for them.
-// HBM traffic: the residual stream in, the skip in, the output out (12 B per element instead of ~48).
+// Conv by conv (conv_split_kernel<128, 1, true, true>, six launches + alive_gelu_film per window batch) every k5 conv of the 256-channel
+// block read one fp16 plane and wrote one, every second one also streamed the fp32 residual in and out, and each launch ran at ~0.2 of
+// the matrix pipe.  Here a block keeps a tile -- 128 columns x 256 channels or 512 x 64: 64 KB -- on chip through all six
+// GELU -> FiLM -> reflect-left causal k5 convs (dilations 1, 1, 2, 2, 4, 4):
+//   * the modulated conv input lives in two LDS buffers as ONE fp16 plane, [column][C channels], 16-byte chunks XOR-swizzled per row
+//     (Geo::swz): a 32x32x16 B fragment is one conflict-free ds_read_b128 at any tap shift;
+//   * a wave owns 32 RG output channels x 128 columns: a k-step (one tap x 16 channels) is RG A fragments of the weights, streamed from
+//     L2 in the k-blocked fp16 slab of module/_pack.py::pack_conv_split_h -- each fragment once per block and conv at C = 256 --,
+//     four B fragments from LDS and 4 RG MFMAs, ONE memory instruction behind each MFMA;
+//   * the fp32 residual stream of the wave's outputs stays in registers from the tile's load to its store (+ U-Net skip);
+//   * the batch is ONE sequence of tiles, window after window; a block takes a run of them, every tile all-new columns, and each conv's
+//     causal context -- the last 16 columns of its input -- waits for the next tile in the block's slice of a workspace (L2); a run that
+//     starts inside a window begins with a warm-up tile that is not stored; at a window's first tile the context is the reflection of
+//     the tile's own columns 1 .. 16 (ReflectionPad1d, common.py:88);
+//   * bufY has no context rows of its own: its rows -16 .. -1 ARE bufZ's last 16 rows (the buffers are adjacent), which are dead
+//     whenever bufY is read -- their content (the tail of the previous conv's input) has gone to the workspace by then;
+//   * the FiLM rows a wave applies are those of its own channels: each wave stages them in a private LDS table (loads: a lane per
+//     FRAME, several rows per instruction) -- no block barrier for them;
+//   * every LDS access goes through address-space-3 pointers (lds_get / lds_put): see the note there.
+// HBM traffic: the residual stream in, the skip in, the output out, the FiLM rows (12 B per value instead of ~48).
 #include "conv_epilogue.h"
 #include <stdlib.h>
 
