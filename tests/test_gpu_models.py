@@ -214,6 +214,46 @@ def test_decoder_precision_modes(golden_dir, nets):
     assert d12 > 1e-7                                  # the two modes really are different kernels
 
 
+@pytest.mark.parametrize("switch", ["ALIVE_FB256=0", "ALIVE_FB64S=0", "ALIVE_FB256_WAVES=4"])
+def test_decoder_forms_behind_the_filter_switches_stay_within_the_fixture_bar(golden_dir, switch):
+    """Round 6: the 256- and 64-channel FilterBlocks of decoder precision mode 1 run on csrc/filter_big.hip; the kernels they replaced
+    (conv by conv; filter_mid.hip's sweep kernel) and the one-wave-per-SIMD form stay behind environment switches that are read once per
+    process -- one subprocess per switch decodes the reference's 450-frame fixture: same bar as the default form (4e-5 of max(1, RMS);
+    measured 2.9e-5 each), no fp16 saturation, and the three forms really differ (or, for the wave count, do not: the sums are the same)."""
+    import subprocess
+    import sys
+    child = r"""
+import os, sys, json
+import numpy as np, torch
+sys.path.insert(0, os.path.join(%(root)r, "alive-vc_amd")); sys.path.insert(0, os.path.join(%(root)r, "oracle"))
+import alive_oracle as O
+from module import schema, synthetic, ops
+from module.decoder import Decoder
+z = np.load(os.path.join(%(gold)r, "full_T450.npz"))
+sce = synthetic.make_state_dict(schema.content_encoder_schema(), 2, "ce.")
+sdec = synthetic.make_state_dict(schema.decoder_schema(), 2, "dec.")
+dec = Decoder(); dec.load_state_dict(sdec); dec = dec.to("cuda"); dec.precision = 1
+feat = O.content_encoder(sce, O.spectrogram(torch.from_numpy(z["wav"]))).cuda()
+wave, _ = dec(feat, torch.from_numpy(z["f0_dec"]).cuda())
+ref = torch.from_numpy(z["wave"]).double()
+err = (wave.double().cpu() - ref).pow(2).mean().sqrt().item() / max(1.0, ref.pow(2).mean().sqrt().item())
+import hashlib
+print("RESULT " + json.dumps({"err": err, "sat": ops.f16_saturations(reset=True), "digest": hashlib.sha256(wave.cpu().numpy().tobytes()).hexdigest()}))
+"""
+    root = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    res = {}
+    for name, env in (("default", {}), (switch, dict([switch.split("=")]))):
+        clean = {k: v for k, v in os.environ.items() if k not in ("ALIVE_FB256", "ALIVE_FB64S", "ALIVE_FB256_WAVES")}
+        r = subprocess.run([sys.executable, "-c", child % {"root": root, "gold": golden_dir}], env=dict(clean, **env), capture_output=True, text=True,
+                           timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+        assert line, (r.stdout[-1500:], r.stderr[-1500:])
+        res[name] = __import__("json").loads(line[0][7:])
+        assert res[name]["err"] < 4e-5 and res[name]["sat"] == 0, (name, res[name])
+    same = res["default"]["digest"] == res[switch]["digest"]
+    assert same == (switch == "ALIVE_FB256_WAVES=4"), (switch, res)
+
+
 @pytest.mark.parametrize("n,lf", [(2, 27), (1, 15), (3, 33)])
 def test_decoder_odd_frame_counts_in_both_precision_modes(nets, n, lf):
     """Odd frame counts: the 256-channel scale then has L = 10 Lf columns with L % 4 == 2, so its convs run WITHOUT plane operands -- the
