@@ -53,7 +53,8 @@ struct Geo {
     // accumulators' initialisation), bufZ's 16 context rows (its end: from there to the end of the k-loop, even convs), the waves' FiLM
     // tables (all of it: from the barrier behind the k-loop to the end of the epilogue).  At C = 256 with bufZ and bufY: all 160 KB.
     static constexpr int FS_BYTES = NW * FS_WAVE;            // 32 KB / 16 KB
-    static constexpr int LDS_BYTES = FS_BYTES + 2 * BUFB;
+    static constexpr int SLOTS = C == 64 ? NCONV * GUARD : 0;   // C = 64: the convs' contexts wait for the next tile in LDS (12 KB); C = 256: workspace
+    static constexpr int LDS_BYTES = FS_BYTES + 2 * BUFB + SLOTS;
     static constexpr int NKC = C / 16;                       // k-steps per tap
     static constexpr int NKS = KW * NKC;                     // 80 / 20 k-steps per conv
     static_assert(FS_BYTES >= GUARD && FS_BYTES >= NW * CW * 4 && NKC % 2 == 0, "region in front of bufZ");
@@ -110,6 +111,7 @@ __global__ __launch_bounds__((Geo<C, RG>::NT), 1) void filter_block256_kernel(co
     auto swz = [](int row) { return G::swz(row); };
     const int bufZ = sm0 + G::FS_BYTES;
     const int bufY = bufZ + BUFB;
+    const int slots = bufY + BUFB;                              // (C = 64 only)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -271,7 +273,7 @@ __global__ __launch_bounds__((Geo<C, RG>::NT), 1) void filter_block256_kernel(co
                 for (int u = 0; u < NP; ++u) {
                     u32x4 c0 = {0u, 0u, 0u, 0u};                 // (a warm-up tile has no context: its stored columns' cone does not reach it)
                     if (NCH % NT == 0 || tid + NT * u < NCH) {
-                        if (!warm) c0 = *(const u32x4*)(ctx_ws + q * GUARD + NT * 16 * u);
+                        if (!warm) c0 = G::SLOTS ? lds_get<u32x4>(slots + q * GUARD + tid * 16, NT * 16 * u) : *(const u32x4*)(ctx_ws + q * GUARD + NT * 16 * u);
                         lds_put<u32x4>(buf - GUARD + tid * 16, NT * 16 * u, c0);
                     }
                 }
@@ -280,8 +282,11 @@ __global__ __launch_bounds__((Geo<C, RG>::NT), 1) void filter_block256_kernel(co
         auto take_context = [&](int buf, int q) {          // rows BL - 16 .. BL - 1 of a conv's complete input
 #pragma unroll
             for (int u = 0; u < NP; ++u)
-                if (NCH % NT == 0 || tid + NT * u < NCH)
-                    *(u32x4*)(ctx_ws + q * GUARD + NT * 16 * u) = lds_get<u32x4>(buf + (BL - CTX) * ROWB + tid * 16, NT * 16 * u);
+                if (NCH % NT == 0 || tid + NT * u < NCH) {
+                    const u32x4 v = lds_get<u32x4>(buf + (BL - CTX) * ROWB + tid * 16, NT * 16 * u);
+                    if (G::SLOTS) lds_put<u32x4>(slots + q * GUARD + tid * 16, NT * 16 * u, v);
+                    else *(u32x4*)(ctx_ws + q * GUARD + NT * 16 * u) = v;
+                }
         };
 
         PROF(0);
@@ -486,7 +491,8 @@ int fb_launch(const char* name, const float* U, int N, int L, const void* const*
 // U[N][C][L] (the block's residual stream: the output of the composed transposed conv) -> out = FilterBlock(U) + skip, fp32.
 // w16[q] / bias[q], q = 0 .. 5: blocks[q / 2].c1 / .c2 -- the fp16 slab of module/_pack.py::pack_conv_split_h and the fp32 bias.
 // film[N][film_rows][film_ld]: rows film_off + q * 2 C + (0 .. C - 1 scale | C .. 2 C - 1 shift) for conv q; frame range as alive_filter_block64_range.
-// workspace: six contexts (16 columns x C channels, fp16) per block, at most one block per tile
+// workspace: six contexts (16 columns x C channels, fp16) per block, at most one block per tile (C = 64: the contexts stay in LDS and the
+// workspace is not touched; the argument is checked all the same)
 extern "C" int64_t alive_filter_block256_workspace_bytes(int N, int L) {
     return N > 0 && L > 0 ? (int64_t)N * cdiv(L, Geo<256, 1>::BL) * NCONV * Geo<256, 1>::GUARD : 0;
 }
